@@ -1,0 +1,289 @@
+"""CPU restatement (torch CPU tensors, explicit formulas) of the reference's hot-path operators.
+
+TEST INFRASTRUCTURE — see oracle/__init__.py.  Every function cites the reference file:line it
+follows (paths relative to /root/reference).  All arithmetic is IEEE fp32, one rounding per
+elementwise op (torch CPU never contracts a*b+c into an FMA across ops), which is what makes the
+`mask >= 1.0` bits of the warp reproducible.
+"""
+import torch
+import torch.nn.functional as F
+
+R = 4          # max_displacement (model/upflow.py:335, :561)
+D = 2 * R + 1  # 9
+ND = D * D     # 81
+
+
+# ------------------------------------------------------------------------------------------------
+# cost volume
+# ------------------------------------------------------------------------------------------------
+def corr81(f1, f2):
+    """out[n, 9*(dy+4)+(dx+4), y, x] = (1/C) * sum_c f1[n,c,y,x] * f2[n,c,y+dy,x+dx], f2 zero outside.
+
+    Direct statement of what `correlation_forward<T>` computes with the only parameters the model
+    uses, (pad,k,md,s1,s2) = (4,1,4,1,1): model/correlation_package/correlation_cuda_kernel.cu:41-114
+    (channel order tc = (tj+r)*(2r+1)+(ti+r), :106; division by nelems = k*k*C, :73,:108), called at
+    model/upflow.py:561-562.  Same result as utils/pytorch_correlation.py:27-50 (mean over C, :47).
+    Accumulates in the input dtype, channel by channel (fp32 -> fp32 like the CUDA kernel's scalar_t).
+    """
+    B, C, H, W = f1.shape
+    f2p = F.pad(f2, (R, R, R, R))
+    out = f1.new_zeros(B, ND, H, W)
+    for dy in range(D):
+        for dx in range(D):
+            out[:, dy * D + dx] = (f1 * f2p[:, :, dy:dy + H, dx:dx + W]).sum(1) / C
+    return out
+
+
+def corr81_unfold(in1, in2, pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1):
+    """The reference's pure-PyTorch fallback algorithm, restated: utils/pytorch_correlation.py:27-50.
+
+    unfold(k=1) both inputs (:30-31) -> view the second as B*C single-channel images (:35-36) ->
+    unfold again with a kernel as large as the image and padding=pad, which enumerates the 81
+    shifted copies (:38) -> [B, C, H*W, 81] materialised -> multiply by f1 (:45) -> mean over C (:46).
+    This is the algorithm `bench.py`'s cpu_baseline times.
+    """
+    assert pad_size == max_displacement and stride1 == stride2 == 1
+    B, C, H, W = in1.shape
+    k = kernel_size
+    a = F.unfold(in1, kernel_size=k, padding=k // 2, stride=stride1)          # [B, C*k*k, H*W]
+    b = F.unfold(in2, kernel_size=k, padding=k // 2, stride=stride2)
+    ck = b.shape[1]
+    b = b.reshape(B * ck, 1, H, W)
+    b = F.unfold(b, kernel_size=(H, W), padding=pad_size, stride=stride2)      # [B*ck, H*W, 81]
+    nwin = b.shape[2]
+    b = b.reshape(B, ck, H * W, nwin).permute(0, 3, 1, 2)                      # [B, 81, ck, H*W]
+    res = (b * a.unsqueeze(1)).mean(dim=2)
+    return res.reshape(B, nwin, H, W)
+
+
+def corr81_backward(f1, f2, grad_out):
+    """gI1[n,c,y,x] = (1/C) sum_d gO[n,d,y,x] * f2[n,c,y+dy,x+dx];
+    gI2[n,c,y,x] = (1/C) sum_d gO[n,d,y-dy,x-dx] * f1[n,c,y-dy,x-dx]  (out-of-range terms dropped).
+
+    model/correlation_package/correlation_cuda_kernel.cu:116-207 (input1), :209-300 (input2) with
+    (pad,k,md,s1,s2) = (4,1,4,1,1).
+    """
+    B, C, H, W = f1.shape
+    f2p = F.pad(f2, (R, R, R, R))
+    g1 = torch.zeros_like(f1)
+    g2p = f1.new_zeros(B, C, H + 2 * R, W + 2 * R)
+    for dy in range(D):
+        for dx in range(D):
+            go = grad_out[:, dy * D + dx].unsqueeze(1)
+            g1 += go * f2p[:, :, dy:dy + H, dx:dx + W]
+            g2p[:, :, dy:dy + H, dx:dx + W] += go * f1
+    return g1 / C, g2p[:, :, R:R + H, R:R + W] / C
+
+
+def correlation_general(f1, f2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """General-parameter cost volume, restating correlation_cuda_kernel.cu:41-114 and the shape math
+    of correlation_cuda.cc:19-34: padded inputs, kernel radius kr=(k-1)/2, displacement radius
+    dr=md/stride2, output (2dr+1)^2 channels of size ceil((H+2p-2(kr+md))/s1).
+    Unpinned beyond the (4,1,4,1,1) case (the reference's Python fallback asserts pad==md, s=1).
+    """
+    import math
+    B, C, H, W = f1.shape
+    kr = (kernel_size - 1) // 2
+    br = kr + max_displacement
+    pH, pW = H + 2 * pad_size, W + 2 * pad_size
+    oH = int(math.ceil((pH - 2 * br) / stride1))
+    oW = int(math.ceil((pW - 2 * br) / stride1))
+    dr = max_displacement // stride2
+    ds = 2 * dr + 1
+    p1 = F.pad(f1, (pad_size,) * 4)
+    p2 = F.pad(f2, (pad_size,) * 4)
+    out = f1.new_zeros(B, ds * ds, oH, oW)
+    nelems = kernel_size * kernel_size * C
+    ys = torch.arange(oH) * stride1 + max_displacement
+    xs = torch.arange(oW) * stride1 + max_displacement
+    for tj in range(-dr, dr + 1):
+        for ti in range(-dr, dr + 1):
+            acc = f1.new_zeros(B, oH, oW)
+            for j in range(-kr, kr + 1):
+                for i in range(-kr, kr + 1):
+                    a = p1[:, :, (ys + j)][:, :, :, (xs + i)]
+                    b = p2[:, :, (ys + tj * stride2 + j)][:, :, :, (xs + ti * stride2 + i)]
+                    acc += (a * b).sum(1)
+            out[:, (tj + dr) * ds + (ti + dr)] = acc / nelems
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# backward warp  (grid_sample, bilinear, zeros padding, torch-1.1 align_corners=True semantics)
+# ------------------------------------------------------------------------------------------------
+def _sample_coords(flow, H, W):
+    """Sampling position in pixels, with the reference's normalise -> un-normalise round trip.
+
+    model/pwc_modules.py:187-199: vgrid = meshgrid + flow; vgrid_x = 2*vgrid_x/max(W-1,1) - 1.
+    ATen grid_sampler_unnormalize(align_corners=True): ((g + 1) / 2) * (size - 1).
+    """
+    B = flow.shape[0]
+    xx = torch.arange(W, dtype=torch.float32).view(1, 1, W).expand(B, H, W)
+    yy = torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(B, H, W)
+    gx = 2.0 * (xx + flow[:, 0]) / max(W - 1, 1) - 1.0
+    gy = 2.0 * (yy + flow[:, 1]) / max(H - 1, 1) - 1.0
+    ix = ((gx + 1.0) / 2.0) * (W - 1)
+    iy = ((gy + 1.0) / 2.0) * (H - 1)
+    return ix, iy
+
+
+def _taps(ix, iy, H, W):
+    x0 = torch.floor(ix)
+    y0 = torch.floor(iy)
+    x1 = x0 + 1
+    y1 = y0 + 1
+    # ATen bilinear weights: nw=(x1-ix)(y1-iy), ne=(ix-x0)(y1-iy), sw=(x1-ix)(iy-y0), se=(ix-x0)(iy-y0)
+    wts = [(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)]
+    pos = [(x0, y0), (x1, y0), (x0, y1), (x1, y1)]
+    inb = [((px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)) for px, py in pos]
+    return wts, pos, inb
+
+
+def warp_mask(flow, H, W, mode='literal'):
+    """Validity mask of WarpingLayer_no_div (model/pwc_modules.py:201-206).
+
+    'literal': grid_sample(ones) >= 1.0 — the four weight*tap products summed sequentially
+    ((nw+ne)+sw)+se in fp32 without FMA (bit-exact vs ATen).
+    'robust' : exact in-bounds predicate 0<=x<=W-1 and 0<=y<=H-1 on meshgrid+flow (H2/P3b; non-default).
+    """
+    if mode == 'robust':
+        B = flow.shape[0]
+        xx = torch.arange(W, dtype=torch.float32).view(1, 1, W).expand(B, H, W)
+        yy = torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(B, H, W)
+        px, py = xx + flow[:, 0], yy + flow[:, 1]
+        return ((px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)).unsqueeze(1)
+    ix, iy = _sample_coords(flow, H, W)
+    wts, _, inb = _taps(ix, iy, H, W)
+    s = torch.zeros_like(ix)
+    for w, m in zip(wts, inb):
+        s = s + torch.where(m, w, torch.zeros_like(w))
+    return (s >= 1.0).unsqueeze(1)
+
+
+def warp(x, flow, mask_mode='literal'):
+    """Backward warp.  mask_mode None -> tools.torch_warp (utils/tools.py:1274-1319);
+    'literal' / 'robust' -> WarpingLayer_no_div.forward (model/pwc_modules.py:184-207).
+    Differentiable w.r.t. x and flow (the mask is a constant factor), so autograd through this
+    function is the oracle for the backward kernels too.
+    """
+    B, C, H, W = x.shape
+    ix, iy = _sample_coords(flow, H, W)
+    wts, pos, inb = _taps(ix, iy, H, W)
+    xf = x.reshape(B, C, H * W)
+    out = None
+    for w, (px, py), m in zip(wts, pos, inb):
+        idx = (py.clamp(0, H - 1) * W + px.clamp(0, W - 1)).long().view(B, 1, H * W).expand(B, C, H * W)
+        v = torch.gather(xf, 2, idx).view(B, C, H, W)
+        term = v * torch.where(m, w, torch.zeros_like(w)).unsqueeze(1)
+        out = term if out is None else out + term
+    if mask_mode is not None:
+        out = out * warp_mask(flow.detach(), H, W, mask_mode).to(out.dtype)
+    return out
+
+
+def warp_backward(x, flow, grad_out, mask_mode='literal'):
+    xr = x.detach().clone().requires_grad_(True)
+    fr = flow.detach().clone().requires_grad_(True)
+    y = warp(xr, fr, mask_mode)
+    return torch.autograd.grad(y, (xr, fr), grad_out)
+
+
+# ------------------------------------------------------------------------------------------------
+# flow up-sampling
+# ------------------------------------------------------------------------------------------------
+def _bilinear_ac(x, h, w):
+    """F.interpolate(bilinear, align_corners=True) restated: src = dst*(in-1)/(out-1) (0 if out==1),
+    i0 = floor(src), l1 = src - i0, value = l0h*(l0w*a + l1w*b) + l1h*(l0w*c + l1w*d).
+    Call sites model/pwc_modules.py:74,79,101."""
+    B, C, h_, w_ = x.shape
+    sy = (h_ - 1) / (h - 1) if h > 1 else 0.0
+    sx = (w_ - 1) / (w - 1) if w > 1 else 0.0
+    ys = torch.arange(h, dtype=torch.float32) * torch.tensor(sy, dtype=torch.float32)
+    xs = torch.arange(w, dtype=torch.float32) * torch.tensor(sx, dtype=torch.float32)
+    y0 = ys.floor().long().clamp(max=h_ - 1)
+    x0 = xs.floor().long().clamp(max=w_ - 1)
+    y1 = (y0 + 1).clamp(max=h_ - 1)
+    x1 = (x0 + 1).clamp(max=w_ - 1)
+    ly1 = (ys - y0.float()).view(1, 1, h, 1)
+    lx1 = (xs - x0.float()).view(1, 1, 1, w)
+    ly0, lx0 = 1.0 - ly1, 1.0 - lx1
+    a = x[:, :, y0][:, :, :, x0]
+    b = x[:, :, y0][:, :, :, x1]
+    c = x[:, :, y1][:, :, :, x0]
+    d = x[:, :, y1][:, :, :, x1]
+    return ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * c + lx1 * d)
+
+
+def flow_upsample(x, h, w, if_rate=True):
+    """upsample2d_flow_as (model/pwc_modules.py:77-90) / upsample_flow (:93-104): bilinear
+    align_corners=True resize, then u *= w/w_, v *= h/h_ (size ratios, python floats)."""
+    _, _, h_, w_ = x.shape
+    res = _bilinear_ac(x, h, w)
+    if if_rate:
+        scale = torch.tensor([w / w_, h / h_], dtype=torch.float32).view(1, 2, 1, 1)
+        res = res * scale
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# SGU interpolation-blend
+# ------------------------------------------------------------------------------------------------
+def sgu_blend(flow_init, x_out, output_level_flow=None):
+    """model/upflow.py:79-88.  inter_flow = x_out[:, :2]; inter_mask = sigmoid(x_out[:, 2:3]); with
+    output_level_flow both are bilinearly up-sampled to its size (flow channels rescaled, :85-86) and
+    flow_init := output_level_flow (:87); flow_up = torch_warp(flow_init, inter_flow)*(1-mask) +
+    flow_init*mask (:88).  Returns (flow_init, flow_up, inter_flow, inter_mask) like :89."""
+    inter_flow = x_out[:, :2]
+    inter_mask = torch.sigmoid(x_out[:, 2:3])
+    if output_level_flow is not None:
+        h, w = output_level_flow.shape[2:]
+        inter_flow = flow_upsample(inter_flow, h, w, if_rate=True)
+        inter_mask = flow_upsample(inter_mask, h, w, if_rate=False)
+        flow_init = output_level_flow
+    flow_up = warp(flow_init, inter_flow, None) * (1 - inter_mask) + flow_init * inter_mask
+    return flow_init, flow_up, inter_flow, inter_mask
+
+
+# ------------------------------------------------------------------------------------------------
+# feature normalisation, occlusion check, metric
+# ------------------------------------------------------------------------------------------------
+def normalize_pair(a, b):
+    """network_tools.normalize_features with the inference flags of test.py:22-30
+    (moments_across_channels=False, moments_across_images=False): per tensor, per sample, per channel
+    mean and UNBIASED variance over H*W, (f - mean) / sqrt(var + 1e-16).  model/upflow.py:110-137."""
+    out = []
+    for f in (a, b):
+        mean = f.mean(dim=(2, 3), keepdim=True)
+        var = f.var(dim=(2, 3), keepdim=True)
+        out.append((f - mean) / torch.sqrt(var + 1e-16))
+    return out
+
+
+def occ_check(flow_f, flow_b, alpha1=0.1, alpha2=0.5):
+    """tools.occ_check_model(obj_out_all='obj') as configured at model/upflow.py:364-365:
+    forward-backward check (utils/tools.py:550-588, |.|_1 magnitude :559) OR-ed with the
+    outgoing-flow mask (:641-677): result = 1 where (consistent) or (flow leaves the image)."""
+    def mag(v):
+        return torch.sum(torch.pow(v ** 2, 0.5), dim=1, keepdim=True)
+    m = mag(flow_f) + mag(flow_b)
+    bw_w = warp(flow_b, flow_f, None)
+    fw_w = warp(flow_f, flow_b, None)
+    thr = alpha1 * m + alpha2
+    occ_fw = (mag(flow_f + bw_w) < thr).float()
+    occ_bw = (mag(flow_b + fw_w) < thr).float()
+
+    def outgoing(flow):
+        B, _, H, W = flow.shape
+        xx = torch.arange(W, dtype=torch.float32).view(1, 1, 1, W)
+        yy = torch.arange(H, dtype=torch.float32).view(1, 1, H, 1)
+        px, py = xx + flow[:, 0:1], yy + flow[:, 1:2]
+        return ((px <= W - 1) & (px >= 0) & (py <= H - 1) & (py >= 0)).float()
+
+    def merge(occ, out):
+        return ((occ == 1) | (out == 0)).float()
+    return merge(occ_fw, outgoing(flow_f)), merge(occ_bw, outgoing(flow_b))
+
+
+def epe(a, b):
+    """Mean end-point error, dataset/kitti_dataset.py:464-475 with mask == 1."""
+    return float((a.double() - b.double()).pow(2).sum(1).sqrt().mean())

@@ -1,0 +1,400 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box never sees the reference.
+The fixtures are data only: seeded inputs and the reference's outputs.
+
+Harness shims — none of them changes reference code:
+  1. empty stub modules for cv2 / png / imageio / correlation_cuda (never touched on this path);
+  2. torch.utils.data.dataloader._DataLoaderIter alias (utils/tools.py:2 wants torch 1.1);
+  3. grid_sample(align_corners=None) -> align_corners=True, the torch-1.1 behaviour the model was
+     written for (requirements.txt:12; pwc_modules.py:197-200 normalises with W-1 / H-1);
+  4. train mode only: model.upflow.upsample2d_flow_as replaced by its out-of-place equivalent
+     (pwc_modules.py:86-88 mutates chunk views in place, which torch 2.x autograd rejects).
+
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import io
+import contextlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _weights  # noqa: E402
+
+REF = '/root/reference'
+
+
+def import_reference():
+    for m in ['cv2', 'png', 'imageio', 'correlation_cuda']:
+        sys.modules.setdefault(m, types.ModuleType(m))
+    import torch.utils.data.dataloader as dl
+    if not hasattr(dl, '_DataLoaderIter'):
+        dl._DataLoaderIter = dl._BaseDataLoaderIter
+    import torch.nn.functional as F
+    if not getattr(F.grid_sample, '_upf_shim', False):
+        _gs = F.grid_sample
+
+        def grid_sample(input, grid, mode='bilinear', padding_mode='zeros', align_corners=None):
+            return _gs(input, grid, mode=mode, padding_mode=padding_mode,
+                       align_corners=True if align_corners is None else align_corners)
+        grid_sample._upf_shim = True
+        F.grid_sample = grid_sample
+    sys.path.insert(0, REF)
+    import model.upflow as upflow
+    import model.pwc_modules as pwc
+    from utils.tools import tools
+    from utils.pytorch_correlation import Corr_pyTorch
+    return upflow, pwc, tools, Corr_pyTorch
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+TEST_FLAGS = {  # test.py:22-30
+    'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+    'norm_moments_across_images': False, 'if_froze_pwc': False,
+    'if_use_cor_pytorch': True, 'if_sgu_upsample': True,
+}
+
+
+def build_net(upflow, extra=None, seed=0, head_scale=1.0):
+    conf = upflow.UPFlow_net.config()
+    d = dict(TEST_FLAGS)
+    d.update(extra or {})
+    quiet(conf.update, d)
+    net = conf()
+    sd = _weights.make_state_dict(seed, head_scale=head_scale)
+    net.load_state_dict(sd)
+    net.eval()
+    return net
+
+
+# ------------------------------------------------------------------------------------------------
+def golden_corr(Corr_pyTorch):
+    corr = Corr_pyTorch(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1)
+    for i, (B, C, H, W) in enumerate([(2, 32, 24, 40), (1, 7, 5, 9), (1, 196, 6, 20), (1, 3, 3, 3)]):
+        g = gen(2100 + i)
+        f1 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+        f2 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+        out = corr(f1, f2)
+        go = torch.randn(out.shape, generator=g)
+        g1, g2 = torch.autograd.grad(out, (f1, f2), go)
+        save('corr_%d' % i, f1=f1, f2=f2, out=out, grad_out=go, g1=g1, g2=g2)
+
+
+def flow_cases(B, H, W, base_seed):
+    g = gen(base_seed)
+    return {
+        'zero': torch.zeros(B, 2, H, W),
+        'int2': torch.full((B, 2, H, W), 2.0),
+        'n3': torch.randn(B, 2, H, W, generator=g) * 3.0,
+        'n5': torch.randn(B, 2, H, W, generator=g) * 5.0,
+        'edge': torch.cat([torch.linspace(-6, W + 5, W).view(1, 1, 1, W).expand(B, 1, H, W)
+                           - torch.arange(W).float().view(1, 1, 1, W),
+                           torch.linspace(-3, H + 2, H).view(1, 1, H, 1).expand(B, 1, H, W)
+                           - torch.arange(H).float().view(1, 1, H, 1)], 1).contiguous(),
+    }
+
+
+def golden_warp(pwc, tools):
+    layer = pwc.WarpingLayer_no_div()
+    for si, (B, C, H, W) in enumerate([(1, 3, 48, 160), (1, 2, 96, 320), (1, 5, 6, 20), (1, 2, 1, 2)]):
+        g = gen(2200 + si)
+        x = torch.rand(B, C, H, W, generator=g) + 1.0
+        for name, flow in flow_cases(B, H, W, 2250 + si).items():
+            if si == 1 and name not in ('zero', 'n5'):
+                continue  # keep the 96x320 fixtures small
+            xr = x.clone().requires_grad_(True)
+            fr = flow.clone().requires_grad_(True)
+            y = layer(xr, fr)
+            # the validity mask itself (pwc_modules.py:201-206), recomputed through the reference's
+            # own formula: warp a ones tensor and test >= 1.0
+            ones = torch.ones(B, 1, H, W)
+            mask = (layer(ones, flow) > 0).to(torch.uint8)
+            go = torch.randn(y.shape, generator=g)
+            gx, gf = torch.autograd.grad(y, (xr, fr), go)
+            # unmasked variant: tools.torch_warp (utils/tools.py:1274-1319)
+            xr2 = x.clone().requires_grad_(True)
+            fr2 = flow.clone().requires_grad_(True)
+            y2 = tools.torch_warp(xr2, fr2)
+            gx2, gf2 = torch.autograd.grad(y2, (xr2, fr2), go)
+            save('warp_%d_%s' % (si, name), x=x, flow=flow, y=y, mask=np.packbits(mask.numpy()),
+                 grad_out=go, gx=gx, gflow=gf, y_nomask=y2, gx_nomask=gx2, gflow_nomask=gf2)
+
+
+def oop_upsample2d_flow_as(inputs, target_as, mode="bilinear", if_rate=False):
+    """Out-of-place equivalent of pwc_modules.py:77-90 (shim 4)."""
+    import torch.nn.functional as F
+    _, _, h, w = target_as.size()
+    res = F.interpolate(inputs, [h, w], mode=mode, align_corners=True)
+    if if_rate:
+        _, _, h_, w_ = inputs.size()
+        u, v = res.chunk(2, dim=1)
+        res = torch.cat([u * (w / w_), v * (h / h_)], dim=1)
+    return res
+
+
+def golden_upsample(pwc):
+    for i, ((h_, w_), (h, w)) in enumerate([((6, 20), (12, 40)), ((24, 80), (96, 320)), ((4, 13), (8, 26)),
+                                            ((7, 16), (14, 32)), ((1, 2), (2, 4)), ((5, 7), (5, 7))]):
+        g = gen(2300 + i)
+        x = torch.randn(2, 2, h_, w_, generator=g) * 4
+        tgt = torch.zeros(2, 1, h, w)
+        y = pwc.upsample2d_flow_as(x.clone(), tgt, mode='bilinear', if_rate=True)
+        y_norate = pwc.upsample2d_flow_as(x.clone(), tgt, mode='bilinear', if_rate=False)
+        y_uf = pwc.upsample_flow(x.clone(), target_size=(h, w))
+        xr = x.clone().requires_grad_(True)
+        go = torch.randn(y.shape, generator=g)
+        gx, = torch.autograd.grad(oop_upsample2d_flow_as(xr, tgt, if_rate=True), xr, go)
+        save('upsample_%d' % i, x=x, y=y, y_norate=y_norate, y_upsample_flow=y_uf, grad_out=go, gx=gx,
+             size=np.array([h, w]))
+
+
+def golden_normalize(upflow):
+    nt = upflow.network_tools
+    for i, (B, C, H, W) in enumerate([(2, 32, 12, 20), (1, 196, 6, 20), (2, 5, 3, 7)]):
+        g = gen(2400 + i)
+        a = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+        b = torch.randn(B, C, H, W, generator=g) * 0.3 - 1
+        ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        na, nb = nt.normalize_features((ar, br), normalize=True, center=True,
+                                       moments_across_channels=False, moments_across_images=False)
+        goa = torch.randn(na.shape, generator=g)
+        gob = torch.randn(nb.shape, generator=g)
+        ga, gb = torch.autograd.grad([na, nb], [ar, br], [goa, gob])
+        save('normalize_%d' % i, a=a, b=b, na=na, nb=nb, goa=goa, gob=gob, ga=ga, gb=gb)
+
+
+def golden_sgu_blend(upflow, tools):
+    """The interpolation-blend of model/upflow.py:79-88, driven through the reference's own
+    sgu_model.forward with its dense estimator replaced by a recorded x_out."""
+    for i, (B, H, W, Hf, Wf) in enumerate([(2, 24, 80, None, None), (1, 6, 20, None, None),
+                                           (2, 12, 40, 48, 160), (1, 16, 32, 64, 128)]):
+        g = gen(2500 + i)
+        sgu = upflow.network_tools.sgu_model()
+        sgu.eval()
+        x_out = torch.randn(B, 3, H, W, generator=g) * torch.tensor([2.0, 2.0, 1.5]).view(1, 3, 1, 1)
+        x_out = x_out.requires_grad_(True)
+
+        class Fixed(torch.nn.Module):
+            def forward(self, x):
+                return x, x_out
+        sgu.dense_estimator_mask = Fixed()
+        flow_init = (torch.randn(B, 2, H, W, generator=g) * 3).requires_grad_(True)
+        f1 = torch.randn(B, 32, H, W, generator=g)
+        f2 = torch.randn(B, 32, H, W, generator=g)
+        olf = None
+        if Hf is not None:
+            # a smooth field (like a real up-sampled flow): white noise would turn the fp32 ulp of the
+            # sampling position (1.5e-5 at x~160) into 1e-4 output differences and pin nothing
+            import torch.nn.functional as F_
+            olf = F_.interpolate(torch.randn(B, 2, Hf // 8, Wf // 8, generator=g) * 5, size=(Hf, Wf),
+                                 mode='bicubic', align_corners=True).contiguous().requires_grad_(True)
+        import model.upflow as mu
+        old = mu.upsample2d_flow_as
+        mu.upsample2d_flow_as = oop_upsample2d_flow_as
+        try:
+            fi, flow_up, inter_flow, inter_mask = sgu(flow_init, f1, f2, output_level_flow=olf)
+        finally:
+            mu.upsample2d_flow_as = old
+        go = torch.randn(flow_up.shape, generator=g)
+        ins = [x_out, flow_init] + ([olf] if olf is not None else [])
+        grads = torch.autograd.grad(flow_up, ins, go, allow_unused=True)
+        d = dict(x_out=x_out, flow_init=flow_init, flow_up=flow_up, inter_flow=inter_flow, inter_mask=inter_mask,
+                 grad_out=go, g_x_out=grads[0])
+        if olf is not None:
+            d.update(output_level_flow=olf, g_output_level_flow=grads[2])
+        else:
+            d.update(g_flow_init=grads[1])
+        save('sgu_blend_%d' % i, **d)
+
+
+def golden_occ(tools):
+    occ = tools.occ_check_model(occ_type='for_back_check', occ_alpha_1=0.1, occ_alpha_2=0.5, obj_out_all='obj')
+    for i, (B, H, W) in enumerate([(2, 24, 80), (1, 64, 128)]):
+        g = gen(2600 + i)
+        ff = torch.randn(B, 2, H, W, generator=g) * 2
+        fb = -ff + torch.randn(B, 2, H, W, generator=g) * 0.5
+        o1, o2 = occ(flow_f=ff, flow_b=fb)
+        save('occ_%d' % i, flow_f=ff, flow_b=fb, occ_fw=o1, occ_bw=o2)
+
+
+# ------------------------------------------------------------------------------------------------
+class Tracer:
+    """Records inputs/outputs of every hot-op call of one reference forward, in call order."""
+
+    def __init__(self, upflow, pwc, tools, net):
+        self.events = []
+        self.arrays = {}
+        self.upflow, self.pwc, self.tools, self.net = upflow, pwc, tools, net
+        self._x_out = None
+
+    def rec(self, op, **tensors):
+        idx = len(self.events)
+        ev = {'op': op, 'idx': idx, 'keys': sorted(tensors)}
+        for k, v in tensors.items():
+            self.arrays['e%03d_%s' % (idx, k)] = v.detach().clone().numpy()
+        self.events.append(ev)
+
+    def __enter__(self):
+        import model.upflow as mu
+        self.mu = mu
+        T = self
+        self.handles = []
+        self.handles.append(self.net.correlation_pytorch.register_forward_hook(
+            lambda m, i, o: T.rec('corr', f1=i[0], f2=i[1], out=o)))
+
+        def warp_hook(m, i, o):
+            T.rec('warp_mask', x=i[0], flow=i[1], y=o)
+        self.handles.append(self.net.warping_layer.register_forward_hook(warp_hook))
+        self.handles.append(self.net.sgi_model.warping_layer.register_forward_hook(warp_hook))
+
+        def est_hook(m, i, o):
+            T._x_out = o[1]
+        self.handles.append(self.net.sgi_model.dense_estimator_mask.register_forward_hook(est_hook))
+
+        def sgu_hook(m, args, kwargs, o):
+            olf = kwargs.get('output_level_flow', args[3] if len(args) > 3 else None)
+            d = dict(flow_init=o[0], x_out=T._x_out, flow_up=o[1], inter_flow=o[2], inter_mask=o[3])
+            if olf is not None:
+                d['output_level_flow'] = olf
+            T.rec('sgu_blend', **d)
+        self.handles.append(self.net.sgi_model.register_forward_hook(sgu_hook, with_kwargs=True))
+
+        self.old_tw = self.tools.torch_warp
+
+        def torch_warp(x, flo):
+            y = T.old_tw(x, flo)
+            T.rec('warp', x=x, flow=flo, y=y)
+            return y
+        self.tools.torch_warp = torch_warp
+
+        self.old_up = mu.upsample2d_flow_as
+
+        def up(inputs, target_as, mode="bilinear", if_rate=False):
+            x_in = inputs.detach().clone()
+            y = T.old_up(inputs, target_as, mode=mode, if_rate=if_rate)
+            T.rec('upsample_rate' if if_rate else 'upsample', x=x_in, y=y)
+            return y
+        mu.upsample2d_flow_as = up
+
+        self.old_norm = self.upflow.network_tools.normalize_features
+
+        def norm(feature_list, normalize, center, moments_across_channels=True, moments_across_images=True):
+            out = T.old_norm(feature_list, normalize, center, moments_across_channels=moments_across_channels,
+                             moments_across_images=moments_across_images)
+            T.rec('normalize', a=feature_list[0], b=feature_list[1], na=out[0], nb=out[1])
+            return out
+        self.upflow.network_tools.normalize_features = norm
+        return self
+
+    def __exit__(self, *a):
+        for h in self.handles:
+            h.remove()
+        self.tools.torch_warp = self.old_tw
+        self.mu.upsample2d_flow_as = self.old_up
+        self.upflow.network_tools.normalize_features = self.old_norm
+
+
+def robust_mask_patch(pwc):
+    """H2/P3b: the same warp with the exact in-bounds predicate instead of `mask >= 1.0`.
+    Oracle-side monkeypatch of WarpingLayer_no_div.forward; reference code untouched on disk."""
+    import torch.nn.functional as F
+    old = pwc.WarpingLayer_no_div.forward
+
+    def forward(self, x, flow):
+        B, C, H, W = x.size()
+        xx = torch.arange(0, W).view(1, 1, 1, W).expand(B, 1, H, W).float()
+        yy = torch.arange(0, H).view(1, 1, H, 1).expand(B, 1, H, W).float()
+        px = xx + flow[:, 0:1]
+        py = yy + flow[:, 1:2]
+        gx = 2.0 * px / max(W - 1, 1) - 1.0
+        gy = 2.0 * py / max(H - 1, 1) - 1.0
+        vgrid = torch.cat([gx, gy], 1).permute(0, 2, 3, 1)
+        x_warp = F.grid_sample(x, vgrid, padding_mode='zeros')
+        mask = ((px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)).float()
+        return x_warp * mask
+    pwc.WarpingLayer_no_div.forward = forward
+    return old
+
+
+def golden_net(upflow, pwc, tools):
+    meta = {'weights_sha256': _weights.state_dict_sha256(_weights.make_state_dict(0)),
+            'weights_sha256_hs': _weights.state_dict_sha256(_weights.make_state_dict(0, head_scale=0.1))}
+    cases = [('net_64x128', 1, 64, 128, 1), ('net_256x256', 1, 256, 256, 1)]
+    for name, B, H, W, cid in cases:
+        for variant in ['literal', 'robust']:
+            old = robust_mask_patch(pwc) if variant == 'robust' else None
+            try:
+                net = build_net(upflow, head_scale=0.1)
+                im1, im2 = _weights.make_smooth_images(cid, B, H, W)
+                with torch.no_grad():
+                    if name == 'net_64x128' and variant == 'literal':
+                        with Tracer(upflow, pwc, tools, net) as tr:
+                            out = net({'im1': im1, 'im2': im2, 'if_loss': False})
+                        save('trace_64x128', **tr.arrays)
+                        with open(os.path.join(HERE, 'trace_64x128.json'), 'w') as f:
+                            json.dump(tr.events, f, indent=0)
+                    else:
+                        out = net({'im1': im1, 'im2': im2, 'if_loss': False})
+                    # self-sensitivity of the reference (H2/P3a): same forward, N(0,1e-7²) on im1
+                    g = gen(77)
+                    out_n = net({'im1': im1 + 1e-7 * torch.randn(im1.shape, generator=g), 'im2': im2, 'if_loss': False})
+                sens = float((out['flow_f_out'] - out_n['flow_f_out']).pow(2).sum(1).sqrt().mean())
+                meta['%s_%s_self_sensitivity_epe' % (name, variant)] = sens
+                save('%s_%s' % (name, variant), flow_f_out=out['flow_f_out'], flow_b_out=out['flow_b_out'],
+                     occ_fw=out['occ_fw'].to(torch.uint8), occ_bw=out['occ_bw'].to(torch.uint8))
+            finally:
+                if old is not None:
+                    pwc.WarpingLayer_no_div.forward = old
+    with open(os.path.join(HERE, 'net_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1)
+    print(json.dumps(meta, indent=1))
+
+
+def main():
+    torch.set_num_threads(8)
+    upflow, pwc, tools, Corr_pyTorch = import_reference()
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'net']
+    if 'corr' in which:
+        golden_corr(Corr_pyTorch)
+    if 'warp' in which:
+        golden_warp(pwc, tools)
+    if 'upsample' in which:
+        golden_upsample(pwc)
+    if 'normalize' in which:
+        golden_normalize(upflow)
+    if 'sgu' in which:
+        golden_sgu_blend(upflow, tools)
+    if 'occ' in which:
+        golden_occ(tools)
+    if 'net' in which:
+        golden_net(upflow, pwc, tools)
+
+
+if __name__ == '__main__':
+    main()

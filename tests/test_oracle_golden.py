@@ -1,0 +1,105 @@
+"""Pin the oracle (oracle/ops.py) against the vectors generated from the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import glob
+import os
+
+import pytest
+import torch
+
+import oracle
+from oracle import ops
+from conftest import load_golden, unpack_mask, GOLDEN
+
+
+@pytest.mark.parametrize('i', [0, 1, 2, 3])
+def test_corr_forward_backward(i):
+    g = load_golden('corr_%d' % i)
+    out = oracle.corr81(g['f1'], g['f2'])
+    # bit-exact at even sizes was the survey's probe; summation order differs from unfold+mean at
+    # some shapes, so allow 1 ulp-class error
+    assert (out - g['out']).abs().max() <= 2e-6
+    out_u = oracle.corr81_unfold(g['f1'], g['f2'])
+    assert torch.equal(out_u, g['out']), 'unfold restatement must be bit-identical to Corr_pyTorch'
+    g1, g2 = oracle.corr81_backward(g['f1'], g['f2'], g['grad_out'])
+    assert (g1 - g['g1']).abs().max() <= 2e-6
+    assert (g2 - g['g2']).abs().max() <= 2e-6
+
+
+WARP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'warp_*.npz')))
+
+
+@pytest.mark.parametrize('name', WARP_CASES)
+def test_warp(name):
+    g = load_golden(name)
+    x, flow = g['x'], g['flow']
+    B, C, H, W = x.shape
+    mask = ops.warp_mask(flow, H, W, 'literal')
+    ref_mask = unpack_mask(g['mask'], (B, 1, H, W))
+    assert torch.equal(mask, ref_mask), 'mask bits differ: %d' % int((mask != ref_mask).sum())
+    y = oracle.warp(x, flow, 'literal')
+    assert (y - g['y']).abs().max() <= 1e-6 * max(1.0, float(g['y'].abs().max()))
+    y2 = oracle.warp(x, flow, None)
+    assert (y2 - g['y_nomask']).abs().max() <= 1e-6 * max(1.0, float(g['y_nomask'].abs().max()))
+    gx, gf = oracle.warp_backward(x, flow, g['grad_out'], 'literal')
+    assert (gx - g['gx']).abs().max() <= 1e-5
+    assert (gf - g['gflow']).abs().max() <= 1e-4 * max(1.0, float(g['gflow'].abs().max()))
+    gx2, gf2 = oracle.warp_backward(x, flow, g['grad_out'], None)
+    assert (gx2 - g['gx_nomask']).abs().max() <= 1e-5
+    assert (gf2 - g['gflow_nomask']).abs().max() <= 1e-4 * max(1.0, float(g['gflow_nomask'].abs().max()))
+
+
+@pytest.mark.parametrize('i', range(6))
+def test_flow_upsample(i):
+    g = load_golden('upsample_%d' % i)
+    h, w = [int(v) for v in g['size']]
+    y = oracle.flow_upsample(g['x'], h, w, True)
+    tol = 2e-6 * max(1.0, float(g['y'].abs().max()))
+    assert (y - g['y']).abs().max() <= tol
+    assert (oracle.flow_upsample(g['x'], h, w, False) - g['y_norate']).abs().max() <= tol
+    assert (y - g['y_upsample_flow']).abs().max() <= tol
+    xr = g['x'].clone().requires_grad_(True)
+    gx, = torch.autograd.grad(oracle.flow_upsample(xr, h, w, True), xr, g['grad_out'])
+    assert (gx - g['gx']).abs().max() <= 1e-5 * max(1.0, float(g['gx'].abs().max()))
+
+
+@pytest.mark.parametrize('i', range(3))
+def test_normalize(i):
+    g = load_golden('normalize_%d' % i)
+    na, nb = oracle.normalize_pair(g['a'], g['b'])
+    assert (na - g['na']).abs().max() <= 1e-6 * max(1.0, float(g['na'].abs().max()))
+    assert (nb - g['nb']).abs().max() <= 1e-6 * max(1.0, float(g['nb'].abs().max()))
+
+
+@pytest.mark.parametrize('i', range(4))
+def test_sgu_blend(i):
+    g = load_golden('sgu_blend_%d' % i)
+    olf = g.get('output_level_flow')
+    fi, flow_up, inter_flow, inter_mask = oracle.sgu_blend(g['flow_init'], g['x_out'], olf)
+    tol = 2e-6 * max(1.0, float(g['flow_up'].abs().max()))
+    # flow_up samples flow_init at x + inter_flow: a 1-ulp difference of the up-sampled inter_flow
+    # (3e-6 at |v|~28) times the field's gradient (<~10/px) bounds what can be pinned here
+    assert (flow_up - g['flow_up']).abs().max() <= (tol if olf is None else 5e-5)
+    assert (inter_flow - g['inter_flow']).abs().max() <= tol
+    assert (inter_mask - g['inter_mask']).abs().max() <= 1e-6
+    # gradients through the blend
+    xo = g['x_out'].clone().requires_grad_(True)
+    if olf is None:
+        f0 = g['flow_init'].clone().requires_grad_(True)
+        up = oracle.sgu_blend(f0, xo, None)[1]
+        gxo, gf0 = torch.autograd.grad(up, (xo, f0), g['grad_out'])
+        assert (gf0 - g['g_flow_init']).abs().max() <= 1e-4 * max(1.0, float(g['g_flow_init'].abs().max()))
+    else:
+        o = olf.clone().requires_grad_(True)
+        up = oracle.sgu_blend(g['flow_init'], xo, o)[1]
+        gxo, go = torch.autograd.grad(up, (xo, o), g['grad_out'])
+        assert (go - g['g_output_level_flow']).abs().max() <= 1e-4 * max(1.0, float(g['g_output_level_flow'].abs().max()))
+    assert (gxo - g['g_x_out']).abs().max() <= 1e-4 * max(1.0, float(g['g_x_out'].abs().max()))
+
+
+@pytest.mark.parametrize('i', range(2))
+def test_occ_check(i):
+    g = load_golden('occ_%d' % i)
+    o1, o2 = oracle.occ_check(g['flow_f'], g['flow_b'])
+    # thresholded floats: allow a handful of borderline pixels
+    assert (o1 != g['occ_fw']).float().mean() <= 1e-4
+    assert (o2 != g['occ_bw']).float().mean() <= 1e-4
