@@ -1,0 +1,139 @@
+/*
+ * upflow_hip.h — C-ABI of libupflow_hip.so: the MI355X (gfx950) native operators of the UPFlow
+ * hot path.  Plain pointers, sizes and a HIP stream; no torch types.
+ *
+ * This is the drop-in boundary.  The reference crosses Python -> native exactly once on this path,
+ * through the pybind11 module `correlation_cuda`
+ *     /root/reference/model/correlation_package/correlation_cuda.cc:169-172
+ *         forward (input1,input2,rInput1,rInput2,output, pad,k,max_disp,s1,s2,mult)      :10-87
+ *         backward(input1,input2,rInput1,rInput2,gradOutput,gradInput1,gradInput2, ...)  :89-167
+ * and reaches ATen's native grid_sample / interpolate kernels at
+ *     model/pwc_modules.py:79,200,205   utils/tools.py:1304   model/upflow.py:79-88.
+ * Each entry point below names the reference interface it replaces.  The reference-side binding
+ * a maintainer would add is in INTEGRATION.md; ours is upflow_pytorch_amd/_lib.py (ctypes).
+ *
+ * Conventions (all entry points)
+ *   - device pointers, tensors are contiguous NCHW (the reference kernels assume that too,
+ *     correlation_cuda_kernel.cu:15-39 ignores the strides it is handed);
+ *   - `dtype` selects the element type of feature-like tensors: UPF_F32 / UPF_F16 / UPF_BF16;
+ *     flows, sampling positions, masks and every accumulator are always fp32;
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream); calls only enqueue work, they
+ *     never synchronise, allocate or free, so they can be captured into a hipGraph;
+ *   - return value: 0 (UPF_OK) on success, a negative UPF_E* code on a rejected argument, a
+ *     positive hipError_t if the launch failed; upf_last_error() gives the message of the last
+ *     failure on the calling thread (the reference printf()s and returns 0,
+ *     correlation_cuda_kernel.cu:383-392, which its .cc turns into AT_ERROR, :81-83).
+ */
+#ifndef UPFLOW_HIP_H
+#define UPFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { UPF_F32 = 0, UPF_F16 = 1, UPF_BF16 = 2 };
+enum { UPF_OK = 0, UPF_EINVAL = -1, UPF_EDTYPE = -2, UPF_EALIGN = -3, UPF_EUNSUPPORTED = -4 };
+enum { UPF_MASK_NONE = 0, UPF_MASK_LITERAL = 1, UPF_MASK_ROBUST = 2 };
+
+/* library identity: "upflow_hip <version> gfx950" */
+const char* upf_version(void);
+const char* upf_last_error(void);
+
+/* ---- cost volume ------------------------------------------------------------------------------
+ * 81-neighbour correlation, (pad,k,max_disp,s1,s2) = (4,1,4,1,1), the only configuration the model
+ * instantiates (model/upflow.py:561-562):
+ *     out[n, 9*(dy+4)+(dx+4), y, x] = (1/C) * sum_c f1[n,c,y,x] * f2[n,c,y+dy,x+dx]   (f2 = 0 outside)
+ * Replaces correlation_cuda.forward (correlation_cuda.cc:10-87 -> correlation_cuda_kernel.cu:302-393:
+ * 2x channels_first + correlation_forward) without the padded-NHWC staging copies.
+ *   f1,f2 : [B,C,H,W] of `dtype`;  out : [B,81,H,W] of `dtype`, batch stride `out_batch_stride`
+ *   elements (0 = 81*H*W) so the volume can be written straight into the first 81 channels of the
+ *   115-channel estimator input (model/upflow.py:565).
+ *   leaky_slope != 0 fuses LeakyReLU(slope) (model/upflow.py:563-564); 0 = plain correlation.
+ * fp32 accumulation for every dtype.
+ */
+int upf_corr81_forward(const void* f1, const void* f2, void* out,
+                       int B, int C, int H, int W, int dtype,
+                       long long out_batch_stride, float leaky_slope, void* stream);
+
+/* Gradients of the above (correlation_cuda.backward, correlation_cuda.cc:89-167 ->
+ * correlation_cuda_kernel.cu:116-300, 396-530):
+ *   g1[n,c,y,x] = (1/C) sum_d gO[n,d,y,x]       * f2[n,c,y+dy,x+dx]
+ *   g2[n,c,y,x] = (1/C) sum_d gO[n,d,y-dy,x-dx] * f1[n,c,y-dy,x-dx]
+ * grad_out : [B,81,H,W] of `dtype` (contiguous);  g1,g2 : [B,C,H,W] of `dtype`. */
+int upf_corr81_backward(const void* f1, const void* f2, const void* grad_out, void* g1, void* g2,
+                        int B, int C, int H, int W, int dtype, void* stream);
+
+/* General-parameter cost volume with the reference's full argument list (correlation_cuda.cc:10-17):
+ * any pad/kernel/max_displacement/stride1/stride2; output [B,(2*(md/s2)+1)^2,outH,outW] with
+ * outH = ceil((H+2*pad-2*((k-1)/2+md))/s1) (correlation_cuda.cc:24-34).  Dispatches to the tuned
+ * 81-neighbour kernel for (4,1,4,1,1), otherwise to a plain one-thread-per-output kernel.
+ * corr_type_multiply is accepted and unused, as in the reference (correlation_cuda_kernel.cu:302+). */
+int upf_correlation_forward(const void* in1, const void* in2, void* out,
+                            int B, int C, int H, int W, int dtype,
+                            int pad_size, int kernel_size, int max_displacement,
+                            int stride1, int stride2, int corr_type_multiply, void* stream);
+/* output geometry of upf_correlation_forward */
+int upf_correlation_out_shape(int H, int W, int pad_size, int kernel_size, int max_displacement,
+                              int stride1, int stride2, int* out_channels, int* out_h, int* out_w);
+
+/* ---- backward warp ----------------------------------------------------------------------------
+ * y[n,c,i,j] = bilinear sample of x[n,c] at (j + flow[n,0,i,j], i + flow[n,1,i,j]), zeros outside,
+ * torch-1.1 grid_sample semantics (align_corners=True), times a validity mask:
+ *   UPF_MASK_NONE    tools.torch_warp                  utils/tools.py:1274-1319
+ *   UPF_MASK_LITERAL WarpingLayer_no_div.forward       model/pwc_modules.py:184-207
+ *                    mask = grid_sample(ones) >= 1.0, reproduced bit-exactly: the four weight*tap
+ *                    products in fp32, summed ((nw+ne)+sw)+se, no FMA contraction
+ *   UPF_MASK_ROBUST  exact in-bounds predicate (non-default; SURVEY.md §7-H2 protocol P3b)
+ *   x,y : [B,C,H,W] of `dtype`;  flow : [B,2,H,W] fp32. */
+int upf_warp_forward(const void* x, const float* flow, void* y,
+                     int B, int C, int H, int W, int dtype, int mask_mode, void* stream);
+/* grad wrt x (scatter-add, fp32 buffer gx32 [B,C,H,W] that the CALLER has zero-filled) and wrt
+ * flow (gflow [B,2,H,W] fp32, fully written).  grad_y : [B,C,H,W] of `dtype`. */
+int upf_warp_backward(const void* x, const float* flow, const void* grad_y,
+                      float* gx32, float* gflow,
+                      int B, int C, int H, int W, int dtype, int mask_mode, void* stream);
+
+/* ---- flow up-sampling -------------------------------------------------------------------------
+ * upsample2d_flow_as / upsample_flow (model/pwc_modules.py:77-104): bilinear align_corners=True
+ * resize [B,C,h,w] -> [B,C,H,W] fp32; with if_rate channel 0 *= W/w and channel 1 *= H/h. */
+int upf_flow_upsample_forward(const float* x, float* y, int B, int C, int h, int w, int H, int W,
+                              int if_rate, void* stream);
+int upf_flow_upsample_backward(const float* grad_y, float* gx, int B, int C, int h, int w, int H, int W,
+                               int if_rate, void* stream);
+
+/* ---- SGU interpolation-blend  (model/upflow.py:79-88) -----------------------------------------
+ * x_out [B,3,h,w] of `dtype` = (inter_flow_x, inter_flow_y, mask_logit) from the SGU estimator.
+ *   inter_flow = x_out[:, :2]; inter_mask = sigmoid(x_out[:, 2])
+ *   decoder level (Hf = h, Wf = w):      flow_init [B,2,h,w]
+ *   final level   (Hf,Wf = full size):   inter_flow, inter_mask bilinearly up-sampled (align_corners,
+ *                                        flow channels * Wf/w, Hf/h), flow_init = output_level_flow
+ *   flow_up = torch_warp(flow_init, inter_flow) * (1 - inter_mask) + flow_init * inter_mask
+ * flow_init, flow_up : [B,2,Hf,Wf] fp32; inter_flow [B,2,Hf,Wf], inter_mask [B,1,Hf,Wf] fp32 are
+ * optional outputs (NULL = do not materialise).  One launch instead of ~8 ATen launches. */
+int upf_sgu_blend_forward(const float* flow_init, const void* x_out, float* flow_up,
+                          float* inter_flow, float* inter_mask,
+                          int B, int h, int w, int Hf, int Wf, int dtype, void* stream);
+/* g_flow_init32 [B,2,Hf,Wf] fp32 must be zero-filled by the caller (scatter-add);
+ * g_x_out32 [B,3,h,w] fp32 must be zero-filled by the caller when (Hf,Wf) != (h,w). */
+int upf_sgu_blend_backward(const float* flow_init, const void* x_out, const float* grad_flow_up,
+                           float* g_flow_init32, float* g_x_out32,
+                           int B, int h, int w, int Hf, int Wf, int dtype, void* stream);
+
+/* ---- feature normalisation  (network_tools.normalize_features, model/upflow.py:94-137) ---------
+ * inference flags of test.py:22-30: per sample, per channel mean and UNBIASED variance over H*W,
+ * y = (x - mean) / sqrt(var + 1e-16).  x,y : [N,HW] rows (N = B*C) of `dtype`;
+ * mean, rstd : [N] fp32 optional outputs (saved for backward). */
+int upf_normalize_forward(const void* x, void* y, float* mean, float* rstd,
+                          long long N, int HW, int dtype, void* stream);
+int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd, void* gx,
+                           long long N, int HW, int dtype, void* stream);
+
+/* ---- occlusion check  (tools.occ_check_model(obj), utils/tools.py:519-588, 641-677) -------------
+ * flow_f, flow_b : [B,2,H,W] fp32 -> occ_fw, occ_bw : [B,1,H,W] fp32 in {0,1}. */
+int upf_occ_check(const float* flow_f, const float* flow_b, float* occ_fw, float* occ_bw,
+                  int B, int H, int W, float alpha1, float alpha2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPFLOW_HIP_H */

@@ -1,0 +1,55 @@
+"""The C-ABI library builds, loads, and exports every symbol include/upflow_hip.h declares
+(no compute: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'upflow_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(upf_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_header_symbols_exported():
+    import __graft_entry__ as g
+    g.build()
+    from upflow_pytorch_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), 'missing symbol %s' % n
+    bound = set(_lib.SIGNATURES) | {'upf_version', 'upf_last_error'}
+    assert bound == set(names), (bound ^ set(names))
+
+
+def test_version_and_error_strings():
+    from upflow_pytorch_amd import _lib
+    assert 'gfx950' in _lib.version()
+    assert isinstance(_lib.lib().upf_last_error().decode(), str)
+
+
+def test_no_cpu_fallback():
+    """The product has no CPU path: CPU tensors are rejected loudly (never silently computed)."""
+    import pytest
+    import torch
+    from upflow_pytorch_amd import ops
+    a = torch.zeros(1, 4, 8, 8)
+    with pytest.raises(RuntimeError):
+        ops.corr81(a, a)
+    with pytest.raises(RuntimeError):
+        ops.warp(a, torch.zeros(1, 2, 8, 8))
+    with pytest.raises(RuntimeError):
+        ops.normalize(a)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'upflow_pytorch_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(d, f)

@@ -1,0 +1,102 @@
+"""Whole-network parity of the HIP path (SURVEY.md §7-H2 protocols):
+  P2  teacher-forced replay of the recorded reference trace under LITERAL mask semantics;
+  P3b free-running, exact-predicate mask on both sides -> EPE <= 1e-4 vs the reference's output;
+  P3a free-running literal mask, judged against the reference's own self-sensitivity floor;
+  bf16 / fp16 deltas reported (and loosely bounded) separately.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import oracle
+import _weights
+from conftest import load_golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+META = json.load(open(os.path.join(GOLDEN, 'net_meta.json')))
+FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+         'norm_moments_across_images': False, 'if_sgu_upsample': True}
+
+
+def build(mask_mode='literal', dtype=torch.float32):
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    conf = UPFlow_net.config()
+    d = dict(FLAGS)
+    d['warp_mask_mode'] = mask_mode
+    conf.update(d, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
+    return net.cuda().to(dtype).eval()
+
+
+def test_teacher_forced_trace():
+    import _trace
+    from upflow_pytorch_amd import ops
+
+    class P:
+        corr81 = staticmethod(ops.corr81)
+        warp = staticmethod(ops.warp)
+        flow_upsample = staticmethod(ops.flow_upsample)
+        normalize_pair = staticmethod(ops.normalize_pair)
+        sgu_blend = staticmethod(ops.sgu_blend)
+    r = _trace.replay(P, to_dev=lambda t: t.cuda(), to_cpu=lambda t: t.cpu())
+    print('P2', {k: max(v) for k, v in r['errs'].items()}, 'mask mismatches', r['mask_mismatch'], 'EPE', r['final_epe'])
+    assert r['mask_mismatch'] == 0
+    assert r['final_epe'] <= 1e-4
+    for op, v in r['errs'].items():
+        assert max(v) <= 2e-5, op
+
+
+@pytest.mark.parametrize('name,H,W', [('net_64x128', 64, 128), ('net_256x256', 256, 256)])
+def test_free_running_robust(name, H, W):
+    net = build('robust')
+    im1, im2 = _weights.make_smooth_images(1, 1, H, W)
+    g = load_golden(name + '_robust')
+    with torch.no_grad():
+        out = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    ef = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
+    eb = oracle.epe(out['flow_b_out'].cpu(), g['flow_b_out'])
+    print('P3b %s EPE fwd %.3g bwd %.3g (mean |flow| %.3g)' % (name, ef, eb, float(g['flow_f_out'].abs().mean())))
+    assert ef <= 1e-4 and eb <= 1e-4
+    assert (out['occ_fw'].cpu() != g['occ_fw'].float()).float().mean() <= 2e-3
+
+
+def test_free_running_literal_vs_noise_floor():
+    net = build('literal')
+    im1, im2 = _weights.make_smooth_images(1, 1, 64, 128)
+    g = load_golden('net_64x128_literal')
+    with torch.no_grad():
+        out = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    e = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
+    floor = META['net_64x128_literal_self_sensitivity_epe']
+    print('P3a literal free-running EPE %.3g; reference self-sensitivity under 1e-7 input noise %.3g' % (e, floor))
+    assert e <= 3 * floor
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_reduced_precision_delta(dtype):
+    """bf16/fp16 is new behaviour (the reference has no half path, §7-H3): report the EPE delta vs the
+    fp32 reference output under the robust mask (so chaos is excluded)."""
+    net = build('robust', dtype)
+    im1, im2 = _weights.make_smooth_images(1, 1, 256, 256)
+    g = load_golden('net_256x256_robust')
+    with torch.no_grad():
+        out = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    assert out['flow_f_out'].dtype == torch.float32
+    e = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
+    mag = float(g['flow_f_out'].pow(2).sum(1).sqrt().mean())
+    print('%s EPE vs fp32 reference %.3g px (mean |flow| %.3g px)' % (dtype, e, mag))
+    assert e <= (0.25 if dtype == torch.bfloat16 else 0.05) * max(mag, 1.0)
+
+
+def test_batch_independence_and_determinism():
+    net = build('literal')
+    im1, im2 = _weights.make_images(2, 3, 64, 128)
+    with torch.no_grad():
+        a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})['flow_f_out']
+        b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})['flow_f_out']
+        c = net({'im1': im1[1:2].cuda(), 'im2': im2[1:2].cuda(), 'if_loss': False})['flow_f_out']
+    assert torch.equal(a, b), 'run-to-run must be bit-identical'
+    assert oracle.epe(a[1:2].cpu(), c.cpu()) <= 1e-3

@@ -1,0 +1,249 @@
+"""P1 — operator-level parity of the HIP kernels (through the C-ABI) against
+  (a) the golden vectors generated from the imported reference (tests/golden/*.npz), and
+  (b) the CPU oracle on seeded random inputs, incl. ragged / tiny / maximum-displacement shapes.
+Tolerances: warp mask bits identical; fp32 values <= 1e-6 relative (a few ulp of fp32); bf16/fp16
+I/O compared against the oracle evaluated on the SAME rounded inputs, within output rounding.
+"""
+import glob
+import os
+
+import pytest
+import torch
+
+import oracle
+from oracle import ops as oops
+from conftest import load_golden, unpack_mask, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    from upflow_pytorch_amd import ops
+    return ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+# ---------------------------------------------------------------------------------- correlation
+@pytest.mark.parametrize('i', [0, 1, 2, 3])
+def test_corr_golden(hip, i):
+    g = load_golden('corr_%d' % i)
+    out = hip.corr81(dev(g['f1']), dev(g['f2'])).cpu()
+    assert (out - g['out']).abs().max() <= 2e-6
+    g1, g2 = hip.corr81_backward_raw(dev(g['f1']), dev(g['f2']), dev(g['grad_out']))
+    assert (g1.cpu() - g['g1']).abs().max() <= 2e-6
+    assert (g2.cpu() - g['g2']).abs().max() <= 2e-6
+
+
+CORR_SHAPES = [(1, 1, 1, 1), (1, 3, 2, 5), (2, 32, 8, 32), (1, 32, 9, 33), (1, 33, 17, 44), (2, 64, 48, 160),
+               (1, 196, 6, 20), (1, 128, 12, 40), (1, 96, 24, 80), (4, 32, 96, 320), (1, 16, 7, 13), (1, 5, 40, 36)]
+
+
+@pytest.mark.parametrize('shape', CORR_SHAPES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_corr_vs_oracle(hip, shape, dtype):
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    f1 = torch.randn(shape, generator=g).to(dtype)
+    f2 = torch.randn(shape, generator=g).to(dtype)
+    want = oracle.corr81(f1.float(), f2.float())
+    got = hip.corr81(dev(f1), dev(f2)).cpu()
+    assert got.dtype == dtype and got.shape == (B, 81, H, W)
+    if dtype == torch.float32:
+        assert (got - want).abs().max() <= 2e-6
+    else:
+        # exact products, fp32 accumulation: only the output rounding differs
+        eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        assert (got.float() - want).abs().max() <= eps * max(1.0, float(want.abs().max())) + 1e-6
+    # fused LeakyReLU(0.1)
+    got_l = hip.corr81(dev(f1), dev(f2), 0.1).cpu().float()
+    want_l = torch.nn.functional.leaky_relu(want, 0.1)
+    tol = 2e-6 if dtype == torch.float32 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * max(1.0, float(want.abs().max())) + 1e-6
+    assert (got_l - want_l).abs().max() <= tol
+
+
+def test_corr_into_wider_buffer(hip):
+    """out_batch_stride: write straight into the first 81 of 115 channels (model/upflow.py:565)."""
+    g = torch.Generator().manual_seed(3)
+    f1 = torch.randn(2, 32, 24, 40, generator=g)
+    f2 = torch.randn(2, 32, 24, 40, generator=g)
+    buf = torch.full((2, 115, 24, 40), 7.0).cuda()
+    hip.corr81_forward_raw(dev(f1), dev(f2), out=buf[:, :81])
+    assert (buf[:, :81].cpu() - oracle.corr81(f1, f2)).abs().max() <= 2e-6
+    assert bool((buf[:, 81:] == 7.0).all())
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 2, 5), (2, 32, 24, 40), (1, 33, 17, 44), (1, 196, 6, 20), (2, 32, 64, 208)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_corr_backward_vs_oracle(hip, shape, dtype):
+    g = torch.Generator().manual_seed(11 + sum(shape))
+    f1 = torch.randn(shape, generator=g).to(dtype)
+    f2 = torch.randn(shape, generator=g).to(dtype)
+    go = torch.randn(shape[0], 81, shape[2], shape[3], generator=g).to(dtype)
+    w1, w2 = oracle.corr81_backward(f1.float(), f2.float(), go.float())
+    a = dev(f1).requires_grad_(True)
+    b = dev(f2).requires_grad_(True)
+    out = hip.corr81(a, b)
+    g1, g2 = torch.autograd.grad(out, (a, b), dev(go))
+    tol = 5e-6 if dtype == torch.float32 else 2.0 ** -8 * max(1.0, float(w1.abs().max()))
+    assert (g1.cpu().float() - w1).abs().max() <= tol
+    assert (g2.cpu().float() - w2).abs().max() <= tol
+
+
+def test_corr_general_parameters(hip):
+    """upf_correlation_forward with the reference's full parameter list; pinned only through the
+    oracle's restatement of correlation_cuda_kernel.cu:41-114 for sets the model never uses."""
+    g = torch.Generator().manual_seed(21)
+    f1 = torch.randn(2, 6, 20, 28, generator=g)
+    f2 = torch.randn(2, 6, 20, 28, generator=g)
+    for (pad, k, md, s1, s2) in [(4, 1, 4, 1, 1), (3, 3, 2, 1, 1), (4, 1, 4, 2, 2), (20, 1, 20, 1, 2), (2, 3, 2, 2, 1)]:
+        want = oops.correlation_general(f1, f2, pad, k, md, s1, s2)
+        got = hip.correlation_forward_general(dev(f1), dev(f2), pad, k, md, s1, s2).cpu()
+        assert got.shape == want.shape, (pad, k, md, s1, s2)
+        assert (got - want).abs().max() <= 5e-6, (pad, k, md, s1, s2)
+
+
+# ------------------------------------------------------------------------------------------ warp
+WARP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'warp_*.npz')))
+
+
+@pytest.mark.parametrize('name', WARP_CASES)
+def test_warp_golden(hip, name):
+    g = load_golden(name)
+    x, flow = g['x'], g['flow']
+    B, C, H, W = x.shape
+    xd = dev(x).requires_grad_(True)
+    fd = dev(flow).requires_grad_(True)
+    y = hip.warp(xd, fd, 'literal')
+    # mask bits: warp a ones tensor, exactly how the fixture extracted them from the reference
+    mask = hip.warp(torch.ones(B, 1, H, W).cuda(), dev(flow), 'literal').cpu() > 0
+    ref_mask = unpack_mask(g['mask'], (B, 1, H, W))
+    assert torch.equal(mask, ref_mask), 'mask bits differ at %d pixels' % int((mask != ref_mask).sum())
+    assert relerr(y.detach().cpu(), g['y']) <= 1e-6
+    gx, gf = torch.autograd.grad(y, (xd, fd), dev(g['grad_out']))
+    assert (gx.cpu() - g['gx']).abs().max() <= 1e-5
+    assert relerr(gf.cpu(), g['gflow']) <= 1e-4
+    x2 = dev(x).requires_grad_(True)
+    f2 = dev(flow).requires_grad_(True)
+    y2 = hip.warp(x2, f2, None)
+    assert relerr(y2.detach().cpu(), g['y_nomask']) <= 1e-6
+    gx2, gf2 = torch.autograd.grad(y2, (x2, f2), dev(g['grad_out']))
+    assert (gx2.cpu() - g['gx_nomask']).abs().max() <= 1e-5
+    assert relerr(gf2.cpu(), g['gflow_nomask']) <= 1e-4
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1, 1), (2, 3, 5, 7), (1, 32, 96, 320), (2, 128, 12, 40), (1, 7, 33, 65)])
+@pytest.mark.parametrize('mode', ['literal', 'robust', None])
+def test_warp_vs_oracle(hip, shape, mode):
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(31 + sum(shape))
+    x = torch.randn(shape, generator=g)
+    flow = torch.randn(B, 2, H, W, generator=g) * 4
+    want = oracle.warp(x, flow, mode)
+    got = hip.warp(dev(x), dev(flow), mode).cpu()
+    assert torch.equal(got == 0, want == 0) or mode is None, 'mask pattern differs'
+    assert relerr(got, want) <= 1e-6
+    for dt in (torch.bfloat16, torch.float16):
+        xq = x.to(dt)
+        want_q = oracle.warp(xq.float(), flow, mode)
+        got_q = hip.warp(dev(xq), dev(flow), mode).cpu().float()
+        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        assert (got_q - want_q).abs().max() <= eps * max(1.0, float(want_q.abs().max()))
+
+
+def test_warp_nan_inf_flow_is_safe(hip):
+    x = torch.ones(1, 2, 8, 8).cuda()
+    flow = torch.zeros(1, 2, 8, 8)
+    flow[0, 0, 0, 0] = float('nan')
+    flow[0, 1, 1, 1] = float('inf')
+    flow[0, 0, 2, 2] = -1e30
+    y = hip.warp(x, flow.cuda(), 'literal').cpu()
+    assert y[0, :, 0, 0].abs().sum() == 0 and y[0, :, 1, 1].abs().sum() == 0 and y[0, :, 2, 2].abs().sum() == 0
+    assert bool((y[0, :, 4:, 4:] == 1).all())
+
+
+# ---------------------------------------------------------------------------------- flow upsample
+@pytest.mark.parametrize('i', range(6))
+def test_flow_upsample_golden(hip, i):
+    g = load_golden('upsample_%d' % i)
+    h, w = [int(v) for v in g['size']]
+    xd = dev(g['x']).requires_grad_(True)
+    y = hip.flow_upsample(xd, h, w, True)
+    assert relerr(y.detach().cpu(), g['y']) <= 2e-6
+    assert relerr(hip.flow_upsample(dev(g['x']), h, w, False).cpu(), g['y_norate']) <= 2e-6
+    gx, = torch.autograd.grad(y, xd, dev(g['grad_out']))
+    assert relerr(gx.cpu(), g['gx']) <= 1e-5
+
+
+# -------------------------------------------------------------------------------------- SGU blend
+@pytest.mark.parametrize('i', range(4))
+def test_sgu_blend_golden(hip, i):
+    g = load_golden('sgu_blend_%d' % i)
+    olf = g.get('output_level_flow')
+    xo = dev(g['x_out']).requires_grad_(True)
+    fi = dev(g['flow_init']).requires_grad_(True)
+    od = dev(olf).requires_grad_(True) if olf is not None else None
+    _, up, inter_flow, inter_mask = hip.sgu_blend(fi, xo, od)
+    tol = 2e-6 * max(1.0, float(g['flow_up'].abs().max()))
+    assert (up.detach().cpu() - g['flow_up']).abs().max() <= (tol if olf is None else 5e-5)
+    assert (inter_flow.cpu() - g['inter_flow']).abs().max() <= tol
+    assert (inter_mask.cpu() - g['inter_mask']).abs().max() <= 1e-6
+    if olf is None:
+        gxo, gfi = torch.autograd.grad(up, (xo, fi), dev(g['grad_out']))
+        assert relerr(gfi.cpu(), g['g_flow_init']) <= 1e-4
+    else:
+        gxo, go = torch.autograd.grad(up, (xo, od), dev(g['grad_out']))
+        assert relerr(go.cpu(), g['g_output_level_flow']) <= 1e-4
+    assert relerr(gxo.cpu(), g['g_x_out']) <= 1e-4
+
+
+# -------------------------------------------------------------------------------------- normalize
+@pytest.mark.parametrize('i', range(3))
+def test_normalize_golden(hip, i):
+    g = load_golden('normalize_%d' % i)
+    a = dev(g['a']).requires_grad_(True)
+    b = dev(g['b']).requires_grad_(True)
+    na, nb = hip.normalize_pair(a, b)
+    assert relerr(na.detach().cpu(), g['na']) <= 2e-6
+    assert relerr(nb.detach().cpu(), g['nb']) <= 2e-6
+    ga, gb = torch.autograd.grad([na, nb], [a, b], [dev(g['goa']), dev(g['gob'])])
+    assert relerr(ga.cpu(), g['ga']) <= 1e-4
+    assert relerr(gb.cpu(), g['gb']) <= 1e-4
+
+
+def test_normalize_bf16(hip):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(2, 32, 96, 320, generator=g) * 3 + 1).to(torch.bfloat16)
+    want = oracle.normalize_pair(x.float(), x.float())[0]
+    got = hip.normalize(dev(x)).cpu().float()
+    assert (got - want).abs().max() <= 2.0 ** -7 * float(want.abs().max())
+
+
+# -------------------------------------------------------------------------------------- occlusion
+@pytest.mark.parametrize('i', range(2))
+def test_occ_golden(hip, i):
+    g = load_golden('occ_%d' % i)
+    o1, o2 = hip.occ_check(dev(g['flow_f']), dev(g['flow_b']))
+    assert (o1.cpu() != g['occ_fw']).float().mean() <= 1e-4
+    assert (o2.cpu() != g['occ_bw']).float().mean() <= 1e-4
+
+
+# ---------------------------------------------------------------------------------- error behaviour
+def test_errors_are_loud(hip):
+    a = torch.zeros(1, 4, 8, 8).cuda()
+    with pytest.raises(RuntimeError):
+        hip.corr81(a, torch.zeros(1, 4, 8, 9).cuda())
+    with pytest.raises(RuntimeError):
+        hip.corr81(a, a.double())
+    with pytest.raises(RuntimeError):
+        hip.warp(a, torch.zeros(1, 2, 8, 9).cuda())
+    with pytest.raises(RuntimeError):
+        hip.correlation_forward_general(a, a, 0, 1, 4, 1, 1)      # empty output (H+0-8 <= 0)

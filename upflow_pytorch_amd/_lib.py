@@ -1,0 +1,107 @@
+"""ctypes binding of libupflow_hip.so (include/upflow_hip.h) — the only way this package computes.
+
+There is deliberately NO CPU fallback: if the library is missing or a call is made on a non-GPU
+tensor the call raises.  (The CPU restatement of the reference lives in oracle/ and is test
+infrastructure only.)
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libupflow_hip.so')
+
+UPF_F32, UPF_F16, UPF_BF16 = 0, 1, 2
+MASK_NONE, MASK_LITERAL, MASK_ROBUST = 0, 1, 2
+_DTYPES = {torch.float32: UPF_F32, torch.float16: UPF_F16, torch.bfloat16: UPF_BF16}
+
+_c = ctypes
+_vp, _i, _f, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_longlong
+
+# symbol -> argtypes; every function declared in include/upflow_hip.h (tests check the two lists agree)
+SIGNATURES = {
+    'upf_corr81_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp],
+    'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_correlation_out_shape': [_i, _i, _i, _i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],
+    'upf_warp_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_flow_upsample_forward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_flow_upsample_backward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_sgu_blend_forward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_sgu_blend_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_normalize_forward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    'upf_occ_check': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
+}
+
+_lib = None
+
+
+class UpflowHipError(RuntimeError):
+    """Raised for a rejected argument or a failed launch (the reference raises RuntimeError through
+    AT_ERROR("CUDA call failed"), correlation_cuda.cc:81-83)."""
+
+
+def lib():
+    """Load libupflow_hip.so once; fail loudly if it was not built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UpflowHipError(
+                '%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = _i
+        L.upf_version.restype = _c.c_char_p
+        L.upf_last_error.restype = _c.c_char_p
+        _lib = L
+    return _lib
+
+
+def version():
+    return lib().upf_version().decode()
+
+
+def dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise UpflowHipError('unsupported dtype %s (float32 / float16 / bfloat16 only)' % t.dtype)
+
+
+def check_gpu(*tensors):
+    """Every operand must be a contiguous tensor on the same GPU (the reference's kernels assume
+    contiguous NCHW, correlation_cuda_kernel.cu:15-39, and never validate; we do)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise UpflowHipError('upflow_pytorch_amd operators run on the GPU only (got a %s tensor); '
+                                 'there is no CPU fallback' % t.device)
+        if not t.is_contiguous():
+            raise UpflowHipError('operand must be contiguous NCHW')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise UpflowHipError('operands on different devices: %s vs %s' % (dev, t.device))
+    return dev
+
+
+def stream_ptr(device):
+    return _vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise UpflowHipError('%s failed (%d): %s' % (name, rc, lib().upf_last_error().decode()))

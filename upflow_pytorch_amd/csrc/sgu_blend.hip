@@ -1,0 +1,236 @@
+// Self-guided-upsample interpolation-blend and flow up-sampling — gfx950.
+//
+// sgu_blend replaces the tail of sgu_model.forward (/root/reference/model/upflow.py:79-88): slice,
+// sigmoid, (at the final level) two bilinear up-samplings with flow rescale, a torch_warp of the
+// 2-channel flow and the blend — ~8 ATen launches and as many intermediate tensors — with ONE launch
+// that reads flow_init and x_out once and writes flow_up once:
+//   bytes (decoder level) = B*H*W*(8 + 3*s + 8)      bytes (final level) = B*Hf*Wf*16 + B*h*w*3*s
+// flow_upsample replaces upsample2d_flow_as / upsample_flow (model/pwc_modules.py:77-104).
+// Compiled with -ffp-contract=off.
+#include "sampling.hpp"
+
+namespace upf {
+namespace sgu {
+
+constexpr int THREADS = 256;
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// inter_flow (2) and inter_mask (1) at output pixel (i, j): direct read at a decoder level,
+// align_corners bilinear up-sampling of x_out[:, :2] * ratio and of sigmoid(x_out[:, 2]) at the final
+// level (upflow.py:82 applies the sigmoid BEFORE the up-sampling of :86).
+template <typename T>
+__device__ __forceinline__ void inter_at(const T* __restrict__ xo, int h, int w, int Hf, int Wf, int i, int j,
+                                         float& ifx, float& ify, float& m, Lerp& ly, Lerp& lx) {
+  const int hw = h * w;
+  if (Hf == h && Wf == w) {
+    const int q = i * w + j;
+    ifx = Elem<T>::load(xo + q);
+    ify = Elem<T>::load(xo + hw + q);
+    m = sigmoidf(Elem<T>::load(xo + 2 * hw + q));
+    return;
+  }
+  ly = make_lerp(i, h, Hf);
+  lx = make_lerp(j, w, Wf);
+  const int q00 = ly.i0 * w + lx.i0, q01 = ly.i0 * w + lx.i1, q10 = ly.i1 * w + lx.i0, q11 = ly.i1 * w + lx.i1;
+  auto lerp4 = [&](float a, float b, float c, float d) {
+    return ly.l0 * (lx.l0 * a + lx.l1 * b) + ly.l1 * (lx.l0 * c + lx.l1 * d);
+  };
+  const float su = (float)((double)Wf / (double)w), sv = (float)((double)Hf / (double)h);
+  ifx = lerp4(Elem<T>::load(xo + q00), Elem<T>::load(xo + q01), Elem<T>::load(xo + q10), Elem<T>::load(xo + q11)) * su;
+  ify = lerp4(Elem<T>::load(xo + hw + q00), Elem<T>::load(xo + hw + q01), Elem<T>::load(xo + hw + q10), Elem<T>::load(xo + hw + q11)) * sv;
+  m = lerp4(sigmoidf(Elem<T>::load(xo + 2 * hw + q00)), sigmoidf(Elem<T>::load(xo + 2 * hw + q01)),
+            sigmoidf(Elem<T>::load(xo + 2 * hw + q10)), sigmoidf(Elem<T>::load(xo + 2 * hw + q11)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(THREADS)
+void blend_fwd_kernel(const float* __restrict__ flow_init, const T* __restrict__ x_out, float* __restrict__ flow_up,
+                      float* __restrict__ inter_flow, float* __restrict__ inter_mask, int h, int w, int Hf, int Wf) {
+  const int HW = Hf * Wf;
+  const int p = blockIdx.x * THREADS + threadIdx.x;
+  if (p >= HW) return;
+  const int n = blockIdx.y;
+  const int i = p / Wf, j = p - i * Wf;
+  float ifx, ify, m;
+  Lerp ly, lx;
+  inter_at<T>(x_out + (size_t)n * 3 * h * w, h, w, Hf, Wf, i, j, ifx, ify, m, ly, lx);
+  const float* f0 = flow_init + (size_t)n * 2 * HW;
+  const Taps t = make_taps(j, i, ifx, ify, Hf, Wf);
+  const int xa = min(max(t.x0, 0), Wf - 1), xb = min(max(t.x0 + 1, 0), Wf - 1);
+  const int ya = min(max(t.y0, 0), Hf - 1), yb = min(max(t.y0 + 1, 0), Hf - 1);
+  const int o0 = ya * Wf + xa, o1 = ya * Wf + xb, o2 = yb * Wf + xa, o3 = yb * Wf + xb;
+  const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f;
+  const float w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
+  const float om = 1.0f - m;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float* f = f0 + c * HW;
+    const float warped = ((f[o0] * w0 + f[o1] * w1) + f[o2] * w2) + f[o3] * w3;
+    flow_up[((size_t)n * 2 + c) * HW + p] = warped * om + f[p] * m;     // upflow.py:88
+  }
+  if (inter_flow) {
+    inter_flow[((size_t)n * 2 + 0) * HW + p] = ifx;
+    inter_flow[((size_t)n * 2 + 1) * HW + p] = ify;
+  }
+  if (inter_mask) inter_mask[(size_t)n * HW + p] = m;
+}
+
+// Backward of the blend.  g = grad of flow_up (2 channels).
+//   d/d flow_init : m*g at p, plus (1-m)*g*w_tap scattered to the 4 taps        (atomics)
+//   d/d inter_flow: (1-m) * sum_c g_c * d(warp_c)/d(pos)
+//   d/d m         : sum_c g_c * (flow_init_c(p) - warped_c);  d/d logit through sigmoid' (and through
+//                   the bilinear up-sampling weights at the final level)         (atomics at final level)
+template <typename T>
+__global__ __launch_bounds__(THREADS)
+void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__ x_out, const float* __restrict__ g_up,
+                      float* __restrict__ g_init, float* __restrict__ g_xo, int h, int w, int Hf, int Wf) {
+  const int HW = Hf * Wf, hw = h * w;
+  const int p = blockIdx.x * THREADS + threadIdx.x;
+  if (p >= HW) return;
+  const int n = blockIdx.y;
+  const int i = p / Wf, j = p - i * Wf;
+  float ifx, ify, m;
+  Lerp ly, lx;
+  const T* xo = x_out + (size_t)n * 3 * hw;
+  inter_at<T>(xo, h, w, Hf, Wf, i, j, ifx, ify, m, ly, lx);
+  const float* f0 = flow_init + (size_t)n * 2 * HW;
+  const Taps t = make_taps(j, i, ifx, ify, Hf, Wf);
+  const int xa = min(max(t.x0, 0), Wf - 1), xb = min(max(t.x0 + 1, 0), Wf - 1);
+  const int ya = min(max(t.y0, 0), Hf - 1), yb = min(max(t.y0 + 1, 0), Hf - 1);
+  const int o[4] = {ya * Wf + xa, ya * Wf + xb, yb * Wf + xa, yb * Wf + xb};
+  const float ax = (float)(t.x0 + 1) - t.ix, bx = t.ix - (float)t.x0;
+  const float ay = (float)(t.y0 + 1) - t.iy, by = t.iy - (float)t.y0;
+  const float dwx[4] = {-ay, ay, -by, by}, dwy[4] = {-ax, -bx, ax, bx};
+  const float om = 1.0f - m;
+  float gix = 0.f, giy = 0.f, gm = 0.f;
+  float* gi = g_init + (size_t)n * 2 * HW;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float* f = f0 + c * HW;
+    const float g = g_up[((size_t)n * 2 + c) * HW + p];
+    float warped = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!t.in[k]) continue;
+      const float v = f[o[k]];
+      warped += v * t.w[k];
+      atomicAdd(gi + c * HW + o[k], om * g * t.w[k]);
+      gix += v * dwx[k] * g;
+      giy += v * dwy[k] * g;
+    }
+    atomicAdd(gi + c * HW + p, m * g);
+    gm += g * (f[p] - warped);
+  }
+  const float mx = ((float)(Wf - 1) * 0.5f) * (2.0f / (float)max(Wf - 1, 1));
+  const float my = ((float)(Hf - 1) * 0.5f) * (2.0f / (float)max(Hf - 1, 1));
+  gix *= om * mx;
+  giy *= om * my;
+  float* gx = g_xo + (size_t)n * 3 * hw;
+  if (Hf == h && Wf == w) {
+    gx[p] = gix;
+    gx[hw + p] = giy;
+    gx[2 * hw + p] = gm * m * (1.0f - m);
+    return;
+  }
+  const float su = (float)((double)Wf / (double)w), sv = (float)((double)Hf / (double)h);
+  const int q[4] = {ly.i0 * w + lx.i0, ly.i0 * w + lx.i1, ly.i1 * w + lx.i0, ly.i1 * w + lx.i1};
+  const float bw[4] = {ly.l0 * lx.l0, ly.l0 * lx.l1, ly.l1 * lx.l0, ly.l1 * lx.l1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    atomicAdd(gx + q[k], gix * su * bw[k]);
+    atomicAdd(gx + hw + q[k], giy * sv * bw[k]);
+    const float s = sigmoidf(Elem<T>::load(xo + 2 * hw + q[k]));
+    atomicAdd(gx + 2 * hw + q[k], gm * bw[k] * s * (1.0f - s));
+  }
+}
+
+// ---- flow up-sampling -------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS)
+void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int h, int w, int H, int W, int if_rate) {
+  const int HW = H * W;
+  const int p = blockIdx.x * THREADS + threadIdx.x;
+  if (p >= HW) return;
+  const int nc = blockIdx.y, c = nc % C;
+  const int i = p / W, j = p - i * W;
+  const Lerp ly = make_lerp(i, h, H), lx = make_lerp(j, w, W);
+  const float* s = x + (size_t)nc * h * w;
+  float v = ly.l0 * (lx.l0 * s[ly.i0 * w + lx.i0] + lx.l1 * s[ly.i0 * w + lx.i1]) +
+            ly.l1 * (lx.l0 * s[ly.i1 * w + lx.i0] + lx.l1 * s[ly.i1 * w + lx.i1]);
+  if (if_rate) v *= (c == 0) ? (float)((double)W / (double)w) : (float)((double)H / (double)h);   // pwc_modules.py:84-88
+  y[(size_t)nc * HW + p] = v;
+}
+
+__global__ __launch_bounds__(THREADS)
+void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate) {
+  const int HW = H * W;
+  const int p = blockIdx.x * THREADS + threadIdx.x;
+  if (p >= HW) return;
+  const int nc = blockIdx.y, c = nc % C;
+  const int i = p / W, j = p - i * W;
+  const Lerp ly = make_lerp(i, h, H), lx = make_lerp(j, w, W);
+  float g = gy[(size_t)nc * HW + p];
+  if (if_rate) g *= (c == 0) ? (float)((double)W / (double)w) : (float)((double)H / (double)h);
+  float* d = gx + (size_t)nc * h * w;
+  atomicAdd(d + ly.i0 * w + lx.i0, g * ly.l0 * lx.l0);
+  atomicAdd(d + ly.i0 * w + lx.i1, g * ly.l0 * lx.l1);
+  atomicAdd(d + ly.i1 * w + lx.i0, g * ly.l1 * lx.l0);
+  atomicAdd(d + ly.i1 * w + lx.i1, g * ly.l1 * lx.l1);
+}
+
+}  // namespace sgu
+}  // namespace upf
+
+extern "C" int upf_sgu_blend_forward(const float* flow_init, const void* x_out, float* flow_up, float* inter_flow,
+                                     float* inter_mask, int B, int h, int w, int Hf, int Wf, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(flow_init && x_out && flow_up, UPF_EINVAL, "sgu_blend_forward: null pointer");
+  UPF_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && Hf >= h && Wf >= w, UPF_EINVAL,
+              "sgu_blend_forward: bad shape B=%d x_out %dx%d flow %dx%d", B, h, w, Hf, Wf);
+  dim3 grid(cdiv(Hf * Wf, sgu::THREADS), B);
+  UPF_DISPATCH(dtype, T,
+               hipLaunchKernelGGL((sgu::blend_fwd_kernel<T>), grid, dim3(sgu::THREADS), 0, (hipStream_t)stream,
+                                  flow_init, (const T*)x_out, flow_up, inter_flow, inter_mask, h, w, Hf, Wf));
+  return check_launch("sgu_blend_forward");
+}
+
+extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out, const float* grad_flow_up,
+                                      float* g_flow_init32, float* g_x_out32, int B, int h, int w, int Hf, int Wf,
+                                      int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(flow_init && x_out && grad_flow_up && g_flow_init32 && g_x_out32, UPF_EINVAL, "sgu_blend_backward: null pointer");
+  UPF_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && Hf >= h && Wf >= w, UPF_EINVAL, "sgu_blend_backward: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(g_flow_init32, 0, (size_t)B * 2 * Hf * Wf * sizeof(float), s);
+  if (e == hipSuccess) e = hipMemsetAsync(g_x_out32, 0, (size_t)B * 3 * h * w * sizeof(float), s);
+  UPF_REQUIRE(e == hipSuccess, (int)e, "sgu_blend_backward: memset failed: %s", hipGetErrorString(e));
+  dim3 grid(cdiv(Hf * Wf, sgu::THREADS), B);
+  UPF_DISPATCH(dtype, T,
+               hipLaunchKernelGGL((sgu::blend_bwd_kernel<T>), grid, dim3(sgu::THREADS), 0, s,
+                                  flow_init, (const T*)x_out, grad_flow_up, g_flow_init32, g_x_out32, h, w, Hf, Wf));
+  return check_launch("sgu_blend_backward");
+}
+
+extern "C" int upf_flow_upsample_forward(const float* x, float* y, int B, int C, int h, int w, int H, int W,
+                                         int if_rate, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && y, UPF_EINVAL, "flow_upsample_forward: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && (long long)B * C <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, UPF_EINVAL, "flow_upsample_forward: bad shape");
+  UPF_REQUIRE(!if_rate || C == 2, UPF_EINVAL, "flow_upsample_forward: if_rate needs a 2-channel flow, got C=%d", C);
+  dim3 grid(cdiv(H * W, sgu::THREADS), B * C);
+  hipLaunchKernelGGL(sgu::upsample_fwd_kernel, grid, dim3(sgu::THREADS), 0, (hipStream_t)stream, x, y, C, h, w, H, W, if_rate);
+  return check_launch("flow_upsample_forward");
+}
+
+extern "C" int upf_flow_upsample_backward(const float* grad_y, float* gx, int B, int C, int h, int w, int H, int W,
+                                          int if_rate, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(grad_y && gx, UPF_EINVAL, "flow_upsample_backward: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && (long long)B * C <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, UPF_EINVAL, "flow_upsample_backward: bad shape");
+  UPF_REQUIRE(!if_rate || C == 2, UPF_EINVAL, "flow_upsample_backward: if_rate needs a 2-channel flow, got C=%d", C);
+  hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * C * h * w * sizeof(float), (hipStream_t)stream);
+  UPF_REQUIRE(e == hipSuccess, (int)e, "flow_upsample_backward: memset failed: %s", hipGetErrorString(e));
+  dim3 grid(cdiv(H * W, sgu::THREADS), B * C);
+  hipLaunchKernelGGL(sgu::upsample_bwd_kernel, grid, dim3(sgu::THREADS), 0, (hipStream_t)stream, grad_y, gx, C, h, w, H, W, if_rate);
+  return check_launch("flow_upsample_backward");
+}

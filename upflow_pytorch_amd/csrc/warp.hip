@@ -1,0 +1,147 @@
+// Backward flow warp (bilinear grid_sample + validity mask), forward and backward — gfx950.
+//
+// Replaces WarpingLayer_no_div.forward (/root/reference/model/pwc_modules.py:184-207: meshgrid built
+// on the CPU and copied to the device every call, two grid_sample launches, a materialised ones
+// tensor, a compare and a multiply) and tools.torch_warp (utils/tools.py:1274-1319) with ONE launch:
+// the sampling position, the four weights and the mask bit are computed once per pixel in registers
+// and reused for every channel.
+//
+// HBM-bound: algorithmic bytes = B*H*W*(2*s*C + 8) (x read once through the taps, y written once,
+// flow read as fp32).  A thread owns one pixel and CPT channels; lanes of a wave are consecutive in
+// x, so the y stores are fully coalesced and the four tap loads of neighbouring lanes fall into the
+// same or adjacent cache lines for smooth flows.
+//
+// Compiled with -ffp-contract=off (see sampling.hpp: the mask is bit-sensitive).
+#include "sampling.hpp"
+
+namespace upf {
+namespace warp {
+
+constexpr int THREADS = 256;
+
+template <typename T>
+__global__ __launch_bounds__(THREADS)
+void warp_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, T* __restrict__ y,
+                     int C, int H, int W, int cpt, int mask_mode) {
+  const int HW = H * W;
+  const int p = blockIdx.x * THREADS + threadIdx.x;
+  if (p >= HW) return;
+  const int n = blockIdx.z;
+  const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
+  const int i = p / W, j = p - i * W;
+  const float fx = flow[((size_t)n * 2 + 0) * HW + p];
+  const float fy = flow[((size_t)n * 2 + 1) * HW + p];
+  const Taps t = make_taps(j, i, fx, fy, H, W);
+  const bool valid = taps_valid(t, mask_mode, j, i, fx, fy, H, W);
+
+  const T* xb = x + ((size_t)n * C + c_begin) * HW;
+  T* yb = y + ((size_t)n * C + c_begin) * HW + p;
+  if (!valid) {
+    for (int c = c_begin; c < c_end; ++c, yb += HW) Elem<T>::store(yb, 0.f);
+    return;
+  }
+  // clamped tap offsets; out-of-image taps get weight 0 (zeros padding)
+  const int xa = min(max(t.x0, 0), W - 1), xb1 = min(max(t.x0 + 1, 0), W - 1);
+  const int ya = min(max(t.y0, 0), H - 1), yb1 = min(max(t.y0 + 1, 0), H - 1);
+  const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
+  const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f;
+  const float w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
+#pragma unroll 4
+  for (int c = c_begin; c < c_end; ++c, xb += HW, yb += HW) {
+    const float v0 = Elem<T>::load(xb + o0), v1 = Elem<T>::load(xb + o1);
+    const float v2 = Elem<T>::load(xb + o2), v3 = Elem<T>::load(xb + o3);
+    // same association as ATen: ((nw*w + ne*w) + sw*w) + se*w
+    const float r = ((v0 * w0 + v1 * w1) + v2 * w2) + v3 * w3;
+    Elem<T>::store(yb, r);
+  }
+}
+
+// Backward: one thread per pixel, loops over its channel slice.
+//   gx[tap] += w_tap * gy            (fp32 atomics into gx32)
+//   gflow   += gy * d(sample)/d(pos) (summed over the slice, one atomic per thread per component
+//                                     when the channel range is split over blockIdx.y)
+template <typename T>
+__global__ __launch_bounds__(THREADS)
+void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, const T* __restrict__ gy,
+                     float* __restrict__ gx32, float* __restrict__ gflow,
+                     int C, int H, int W, int cpt, int mask_mode) {
+  const int HW = H * W;
+  const int p = blockIdx.x * THREADS + threadIdx.x;
+  if (p >= HW) return;
+  const int n = blockIdx.z;
+  const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
+  const int i = p / W, j = p - i * W;
+  const float fx = flow[((size_t)n * 2 + 0) * HW + p];
+  const float fy = flow[((size_t)n * 2 + 1) * HW + p];
+  const Taps t = make_taps(j, i, fx, fy, H, W);
+  if (!taps_valid(t, mask_mode, j, i, fx, fy, H, W)) return;   // mask is a constant factor: zero grads
+
+  const int xa = min(max(t.x0, 0), W - 1), xb1 = min(max(t.x0 + 1, 0), W - 1);
+  const int ya = min(max(t.y0, 0), H - 1), yb1 = min(max(t.y0 + 1, 0), H - 1);
+  const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
+  // d w / d ix, d w / d iy  for nw, ne, sw, se
+  const float ax = (float)(t.x0 + 1) - t.ix, bx = t.ix - (float)t.x0;
+  const float ay = (float)(t.y0 + 1) - t.iy, by = t.iy - (float)t.y0;
+  const T* xb = x + ((size_t)n * C + c_begin) * HW;
+  const T* gb = gy + ((size_t)n * C + c_begin) * HW + p;
+  float* gxb = gx32 + ((size_t)n * C + c_begin) * HW;
+  float gix = 0.f, giy = 0.f;
+  for (int c = c_begin; c < c_end; ++c, xb += HW, gb += HW, gxb += HW) {
+    const float g = Elem<T>::load(gb);
+    if (t.in[0]) { const float v = Elem<T>::load(xb + o0); atomicAdd(gxb + o0, t.w[0] * g); gix -= v * ay * g; giy -= v * ax * g; }
+    if (t.in[1]) { const float v = Elem<T>::load(xb + o1); atomicAdd(gxb + o1, t.w[1] * g); gix += v * ay * g; giy -= v * bx * g; }
+    if (t.in[2]) { const float v = Elem<T>::load(xb + o2); atomicAdd(gxb + o2, t.w[2] * g); gix -= v * by * g; giy += v * ax * g; }
+    if (t.in[3]) { const float v = Elem<T>::load(xb + o3); atomicAdd(gxb + o3, t.w[3] * g); gix += v * by * g; giy += v * bx * g; }
+  }
+  // chain rule through un-normalise ((W-1)/2) and the python-side normalise (2/max(W-1,1))
+  const float mx = ((float)(W - 1) * 0.5f) * (2.0f / (float)max(W - 1, 1));
+  const float my = ((float)(H - 1) * 0.5f) * (2.0f / (float)max(H - 1, 1));
+  float* gf = gflow + (size_t)n * 2 * HW + p;
+  if (gridDim.y == 1) { gf[0] = gix * mx; gf[HW] = giy * my; }
+  else { atomicAdd(gf, gix * mx); atomicAdd(gf + HW, giy * my); }
+}
+
+static int pick_cpt(int B, int C, int HW) {
+  // split channels over blockIdx.y until the grid has a few waves per SIMD (256 CUs x 4 SIMDs)
+  const long long pix_blocks = (long long)B * cdiv(HW, THREADS);
+  int split = 1;
+  while (split < C && pix_blocks * split < 2048 && C / (split * 2) >= 4) split *= 2;
+  return cdiv(C, split);
+}
+
+}  // namespace warp
+}  // namespace upf
+
+extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B, int C, int H, int W,
+                                int dtype, int mask_mode, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && flow && y, UPF_EINVAL, "warp_forward: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+  UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_forward: bad mask_mode %d", mask_mode);
+  const int HW = H * W;
+  const int cpt = warp::pick_cpt(B, C, HW);
+  dim3 grid(cdiv(HW, warp::THREADS), cdiv(C, cpt), B);
+  UPF_DISPATCH(dtype, T,
+               hipLaunchKernelGGL((warp::warp_fwd_kernel<T>), grid, dim3(warp::THREADS), 0, (hipStream_t)stream,
+                                  (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode));
+  return check_launch("warp_forward");
+}
+
+extern "C" int upf_warp_backward(const void* x, const float* flow, const void* grad_y, float* gx32, float* gflow,
+                                 int B, int C, int H, int W, int dtype, int mask_mode, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && flow && grad_y && gx32 && gflow, UPF_EINVAL, "warp_backward: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_backward: bad shape");
+  UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_backward: bad mask_mode %d", mask_mode);
+  const int HW = H * W;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(gx32, 0, (size_t)B * C * HW * sizeof(float), s);
+  if (e == hipSuccess) e = hipMemsetAsync(gflow, 0, (size_t)B * 2 * HW * sizeof(float), s);
+  UPF_REQUIRE(e == hipSuccess, (int)e, "warp_backward: memset failed: %s", hipGetErrorString(e));
+  const int cpt = warp::pick_cpt(B, C, HW);
+  dim3 grid(cdiv(HW, warp::THREADS), cdiv(C, cpt), B);
+  UPF_DISPATCH(dtype, T,
+               hipLaunchKernelGGL((warp::warp_bwd_kernel<T>), grid, dim3(warp::THREADS), 0, s,
+                                  (const T*)x, flow, (const T*)grad_y, gx32, gflow, C, H, W, cpt, mask_mode));
+  return check_launch("warp_backward");
+}

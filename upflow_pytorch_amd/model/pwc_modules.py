@@ -1,0 +1,199 @@
+"""Host-side mirror of `/root/reference/model/pwc_modules.py`: the same module/function names,
+constructor arguments and state_dict keys, so `UPFlow_net` checkpoints load unchanged.
+
+What runs where: convolutions stay PyTorch-ROCm (MIOpen) as BASELINE.json's north star asks; the
+backward warp and the flow up-sampling are single HIP launches from libupflow_hip.so.
+"""
+import logging
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as tf
+
+from .. import ops
+from ..utils.tools import tools
+
+
+def conv(in_planes, out_planes, kernel_size=3, stride=1, dilation=1, isReLU=True, if_IN=False, IN_affine=False, if_BN=False):
+    """Conv2d('same'-style padding) [+ LeakyReLU(0.1)] [+ InstanceNorm | BatchNorm], as a Sequential
+    whose conv is element 0 (keys `<name>.0.weight/bias`).  model/pwc_modules.py:10-49."""
+    layers = [nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, dilation=dilation,
+                        padding=((kernel_size - 1) * dilation) // 2, bias=True)]
+    if isReLU:
+        layers.append(nn.LeakyReLU(0.1, inplace=True))
+    if if_IN:
+        layers.append(nn.InstanceNorm2d(out_planes, affine=IN_affine))
+    elif if_BN:
+        layers.append(nn.BatchNorm2d(out_planes, affine=IN_affine))
+    return nn.Sequential(*layers)
+
+
+def initialize_msra(modules):
+    """Kaiming-normal weights, zero biases for every (transposed) convolution. pwc_modules.py:52-69."""
+    logging.info("Initializing MSRA")
+    for layer in modules:
+        if isinstance(layer, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.kaiming_normal_(layer.weight)
+            if layer.bias is not None:
+                nn.init.constant_(layer.bias, 0)
+
+
+def upsample2d_as(inputs, target_as, mode="bilinear"):
+    _, _, h, w = target_as.size()
+    return tf.interpolate(inputs, [h, w], mode=mode, align_corners=True)     # pwc_modules.py:72-74
+
+
+def _resize_flow(inputs, h, w, mode, if_rate):
+    if mode != "bilinear":
+        res = tf.interpolate(inputs, [h, w], mode=mode)
+        if if_rate:
+            _, _, h_, w_ = inputs.size()
+            scale = torch.tensor([w / w_, h / h_], dtype=res.dtype, device=res.device).view(1, 2, 1, 1)
+            res = res * scale
+        return res
+    return ops.flow_upsample(inputs, h, w, if_rate)
+
+
+def upsample2d_flow_as(inputs, target_as, mode="bilinear", if_rate=False):
+    """Bilinear align_corners=True resize to `target_as`'s size; with `if_rate` the u/v channels are
+    multiplied by w/w_ and h/h_ (pwc_modules.py:77-90).  Out of place (the reference mutates chunk
+    views, which torch-2 autograd rejects: SURVEY.md §7-H6) and fused into one HIP launch."""
+    _, _, h, w = target_as.size()
+    return _resize_flow(inputs, h, w, mode, if_rate)
+
+
+def upsample_flow(inputs, target_size=None, target_flow=None, mode="bilinear"):
+    """pwc_modules.py:93-104: always rescales the flow values."""
+    if target_size is not None:
+        h, w = target_size
+    elif target_flow is not None:
+        _, _, h, w = target_flow.size()
+    else:
+        raise ValueError('wrong input')
+    return _resize_flow(inputs, h, w, mode, True)
+
+
+def rescale_flow(flow, div_flow, width_im, height_im, to_local=True):
+    """pwc_modules.py:107-119."""
+    if to_local:
+        u_scale = float(flow.size(3) / width_im / div_flow)
+        v_scale = float(flow.size(2) / height_im / div_flow)
+    else:
+        u_scale = float(width_im * div_flow / flow.size(3))
+        v_scale = float(height_im * div_flow / flow.size(2))
+    scale = torch.tensor([u_scale, v_scale], dtype=flow.dtype, device=flow.device).view(1, 2, 1, 1)
+    return flow * scale
+
+
+class FeatureExtractor(nn.Module):
+    """Six [stride-2 conv, conv] stages; returns the pyramid coarsest first. pwc_modules.py:122-142."""
+
+    def __init__(self, num_chs, if_end_relu=True, if_end_norm=False):
+        super(FeatureExtractor, self).__init__()
+        self.num_chs = num_chs
+        self.convs = nn.ModuleList(
+            nn.Sequential(conv(ci, co, stride=2), conv(co, co, isReLU=if_end_relu, if_IN=if_end_norm))
+            for ci, co in zip(num_chs[:-1], num_chs[1:]))
+
+    def forward(self, x):
+        pyramid = []
+        for stage in self.convs:
+            x = stage(x)
+            pyramid.append(x)
+        return pyramid[::-1]
+
+
+class WarpingLayer_no_div(nn.Module):
+    """Backward warp by a pixel-unit flow with the `grid_sample(ones) >= 1.0` validity mask
+    (pwc_modules.py:179-207) — one fused HIP launch (csrc/warp.hip).
+
+    `mask_mode`: 'literal' (default) reproduces the reference's mask bits exactly; 'robust' is the
+    exact in-bounds predicate, an explicit non-default switch used for well-posed whole-network
+    parity (protocol P3b)."""
+
+    def __init__(self, mask_mode='literal'):
+        super(WarpingLayer_no_div, self).__init__()
+        self.mask_mode = mask_mode
+
+    def forward(self, x, flow):
+        return ops.warp(x, flow, self.mask_mode)
+
+
+class WarpingLayer(nn.Module):
+    """The div_flow variant of pwc_modules.py:156-176: flow is divided by `div_flow` and normalised
+    by the IMAGE size; expressed through the same kernel by rescaling the flow to feature pixels."""
+
+    def __init__(self, mask_mode='literal'):
+        super(WarpingLayer, self).__init__()
+        self.mask_mode = mask_mode
+
+    def forward(self, x, flow, height_im, width_im, div_flow):
+        H, W = x.shape[2:]
+        sx = (W - 1) / max(width_im - 1, 1) / div_flow
+        sy = (H - 1) / max(height_im - 1, 1) / div_flow
+        scale = torch.tensor([sx, sy], dtype=torch.float32, device=flow.device).view(1, 2, 1, 1)
+        return ops.warp(x, flow.float() * scale, self.mask_mode)
+
+
+class _DenseStack(tools.abstract_model):
+    """conv1..conv5 each see everything before them; new features are concatenated in front
+    (pwc_modules.py:279-286 / model/upflow.py:53-60)."""
+
+    def _build(self, ch_in, f_channels, out_channel):
+        n = ch_in
+        for i, f in enumerate(f_channels):
+            setattr(self, 'conv%d' % (i + 1), conv(n, f))
+            n += f
+        self.conv_last = conv(n, out_channel, isReLU=False)
+        return n
+
+    def forward(self, x):
+        for name in ('conv1', 'conv2', 'conv3', 'conv4', 'conv5'):
+            x = torch.cat([getattr(self, name)(x), x], dim=1)
+        return x, self.conv_last(x)
+
+
+class FlowEstimatorDense_v2(_DenseStack):
+    def __init__(self, ch_in, f_channels=(128, 128, 96, 64, 32), out_channel=2):
+        super(FlowEstimatorDense_v2, self).__init__()
+        self.n_channels = self._build(ch_in, f_channels, out_channel)
+
+
+class FlowEstimatorDense(FlowEstimatorDense_v2):
+    """pwc_modules.py:229-247 = the v2 stack with its default widths."""
+
+    def __init__(self, ch_in):
+        super(FlowEstimatorDense, self).__init__(ch_in)
+
+
+class OpticalFlowEstimator(nn.Module):
+    """Plain (non-dense) estimator, pwc_modules.py:210-226."""
+
+    def __init__(self, ch_in):
+        super(OpticalFlowEstimator, self).__init__()
+        self.convs = nn.Sequential(conv(ch_in, 128), conv(128, 128), conv(128, 96), conv(96, 64), conv(64, 32))
+        self.conv_last = conv(32, 2, isReLU=False)
+
+    def forward(self, x):
+        x_intm = self.convs(x)
+        return x_intm, self.conv_last(x_intm)
+
+
+class ContextNetwork_v2_(nn.Module):
+    """Seven 3x3 convs with dilations 1,2,4,8,16,1,1; last one linear. pwc_modules.py:396-412."""
+
+    def __init__(self, ch_in, f_channels=(128, 128, 128, 96, 64, 32, 2)):
+        super(ContextNetwork_v2_, self).__init__()
+        dil = (1, 2, 4, 8, 16, 1, 1)
+        chans = (ch_in,) + tuple(f_channels)
+        self.convs = nn.Sequential(*[conv(chans[i], chans[i + 1], 3, 1, dil[i], isReLU=(i < 6)) for i in range(7)])
+
+    def forward(self, x):
+        return self.convs(x)
+
+
+class ContextNetwork(ContextNetwork_v2_):
+    """pwc_modules.py:377-393."""
+
+    def __init__(self, ch_in):
+        super(ContextNetwork, self).__init__(ch_in)

@@ -1,0 +1,395 @@
+"""UPFlow_net — drop-in shell of `/root/reference/model/upflow.py` on the MI355X-native operators.
+
+Same class names (`UPFlow_net`, `UPFlow_net.config`, `network_tools.sgu_model`), the same config
+flags, the same `net(input_dict) -> output_dict` contract (model/upflow.py:370-392) and the same 80
+state_dict keys, so `net.load_model('upflow_kitti2015.pth', if_relax=True)` works as in test.py:33.
+
+What is native here (one hand-written HIP launch each, csrc/*.hip):
+    cost volume (+LeakyReLU, written straight into the estimator's 115-channel input buffer),
+    backward warp (+validity mask), flow up-sampling (+rescale), SGU interpolation-blend,
+    feature normalisation, occlusion check.
+Convolutions stay PyTorch-ROCm.  Precision: with bf16/fp16 weights (net.bfloat16()) features and
+conv activations are 16-bit, while flows, sampling positions, masks, normalisation statistics and
+all accumulators stay fp32; fp32 weights give the parity mode.
+
+Extra (non-reference) config flags, all defaulting to the reference's behaviour:
+    warp_mask_mode = 'literal' | 'robust'   validity-mask semantics of the feature warps (§7-H2)
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.tools import tools
+from ..utils.loss import loss_functions
+from .pwc_modules import (conv, initialize_msra, upsample2d_flow_as, upsample_flow, FlowEstimatorDense_v2,
+                          ContextNetwork_v2_, WarpingLayer_no_div, FeatureExtractor, _DenseStack)
+from .correlation_package.correlation import Correlation
+
+
+class network_tools():
+    class sgu_model(tools.abstract_model):
+        """Self-guided upsample module (model/upflow.py:20-92)."""
+
+        def __init__(self, mask_mode='literal'):
+            super(network_tools.sgu_model, self).__init__()
+
+            class FlowEstimatorDense_temp(_DenseStack):
+                def __init__(self, ch_in, f_channels=(128, 128, 96, 64, 32), ch_out=2):
+                    super(FlowEstimatorDense_temp, self).__init__()
+                    self.num_feature_channel = self._build(ch_in, f_channels, ch_out)
+
+            self.warping_layer = WarpingLayer_no_div(mask_mode)
+            self.dense_estimator_mask = FlowEstimatorDense_temp(64, f_channels=(32, 32, 32, 16, 8), ch_out=3)
+            self.upsample_output_conv = nn.Sequential(conv(3, 16, kernel_size=3, stride=1, dilation=1),
+                                                      conv(16, 16, stride=2),
+                                                      conv(16, 32, kernel_size=3, stride=1, dilation=1),
+                                                      conv(32, 32, stride=2), )
+
+        def forward(self, flow_init, feature_1, feature_2, output_level_flow=None):
+            """-> (flow_init, flow_up, inter_flow, inter_mask), model/upflow.py:71-89."""
+            if flow_init.shape[2:] != feature_1.shape[2:]:
+                flow_init = upsample2d_flow_as(flow_init, feature_1, mode="bilinear", if_rate=True)
+            feature_2_warp = self.warping_layer(feature_2, flow_init)
+            _, x_out = self.dense_estimator_mask(torch.cat((feature_1, feature_2_warp), dim=1))
+            # slice + sigmoid + (up-sampling) + torch_warp + blend: ONE launch (csrc/sgu_blend.hip)
+            return ops.sgu_blend(flow_init, x_out, output_level_flow)
+
+        def output_conv(self, x):
+            return self.upsample_output_conv(x)
+
+    @classmethod
+    def normalize_features(cls, feature_list, normalize, center, moments_across_channels=True, moments_across_images=True):
+        """model/upflow.py:94-137.  The flag combination the published model uses (per-channel,
+        per-image statistics, center and normalize: test.py:24-26) is one fused HIP launch per
+        tensor; other combinations use the same arithmetic spelled in torch ops."""
+        if normalize and center and not moments_across_channels and not moments_across_images:
+            return [ops.normalize(f) for f in feature_list]
+        axes = [1, 2, 3] if moments_across_channels else [2, 3]
+        means = [torch.mean(f.float(), dim=axes, keepdim=True) for f in feature_list]
+        vars_ = [torch.var(f.float(), dim=axes, keepdim=True) for f in feature_list]
+        if moments_across_images:
+            means = [torch.mean(torch.stack(means, dim=0), dim=(0,))] * len(feature_list)
+            vars_ = [torch.var(torch.stack(vars_, dim=0), dim=(0,))] * len(feature_list)      # sic, upflow.py:124
+        stds = [torch.sqrt(v + 1e-16) for v in vars_]
+        out = list(feature_list)
+        if center:
+            out = [f - m.to(f.dtype) for f, m in zip(out, means)]
+        if normalize:
+            out = [f / s.to(f.dtype) for f, s in zip(out, stds)]
+        return out
+
+    # ---- loss terms (training only; plain torch ops) --------------------------------------------
+    @classmethod
+    def edge_aware_smoothness_order1(cls, img, pred):
+        """model/upflow.py:197-216."""
+        def dx(t):
+            return t[:, :, :-1, :] - t[:, :, 1:, :]
+
+        def dy(t):
+            return t[:, :, :, :-1] - t[:, :, :, 1:]
+        wx = torch.exp(-dx(img).abs().mean(1, keepdim=True))
+        wy = torch.exp(-dy(img).abs().mean(1, keepdim=True))
+        return (dx(pred).abs() * wx).mean() + (dy(pred).abs() * wy).mean()
+
+    @classmethod
+    def edge_aware_smoothness_order2(cls, img, pred):
+        """model/upflow.py:218-243."""
+        def dx(t, s=1):
+            return t[:, :, :-s, :] - t[:, :, s:, :]
+
+        def dy(t, s=1):
+            return t[:, :, :, :-s] - t[:, :, :, s:]
+        wx = torch.exp(-dx(img, 2).abs().mean(1, keepdim=True))
+        wy = torch.exp(-dy(img, 2).abs().mean(1, keepdim=True))
+        return (dx(dx(pred)).abs() * wx).mean() + (dy(dy(pred)).abs() * wy).mean()
+
+    @classmethod
+    def flow_smooth_delta(cls, flow, if_second_order=False):
+        return loss_functions.flow_smooth_delta(flow, if_second_order)
+
+    @classmethod
+    def weighted_ssim(cls, x, y, weight, c1=float('inf'), c2=9e-6, weight_epsilon=0.01):
+        """model/upflow.py:139-195."""
+        if c1 == float('inf') and c2 == float('inf'):
+            raise ValueError('Both c1 and c2 are infinite, SSIM loss is zero. This is likely unintended.')
+
+        def pool(z):
+            return F.avg_pool2d(z, (3, 3), (1, 1))
+        w_avg = pool(weight)
+        w_eps = weight + weight_epsilon
+        inv = 1.0 / (w_avg + weight_epsilon)
+
+        def wpool(z):
+            return pool(z * w_eps) * inv
+        mu_x, mu_y = wpool(x), wpool(y)
+        sigma_x = wpool(x ** 2) - mu_x ** 2
+        sigma_y = wpool(y ** 2) - mu_y ** 2
+        sigma_xy = wpool(x * y) - mu_x * mu_y
+        if c1 == float('inf'):
+            n, d = (2 * sigma_xy + c2), (sigma_x + sigma_y + c2)
+        elif c2 == float('inf'):
+            n, d = 2 * mu_x * mu_y + c1, mu_x ** 2 + mu_y ** 2 + c1
+        else:
+            n = (2 * mu_x * mu_y + c1) * (2 * sigma_xy + c2)
+            d = (mu_x ** 2 + mu_y ** 2 + c1) * (sigma_x + sigma_y + c2)
+        return torch.clamp((1 - n / d) / 2, 0, 1), w_avg
+
+    @classmethod
+    def photo_loss_multi_type(cls, x, y, occ_mask, photo_loss_type='abs_robust', photo_loss_delta=0.4, photo_loss_use_occ=False):
+        """model/upflow.py:265-288."""
+        occ_weight = occ_mask
+        if photo_loss_type == 'abs_robust':
+            loss_diff = ((x - y).abs() + 0.01).pow(photo_loss_delta)
+        elif photo_loss_type == 'charbonnier':
+            loss_diff = ((x - y) ** 2 + 1e-6).pow(photo_loss_delta)
+        elif photo_loss_type == 'L1':
+            loss_diff = (x - y + 1e-6).abs()
+        elif photo_loss_type == 'SSIM':
+            loss_diff, occ_weight = cls.weighted_ssim(x, y, occ_mask)
+        else:
+            raise ValueError('wrong photo_loss type: %s' % photo_loss_type)
+        if photo_loss_use_occ:
+            return torch.sum(loss_diff * occ_weight) / (torch.sum(occ_weight) + 1e-6)
+        return torch.mean(loss_diff)
+
+
+class UPFlow_net(tools.abstract_model):
+    class config(tools.abstract_config):
+        def __init__(self):
+            # defaults of model/upflow.py:293-323
+            self.occ_type = 'for_back_check'
+            self.alpha_1 = 0.1
+            self.alpha_2 = 0.5
+            self.occ_check_obj_out_all = 'obj'
+            self.stop_occ_gradient = False
+            self.smooth_level = 'final'
+            self.smooth_type = 'edge'
+            self.smooth_order_1_weight = 1
+            self.smooth_order_2_weight = 0
+            self.photo_loss_type = 'abs_robust'
+            self.photo_loss_delta = 0.4
+            self.photo_loss_use_occ = False
+            self.photo_loss_census_weight = 0
+            self.if_norm_before_cost_volume = False
+            self.norm_moments_across_channels = True
+            self.norm_moments_across_images = True
+            self.multi_scale_distillation_weight = 0
+            self.multi_scale_distillation_style = 'upup'
+            self.multi_scale_distillation_occ = True
+            self.if_froze_pwc = False
+            self.input_or_sp_input = 1
+            self.if_use_boundary_warp = True
+            self.if_sgu_upsample = False
+            self.if_use_cor_pytorch = False
+            # --- not in the reference; defaults keep its behaviour
+            self.warp_mask_mode = 'literal'
+
+        def __call__(self, ):
+            return UPFlow_net(self)
+
+    def __init__(self, conf: config):
+        super(UPFlow_net, self).__init__()
+        self.conf = conf
+        if conf.if_use_cor_pytorch:
+            raise ops.UpflowHipError(
+                "if_use_cor_pytorch=True selects the reference's CPU fallback (utils/pytorch_correlation.py); "
+                "this package has no CPU path — its restatement lives in oracle/ as test infrastructure")
+        # same construction order as model/upflow.py:335-361 (=> same state_dict key order)
+        self.search_range = 4
+        self.num_chs = [3, 16, 32, 64, 96, 128, 196]
+        self.estimator_f_channels = (128, 128, 96, 64, 32)
+        self.context_f_channels = (128, 128, 128, 96, 64, 32, 2)
+        self.output_level = 4
+        self.num_levels = 7
+        self.leakyRELU = nn.LeakyReLU(0.1, inplace=True)
+        self.feature_pyramid_extractor = FeatureExtractor(self.num_chs)
+        self.warping_layer = WarpingLayer_no_div(conf.warp_mask_mode)
+        self.dim_corr = (self.search_range * 2 + 1) ** 2
+        self.num_ch_in = self.dim_corr + 32 + 2
+        self.flow_estimators = FlowEstimatorDense_v2(self.num_ch_in, f_channels=self.estimator_f_channels)
+        self.context_networks = ContextNetwork_v2_(self.flow_estimators.n_channels + 2, f_channels=self.context_f_channels)
+        self.conv_1x1 = nn.ModuleList([conv(c, 32, kernel_size=1, stride=1, dilation=1) for c in (196, 128, 96, 64, 32)])
+        self.correlation = Correlation(pad_size=self.search_range, kernel_size=1, max_displacement=self.search_range,
+                                       stride1=1, stride2=1, corr_multiply=1)
+        self.sgi_model = network_tools.sgu_model(conf.warp_mask_mode) if conf.if_sgu_upsample else None
+        self.occ_check_model = tools.occ_check_model(occ_type=conf.occ_type, occ_alpha_1=conf.alpha_1,
+                                                     occ_alpha_2=conf.alpha_2, obj_out_all=conf.occ_check_obj_out_all)
+        initialize_msra(self.modules())
+        if conf.if_froze_pwc:
+            self.froze_PWC()
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, input_dict: dict):
+        """input_dict: im1, im2, if_loss [, im1_raw, im2_raw, start, im1_sp, im2_sp]
+        -> output_dict: flow_f_out, flow_b_out, occ_fw, occ_bw [, smooth_loss, photo_loss, im1_warp,
+        im2_warp, census_loss, msd_loss]          (model/upflow.py:370-492)"""
+        im1_ori, im2_ori = input_dict['im1'], input_dict['im2']
+        if input_dict['if_loss'] and self.conf.input_or_sp_input != 1:
+            im1, im2 = input_dict['im1_sp'], input_dict['im2_sp']
+        else:
+            im1, im2 = im1_ori, im2_ori
+        flow_f, flow_b, flows = self.forward_2_frame_v3(im1, im2, if_loss=input_dict['if_loss'])
+        occ_fw, occ_bw = self.occ_check_model(flow_f=flow_f, flow_b=flow_b)
+        out = {'flow_f_out': flow_f, 'flow_b_out': flow_b, 'occ_fw': occ_fw, 'occ_bw': occ_bw}
+        if input_dict['if_loss']:
+            self._losses(input_dict, out, flows, im1_ori.float(), im2_ori.float())
+        return out
+
+    def _losses(self, input_dict, out, flows, im1, im2):
+        """Unsupervised losses, model/upflow.py:394-491 (plain torch ops on top of the HIP warps)."""
+        c = self.conf
+        nt = network_tools
+        flow_f, flow_b, occ_fw, occ_bw = out['flow_f_out'], out['flow_b_out'], out['occ_fw'], out['occ_bw']
+        # smoothness
+        if c.smooth_level == 'final':
+            s_f, s_b, s_im1, s_im2 = flow_f, flow_b, im1, im2
+        elif c.smooth_level == '1/4':
+            s_f, s_b = flows[0]
+            s_im1 = F.interpolate(im1, s_f.shape[2:], mode='area')
+            s_im2 = F.interpolate(im2, s_f.shape[2:], mode='area')
+        else:
+            raise ValueError('wrong smooth level choosed: %s' % c.smooth_level)
+        smooth = 0
+        for order, weight in ((1, c.smooth_order_1_weight), (2, c.smooth_order_2_weight)):
+            if weight <= 0:
+                continue
+            if c.smooth_type == 'edge':
+                fn = nt.edge_aware_smoothness_order1 if order == 1 else nt.edge_aware_smoothness_order2
+                smooth = smooth + weight * fn(img=s_im1, pred=s_f) + weight * fn(img=s_im2, pred=s_b)
+            elif c.smooth_type == 'delta':
+                smooth = smooth + weight * nt.flow_smooth_delta(s_f, order == 2) + weight * nt.flow_smooth_delta(s_b, order == 2)
+            else:
+                raise ValueError('wrong smooth_type: %s' % c.smooth_type)
+        out['smooth_loss'] = smooth
+        # photometric
+        if c.if_use_boundary_warp:
+            im1_s, im2_s, start = input_dict['im1_raw'].float(), input_dict['im2_raw'].float(), input_dict['start']
+            im1_warp = tools.boundary_dilated_warp.warp_im(im2_s, flow_f, start)
+            im2_warp = tools.boundary_dilated_warp.warp_im(im1_s, flow_b, start)
+        else:
+            im1_warp = tools.torch_warp(im2, flow_f)
+            im2_warp = tools.torch_warp(im1, flow_b)
+        if c.stop_occ_gradient:
+            occ_fw, occ_bw = occ_fw.clone().detach(), occ_bw.clone().detach()
+        kw = dict(photo_loss_type=c.photo_loss_type, photo_loss_delta=c.photo_loss_delta, photo_loss_use_occ=c.photo_loss_use_occ)
+        out['photo_loss'] = nt.photo_loss_multi_type(im1, im1_warp, occ_fw, **kw) + nt.photo_loss_multi_type(im2, im2_warp, occ_bw, **kw)
+        out['im1_warp'], out['im2_warp'] = im1_warp, im2_warp
+        # census
+        if c.photo_loss_census_weight > 0:
+            ckw = dict(q=c.photo_loss_delta, charbonnier_or_abs_robust=False, if_use_occ=c.photo_loss_use_occ, averge=True)
+            census = loss_functions.census_loss_torch(img1=im1, img1_warp=im1_warp, mask=occ_fw, **ckw) + \
+                loss_functions.census_loss_torch(img1=im2, img1_warp=im2_warp, mask=occ_bw, **ckw)
+            out['census_loss'] = census * c.photo_loss_census_weight
+        else:
+            out['census_loss'] = None
+        # pyramid distillation (model/upflow.py:461-487): detached final flow teaches every level
+        if c.multi_scale_distillation_weight > 0:
+            label_f, label_b = flow_f.clone().detach(), flow_b.clone().detach()
+            terms = []
+            for lvl_f, lvl_b in flows:
+                if c.multi_scale_distillation_style == 'down':
+                    tf_, tb_ = upsample_flow(label_f, target_flow=lvl_f), upsample_flow(label_b, target_flow=lvl_b)
+                    of_ = F.interpolate(occ_fw, lvl_f.shape[2:], mode='nearest')
+                    ob_ = F.interpolate(occ_bw, lvl_b.shape[2:], mode='nearest')
+                elif c.multi_scale_distillation_style == 'upup':
+                    tf_, tb_, of_, ob_ = label_f, label_b, occ_fw, occ_bw
+                    lvl_f, lvl_b = upsample_flow(lvl_f, target_flow=label_f), upsample_flow(lvl_b, target_flow=label_b)
+                else:
+                    raise ValueError('wrong multi_scale_distillation_style: %s' % c.multi_scale_distillation_style)
+                mkw = dict(photo_loss_type='abs_robust', photo_loss_use_occ=c.multi_scale_distillation_occ)
+                terms.append(nt.photo_loss_multi_type(x=lvl_f, y=tf_, occ_mask=of_, **mkw))
+                terms.append(nt.photo_loss_multi_type(x=lvl_b, y=tb_, occ_mask=ob_, **mkw))
+            out['msd_loss'] = c.multi_scale_distillation_weight * sum(terms)
+        else:
+            out['msd_loss'] = None
+
+    # -------------------------------------------------------------------------------------------
+    def forward_2_frame_v3(self, x1_raw, x2_raw, if_loss=False):
+        """Coarse-to-fine bidirectional decode, model/upflow.py:494-533."""
+        cdt = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype      # compute dtype of the convs
+        x1_raw = x1_raw.to(cdt)
+        x2_raw = x2_raw.to(cdt)
+        x1_pyramid = self.feature_pyramid_extractor(x1_raw)
+        x2_pyramid = self.feature_pyramid_extractor(x2_raw)
+        B, _, h0, w0 = x1_pyramid[0].shape
+        flow_f = torch.zeros(B, 2, h0, w0, dtype=torch.float32, device=x1_raw.device)
+        flow_b = torch.zeros_like(flow_f)
+        flows = []
+        for level in range(self.output_level + 1):
+            x1, x2 = x1_pyramid[level], x2_pyramid[level]
+            flow_f, flow_b, res_f, res_b = self.decode_level_res(
+                level=level, flow_1=flow_f, flow_2=flow_b, feature_1=x1, feature_1_1x1=self.conv_1x1[level](x1),
+                feature_2=x2, feature_2_1x1=self.conv_1x1[level](x2), img_ori_1=x1_raw, img_ori_2=x2_raw)
+            flow_f = flow_f + res_f
+            flow_b = flow_b + res_b
+            flows.append([flow_f, flow_b])
+        flow_f_out = upsample2d_flow_as(flow_f, x1_raw, mode="bilinear", if_rate=True)
+        flow_b_out = upsample2d_flow_as(flow_b, x1_raw, mode="bilinear", if_rate=True)
+        if self.conf.if_sgu_upsample:
+            g1 = self.sgi_model.output_conv(x1_raw)
+            g2 = self.sgi_model.output_conv(x2_raw)
+            flow_f_out = self.self_guided_upsample(flow_up_bilinear=flow_f, feature_1=g1, feature_2=g2, output_level_flow=flow_f_out)
+            flow_b_out = self.self_guided_upsample(flow_up_bilinear=flow_b, feature_1=g2, feature_2=g1, output_level_flow=flow_b_out)
+        return flow_f_out, flow_b_out, flows[::-1]
+
+    def _estimator_input(self, f_a, f_b_warp, feat_1x1, flow):
+        """cat[LeakyReLU(corr81(f_a, f_b_warp)), feat_1x1, flow]  (model/upflow.py:557-566).
+        Inference: the kernel applies the LeakyReLU and writes the 81 channels straight into the
+        115-channel buffer, so the cost volume is never re-read for an activation or a concat."""
+        if torch.is_grad_enabled() and (f_a.requires_grad or f_b_warp.requires_grad):
+            c = self.leakyRELU(self.correlation(f_a, f_b_warp))
+            return torch.cat([c, feat_1x1, flow.to(c.dtype)], dim=1)
+        B, _, H, W = f_a.shape
+        buf = torch.empty((B, self.num_ch_in, H, W), dtype=f_a.dtype, device=f_a.device)
+        ops.corr81_forward_raw(f_a.contiguous(), f_b_warp.contiguous(), out=buf[:, :self.dim_corr], leaky_slope=0.1)
+        buf[:, self.dim_corr:self.dim_corr + 32] = feat_1x1
+        buf[:, self.dim_corr + 32:] = flow
+        return buf
+
+    def decode_level_res(self, level, flow_1, flow_2, feature_1, feature_1_1x1, feature_2, feature_2_1x1, img_ori_1, img_ori_2):
+        """One pyramid level, both directions (model/upflow.py:535-573)."""
+        flow_1_up = upsample2d_flow_as(flow_1, feature_1, mode="bilinear", if_rate=True)
+        flow_2_up = upsample2d_flow_as(flow_2, feature_2, mode="bilinear", if_rate=True)
+        if level == 0:
+            feature_2_warp, feature_1_warp = feature_2, feature_1
+        else:
+            if self.conf.if_sgu_upsample:
+                flow_1_up = self.self_guided_upsample(flow_up_bilinear=flow_1_up, feature_1=feature_1_1x1, feature_2=feature_2_1x1)
+                flow_2_up = self.self_guided_upsample(flow_up_bilinear=flow_2_up, feature_1=feature_2_1x1, feature_2=feature_1_1x1)
+            feature_2_warp = self.warping_layer(feature_2, flow_1_up)
+            feature_1_warp = self.warping_layer(feature_1, flow_2_up)
+        if self.conf.if_norm_before_cost_volume:
+            kw = dict(normalize=True, center=True, moments_across_channels=self.conf.norm_moments_across_channels,
+                      moments_across_images=self.conf.norm_moments_across_images)
+            feature_1, feature_2_warp = network_tools.normalize_features((feature_1, feature_2_warp), **kw)
+            feature_2, feature_1_warp = network_tools.normalize_features((feature_2, feature_1_warp), **kw)
+        in_1 = self._estimator_input(feature_1, feature_2_warp, feature_1_1x1, flow_1_up)
+        in_2 = self._estimator_input(feature_2, feature_1_warp, feature_2_1x1, flow_2_up)
+        feat_1, res_1 = self.flow_estimators(in_1)
+        feat_2, res_2 = self.flow_estimators(in_2)
+        res_1, res_2 = res_1.float(), res_2.float()
+        fine_1 = self.context_networks(torch.cat([feat_1, (flow_1_up + res_1).to(feat_1.dtype)], dim=1)).float()
+        fine_2 = self.context_networks(torch.cat([feat_2, (flow_2_up + res_2).to(feat_2.dtype)], dim=1)).float()
+        return flow_1_up, flow_2_up, res_1 + fine_1, res_2 + fine_2
+
+    def froze_PWC(self):
+        for part in (self.feature_pyramid_extractor, self.flow_estimators, self.context_networks, self.conv_1x1):
+            for p in part.parameters():
+                p.requires_grad = False
+
+    def self_guided_upsample(self, flow_up_bilinear, feature_1, feature_2, output_level_flow=None):
+        return self.sgi_model(flow_up_bilinear, feature_1, feature_2, output_level_flow=output_level_flow)[1]
+
+    @classmethod
+    def demo(cls, device='cuda'):
+        """Smoke run in the spirit of model/upflow.py:589-637, on the GPU."""
+        conf = UPFlow_net.config()
+        conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+                     'norm_moments_across_images': False, 'if_sgu_upsample': True})
+        net = conf().to(device).eval()
+        im = torch.rand(1, 3, 320, 320, device=device)
+        with torch.no_grad():
+            out = net({'im1': im, 'im2': im, 'if_loss': False})
+        for k, v in out.items():
+            tools.check_tensor(v, k)

@@ -1,0 +1,289 @@
+"""Autograd operators over the C-ABI of libupflow_hip.so (include/upflow_hip.h).
+
+Each operator = one HIP launch on the current torch stream.  Flows, sampling positions and masks
+are fp32 whatever the feature dtype.  No CPU path: non-GPU tensors raise.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import MASK_NONE, MASK_LITERAL, MASK_ROBUST, UpflowHipError  # noqa: F401
+
+_MASKS = {None: MASK_NONE, 'none': MASK_NONE, 'literal': MASK_LITERAL, 'robust': MASK_ROBUST,
+          MASK_NONE: MASK_NONE, MASK_LITERAL: MASK_LITERAL, MASK_ROBUST: MASK_ROBUST}
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+# ------------------------------------------------------------------------------------------------
+# cost volume
+# ------------------------------------------------------------------------------------------------
+def corr81_forward_raw(f1, f2, out=None, leaky_slope=0.0):
+    """One launch of upf_corr81_forward.  `out` may be a [B,81,H,W] channel-slice of a wider
+    contiguous [B,Ctot,H,W] buffer (e.g. the 115-channel estimator input, model/upflow.py:565)."""
+    if f1.shape != f2.shape or f1.dim() != 4 or f1.dtype != f2.dtype:
+        raise UpflowHipError('corr81: inputs must be two [B,C,H,W] tensors of one dtype, got %s %s / %s %s'
+                             % (tuple(f1.shape), f1.dtype, tuple(f2.shape), f2.dtype))
+    B, C, H, W = f1.shape
+    dev = _lib.check_gpu(f1, f2)
+    if out is None:
+        out = torch.empty((B, 81, H, W), dtype=f1.dtype, device=f1.device)
+        bstride = 0
+    else:
+        if out.shape != (B, 81, H, W) or out.dtype != f1.dtype or out.device != f1.device:
+            raise UpflowHipError('corr81: bad `out` %s %s' % (tuple(out.shape), out.dtype))
+        if out.stride()[1:] != (H * W, W, 1):
+            raise UpflowHipError('corr81: `out` must be a channel slice of a contiguous NCHW buffer')
+        bstride = out.stride(0)
+    with torch.cuda.device(dev):
+        _lib.call('upf_corr81_forward', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(out), B, C, H, W,
+                  _lib.dtype_code(f1), bstride, float(leaky_slope), _lib.stream_ptr(dev))
+    return out
+
+
+def corr81_backward_raw(f1, f2, grad_out):
+    B, C, H, W = f1.shape
+    grad_out = grad_out.contiguous()
+    dev = _lib.check_gpu(f1, f2, grad_out)
+    g1 = torch.empty_like(f1)
+    g2 = torch.empty_like(f2)
+    with torch.cuda.device(dev):
+        _lib.call('upf_corr81_backward', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(grad_out), _lib.ptr(g1), _lib.ptr(g2),
+                  B, C, H, W, _lib.dtype_code(f1), _lib.stream_ptr(dev))
+    return g1, g2
+
+
+class Corr81Function(Function):
+    """Modern static replacement of the legacy CorrelationFunction
+    (model/correlation_package/correlation.py:6-44) for (pad,k,md,s1,s2) = (4,1,4,1,1)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, leaky_slope=0.0):
+        f1 = f1.contiguous()
+        f2 = f2.contiguous()
+        out = corr81_forward_raw(f1, f2, None, leaky_slope)
+        ctx.slope = float(leaky_slope)
+        if ctx.slope != 0.0:
+            ctx.save_for_backward(f1, f2, out)
+        else:
+            ctx.save_for_backward(f1, f2)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.slope != 0.0:
+            f1, f2, out = ctx.saved_tensors
+            grad_out = torch.where(out > 0, grad_out, grad_out * ctx.slope)
+        else:
+            f1, f2 = ctx.saved_tensors
+        g1, g2 = corr81_backward_raw(f1, f2, grad_out.to(f1.dtype))
+        return g1, g2, None
+
+
+def corr81(f1, f2, leaky_slope=0.0):
+    return Corr81Function.apply(f1, f2, leaky_slope)
+
+
+def correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2):
+    import ctypes
+    oc, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.call('upf_correlation_out_shape', H, W, pad_size, kernel_size, max_displacement, stride1, stride2,
+              ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow))
+    return oc.value, oh.value, ow.value
+
+
+def correlation_forward_general(in1, in2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1):
+    """upf_correlation_forward: the reference's full parameter list (correlation_cuda.cc:10-17)."""
+    in1, in2 = in1.contiguous(), in2.contiguous()
+    B, C, H, W = in1.shape
+    dev = _lib.check_gpu(in1, in2)
+    oc, oh, ow = correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    out = torch.empty((B, oc, oh, ow), dtype=in1.dtype, device=in1.device)
+    with torch.cuda.device(dev):
+        _lib.call('upf_correlation_forward', _lib.ptr(in1), _lib.ptr(in2), _lib.ptr(out), B, C, H, W,
+                  _lib.dtype_code(in1), pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply,
+                  _lib.stream_ptr(dev))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# backward warp
+# ------------------------------------------------------------------------------------------------
+class WarpFunction(Function):
+    @staticmethod
+    def forward(ctx, x, flow, mask_mode):
+        x = x.contiguous()
+        flow = _f32(flow).contiguous()
+        if x.dim() != 4 or flow.shape != (x.shape[0], 2, x.shape[2], x.shape[3]):
+            raise UpflowHipError('warp: x [B,C,H,W] and flow [B,2,H,W] expected, got %s / %s'
+                                 % (tuple(x.shape), tuple(flow.shape)))
+        B, C, H, W = x.shape
+        dev = _lib.check_gpu(x, flow)
+        y = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.call('upf_warp_forward', _lib.ptr(x), _lib.ptr(flow), _lib.ptr(y), B, C, H, W,
+                      _lib.dtype_code(x), mask_mode, _lib.stream_ptr(dev))
+        ctx.mask_mode = mask_mode
+        ctx.save_for_backward(x, flow)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, flow = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = gy.to(x.dtype).contiguous()
+        dev = _lib.check_gpu(x, flow, gy)
+        gx32 = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        gflow = torch.empty_like(flow)
+        with torch.cuda.device(dev):
+            _lib.call('upf_warp_backward', _lib.ptr(x), _lib.ptr(flow), _lib.ptr(gy), _lib.ptr(gx32), _lib.ptr(gflow),
+                      B, C, H, W, _lib.dtype_code(x), ctx.mask_mode, _lib.stream_ptr(dev))
+        return gx32.to(x.dtype), gflow, None
+
+
+def warp(x, flow, mask_mode='literal'):
+    """mask_mode None/'none' = tools.torch_warp; 'literal' = WarpingLayer_no_div; 'robust' = exact
+    in-bounds predicate (non-default)."""
+    return WarpFunction.apply(x, flow, _MASKS[mask_mode])
+
+
+# ------------------------------------------------------------------------------------------------
+# flow up-sampling
+# ------------------------------------------------------------------------------------------------
+class FlowUpsampleFunction(Function):
+    @staticmethod
+    def forward(ctx, x, h, w, if_rate):
+        x = _f32(x).contiguous()
+        B, C, h_, w_ = x.shape
+        dev = _lib.check_gpu(x)
+        y = torch.empty((B, C, h, w), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_flow_upsample_forward', _lib.ptr(x), _lib.ptr(y), B, C, h_, w_, h, w, int(bool(if_rate)),
+                      _lib.stream_ptr(dev))
+        ctx.geom = (B, C, h_, w_, h, w, int(bool(if_rate)))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, h_, w_, h, w, rate = ctx.geom
+        gy = _f32(gy).contiguous()
+        dev = _lib.check_gpu(gy)
+        gx = torch.empty((B, C, h_, w_), dtype=torch.float32, device=gy.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_flow_upsample_backward', _lib.ptr(gy), _lib.ptr(gx), B, C, h_, w_, h, w, rate, _lib.stream_ptr(dev))
+        return gx, None, None, None
+
+
+def flow_upsample(x, h, w, if_rate=True):
+    return FlowUpsampleFunction.apply(x, int(h), int(w), if_rate)
+
+
+# ------------------------------------------------------------------------------------------------
+# SGU interpolation-blend
+# ------------------------------------------------------------------------------------------------
+class SguBlendFunction(Function):
+    @staticmethod
+    def forward(ctx, flow_init, x_out, want_inter):
+        flow_init = _f32(flow_init).contiguous()
+        x_out = x_out.contiguous()
+        B, c3, h, w = x_out.shape
+        Bf, c2, Hf, Wf = flow_init.shape
+        if c3 != 3 or c2 != 2 or Bf != B:
+            raise UpflowHipError('sgu_blend: flow_init [B,2,Hf,Wf], x_out [B,3,h,w] expected, got %s / %s'
+                                 % (tuple(flow_init.shape), tuple(x_out.shape)))
+        dev = _lib.check_gpu(flow_init, x_out)
+        flow_up = torch.empty_like(flow_init)
+        inter_flow = torch.empty_like(flow_init) if want_inter else None
+        inter_mask = torch.empty((B, 1, Hf, Wf), dtype=torch.float32, device=x_out.device) if want_inter else None
+        with torch.cuda.device(dev):
+            _lib.call('upf_sgu_blend_forward', _lib.ptr(flow_init), _lib.ptr(x_out), _lib.ptr(flow_up),
+                      _lib.ptr(inter_flow), _lib.ptr(inter_mask), B, h, w, Hf, Wf, _lib.dtype_code(x_out),
+                      _lib.stream_ptr(dev))
+        ctx.save_for_backward(flow_init, x_out)
+        if want_inter:
+            ctx.mark_non_differentiable(inter_flow, inter_mask)
+            return flow_up, inter_flow, inter_mask
+        return flow_up, None, None
+
+    @staticmethod
+    def backward(ctx, g_up, _gi, _gm):
+        flow_init, x_out = ctx.saved_tensors
+        B, _, h, w = x_out.shape
+        _, _, Hf, Wf = flow_init.shape
+        g_up = _f32(g_up).contiguous()
+        dev = _lib.check_gpu(flow_init, x_out, g_up)
+        g_init = torch.empty_like(flow_init)
+        g_xo = torch.empty((B, 3, h, w), dtype=torch.float32, device=x_out.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_sgu_blend_backward', _lib.ptr(flow_init), _lib.ptr(x_out), _lib.ptr(g_up), _lib.ptr(g_init),
+                      _lib.ptr(g_xo), B, h, w, Hf, Wf, _lib.dtype_code(x_out), _lib.stream_ptr(dev))
+        return g_init, g_xo.to(x_out.dtype), None
+
+
+def sgu_blend(flow_init, x_out, output_level_flow=None, want_inter=True):
+    """model/upflow.py:79-89 -> (flow_init, flow_up, inter_flow, inter_mask).  With
+    `output_level_flow` the blend runs at ITS resolution and it replaces flow_init (:84-87).
+    inter_flow / inter_mask are returned for API parity and are not differentiable outputs here
+    (the reference never uses them downstream: upflow.py:585-587 keeps out_flow only)."""
+    base = output_level_flow if output_level_flow is not None else flow_init
+    flow_up, inter_flow, inter_mask = SguBlendFunction.apply(base, x_out, want_inter)
+    return base, flow_up, inter_flow, inter_mask
+
+
+# ------------------------------------------------------------------------------------------------
+# feature normalisation
+# ------------------------------------------------------------------------------------------------
+class NormalizeFunction(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        dev = _lib.check_gpu(x)
+        y = torch.empty_like(x)
+        rstd = torch.empty((B * C,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_normalize_forward', _lib.ptr(x), _lib.ptr(y), _lib.ptr(None), _lib.ptr(rstd), B * C, H * W,
+                      _lib.dtype_code(x), _lib.stream_ptr(dev))
+        ctx.save_for_backward(y, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, rstd = ctx.saved_tensors
+        B, C, H, W = y.shape
+        gy = gy.to(y.dtype).contiguous()
+        dev = _lib.check_gpu(y, gy)
+        gx = torch.empty_like(y)
+        with torch.cuda.device(dev):
+            _lib.call('upf_normalize_backward', _lib.ptr(y), _lib.ptr(gy), _lib.ptr(rstd), _lib.ptr(gx), B * C, H * W,
+                      _lib.dtype_code(y), _lib.stream_ptr(dev))
+        return gx
+
+
+def normalize(x):
+    """Per-sample, per-channel (x - mean) / sqrt(unbiased var + 1e-16) over H*W."""
+    return NormalizeFunction.apply(x)
+
+
+def normalize_pair(a, b):
+    """network_tools.normalize_features((a, b)) with moments_across_channels=False,
+    moments_across_images=False (model/upflow.py:110-137): statistics are NOT shared."""
+    return normalize(a), normalize(b)
+
+
+# ------------------------------------------------------------------------------------------------
+# occlusion check (no gradient: the outputs are thresholded masks)
+# ------------------------------------------------------------------------------------------------
+def occ_check(flow_f, flow_b, alpha1=0.1, alpha2=0.5):
+    ff = _f32(flow_f.detach()).contiguous()
+    fb = _f32(flow_b.detach()).contiguous()
+    B, _, H, W = ff.shape
+    dev = _lib.check_gpu(ff, fb)
+    o1 = torch.empty((B, 1, H, W), dtype=torch.float32, device=ff.device)
+    o2 = torch.empty_like(o1)
+    with torch.cuda.device(dev):
+        _lib.call('upf_occ_check', _lib.ptr(ff), _lib.ptr(fb), _lib.ptr(o1), _lib.ptr(o2), B, H, W,
+                  float(alpha1), float(alpha2), _lib.stream_ptr(dev))
+    return o1, o2
