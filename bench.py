@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — frame-pairs/sec of the UPFlow inference hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W)
+
+A "step" is one UPFlow_net inference forward (both flow directions + occlusion masks, SGU on, flags
+of the reference's test.py:22-30) over one batch of synthetic frame pairs, inputs already resident in
+HBM.  Workload = BASELINE config 2: 384x1280, bf16, batch 4 per GPU.  Image pairs shard across ranks
+with no data-path collective (replicas, weak scaling); value = pairs all ranks processed / max-over-
+ranks time of exactly K steps bracketed by barrier + synchronize.
+
+The JSON line also carries
+  roofline     — the dominant hand-written kernel (81-neighbour cost volume at the 1/4-res level of
+                 this workload): algorithmic bytes s*B*H*W*(2C+81) / average kernel duration measured
+                 with HIP events recorded around each launch on its stream, vs the 8 TB/s HBM peak;
+  cpu_baseline — the reference's pure-PyTorch fallback path (utils/pytorch_correlation.py algorithm,
+                 restated in oracle/) timed on this box's host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (B per GPU, H, W, dtype)
+    'config2': (4, 384, 1280, 'bf16'),
+    'config4': (8, 448, 1024, 'fp16'),
+    'config5': (1, 960, 2880, 'bf16'),
+}
+DT = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
+FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+         'norm_moments_across_images': False, 'if_froze_pwc': False, 'if_sgu_upsample': True}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_net(dtype, device):
+    import _weights
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    conf = UPFlow_net.config()
+    conf.update(FLAGS, verbose=False)
+    torch.manual_seed(0)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))      # random-init weights of the architecture
+    return net.to(device).to(dtype).eval()
+
+
+def roofline_probe(B, H, W, dtype, device):
+    """Dominant kernel: corr81 forward at the 1/4-resolution level (C=32) of this workload."""
+    from upflow_pytorch_amd import ops
+    C, h, w = 32, (H + 3) // 4, (W + 3) // 4
+    g = torch.Generator(device='cpu').manual_seed(2004)
+    f1 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
+    f2 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
+    out = torch.empty(B, 81, h, w, device=device, dtype=dtype)
+    ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=20)                      # warm
+    avg_us, min_us = ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=200)
+    s = f1.element_size()
+    alg_bytes = s * B * h * w * (2 * C + 81)
+    achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+    return {'bound': 'hbm', 'kernel': 'corr81_fwd_kernel', 'shape': [B, C, h, w], 'achieved': round(achieved, 1),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+            'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2)}
+
+
+def cpu_baseline(H, W):
+    """The reference's CPU fallback (pure-PyTorch unfold correlation inside the full forward), as
+    restated in oracle/, on this box's host cores.  Bounded sample: ONE 384x1280 frame pair."""
+    import _weights
+    from oracle import net as onet
+    sd = _weights.make_state_dict(0, head_scale=0.1)
+    im1, im2 = _weights.make_images(2, 1, H, W)
+    with torch.no_grad():
+        a, b = _weights.make_images(2, 1, 64, 128)
+        onet.forward(sd, a, b, corr='unfold')                                # warm the thread pool
+        t0 = time.time()
+        onet.forward(sd, im1, im2, mask_mode='literal', corr='unfold')
+        dt = time.time() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'frame-pairs/s', 'cores': torch.get_num_threads(),
+            'host_cpus': os.cpu_count(), 'kind': 'port',
+            'sample': '1 frame pair %dx%d fp32, full UPFlow_net forward with the unfold-based fallback correlation '
+                      '(utils/pytorch_correlation.py:27-50 restated in oracle/), %.1f s' % (H, W, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
+    ap.add_argument('--dtype', default=None, choices=sorted(DT))
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from upflow_pytorch_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    assert world == max(args.gpus, 1), 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU path in the product)'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    B, H, W, dname = WORKLOADS[args.workload]
+    dname = args.dtype or dname
+    dtype = DT[dname]
+    import _weights
+    net = build_net(dtype, device)
+    im1, im2 = _weights.make_images(2, B, H, W)
+    im1, im2 = im1.to(device), im2.to(device)                               # inputs resident in HBM
+
+    if args.no_graph:
+        def step():
+            with torch.no_grad():
+                return net({'im1': im1, 'im2': im2, 'if_loss': False})
+    else:
+        from upflow_pytorch_amd.runtime import GraphedInference
+        runner = GraphedInference(net, B, H, W, device=device)
+        runner.load(im1, im2)
+        step = runner.replay
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    assert torch.isfinite(out['flow_f_out']).all()
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        line = {
+            'metric': 'frame-pairs/sec at 384x1280 bf16' if args.workload == 'config2' else 'frame-pairs/sec',
+            'value': round(pairs / elapsed, 3), 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': dname, 'data': 'synthetic',
+            'config': {'workload': '%s: UPFlow_net inference forward (flow fwd+bwd, occlusion masks, SGU on), '
+                                   '%dx%d, batch %d per GPU, random-init weights' % (args.workload, H, W, B),
+                       'global_batch': world * B, 'parallelism': 'replicas x%d (image pairs sharded, no collective)' % world,
+                       'hip_graph': not args.no_graph},
+            'roofline': roofline_probe(B, H, W, dtype, device),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(384, 1280)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

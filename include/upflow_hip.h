@@ -55,6 +55,15 @@ int upf_corr81_forward(const void* f1, const void* f2, void* out,
                        int B, int C, int H, int W, int dtype,
                        long long out_batch_stride, float leaky_slope, void* stream);
 
+/* Measurement helper (bench.py's `roofline` object): `nrep` back-to-back launches of the kernel above,
+ * each bracketed by its own pair of HIP events recorded on `stream` right around the kernel
+ * (hipExtLaunchKernel start/stop events); synchronises the stream and returns the average and the
+ * minimum kernel duration in microseconds.  Not capturable (it synchronises). */
+int upf_corr81_forward_timed(const void* f1, const void* f2, void* out,
+                             int B, int C, int H, int W, int dtype,
+                             long long out_batch_stride, float leaky_slope, void* stream,
+                             int nrep, float* avg_us, float* min_us);
+
 /* Gradients of the above (correlation_cuda.backward, correlation_cuda.cc:89-167 ->
  * correlation_cuda_kernel.cu:116-300, 396-530):
  *   g1[n,c,y,x] = (1/C) sum_d gO[n,d,y,x]       * f2[n,c,y+dy,x+dx]
@@ -113,8 +122,8 @@ int upf_flow_upsample_backward(const float* grad_y, float* gx, int B, int C, int
 int upf_sgu_blend_forward(const float* flow_init, const void* x_out, float* flow_up,
                           float* inter_flow, float* inter_mask,
                           int B, int h, int w, int Hf, int Wf, int dtype, void* stream);
-/* g_flow_init32 [B,2,Hf,Wf] fp32 must be zero-filled by the caller (scatter-add);
- * g_x_out32 [B,3,h,w] fp32 must be zero-filled by the caller when (Hf,Wf) != (h,w). */
+/* g_flow_init32 [B,2,Hf,Wf] and g_x_out32 [B,3,h,w] are fp32 scatter-add targets, zero-filled by the
+ * call itself (hipMemsetAsync on `stream`). */
 int upf_sgu_blend_backward(const float* flow_init, const void* x_out, const float* grad_flow_up,
                            float* g_flow_init32, float* g_x_out32,
                            int B, int h, int w, int Hf, int Wf, int dtype, void* stream);

@@ -247,3 +247,16 @@ def test_errors_are_loud(hip):
         hip.warp(a, torch.zeros(1, 2, 8, 9).cuda())
     with pytest.raises(RuntimeError):
         hip.correlation_forward_general(a, a, 0, 1, 4, 1, 1)      # empty output (H+0-8 <= 0)
+
+
+def test_forward_kernels_are_bit_deterministic(hip):
+    """No atomics on any forward path: two launches on the same bits give the same bits."""
+    g = torch.Generator().manual_seed(9)
+    f1 = torch.randn(2, 64, 48, 160, generator=g).cuda().bfloat16()
+    f2 = torch.randn(2, 64, 48, 160, generator=g).cuda().bfloat16()
+    flow = (torch.randn(2, 2, 48, 160, generator=g) * 3).cuda()
+    xo = torch.randn(2, 3, 48, 160, generator=g).cuda()
+    for fn in (lambda: hip.corr81(f1, f2, 0.1), lambda: hip.warp(f1, flow, 'literal'), lambda: hip.normalize(f1),
+               lambda: hip.sgu_blend(flow, xo)[1], lambda: hip.flow_upsample(flow, 96, 320, True),
+               lambda: hip.occ_check(flow, -flow)[0]):
+        assert torch.equal(fn(), fn())

@@ -1,51 +1,86 @@
 #!/usr/bin/env python3
 """Per-kernel timing of the HIP operators at the pyramid-level shapes of BASELINE configs 2/4/5.
-Algorithmic bytes per SURVEY.md §8(d).  Run under gpurun."""
+
+Each operator is captured NREP times into one HIP graph and the graph replay is timed with events on
+the capture stream: that removes the ~13 us python/ctypes launch overhead, leaving kernel time plus
+the ~1.5 us dependent-kernel boundary.  Algorithmic bytes per SURVEY.md §8(d).  Run under gpurun.
+"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from upflow_pytorch_amd import ops
 
+NREP = 20
 
-def timeit(fn, iters=50, warm=10):
-    for _ in range(warm):
-        fn()
+
+def graph_time(fn, iters=10):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(NREP):
+            fn()
+    g.replay(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
+    best = 1e30
     for _ in range(iters):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3   # us
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / NREP * 1e3)
+    return best  # us per launch
 
 
-def main():
+def main(only=None):
     dev = 'cuda'
     res = []
     levels = {2: (4, [(196, 6, 20), (128, 12, 40), (96, 24, 80), (64, 48, 160), (32, 96, 320)]),
+              3: (4, [(196, 4, 13), (128, 8, 26), (96, 16, 52), (64, 32, 104), (32, 64, 208)]),
               4: (8, [(196, 7, 16), (128, 14, 32), (96, 28, 64), (64, 56, 128), (32, 112, 256)]),
               5: (1, [(196, 15, 45), (128, 30, 90), (96, 60, 180), (64, 120, 360), (32, 240, 720)])}
     for cfg, (B, lv) in levels.items():
+        if only and cfg not in only:
+            continue
         for (C, H, W) in lv:
             for dt in (torch.bfloat16, torch.float32):
                 s = 2 if dt == torch.bfloat16 else 4
                 f1 = torch.randn(B, C, H, W, device=dev).to(dt); f2 = torch.randn(B, C, H, W, device=dev).to(dt)
                 flow = torch.randn(B, 2, H, W, device=dev) * 2
                 out = torch.empty(B, 81, H, W, device=dev, dtype=dt)
-                t = timeit(lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1))
-                byt = s * B * H * W * (2 * C + 81)
-                res.append(dict(op='corr81_fwd', cfg=cfg, B=B, C=C, H=H, W=W, dtype=str(dt), us=t, GBs=byt / t / 1e3))
-                t = timeit(lambda: ops.warp(f2, flow, 'literal'))
-                byt = B * H * W * (2 * s * C + 8)
-                res.append(dict(op='warp_fwd', cfg=cfg, B=B, C=C, H=H, W=W, dtype=str(dt), us=t, GBs=byt / t / 1e3))
-                t = timeit(lambda: ops.normalize(f1))
-                byt = B * H * W * C * 2 * s
-                res.append(dict(op='normalize', cfg=cfg, B=B, C=C, H=H, W=W, dtype=str(dt), us=t, GBs=byt / t / 1e3))
+                go = torch.randn(B, 81, H, W, device=dev).to(dt)
+                y = torch.empty_like(f2)
+
+                def rec(op, t, byt):
+                    res.append(dict(op=op, cfg=cfg, B=B, C=C, H=H, W=W, dtype=str(dt).replace('torch.', ''), us=t, GBs=byt / t / 1e3))
+                rec('corr81_fwd', graph_time(lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)), s * B * H * W * (2 * C + 81))
+                rec('warp_fwd', graph_time(lambda: ops.WarpFunction.apply(f2, flow, 1)), B * H * W * (2 * s * C + 8))
+                rec('normalize', graph_time(lambda: ops.normalize(f1)), B * H * W * C * 2 * s)
+                if cfg == 3:
+                    rec('corr81_bwd', graph_time(lambda: ops.corr81_backward_raw(f1, f2, go)), s * B * H * W * (4 * C + 81))
+            xo = torch.randn(B, 3, H, W, device=dev)
+            fl = torch.randn(B, 2, H, W, device=dev)
+            t = graph_time(lambda: ops.sgu_blend(fl, xo, None, want_inter=False))
+            res.append(dict(op='sgu_blend', cfg=cfg, B=B, C=3, H=H, W=W, dtype='float32', us=t, GBs=B * H * W * (8 + 12 + 8) / t / 1e3))
+        # final-level blend and full-res ops
+        C, H, W = lv[-1]
+        Hf, Wf = 4 * H, 4 * W
+        xo = torch.randn(B, 3, H, W, device=dev)
+        olf = torch.randn(B, 2, Hf, Wf, device=dev)
+        t = graph_time(lambda: ops.sgu_blend(None, xo, olf, want_inter=False))
+        res.append(dict(op='sgu_blend_final', cfg=cfg, B=B, C=3, H=Hf, W=Wf, dtype='float32', us=t, GBs=(B * Hf * Wf * 16 + B * H * W * 12) / t / 1e3))
+        fl = torch.randn(B, 2, H, W, device=dev)
+        t = graph_time(lambda: ops.flow_upsample(fl, Hf, Wf, True))
+        res.append(dict(op='flow_upsample', cfg=cfg, B=B, C=2, H=Hf, W=Wf, dtype='float32', us=t, GBs=(B * Hf * Wf * 8 + B * H * W * 8) / t / 1e3))
+        t = graph_time(lambda: ops.occ_check(olf, olf))
+        res.append(dict(op='occ_check', cfg=cfg, B=B, C=2, H=Hf, W=Wf, dtype='float32', us=t, GBs=(B * Hf * Wf * 24) / t / 1e3))
     for r in res:
-        print('%-11s cfg%d B%d C%3d %4dx%-4d %-15s %8.1f us %8.1f GB/s' % (r['op'], r['cfg'], r['B'], r['C'], r['H'], r['W'], r['dtype'], r['us'], r['GBs']))
+        print('%-15s cfg%d B%d C%3d %4dx%-4d %-9s %8.2f us %8.1f GB/s  %5.1f%% of 8TB/s' % (r['op'], r['cfg'], r['B'], r['C'], r['H'], r['W'], r['dtype'], r['us'], r['GBs'], r['GBs'] / 80.0))
     os.makedirs('gpurun_out', exist_ok=True)
     json.dump(res, open('gpurun_out/kbench.json', 'w'), indent=1)
 
 
 if __name__ == '__main__':
-    main()
+    main([int(a) for a in sys.argv[1:]] or None)

@@ -22,6 +22,7 @@ _vp, _i, _f, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_longlong
 # symbol -> argtypes; every function declared in include/upflow_hip.h (tests check the two lists agree)
 SIGNATURES = {
     'upf_corr81_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp],
+    'upf_corr81_forward_timed': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
     'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_out_shape': [_i, _i, _i, _i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],

@@ -20,6 +20,7 @@
 //     wider channel buffer (out_batch_stride);
 //   * blockIdx is remapped so that each XCD (private L2) gets a contiguous run of tiles.
 #include "common.hpp"
+#include <hip/hip_ext.h>
 
 namespace upf {
 namespace corr {
@@ -217,7 +218,7 @@ void corr81_fwd_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* __
 
 template <typename T>
 int launch_fwd(const void* f1, const void* f2, void* out, int B, int C, int H, int W,
-               long long out_bs, float slope, hipStream_t stream) {
+               long long out_bs, float slope, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   const long long nblocks = (long long)B * tiles_x * tiles_y;
   UPF_REQUIRE(nblocks < (1ll << 31), UPF_EINVAL, "corr81_forward: grid too large");
@@ -229,12 +230,14 @@ int launch_fwd(const void* f1, const void* f2, void* out, int B, int C, int H, i
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr81_fwd_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
+  // hipExtLaunchKernelGGL == hipLaunchKernelGGL plus optional start/stop events recorded right around
+  // THIS kernel on its stream (used by upf_corr81_forward_timed; null events = plain launch)
   if (aligned)
-    hipLaunchKernelGGL((corr81_fwd_kernel<T, true>), dim3((unsigned)nblocks), dim3(NTHREADS), LDS_BYTES, stream,
-                       (const T*)f1, (const T*)f2, (T*)out, C, H, W, tiles_x, tiles_y, out_bs, slope);
+    hipExtLaunchKernelGGL((corr81_fwd_kernel<T, true>), dim3((unsigned)nblocks), dim3(NTHREADS), LDS_BYTES, stream, ev0, ev1, 0,
+                          (const T*)f1, (const T*)f2, (T*)out, C, H, W, tiles_x, tiles_y, out_bs, slope);
   else
-    hipLaunchKernelGGL((corr81_fwd_kernel<T, false>), dim3((unsigned)nblocks), dim3(NTHREADS), LDS_BYTES, stream,
-                       (const T*)f1, (const T*)f2, (T*)out, C, H, W, tiles_x, tiles_y, out_bs, slope);
+    hipExtLaunchKernelGGL((corr81_fwd_kernel<T, false>), dim3((unsigned)nblocks), dim3(NTHREADS), LDS_BYTES, stream, ev0, ev1, 0,
+                          (const T*)f1, (const T*)f2, (T*)out, C, H, W, tiles_x, tiles_y, out_bs, slope);
   return check_launch("corr81_forward");
 }
 
@@ -279,6 +282,35 @@ extern "C" int upf_corr81_forward(const void* f1, const void* f2, void* out, int
   UPF_REQUIRE(out_batch_stride >= (long long)corr::ND * H * W, UPF_EINVAL, "corr81_forward: out_batch_stride %lld < 81*H*W", out_batch_stride);
   UPF_DISPATCH(dtype, T, return corr::launch_fwd<T>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, (hipStream_t)stream));
   return UPF_OK;
+}
+
+extern "C" int upf_corr81_forward_timed(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
+                                        long long out_batch_stride, float leaky_slope, void* stream, int nrep,
+                                        float* avg_us, float* min_us) {
+  using namespace upf;
+  UPF_REQUIRE(f1 && f2 && out && avg_us, UPF_EINVAL, "corr81_forward_timed: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nrep > 0 && nrep <= 1024, UPF_EINVAL, "corr81_forward_timed: bad arguments");
+  if (out_batch_stride == 0) out_batch_stride = (long long)corr::ND * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t* ev = new hipEvent_t[2 * nrep];
+  for (int i = 0; i < 2 * nrep; ++i) (void)hipEventCreate(&ev[i]);
+  int rc = UPF_OK;
+  for (int i = 0; i < nrep && rc == UPF_OK; ++i) {
+    UPF_DISPATCH(dtype, T, rc = corr::launch_fwd<T>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, s, ev[2 * i], ev[2 * i + 1]));
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  if (rc == UPF_OK && e != hipSuccess) { set_error("corr81_forward_timed: %s", hipGetErrorString(e)); rc = (int)e; }
+  double sum = 0.0, mn = 1e30;
+  if (rc == UPF_OK)
+    for (int i = 0; i < nrep; ++i) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+      sum += ms; if (ms < mn) mn = ms;
+    }
+  for (int i = 0; i < 2 * nrep; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  if (rc == UPF_OK) { *avg_us = (float)(sum / nrep * 1e3); if (min_us) *min_us = (float)(mn * 1e3); }
+  return rc;
 }
 
 extern "C" int upf_correlation_out_shape(int H, int W, int pad_size, int kernel_size, int max_displacement,

@@ -43,6 +43,20 @@ def corr81_forward_raw(f1, f2, out=None, leaky_slope=0.0):
     return out
 
 
+def corr81_forward_timed(f1, f2, out, leaky_slope=0.0, nrep=50):
+    """-> (avg_us, min_us) of `nrep` launches, each timed by HIP events recorded around the kernel on
+    the current stream (upf_corr81_forward_timed).  Measurement helper for bench.py."""
+    import ctypes
+    B, C, H, W = f1.shape
+    dev = _lib.check_gpu(f1, f2, out)
+    avg, mn = ctypes.c_float(), ctypes.c_float()
+    with torch.cuda.device(dev):
+        _lib.call('upf_corr81_forward_timed', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(out), B, C, H, W,
+                  _lib.dtype_code(f1), 0, float(leaky_slope), _lib.stream_ptr(dev), int(nrep),
+                  ctypes.byref(avg), ctypes.byref(mn))
+    return avg.value, mn.value
+
+
 def corr81_backward_raw(f1, f2, grad_out):
     B, C, H, W = f1.shape
     grad_out = grad_out.contiguous()
