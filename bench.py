@@ -66,7 +66,7 @@ def roofline_probe(B, H, W, dtype, device):
     s = f1.element_size()
     alg_bytes = s * B * h * w * (2 * C + 81)
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    return {'bound': 'hbm', 'kernel': 'corr81_fwd_kernel', 'shape': [B, C, h, w], 'achieved': round(achieved, 1),
+    return {'bound': 'hbm', 'kernel': 'corr81_mfma_kernel' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w], 'achieved': round(achieved, 1),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
             'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2)}
 
