@@ -90,6 +90,54 @@ def cpu_baseline(H, W):
                       '(utils/pytorch_correlation.py:27-50 restated in oracle/), %.1f s' % (H, W, dt)}
 
 
+TRAIN_FLAGS = {'photo_loss_census_weight': 1, 'multi_scale_distillation_weight': 1, 'multi_scale_distillation_style': 'upup',
+               'multi_scale_distillation_occ': True, 'smooth_order_1_weight': 1, 'if_use_boundary_warp': True}
+
+
+def train_main(args, rank, world, device):
+    """BASELINE config 3: unsupervised training step, global batch 4*N, DDP gradient all-reduce over RCCL."""
+    import _weights
+    from upflow_pytorch_amd import parallel
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.train import Trainer, synthetic_train_batch
+    conf = UPFlow_net.config()
+    d = dict(FLAGS)
+    d.update(TRAIN_FLAGS)
+    conf.update(d, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
+    dname = args.dtype or 'fp32'
+    tr = Trainer(net.to(DT[dname]), device=device)
+    B = 4
+    batch = synthetic_train_batch(B, seed=rank, device=device, dtype=DT[dname])   # a different shard per rank
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+    for _ in range(args.warmup):
+        tr.step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = tr.step(batch)
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training frame-pairs/sec (unsupervised step, 256x832 crops)', 'value': round(world * B * args.steps / elapsed, 3),
+            'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': dname, 'data': 'synthetic',
+            'config': {'workload': 'config3: photometric + smooth + census + pyramid-distillation loss, fwd+bwd+Adam(amsgrad), '
+                                   '256x832 crops of 288x864 frames, batch 4 per GPU', 'global_batch': world * B,
+                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world},
+            'final_loss': stats}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -99,6 +147,8 @@ def main():
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help='train = BASELINE config 3: unsupervised step (fwd+loss+bwd+Adam), 256x832 crops, batch 4 per GPU, DDP')
     args = ap.parse_args()
 
     from upflow_pytorch_amd import parallel
@@ -108,6 +158,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 
+    if args.mode == 'train':
+        return train_main(args, rank, world, device)
     B, H, W, dname = WORKLOADS[args.workload]
     dname = args.dtype or dname
     dtype = DT[dname]

@@ -90,3 +90,24 @@ def make_smooth_images(config_id, B, H, W, shift=2):
     im1 = big[:, :, 8:8 + H, 8:8 + W] - 0.45
     im2 = big[:, :, 8:8 + H, 8 - shift:8 - shift + W] - 0.45
     return im1.contiguous(), im2.contiguous()
+
+
+def make_train_batch(B=2, crop_hw=(128, 192), raw_hw=(160, 256), seed=0):
+    """KITTI-style training batch: crops, the un-cropped frames and the crop offset `start`
+    (scripts/ex_runner.py:146-147).  Smooth texture moved by 2 px so the photometric loss is meaningful."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    H, W = raw_hw
+    h, w = crop_hw
+    base = torch.rand(B, 3, H // 8 + 2, W // 8 + 2, generator=g)
+    big = torch.nn.functional.interpolate(base, size=(H + 8, W + 8), mode='bicubic', align_corners=True) - 0.45
+    im1 = big[:, :, 4:4 + H, 4:4 + W].contiguous()
+    im2 = big[:, :, 4:4 + H, 2:2 + W].contiguous()
+    sy, sx = (H - h) // 2, (W - w) // 2
+    start = torch.tensor([sx, sy], dtype=torch.float32).view(1, 2, 1, 1).repeat(B, 1, 1, 1)
+    return {'im1': im1[:, :, sy:sy + h, sx:sx + w].contiguous(), 'im2': im2[:, :, sy:sy + h, sx:sx + w].contiguous(),
+            'im1_raw': im1, 'im2_raw': im2, 'start': start}
+
+
+TRAIN_FLAGS = {'photo_loss_census_weight': 1, 'multi_scale_distillation_weight': 1, 'multi_scale_distillation_style': 'upup',
+               'multi_scale_distillation_occ': True, 'smooth_order_1_weight': 1, 'photo_loss_type': 'abs_robust',
+               'photo_loss_delta': 0.4, 'photo_loss_use_occ': False, 'if_use_boundary_warp': True}

@@ -376,10 +376,38 @@ def golden_net(upflow, pwc, tools):
     print(json.dumps(meta, indent=1))
 
 
+def golden_train(upflow, pwc, tools):
+    """Train-mode forward + backward of the reference (BASELINE config 3 at a small crop): loss terms and
+    the gradient norm of every parameter.  Robust mask on (so the comparison is well-posed, §7-H2) and the
+    out-of-place upsample2d_flow_as shim (SURVEY.md §8c shim 4)."""
+    import model.upflow as mu
+    old_fwd = robust_mask_patch(pwc)
+    old_up = mu.upsample2d_flow_as
+    mu.upsample2d_flow_as = oop_upsample2d_flow_as
+    try:
+        net = build_net(upflow, extra=_weights.TRAIN_FLAGS, head_scale=0.1)
+        net.train()
+        batch = _weights.make_train_batch()
+        batch['if_loss'] = True
+        out = net(batch)
+        terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')}
+        loss = sum(terms.values())
+        loss.backward()
+        names = sorted(n for n, _ in net.named_parameters())
+        params = dict(net.named_parameters())
+        gnorm = np.array([float(params[n].grad.norm()) for n in names], dtype=np.float64)
+        save('train_128x192', loss=np.array([float(loss)]), **{k: np.array([float(v)]) for k, v in terms.items()},
+             grad_norms=gnorm, flow_f_out=out['flow_f_out'], occ_fw=out['occ_fw'].to(torch.uint8))
+        print({k: float(v) for k, v in terms.items()}, 'grad norm sum', gnorm.sum())
+    finally:
+        pwc.WarpingLayer_no_div.forward = old_fwd
+        mu.upsample2d_flow_as = old_up
+
+
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'net']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'net', 'train']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -394,6 +422,8 @@ def main():
         golden_occ(tools)
     if 'net' in which:
         golden_net(upflow, pwc, tools)
+    if 'train' in which:
+        golden_train(upflow, pwc, tools)
 
 
 if __name__ == '__main__':

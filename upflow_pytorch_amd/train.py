@@ -1,0 +1,97 @@
+"""Unsupervised training step (BASELINE config 3) — one process per GPU, DDP over RCCL/xGMI.
+
+What the reference intends (its published scripts do not run: SURVEY.md §3.3):
+    optimiser  Adam(lr=1e-4, amsgrad=True, weight_decay=1e-4) + ExponentialLR(gamma)
+                                                            scripts/simple_train.py:121-122
+    batch      {'im1','im2' (crops), 'im1_raw','im2_raw' (un-cropped), 'start', 'if_loss': True}
+                                                            scripts/ex_runner.py:146-147
+    loss       photo_loss.mean() + smooth_loss.mean() [+ census_loss.mean()] [+ msd_loss.mean()]
+                                                            scripts/ex_runner.py:151-160, simple_train.py:23-54
+Multi-GPU: the reference wraps the net in single-process nn.DataParallel (utils/tools.py:140); here the
+global batch is sharded across ranks, each rank runs the whole forward/backward on its shard through
+the HIP operators, and the ONLY exchange per step is DDP's all-reduce(mean) of the 3,494,549 fp32
+gradients (13.98 MB — one 25 MB bucket, one ring all-reduce over xGMI) plus a 4-float all-reduce for
+logging.
+"""
+import torch
+import torch.distributed as dist
+
+from . import parallel
+
+
+class Loss_manager():
+    """Sums the loss terms the network returns (scripts/simple_train.py:23-54)."""
+    keys = ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')
+
+    def compute_loss(self, output_dict):
+        total = None
+        parts = {}
+        for k in self.keys:
+            v = output_dict.get(k)
+            if v is None:
+                continue
+            v = v.mean() if torch.is_tensor(v) else torch.as_tensor(float(v))
+            parts[k] = v.detach()
+            total = v if total is None else total + v
+        return total, parts
+
+
+class Trainer():
+    """net: a module with the UPFlow_net dict contract (input_dict -> output_dict with loss terms)."""
+
+    def __init__(self, net, lr=1e-4, weight_decay=1e-4, scheduler_gamma=1.0, device=None, distributed=None):
+        self.device = device
+        self.distributed = dist.is_initialized() if distributed is None else distributed
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.raw_net = net if device is None else net.to(device)
+        self.net = parallel.ddp_wrap(self.raw_net, device) if self.distributed else self.raw_net
+        self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr, amsgrad=True,
+                                          weight_decay=weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=scheduler_gamma)
+        self.loss_manager = Loss_manager()
+
+    def shard(self, batch):
+        """This rank's contiguous-strided slice of a GLOBAL batch dict (DistributedSampler-style)."""
+        if self.world == 1:
+            return batch
+        n = next(v for v in batch.values() if torch.is_tensor(v)).shape[0]
+        idx = parallel.shard_indices(n, self.rank, self.world)
+        return {k: (v[idx] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v) for k, v in batch.items()}
+
+    def step(self, batch):
+        """One optimisation step on this rank's shard; returns the loss terms averaged over ranks."""
+        self.net.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        batch = dict(batch)
+        batch['if_loss'] = True
+        out = self.net(batch)
+        loss, parts = self.loss_manager.compute_loss(out)
+        loss.backward()                      # DDP overlaps the gradient all-reduce with the rest of backward
+        self.optimizer.step()
+        stats = torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
+        if self.distributed:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            stats = stats / self.world
+        names = ['loss'] + sorted(parts)
+        return {k: float(v) for k, v in zip(names, stats.cpu())}
+
+    def end_epoch(self):
+        self.scheduler.step()
+
+
+def synthetic_train_batch(B, crop_hw=(256, 832), raw_hw=(288, 864), seed=0, device='cpu', dtype=torch.float32):
+    """A KITTI-shaped synthetic batch (dataset/kitti_dataset.py:268-342 yields crops of 256x832 plus the
+    un-cropped frames and the crop offset `start`)."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    H, W = raw_hw
+    h, w = crop_hw
+    base = torch.rand(B, 3, H // 8 + 2, W // 8 + 2, generator=g)
+    big = torch.nn.functional.interpolate(base, size=(H + 8, W + 8), mode='bicubic', align_corners=True) - 0.45
+    im1 = big[:, :, 4:4 + H, 4:4 + W].contiguous()
+    im2 = big[:, :, 4:4 + H, 2:2 + W].contiguous()                      # 2-px horizontal motion
+    sy, sx = (H - h) // 2, (W - w) // 2
+    start = torch.tensor([sx, sy], dtype=torch.float32).view(1, 2, 1, 1).repeat(B, 1, 1, 1)
+    batch = {'im1': im1[:, :, sy:sy + h, sx:sx + w].contiguous(), 'im2': im2[:, :, sy:sy + h, sx:sx + w].contiguous(),
+             'im1_raw': im1, 'im2_raw': im2, 'start': start}
+    return {k: v.to(device=device, dtype=dtype if k != 'start' else torch.float32) for k, v in batch.items()}
