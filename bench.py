@@ -66,8 +66,18 @@ def roofline_probe(B, H, W, dtype, device):
     s = f1.element_size()
     alg_bytes = s * B * h * w * (2 * C + 81)
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+    # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) cannot be
+    # collected from inside this process; it is the committed rocprofv3 measurement of the same launch
+    # (profiles/r01_corr81_l4_cfg2_bf16_pmc.json, separate --pmc passes) when shape and dtype match.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_corr81_l4_cfg2_bf16_pmc.json')))['summary']
+        if pmc['shape'] == [B, C, h, w] and pmc['dtype'] == {torch.bfloat16: 'bf16', torch.float16: 'fp16'}.get(dtype, 'fp32'):
+            traffic = int(pmc['traffic_bytes'])
+    except Exception:
+        pass
     return {'bound': 'hbm', 'kernel': 'corr81_mfma_kernel' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w], 'achieved': round(achieved, 1),
-            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
             'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2)}
 
 

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Profile target for rocprofv3: the dominant kernel (corr81 forward, config-2 l4 shape) launched N times.
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python tools/prof_corr.py
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE   --output-format csv -d ... -- python tools/prof_corr.py
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE   --output-format csv -d ... -- python tools/prof_corr.py
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from upflow_pytorch_amd import ops
+
+B, C, H, W = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (4, 32, 96, 320)))
+dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[sys.argv[5] if len(sys.argv) > 5 else 'bf16']
+g = torch.Generator().manual_seed(2004)
+f1 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
+f2 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
+out = torch.empty(B, 81, H, W, device='cuda', dtype=dt)
+# evict the 256 MiB infinity cache between launches so FETCH_SIZE reflects HBM, not MALL hits
+junk = torch.empty(320 * 1024 * 1024, dtype=torch.uint8, device='cuda')
+for i in range(20):
+    junk.add_(1)
+    ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)
+torch.cuda.synchronize()
+# back-to-back (inputs/outputs warm in the infinity cache, as inside the network right after their producer)
+for i in range(20):
+    ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)
+torch.cuda.synchronize()
+print('done')
