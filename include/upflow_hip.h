@@ -131,8 +131,10 @@ int upf_sgu_blend_backward(const float* flow_init, const void* x_out, const floa
 /* ---- feature normalisation  (network_tools.normalize_features, model/upflow.py:94-137) ---------
  * inference flags of test.py:22-30: per sample, per channel mean and UNBIASED variance over H*W,
  * y = (x - mean) / sqrt(var + 1e-16).  x,y : [N,HW] rows (N = B*C) of `dtype`;
- * mean, rstd : [N] fp32 optional outputs (saved for backward). */
-int upf_normalize_forward(const void* x, void* y, float* mean, float* rstd,
+ * mean, rstd : [N] fp32 optional outputs (saved for backward).  Rows are split over several workgroups
+ * (two launches, deterministic merge): `workspace` must hold upf_normalize_workspace_bytes(N, HW) bytes. */
+long long upf_normalize_workspace_bytes(long long N, int HW);
+int upf_normalize_forward(const void* x, void* y, float* mean, float* rstd, void* workspace,
                           long long N, int HW, int dtype, void* stream);
 int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd, void* gx,
                            long long N, int HW, int dtype, void* stream);

@@ -32,7 +32,7 @@ SIGNATURES = {
     'upf_flow_upsample_backward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_sgu_blend_forward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_sgu_blend_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    'upf_normalize_forward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    'upf_normalize_forward': [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_occ_check': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
 }
@@ -58,6 +58,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = _i
+        L.upf_normalize_workspace_bytes.argtypes = [_ll, _i]
+        L.upf_normalize_workspace_bytes.restype = _ll
         L.upf_version.restype = _c.c_char_p
         L.upf_last_error.restype = _c.c_char_p
         _lib = L

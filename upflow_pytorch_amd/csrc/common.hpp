@@ -73,6 +73,42 @@ template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float a, float b) {
 }
 template <> __device__ __forceinline__ uint32_t pack2<float>(float a, float) { return __float_as_uint(a); }
 
+// 16-byte vector access: VecIO<T>::N elements (4 fp32 / 8 bf16 / 8 fp16) <-> fp32 registers
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct VecIO<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3]), pack2<bf16_t>(v[4], v[5]), pack2<bf16_t>(v[6], v[7]));
+  }
+};
+template <> struct VecIO<f16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const f16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = f16_bits_to_f32(w[i] & 0xffffu); v[2 * i + 1] = f16_bits_to_f32(w[i] >> 16); }
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3]), pack2<f16_t>(v[4], v[5]), pack2<f16_t>(v[6], v[7]));
+  }
+};
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), each
 // XCD has a private 4 MiB L2.  Give every XCD a contiguous run of tiles so that neighbouring tiles
 // (which share their 4-pixel halos) hit the same L2.  Bijective for any grid size.

@@ -29,23 +29,73 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return r;
 }
 
-template <typename T>
+// Rows are split into `nseg` segments so that the grid fills the chip even when B*C is small
+// (config 5: 32 rows of 172,800 elements).  Deterministic two-launch scheme, no atomics:
+//   stats kernel : every (row, segment) workgroup writes (count, mean, M2) of its segment to `ws`;
+//   apply kernel : every (row, segment) workgroup merges the row's nseg partials in fixed order with
+//                  Chan's parallel-variance formula (no E[x^2]-E[x]^2 cancellation), then normalises
+//                  its own segment.  The second read of x comes from L2 / infinity cache.
+// VEC: 16-byte accesses (4 fp32 / 8 bf16 / 8 fp16 per lane) when HW, the segment length and the base
+// pointers allow it; otherwise element accesses.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(NT)
-void normalize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ mean_out,
-                          float* __restrict__ rstd_out, int HW) {
+void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, int nseg, int seglen) {
   __shared__ float sh[NT / 64];
-  const size_t row = blockIdx.x;
+  constexpr int V = VEC ? VecIO<T>::N : 1;
+  const size_t row = blockIdx.x / nseg;
+  const int seg = blockIdx.x - (int)row * nseg;
+  const int i0 = seg * seglen, i1 = min(HW, i0 + seglen);
+  const T* xr = x + row * HW;
+  // one sweep: sums of (x - K) and (x - K)^2 about a pivot K taken from the segment itself, so that
+  // M2 = s2 - s1^2/n loses at most a bit or two (|K - mean| is of the order of the spread)
+  const float K = Elem<T>::load(xr + i0);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
+    if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
+    } else { const float d = Elem<T>::load(xr + i) - K; s1 += d; s2 += d * d; }
+  }
+  const float cnt = (float)(i1 - i0);
+  const float t1 = block_sum(s1, sh), t2 = block_sum(s2, sh);
+  const float mean = K + t1 / cnt;
+  const float m2 = fmaxf(t2 - t1 * (t1 / cnt), 0.f);
+  if (threadIdx.x == 0) {
+    float* w = ws + ((size_t)row * nseg + seg) * 3;
+    w[0] = cnt; w[1] = mean; w[2] = m2;
+  }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(NT)
+void normalize_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ ws,
+                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int HW, int nseg, int seglen) {
+  constexpr int V = VEC ? VecIO<T>::N : 1;
+  const size_t row = blockIdx.x / nseg;
+  const int seg = blockIdx.x - (int)row * nseg;
+  // merge the partials (every thread redundantly: nseg is small and the values are L2-resident)
+  const float* w = ws + (size_t)row * nseg * 3;
+  float n = w[0], mean = w[1], m2 = w[2];
+  for (int k = 1; k < nseg; ++k) {
+    const float nb = w[3 * k], mb = w[3 * k + 1], m2b = w[3 * k + 2];
+    const float tot = n + nb, delta = mb - mean;
+    mean = mean + delta * (nb / tot);
+    m2 = m2 + m2b + delta * delta * (n * nb / tot);
+    n = tot;
+  }
+  const float var = m2 / (float)(HW - 1);                           // unbiased, torch.var default (upflow.py:114)
+  const float std = sqrtf(var + 1e-16f);                            // upflow.py:126
+  const int i0 = seg * seglen, i1 = min(HW, i0 + seglen);
   const T* xr = x + row * HW;
   T* yr = y + row * HW;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < HW; i += NT) s += Elem<T>::load(xr + i);
-  const float mean = block_sum(s, sh) / (float)HW;
-  float ss = 0.f;
-  for (int i = threadIdx.x; i < HW; i += NT) { const float d = Elem<T>::load(xr + i) - mean; ss += d * d; }
-  const float var = block_sum(ss, sh) / (float)(HW - 1);          // unbiased, torch.var default (upflow.py:114)
-  const float std = sqrtf(var + 1e-16f);                           // upflow.py:126
-  for (int i = threadIdx.x; i < HW; i += NT) Elem<T>::store(yr + i, (Elem<T>::load(xr + i) - mean) / std);
-  if (threadIdx.x == 0) {
+  for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
+    if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = (v[k] - mean) / std;
+      VecIO<T>::store(yr + i, v);
+    } else Elem<T>::store(yr + i, (Elem<T>::load(xr + i) - mean) / std);
+  }
+  if (threadIdx.x == 0 && seg == 0) {
     if (mean_out) mean_out[row] = mean;
     if (rstd_out) rstd_out[row] = 1.0f / std;
   }
@@ -109,14 +159,35 @@ void occ_check_kernel(const float* __restrict__ ff, const float* __restrict__ fb
 }  // namespace misc
 }  // namespace upf
 
-extern "C" int upf_normalize_forward(const void* x, void* y, float* mean, float* rstd, long long N, int HW,
+// segments per row: enough workgroups for ~4 per CU, at least 2048 elements per segment
+static int normalize_nseg(long long N, int HW) {
+  int nseg = 1;
+  while (N * nseg < 1024 && HW / (nseg * 2) >= 2048) nseg *= 2;
+  return nseg;
+}
+
+extern "C" long long upf_normalize_workspace_bytes(long long N, int HW) {
+  return (long long)N * normalize_nseg(N, HW) * 3 * sizeof(float);
+}
+
+extern "C" int upf_normalize_forward(const void* x, void* y, float* mean, float* rstd, void* workspace, long long N, int HW,
                                      int dtype, void* stream) {
   using namespace upf;
-  UPF_REQUIRE(x && y, UPF_EINVAL, "normalize_forward: null pointer");
-  UPF_REQUIRE(N > 0 && N < (1ll << 31) && HW > 0, UPF_EINVAL, "normalize_forward: bad shape N=%lld HW=%d", N, HW);
-  UPF_DISPATCH(dtype, T,
-               hipLaunchKernelGGL((misc::normalize_fwd_kernel<T>), dim3((unsigned)N), dim3(misc::NT), 0, (hipStream_t)stream,
-                                  (const T*)x, (T*)y, mean, rstd, HW));
+  UPF_REQUIRE(x && y && workspace, UPF_EINVAL, "normalize_forward: null pointer");
+  UPF_REQUIRE(N > 0 && HW > 0, UPF_EINVAL, "normalize_forward: bad shape N=%lld HW=%d", N, HW);
+  const int nseg = normalize_nseg(N, HW);
+  const int seglen = cdiv(HW, nseg);
+  UPF_REQUIRE(N * nseg < (1ll << 31), UPF_EINVAL, "normalize_forward: grid too large");
+  const unsigned grid = (unsigned)(N * nseg);
+  const int vn = (dtype == UPF_F32) ? 4 : 8;
+  const bool vec = (HW % vn == 0) && (seglen % vn == 0) && aligned_to(x, 16) && aligned_to(y, 16);
+#define UPF_NORM_LAUNCH(VEC)                                                                                                   \
+  hipLaunchKernelGGL((misc::normalize_stats_kernel<T, VEC>), dim3(grid), dim3(misc::NT), 0, (hipStream_t)stream, (const T*)x,  \
+                     (float*)workspace, HW, nseg, seglen);                                                                     \
+  hipLaunchKernelGGL((misc::normalize_apply_kernel<T, VEC>), dim3(grid), dim3(misc::NT), 0, (hipStream_t)stream, (const T*)x,  \
+                     (T*)y, (const float*)workspace, mean, rstd, HW, nseg, seglen)
+  UPF_DISPATCH(dtype, T, if (vec) { UPF_NORM_LAUNCH(true); } else { UPF_NORM_LAUNCH(false); });
+#undef UPF_NORM_LAUNCH
   return check_launch("normalize_forward");
 }
 

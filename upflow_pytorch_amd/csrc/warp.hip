@@ -19,40 +19,119 @@ namespace warp {
 
 constexpr int THREADS = 256;
 
+// Per-pixel sampling state, computed once and reused for every channel.  The two horizontally adjacent
+// taps of a row are fetched with ONE load of two elements ("pair"): pc = clamp(x0, 0, W-2) is the pair's
+// first column and (wl, wh) are the bilinear weights of columns pc and pc+1 (zero where the tap lies
+// outside the image), so a clamped pair needs no per-channel fix-up.  Halving the number of gather
+// instructions matters: the kernel is bound by the texture-address pipe (64 distinct addresses per
+// instruction), not by bytes.  2-byte-aligned 4-byte loads are legal on gfx950 (tools/unaligned_probe.hip).
+struct PixelTaps {
+  int oT, oB;                 // element offsets of the top / bottom pair inside a channel plane
+  float wlT, whT, wlB, whB;   // weights of (pc, pc+1) in the top and bottom row
+  bool valid;
+};
+
+__device__ __forceinline__ PixelTaps make_pixel(const float* __restrict__ flow_n, int p, int H, int W, int mask_mode) {
+  PixelTaps r;
+  const int HW = H * W;
+  const int i = p / W, j = p - i * W;
+  const float fx = flow_n[p], fy = flow_n[HW + p];
+  const Taps t = make_taps(j, i, fx, fy, H, W);
+  r.valid = taps_valid(t, mask_mode, j, i, fx, fy, H, W);
+  const int pc = min(max(t.x0, 0), W - 2);
+  const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
+  r.oT = ya * W + pc;
+  r.oB = yb * W + pc;
+  // weight of image column c for the (x0, x0+1) taps of a row whose taps have weights (w_a, w_b)
+  auto colw = [&](int c, float w_a, bool in_a, float w_b, bool in_b) {
+    return (c == t.x0 && in_a) ? w_a : ((c == t.x0 + 1 && in_b) ? w_b : 0.f);
+  };
+  r.wlT = colw(pc, t.w[0], t.in[0], t.w[1], t.in[1]);
+  r.whT = colw(pc + 1, t.w[0], t.in[0], t.w[1], t.in[1]);
+  r.wlB = colw(pc, t.w[2], t.in[2], t.w[3], t.in[3]);
+  r.whB = colw(pc + 1, t.w[2], t.in[2], t.w[3], t.in[3]);
+  return r;
+}
+
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+  static __device__ __forceinline__ void load(const float* p, float& lo, float& hi) {
+    const float2 v = *reinterpret_cast<const float2*>(p); lo = v.x; hi = v.y;       // 8-byte load, 4-byte aligned
+  }
+};
+template <> struct Pair<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float& lo, float& hi) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(p);                       // 4-byte load, 2-byte aligned
+    lo = __uint_as_float(v << 16); hi = __uint_as_float(v & 0xffff0000u);
+  }
+};
+template <> struct Pair<f16_t> {
+  static __device__ __forceinline__ void load(const f16_t* p, float& lo, float& hi) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+    lo = f16_bits_to_f32(v & 0xffffu); hi = f16_bits_to_f32(v >> 16);
+  }
+};
+
+// same association as ATen: ((nw*w + ne*w) + sw*w) + se*w   (terms of out-of-image taps are exact zeros)
 template <typename T>
+__device__ __forceinline__ float sample(const T* __restrict__ plane, const PixelTaps& s) {
+  float a, b, c, d;
+  Pair<T>::load(plane + s.oT, a, b);
+  Pair<T>::load(plane + s.oB, c, d);
+  return ((a * s.wlT + b * s.whT) + c * s.wlB) + d * s.whB;
+}
+
+// PXT pixels per thread (2 for 16-bit types when W is even: 4-byte stores), W >= 2.
+template <typename T, int PXT>
 __global__ __launch_bounds__(THREADS)
 void warp_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, T* __restrict__ y,
                      int C, int H, int W, int cpt, int mask_mode) {
   const int HW = H * W;
+  const int p0 = (blockIdx.x * THREADS + threadIdx.x) * PXT;
+  if (p0 >= HW) return;
+  const int n = blockIdx.z;
+  const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
+  const float* fl = flow + (size_t)n * 2 * HW;
+  PixelTaps s[PXT];
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) s[k] = make_pixel(fl, p0 + k, H, W, mask_mode);
+  const T* xb = x + ((size_t)n * C + c_begin) * HW;
+  T* yb = y + ((size_t)n * C + c_begin) * HW + p0;
+#pragma unroll 4
+  for (int c = c_begin; c < c_end; ++c, xb += HW, yb += HW) {
+    float r[PXT];
+#pragma unroll
+    for (int k = 0; k < PXT; ++k) r[k] = s[k].valid ? sample<T>(xb, s[k]) : 0.f;
+    if constexpr (PXT == 2 && sizeof(typename Elem<T>::store_t) == 2) {
+      *reinterpret_cast<uint32_t*>(yb) = pack2<T>(r[0], r[1]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) Elem<T>::store(yb + k, r[k]);
+    }
+  }
+}
+
+// W == 1 (no pair exists): plain four-tap version
+template <typename T>
+__global__ __launch_bounds__(THREADS)
+void warp_fwd_narrow_kernel(const T* __restrict__ x, const float* __restrict__ flow, T* __restrict__ y,
+                            int C, int H, int W, int mask_mode) {
+  const int HW = H * W;
   const int p = blockIdx.x * THREADS + threadIdx.x;
   if (p >= HW) return;
   const int n = blockIdx.z;
-  const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
   const int i = p / W, j = p - i * W;
-  const float fx = flow[((size_t)n * 2 + 0) * HW + p];
-  const float fy = flow[((size_t)n * 2 + 1) * HW + p];
+  const float fx = flow[((size_t)n * 2 + 0) * HW + p], fy = flow[((size_t)n * 2 + 1) * HW + p];
   const Taps t = make_taps(j, i, fx, fy, H, W);
   const bool valid = taps_valid(t, mask_mode, j, i, fx, fy, H, W);
-
-  const T* xb = x + ((size_t)n * C + c_begin) * HW;
-  T* yb = y + ((size_t)n * C + c_begin) * HW + p;
-  if (!valid) {
-    for (int c = c_begin; c < c_end; ++c, yb += HW) Elem<T>::store(yb, 0.f);
-    return;
-  }
-  // clamped tap offsets; out-of-image taps get weight 0 (zeros padding)
   const int xa = min(max(t.x0, 0), W - 1), xb1 = min(max(t.x0 + 1, 0), W - 1);
   const int ya = min(max(t.y0, 0), H - 1), yb1 = min(max(t.y0 + 1, 0), H - 1);
   const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
-  const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f;
-  const float w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
-#pragma unroll 4
-  for (int c = c_begin; c < c_end; ++c, xb += HW, yb += HW) {
-    const float v0 = Elem<T>::load(xb + o0), v1 = Elem<T>::load(xb + o1);
-    const float v2 = Elem<T>::load(xb + o2), v3 = Elem<T>::load(xb + o3);
-    // same association as ATen: ((nw*w + ne*w) + sw*w) + se*w
-    const float r = ((v0 * w0 + v1 * w1) + v2 * w2) + v3 * w3;
-    Elem<T>::store(yb, r);
+  const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f, w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
+  for (int c = 0; c < C; ++c) {
+    const T* xc = x + ((size_t)n * C + c) * HW;
+    const float r = ((Elem<T>::load(xc + o0) * w0 + Elem<T>::load(xc + o1) * w1) + Elem<T>::load(xc + o2) * w2) + Elem<T>::load(xc + o3) * w3;
+    Elem<T>::store(y + ((size_t)n * C + c) * HW + p, valid ? r : 0.f);
   }
 }
 
@@ -102,10 +181,11 @@ void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, co
 }
 
 static int pick_cpt(int B, int C, int HW) {
-  // split channels over blockIdx.y until the grid has a few waves per SIMD (256 CUs x 4 SIMDs)
+  // split channels over blockIdx.y until there are ~4 workgroups per CU, but keep >= 8 channels per
+  // thread: the per-pixel set-up (two IEEE divisions, weights, mask) costs about as much as 6 channels
   const long long pix_blocks = (long long)B * cdiv(HW, THREADS);
   int split = 1;
-  while (split < C && pix_blocks * split < 2048 && C / (split * 2) >= 4) split *= 2;
+  while (split < C && pix_blocks * split < 1024 && C / (split * 2) >= 8) split *= 2;
   return cdiv(C, split);
 }
 
@@ -119,11 +199,20 @@ extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_forward: bad mask_mode %d", mask_mode);
   const int HW = H * W;
-  const int cpt = warp::pick_cpt(B, C, HW);
-  dim3 grid(cdiv(HW, warp::THREADS), cdiv(C, cpt), B);
+  hipStream_t st = (hipStream_t)stream;
+  if (W < 2) {
+    UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((warp::warp_fwd_narrow_kernel<T>), dim3(cdiv(HW, warp::THREADS), 1, B), dim3(warp::THREADS), 0, st,
+                                              (const T*)x, flow, (T*)y, C, H, W, mask_mode));
+    return check_launch("warp_forward");
+  }
+  // two pixels per thread (4-byte stores) for 16-bit features when rows keep pixel pairs aligned
+  const bool two = (dtype != UPF_F32) && (W % 2 == 0) && aligned_to(y, 4);
+  const int pxt = two ? 2 : 1;
+  const int cpt = warp::pick_cpt(B, C, HW / pxt);
+  dim3 grid(cdiv(cdiv(HW, pxt), warp::THREADS), cdiv(C, cpt), B);
   UPF_DISPATCH(dtype, T,
-               hipLaunchKernelGGL((warp::warp_fwd_kernel<T>), grid, dim3(warp::THREADS), 0, (hipStream_t)stream,
-                                  (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode));
+               if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode);
+               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode));
   return check_launch("warp_forward");
 }
 

@@ -257,8 +257,9 @@ class NormalizeFunction(Function):
         dev = _lib.check_gpu(x)
         y = torch.empty_like(x)
         rstd = torch.empty((B * C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((_lib.lib().upf_normalize_workspace_bytes(B * C, H * W),), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(dev):
-            _lib.call('upf_normalize_forward', _lib.ptr(x), _lib.ptr(y), _lib.ptr(None), _lib.ptr(rstd), B * C, H * W,
+            _lib.call('upf_normalize_forward', _lib.ptr(x), _lib.ptr(y), _lib.ptr(None), _lib.ptr(rstd), _lib.ptr(ws), B * C, H * W,
                       _lib.dtype_code(x), _lib.stream_ptr(dev))
         ctx.save_for_backward(y, rstd)
         return y
