@@ -139,6 +139,20 @@ int upf_normalize_forward(const void* x, void* y, float* mean, float* rstd, void
 int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd, void* gx,
                            long long N, int HW, int dtype, void* stream);
 
+/* ---- 3x3 (dilated) convolution on the matrix cores   -----------------------
+ * The dense flow-estimator / context / SGU-estimator convolutions (model/pwc_modules.py:250-286,
+ * :396-412; model/upflow.py:24-60), bf16 / fp16 only (fp32 stays with MIOpen = the parity mode):
+ *   y[n,co] = act(bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[n,ci, i+(ky-1)d, j+(kx-1)d]),  stride 1, pad d
+ * x / y point at the FIRST input / output channel of channel slices of larger contiguous NCHW buffers
+ * (batch strides in elements), so the estimator's growing concatenation needs no copies.
+ * w_packed: upf_conv3x3_pack_weights() output ([9][pad32(Cout)][pad32(Cin)], done once per layer).
+ * Limits: Cout <= 128, 1 <= dilation <= 8, W % 8 == 0, 16-byte aligned x. */
+long long upf_conv3x3_packed_bytes(int Cin, int Cout);
+int upf_conv3x3_pack_weights(const void* w /* [Cout,Cin,3,3] */, void* w_packed, int Cin, int Cout, int dtype, void* stream);
+int upf_conv3x3_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
+                        void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
+                        int dilation, float leaky_slope, int dtype, void* stream);
+
 /* ---- occlusion check  (tools.occ_check_model(obj), utils/tools.py:519-588, 641-677) -------------
  * flow_f, flow_b : [B,2,H,W] fp32 -> occ_fw, occ_bw : [B,1,H,W] fp32 in {0,1}. */
 int upf_occ_check(const float* flow_f, const float* flow_b, float* occ_fw, float* occ_bw,

@@ -1,0 +1,58 @@
+"""Matrix-core 3x3 convolution (csrc/conv3x3.hip) against torch's conv2d on the same bf16/fp16-rounded
+operands (fp32 reference arithmetic), incl. channel-slice inputs/outputs, dilations, ragged Cin/Cout."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, Cin, Cout, H, W, dilation
+    (1, 32, 32, 8, 32, 1), (2, 115, 128, 24, 40, 1), (1, 243, 128, 16, 64, 1), (1, 371, 96, 9, 24, 1), (1, 467, 64, 8, 8, 1),
+    (1, 563, 2, 12, 40, 1), (1, 565, 128, 16, 32, 1), (1, 128, 128, 24, 48, 2), (1, 128, 128, 24, 48, 4), (1, 128, 96, 40, 64, 8),
+    (2, 64, 32, 17, 56, 1), (1, 184, 3, 8, 16, 1), (1, 7, 5, 3, 8, 1), (4, 96, 32, 96, 320, 1)]
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv3x3_matches_conv2d(case, dtype):
+    from upflow_pytorch_amd import ops
+    B, Cin, Cout, H, W, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).to(dtype).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(dtype).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    want = F.leaky_relu(F.conv2d(x.float(), w.float(), b, padding=d, dilation=d), 0.1)
+    # channel-slice operands of wider buffers, like the dense estimator's concat buffer
+    xbuf = torch.zeros(B, Cin + 5, H, W, dtype=dtype, device='cuda')
+    xbuf[:, 5:] = x
+    ybuf = torch.full((B, Cout + 3, H, W), 7.0, dtype=dtype, device='cuda')
+    assert ops.conv3x3_supported(xbuf[:, 5:], Cout, d) or (5 * H * W * 2) % 16 != 0
+    if not ops.conv3x3_supported(xbuf[:, 5:], Cout, d):
+        xbuf = torch.zeros(B, Cin + 8, H, W, dtype=dtype, device='cuda')
+        xbuf[:, 8:] = x
+        xv = xbuf[:, 8:]
+    else:
+        xv = xbuf[:, 5:]
+    packed = ops.conv3x3_pack(w)
+    ops.conv3x3_forward_raw(xv, packed, b, ybuf[:, 2:2 + Cout], dilation=d, leaky_slope=0.1)
+    got = ybuf[:, 2:2 + Cout].float()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    tol = eps * float(want.abs().max()) + 1e-3
+    assert (got - want).abs().max() <= tol, float((got - want).abs().max())
+    assert bool((ybuf[:, :2] == 7).all()) and bool((ybuf[:, 2 + Cout:] == 7).all()), 'wrote outside its channel slice'
+    # no activation
+    ops.conv3x3_forward_raw(xv, packed, b, ybuf[:, 2:2 + Cout], dilation=d, leaky_slope=0.0)
+    want0 = F.conv2d(x.float(), w.float(), b, padding=d, dilation=d)
+    assert (ybuf[:, 2:2 + Cout].float() - want0).abs().max() <= eps * float(want0.abs().max()) + 1e-3
+
+
+def test_conv3x3_rejects_unsupported():
+    from upflow_pytorch_amd import ops
+    x = torch.zeros(1, 8, 8, 12, dtype=torch.bfloat16, device='cuda')       # W % 8 != 0
+    assert not ops.conv3x3_supported(x, 8, 1)
+    assert not ops.conv3x3_supported(x.float(), 8, 1)
+    x = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda')
+    assert not ops.conv3x3_supported(x, 8, 16) and not ops.conv3x3_supported(x, 200, 1)
+    w = ops.conv3x3_pack(torch.zeros(8, 8, 3, 3, dtype=torch.bfloat16, device='cuda'))
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_forward_raw(x, w, torch.zeros(8, device='cuda'), torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda'), dilation=16)

@@ -17,6 +17,7 @@ SOURCES = [
     ('api.hip', []),
     ('corr81_fwd.hip', []),
     ('corr81_bwd.hip', []),
+    ('conv3x3.hip', []),
     ('warp.hip', ['-ffp-contract=off']),
     ('sgu_blend.hip', ['-ffp-contract=off']),
     ('misc.hip', ['-ffp-contract=off']),

@@ -1,0 +1,265 @@
+// 3x3 (dilated) convolution as an implicit GEMM on the bf16/fp16 matrix cores — gfx950.
+//
+// the dense flow-estimator / context / SGU-estimator convolutions
+// (/root/reference/model/pwc_modules.py:250-286, :396-412, model/upflow.py:24-60) are where an
+// inference step actually spends its time (≈1.5 TFLOP per 384x1280 batch-4 step; MIOpen reaches ≈55
+// TFLOP/s on them through im2col + GEMM + NCHW<->NHWC transposes + separate bias / LeakyReLU / concat
+// kernels).  BASELINE.json's north star allows MFMA exactly here ("a real contraction").
+//
+//   y[n, co, i, j] = act( bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[n, ci, i+(ky-1)d, j+(kx-1)d] )
+//   stride 1, padding = dilation d (same-size output), zero padding, act = LeakyReLU(slope) or identity.
+//
+// x and y are CHANNEL SLICES of larger contiguous NCHW buffers (batch strides given): the dense
+// estimator's growing concatenation (`x1 = cat([conv1(x), x])`, pwc_modules.py:280-285) becomes one
+// 565-channel buffer that every conv reads a suffix of and writes its own slice of — no concat copy,
+// no separate bias or activation pass, no layout transposes, no im2col buffer.
+//
+// GEMM view per image: D[co][pixel] = sum_tap sum_ci W[tap][co][ci] * X[ci][pixel + shift(tap)],
+// v_mfma_f32_32x32x16_{bf16,f16}: A = 32 output channels x 16 k, B = 16 k x 32 pixels (one tile row).
+//   * workgroup = 4 waves = an 8x32 pixel tile of one image, ALL output channels (<= 128, MT tiles of 32);
+//     wave w owns tile rows 2w, 2w+1 -> 2*MT accumulator tiles of 16 fp32 registers;
+//   * per chunk of 32 input channels the x tile + halo is staged ONCE into LDS, transposed in registers
+//     (8 channel rows x 8 pixels -> 8 pixels x 8 channels, 32 v_perm) into 16-byte entries
+//     [channel-octet][row][col]; the 9 taps then read SHIFTED windows of it (per-lane LDS addresses), so
+//     the im2col expansion exists only as LDS read addresses;  halo zeros and channels >= Cin come from
+//     the buffer descriptor's bounds check;
+//   * weights are pre-packed once ([tap][co][ci], ci padded to 32, co to 32) so that a wave's A operand
+//     is a 16-byte LDS read; the 8 KB weight slice of the next tap is staged (double-buffered) while the
+//     current tap's MFMAs run;
+//   * epilogue: + bias, LeakyReLU, convert, store.
+#include "common.hpp"
+
+namespace upf {
+namespace conv {
+
+constexpr int TH = 8, TW = 32, NTHREADS = 256;
+constexpr int KC = 32;                    // input channels per chunk (4 octets, 2 MFMA k-steps)
+constexpr int XW = TW + 16;               // staged columns: [x0-8, x0+40) keeps 16-byte alignment of global loads
+constexpr int MAXD = 8;                   // dilation limit (halo rows); larger dilations fall back to MIOpen
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <typename T> struct Mma32;
+template <> struct Mma32<bf16_t> {
+  static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma32<f16_t> {
+  static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+__host__ __device__ constexpr int pad32(int v) { return (v + 31) / 32 * 32; }
+
+// w [Cout, Cin, 3, 3] -> packed [9][pad32(Cout)][pad32(Cin)], zero padded
+template <typename T>
+__global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, int Cin, int Cout) {
+  const int cip = pad32(Cin), cop = pad32(Cout);
+  const long long total = 9ll * cop * cip;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cip), co = (int)((i / cip) % cop), tap = (int)(i / ((long long)cip * cop));
+    T v; v.v = 0;
+    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 9 + tap];
+    wp[i] = v;
+  }
+}
+
+// MT = number of 32-wide output-channel tiles (1..4)
+template <typename T, int MT>
+__global__ __launch_bounds__(NTHREADS, 2)
+void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
+                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int d, int tiles_x, int tiles_y, float slope) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int rows = TH + 2 * d;                       // staged rows
+  const int XS_E = 4 * rows * XW;                    // entries (16 B = 8 channels of one pixel) of the x tile
+  constexpr int AS_E = 4 * MT * 32;                  // entries of one weight slice: [octet][co]
+  uint4* xs = smem;                                  // [octet 4][rows][XW]
+  uint4* as = smem + XS_E;                           // [2][octet 4][MT*32]
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cip = pad32(Cin), cop = MT * 32;
+  const int HW = H * W;
+
+  // buffer descriptor over this image's Cin input planes: rows/cols outside the image get offset
+  // 0x80000000, channel planes >= Cin fall off the end -> the hardware returns the zero padding
+  const uint32_t plane = (uint32_t)HW * 2u;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, 9u * (uint32_t)cop * (uint32_t)cip * 2u, 0x00020000);
+
+  // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
+  const int ngroups = XW / 8;                        // 6
+  const int ntasks = 4 * rows * ngroups;
+
+  f32x16 acc[2][MT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][m][e] = 0.f;
+
+  const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
+  const int nchunks = cip / KC;
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();                                 // previous chunk fully consumed
+    // ---- stage the x tile (+halo) of channels [32cc, 32cc+32)
+    for (int t = tid; t < ntasks; t += NTHREADS) {
+      const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
+      const int gy = y0 - d + r, gx = x0 - 8 + 8 * g;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;         // W % 8 == 0: a group is all in or all out
+      const uint32_t off = in ? ((uint32_t)((cc * KC + oct * 8) * HW + gy * W + gx) * 2u) : 0x80000000u;
+      u32x4 ch[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + k * plane, 0, 0);
+      uint4* dst = xs + (oct * rows + r) * XW + 8 * g;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
+        uint4 e0, e1;                                // 8 channels of pixel 2pp / 2pp+1
+        e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
+        e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
+        e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
+        e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
+        dst[2 * pp] = e0;
+        dst[2 * pp + 1] = e1;
+      }
+    }
+    // ---- weight slice of tap 0 -> as[0]
+    for (int e = tid; e < AS_E; e += NTHREADS) {
+      const int oct = e / cop, co = e - oct * cop;
+      const uint32_t off = ((uint32_t)((0 * cop + co) * cip + cc * KC + oct * 8)) * 2u;
+      as[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+    }
+    __syncthreads();
+
+    for (int tap = 0; tap < 9; ++tap) {
+      const uint4* acur = as + (tap & 1) * AS_E;
+      // prefetch the next tap's weight slice into the other buffer (consumed after the barrier below)
+      u32x4 wpre[(AS_E + NTHREADS - 1) / NTHREADS];
+      if (tap + 1 < 9) {
+#pragma unroll
+        for (int j = 0; j < (AS_E + NTHREADS - 1) / NTHREADS; ++j) {
+          const int e = tid + j * NTHREADS;
+          const int oct = e / cop, co = e - oct * cop;
+          const uint32_t off = (e < AS_E) ? ((uint32_t)(((tap + 1) * cop + co) * cip + cc * KC + oct * 8)) * 2u : 0x80000000u;
+          wpre[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0);
+        }
+      }
+      const int ky = tap / 3, kx = tap - ky * 3;
+      // shifted window: output pixel (row, px) reads staged entry (row + ky*d, 8 + px + (kx-1)*d)
+      const int col = 8 + px + (kx - 1) * d;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {               // two k-steps of 16 channels
+        const int oct = 2 * ks + kg;
+        uint4 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = acur[oct * cop + m * 32 + px];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const uint4 b = xs[(oct * rows + (2 * wave + r) + ky * d) * XW + col];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
+        }
+      }
+      if (tap + 1 < 9) {
+        uint4* anext = as + ((tap + 1) & 1) * AS_E;
+#pragma unroll
+        for (int j = 0; j < (AS_E + NTHREADS - 1) / NTHREADS; ++j) {
+          const int e = tid + j * NTHREADS;
+          if (e < AS_E) anext[e] = __builtin_bit_cast(uint4, wpre[j]);
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: D[co][pixel]; lane -> pixel column px, regs -> co = (e&3) + 8*(e>>2) + 4*kg
+  using st = uint16_t;
+  st* yb = reinterpret_cast<st*>(y) + (size_t)n * ybs;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int gy = y0 + 2 * wave + r, gx = x0 + px;
+    if (gy >= H || gx >= W) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+        if (co < Cout) {
+          float v = acc[r][m][e] + bias[co];
+          v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
+          T tmp;
+          Elem<T>::store(&tmp, v);
+          yb[(size_t)co * HW + gy * W + gx] = tmp.v;
+        }
+      }
+  }
+}
+
+template <typename T, int MT>
+int launch(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
+           int H, int W, int d, float slope, hipStream_t stream) {
+  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+  const int rows = TH + 2 * d;
+  const size_t lds = (size_t)(4 * rows * XW + 2 * 4 * MT * 32) * 16;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(NTHREADS), lds, stream,
+                     (const T*)x, xbs, (const T*)wp, bias, (T*)y, ybs, Cin, Cout, H, W, d, tiles_x, tiles_y, slope);
+  return check_launch("conv3x3_forward");
+}
+
+}  // namespace conv
+}  // namespace upf
+
+extern "C" long long upf_conv3x3_packed_bytes(int Cin, int Cout) {
+  return 9ll * upf::conv::pad32(Cout) * upf::conv::pad32(Cin) * 2;
+}
+
+extern "C" int upf_conv3x3_pack_weights(const void* w, void* w_packed, int Cin, int Cout, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(w && w_packed && Cin > 0 && Cout > 0, UPF_EINVAL, "conv3x3_pack_weights: bad arguments");
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv3x3: bf16 / fp16 only (fp32 convolutions stay with MIOpen)");
+  const long long total = 9ll * conv::pad32(Cout) * conv::pad32(Cin);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == UPF_BF16)
+    hipLaunchKernelGGL((conv::pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)w_packed, Cin, Cout);
+  else
+    hipLaunchKernelGGL((conv::pack_weights_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)w, (f16_t*)w_packed, Cin, Cout);
+  return check_launch("conv3x3_pack_weights");
+}
+
+extern "C" int upf_conv3x3_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
+                                   void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
+                                   int dilation, float leaky_slope, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv3x3_forward: null pointer");
+  UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Cout <= 128 && H > 0 && W > 0, UPF_EINVAL,
+              "conv3x3_forward: bad shape B=%d Cin=%d Cout=%d H=%d W=%d (Cout <= 128)", B, Cin, Cout, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv3x3_forward: bf16 / fp16 only");
+  UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv3x3_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
+  UPF_REQUIRE(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0, UPF_EALIGN, "conv3x3_forward: needs W %% 8 == 0 and 16-byte aligned x");
+  UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv3x3_forward: image too large for one buffer descriptor");
+  const int mt = (Cout + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+#define UPF_CONV_CASE(T)                                                                                                        \
+  switch (mt) {                                                                                                                 \
+    case 1: return conv::launch<T, 1>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
+    case 2: return conv::launch<T, 2>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
+    case 3: return conv::launch<T, 3>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
+    default: return conv::launch<T, 4>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
+  }
+  if (dtype == UPF_BF16) { UPF_CONV_CASE(bf16_t) } else { UPF_CONV_CASE(f16_t) }
+#undef UPF_CONV_CASE
+}

@@ -46,20 +46,41 @@ void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int
   const int seg = blockIdx.x - (int)row * nseg;
   const int i0 = seg * seglen, i1 = min(HW, i0 + seglen);
   const T* xr = x + row * HW;
-  // one sweep: sums of (x - K) and (x - K)^2 about a pivot K taken from the segment itself, so that
-  // M2 = s2 - s1^2/n loses at most a bit or two (|K - mean| is of the order of the spread)
-  const float K = Elem<T>::load(xr + i0);
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
-    if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
-#pragma unroll
-      for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
-    } else { const float d = Elem<T>::load(xr + i) - K; s1 += d; s2 += d * d; }
-  }
   const float cnt = (float)(i1 - i0);
-  const float t1 = block_sum(s1, sh), t2 = block_sum(s2, sh);
-  const float mean = K + t1 / cnt;
-  const float m2 = fmaxf(t2 - t1 * (t1 / cnt), 0.f);
+  float mean, m2;
+  if constexpr (sizeof(typename Elem<T>::store_t) == 2) {
+    // 16-bit features: ONE sweep — sums of (x - K) and (x - K)^2 about a pivot K taken from the segment
+    // itself, so that M2 = s2 - s1^2/n loses at most a bit or two (far below the bf16/fp16 output rounding)
+    const float K = Elem<T>::load(xr + i0);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
+      if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
+      } else { const float d = Elem<T>::load(xr + i) - K; s1 += d; s2 += d * d; }
+    }
+    const float t1 = block_sum(s1, sh), t2 = block_sum(s2, sh);
+    mean = K + t1 / cnt;
+    m2 = fmaxf(t2 - t1 * (t1 / cnt), 0.f);
+  } else {
+    // fp32 is the parity mode: exact two-sweep mean / M2 (the second sweep hits L2)
+    float s = 0.f;
+    for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
+      if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s += v[k];
+      } else s += Elem<T>::load(xr + i);
+    }
+    mean = block_sum(s, sh) / cnt;
+    float ss = 0.f;
+    for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
+      if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float d = v[k] - mean; ss += d * d; }
+      } else { const float d = Elem<T>::load(xr + i) - mean; ss += d * d; }
+    }
+    m2 = block_sum(ss, sh);
+  }
   if (threadIdx.x == 0) {
     float* w = ws + ((size_t)row * nseg + seg) * 3;
     w[0] = cnt; w[1] = mean; w[2] = m2;

@@ -135,9 +135,46 @@ class WarpingLayer(nn.Module):
         return ops.warp(x, flow.float() * scale, self.mask_mode)
 
 
+class _PackedConv3x3(object):
+    """Lazily packed weights of one `conv(...)` Sequential for the matrix-core kernel (csrc/conv3x3.hip):
+    re-packed when the parameter changes (version counter), dtype or device."""
+
+    def __init__(self, seq):
+        self.conv = seq[0]
+        self.slope = 0.1 if any(isinstance(m, nn.LeakyReLU) for m in seq) else 0.0
+        self.key = None
+        self.packed = None
+        self.bias = None
+
+    def get(self):
+        w = self.conv.weight
+        key = (w._version, w.dtype, w.device, w.data_ptr())
+        if key != self.key:
+            self.packed = ops.conv3x3_pack(w)
+            self.bias = self.conv.bias.detach().float().contiguous()
+            self.key = key
+        return self.packed, self.bias
+
+    def __call__(self, x_view, y_view):
+        packed, bias = self.get()
+        return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, self.conv.dilation[0], self.slope)
+
+
+def _fast_conv_ok(t):
+    """Inference in bf16/fp16 on the GPU with 8-pixel aligned rows: the hand-written MFMA convolution and
+    the copy-free concat buffer apply; otherwise the same arithmetic runs through MIOpen + torch.cat."""
+    return (not torch.is_grad_enabled()) and t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.shape[3] % 8 == 0
+
+
 class _DenseStack(tools.abstract_model):
     """conv1..conv5 each see everything before them; new features are concatenated in front
-    (pwc_modules.py:279-286 / model/upflow.py:53-60)."""
+    (pwc_modules.py:279-286 / model/upflow.py:53-60).
+
+    Fast path: the growing concatenation lives in ONE buffer laid out
+        [conv5 | conv4 | conv3 | conv2 | conv1 | x | tail]
+    every conv reads a channel SUFFIX of it and writes its own slice (bias + LeakyReLU fused), so the five
+    `torch.cat` copies, the separate activation passes and MIOpen's im2col / layout transposes vanish."""
+    _NAMES = ('conv1', 'conv2', 'conv3', 'conv4', 'conv5')
 
     def _build(self, ch_in, f_channels, out_channel):
         n = ch_in
@@ -145,10 +182,37 @@ class _DenseStack(tools.abstract_model):
             setattr(self, 'conv%d' % (i + 1), conv(n, f))
             n += f
         self.conv_last = conv(n, out_channel, isReLU=False)
+        self._ch_in, self._f, self._n_total = ch_in, tuple(f_channels), n
+        self._packed = None
         return n
 
+    def alloc_buffer(self, B, H, W, dtype, device, tail=0):
+        """-> (buf [B, n_total + tail, H, W], x_view = the slot of the stack's input)."""
+        buf = torch.empty((B, self._n_total + tail, H, W), dtype=dtype, device=device)
+        x0 = self._n_total - self._ch_in
+        return buf, buf[:, x0:self._n_total]
+
+    def forward_in_buffer(self, buf, out=None):
+        """buf from alloc_buffer with the input slot filled -> (x5 view [B, n_total, H, W], x_out)."""
+        if self._packed is None:
+            self._packed = [_PackedConv3x3(getattr(self, n)) for n in self._NAMES] + [_PackedConv3x3(self.conv_last)]
+        nt = self._n_total
+        hi = nt - self._ch_in
+        for pc, f in zip(self._packed[:5], self._f):
+            pc(buf[:, hi:nt], buf[:, hi - f:hi])
+            hi -= f
+        x5 = buf[:, :nt]
+        if out is None:
+            out = torch.empty((buf.shape[0], self.conv_last[0].out_channels) + tuple(buf.shape[2:]), dtype=buf.dtype, device=buf.device)
+        self._packed[5](x5, out)
+        return x5, out
+
     def forward(self, x):
-        for name in ('conv1', 'conv2', 'conv3', 'conv4', 'conv5'):
+        if _fast_conv_ok(x):
+            buf, slot = self.alloc_buffer(x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device)
+            slot.copy_(x)
+            return self.forward_in_buffer(buf)
+        for name in self._NAMES:
             x = torch.cat([getattr(self, name)(x), x], dim=1)
         return x, self.conv_last(x)
 
@@ -187,9 +251,21 @@ class ContextNetwork_v2_(nn.Module):
         dil = (1, 2, 4, 8, 16, 1, 1)
         chans = (ch_in,) + tuple(f_channels)
         self.convs = nn.Sequential(*[conv(chans[i], chans[i + 1], 3, 1, dil[i], isReLU=(i < 6)) for i in range(7)])
+        self._packed = None
 
     def forward(self, x):
-        return self.convs(x)
+        if not _fast_conv_ok(x):
+            return self.convs(x)
+        if self._packed is None:
+            self._packed = [_PackedConv3x3(c) for c in self.convs]
+        for seq, pc in zip(self.convs, self._packed):
+            co = seq[0].out_channels
+            if ops.conv3x3_supported(x, co, seq[0].dilation[0]):
+                y = torch.empty((x.shape[0], co) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+                x = pc(x, y)
+            else:                                   # dilation 16: MIOpen
+                x = seq(x.contiguous())
+        return x
 
 
 class ContextNetwork(ContextNetwork_v2_):

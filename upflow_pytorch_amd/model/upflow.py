@@ -23,7 +23,7 @@ from .. import ops
 from ..utils.tools import tools
 from ..utils.loss import loss_functions
 from .pwc_modules import (conv, initialize_msra, upsample2d_flow_as, upsample_flow, FlowEstimatorDense_v2,
-                          ContextNetwork_v2_, WarpingLayer_no_div, FeatureExtractor, _DenseStack)
+                          ContextNetwork_v2_, WarpingLayer_no_div, FeatureExtractor, _DenseStack, _fast_conv_ok)
 from .correlation_package.correlation import Correlation
 
 
@@ -51,7 +51,15 @@ class network_tools():
             if flow_init.shape[2:] != feature_1.shape[2:]:
                 flow_init = upsample2d_flow_as(flow_init, feature_1, mode="bilinear", if_rate=True)
             feature_2_warp = self.warping_layer(feature_2, flow_init)
-            _, x_out = self.dense_estimator_mask(torch.cat((feature_1, feature_2_warp), dim=1))
+            est = self.dense_estimator_mask
+            if _fast_conv_ok(feature_1):
+                # concat-free: both halves of the estimator input are written into its buffer slot
+                buf, slot = est.alloc_buffer(feature_1.shape[0], feature_1.shape[2], feature_1.shape[3], feature_1.dtype, feature_1.device)
+                slot[:, :feature_1.shape[1]] = feature_1
+                slot[:, feature_1.shape[1]:] = feature_2_warp
+                _, x_out = est.forward_in_buffer(buf)
+            else:
+                _, x_out = est(torch.cat((feature_1, feature_2_warp), dim=1))
             # slice + sigmoid + (up-sampling) + torch_warp + blend: ONE launch (csrc/sgu_blend.hip)
             return ops.sgu_blend(flow_init, x_out, output_level_flow)
 
@@ -364,6 +372,8 @@ class UPFlow_net(tools.abstract_model):
                       moments_across_images=self.conf.norm_moments_across_images)
             feature_1, feature_2_warp = network_tools.normalize_features((feature_1, feature_2_warp), **kw)
             feature_2, feature_1_warp = network_tools.normalize_features((feature_2, feature_1_warp), **kw)
+        if _fast_conv_ok(feature_1):
+            return self._decode_fast(feature_1, feature_2_warp, feature_1_1x1, flow_1_up, feature_2, feature_1_warp, feature_2_1x1, flow_2_up)
         in_1 = self._estimator_input(feature_1, feature_2_warp, feature_1_1x1, flow_1_up)
         in_2 = self._estimator_input(feature_2, feature_1_warp, feature_2_1x1, flow_2_up)
         feat_1, res_1 = self.flow_estimators(in_1)
@@ -372,6 +382,31 @@ class UPFlow_net(tools.abstract_model):
         fine_1 = self.context_networks(torch.cat([feat_1, (flow_1_up + res_1).to(feat_1.dtype)], dim=1)).float()
         fine_2 = self.context_networks(torch.cat([feat_2, (flow_2_up + res_2).to(feat_2.dtype)], dim=1)).float()
         return flow_1_up, flow_2_up, res_1 + fine_1, res_2 + fine_2
+
+    def _decode_fast(self, f1, f2w, a1, flow_1_up, f2, f1w, a2, flow_2_up):
+        """Inference fast path of decode_level_res (bf16/fp16): both directions share the weights, so they run
+        as ONE batch of 2B; the estimator input, its five dense outputs and the context input live in one
+        [2B, 565, H, W] buffer: corr81 writes channels 448..528 (LeakyReLU fused), the 1x1 features and the
+        flow go to 529..562, every conv reads a suffix and writes its slice, the refined flow is appended at
+        563..564 for the context network.  No torch.cat, no separate activation or bias kernels."""
+        est = self.flow_estimators
+        B, _, H, W = f1.shape
+        buf, slot = est.alloc_buffer(2 * B, H, W, f1.dtype, f1.device, tail=2)
+        nc = self.dim_corr
+        ops.corr81_forward_raw(f1.contiguous(), f2w.contiguous(), out=slot[:B, :nc], leaky_slope=0.1)
+        ops.corr81_forward_raw(f2.contiguous(), f1w.contiguous(), out=slot[B:, :nc], leaky_slope=0.1)
+        slot[:B, nc:nc + 32] = a1
+        slot[B:, nc:nc + 32] = a2
+        slot[:B, nc + 32:] = flow_1_up
+        slot[B:, nc + 32:] = flow_2_up
+        x5, res = est.forward_in_buffer(buf)
+        res = res.float()
+        flow_up = torch.cat([flow_1_up, flow_2_up], dim=0)
+        nt = est._n_total
+        buf[:, nt:] = flow_up + res
+        fine = self.context_networks(buf).float()
+        total = res + fine
+        return flow_1_up, flow_2_up, total[:B], total[B:]
 
     def froze_PWC(self):
         for part in (self.feature_pyramid_extractor, self.flow_estimators, self.context_networks, self.conv_1x1):
