@@ -93,14 +93,17 @@ int upf_correlation_out_shape(int H, int W, int pad_size, int kernel_size, int m
  *                    mask = grid_sample(ones) >= 1.0, reproduced bit-exactly: the four weight*tap
  *                    products in fp32, summed ((nw+ne)+sw)+se, no FMA contraction
  *   UPF_MASK_ROBUST  exact in-bounds predicate (non-default; SURVEY.md §7-H2 protocol P3b)
- *   x,y : [B,C,H,W] of `dtype`;  flow : [B,2,H,W] fp32. */
+ *   x,y : [B,C,H,W] of `dtype`;  flow : [B,2,H,W] fp32.
+ *   batch_shift: output item n samples x[(n + batch_shift) % B] — with both frames of a pair stacked along
+ *   the batch ([im1 features; im2 features]) batch_shift = B/2 warps "the other frame" for both flow
+ *   directions in one launch, no gather copy.  0 = plain. */
 int upf_warp_forward(const void* x, const float* flow, void* y,
-                     int B, int C, int H, int W, int dtype, int mask_mode, void* stream);
+                     int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
 /* grad wrt x (scatter-add, fp32 buffer gx32 [B,C,H,W] that the CALLER has zero-filled) and wrt
  * flow (gflow [B,2,H,W] fp32, fully written).  grad_y : [B,C,H,W] of `dtype`. */
 int upf_warp_backward(const void* x, const float* flow, const void* grad_y,
                       float* gx32, float* gflow,
-                      int B, int C, int H, int W, int dtype, int mask_mode, void* stream);
+                      int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
 
 /* ---- flow up-sampling -------------------------------------------------------------------------
  * upsample2d_flow_as / upsample_flow (model/pwc_modules.py:77-104): bilinear align_corners=True

@@ -56,7 +56,7 @@ def main(only=None):
                 def rec(op, t, byt):
                     res.append(dict(op=op, cfg=cfg, B=B, C=C, H=H, W=W, dtype=str(dt).replace('torch.', ''), us=t, GBs=byt / t / 1e3))
                 rec('corr81_fwd', graph_time(lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)), s * B * H * W * (2 * C + 81))
-                rec('warp_fwd', graph_time(lambda: ops.WarpFunction.apply(f2, flow, 1)), B * H * W * (2 * s * C + 8))
+                rec('warp_fwd', graph_time(lambda: ops.WarpFunction.apply(f2, flow, 1, 0)), B * H * W * (2 * s * C + 8))
                 rec('normalize', graph_time(lambda: ops.normalize(f1)), B * H * W * C * 2 * s)
                 if cfg == 3:
                     rec('corr81_bwd', graph_time(lambda: ops.corr81_backward_raw(f1, f2, go)), s * B * H * W * (4 * C + 81))

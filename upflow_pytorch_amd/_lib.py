@@ -26,8 +26,8 @@ SIGNATURES = {
     'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_out_shape': [_i, _i, _i, _i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],
-    'upf_warp_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_warp_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_forward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_backward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_sgu_blend_forward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -85,17 +85,18 @@ __device__ __forceinline__ float sample(const T* __restrict__ plane, const Pixel
 template <typename T, int PXT>
 __global__ __launch_bounds__(THREADS)
 void warp_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, T* __restrict__ y,
-                     int C, int H, int W, int cpt, int mask_mode) {
+                     int C, int H, int W, int cpt, int mask_mode, int shift) {
   const int HW = H * W;
   const int p0 = (blockIdx.x * THREADS + threadIdx.x) * PXT;
   if (p0 >= HW) return;
   const int n = blockIdx.z;
+  const int ns = (n + shift) % (int)gridDim.z;          // source image (batch_shift: sample the OTHER frame of a stacked pair)
   const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
   const float* fl = flow + (size_t)n * 2 * HW;
   PixelTaps s[PXT];
 #pragma unroll
   for (int k = 0; k < PXT; ++k) s[k] = make_pixel(fl, p0 + k, H, W, mask_mode);
-  const T* xb = x + ((size_t)n * C + c_begin) * HW;
+  const T* xb = x + ((size_t)ns * C + c_begin) * HW;
   T* yb = y + ((size_t)n * C + c_begin) * HW + p0;
 #pragma unroll 4
   for (int c = c_begin; c < c_end; ++c, xb += HW, yb += HW) {
@@ -115,11 +116,12 @@ void warp_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, T*
 template <typename T>
 __global__ __launch_bounds__(THREADS)
 void warp_fwd_narrow_kernel(const T* __restrict__ x, const float* __restrict__ flow, T* __restrict__ y,
-                            int C, int H, int W, int mask_mode) {
+                            int C, int H, int W, int mask_mode, int shift) {
   const int HW = H * W;
   const int p = blockIdx.x * THREADS + threadIdx.x;
   if (p >= HW) return;
   const int n = blockIdx.z;
+  const int ns = (n + shift) % (int)gridDim.z;
   const int i = p / W, j = p - i * W;
   const float fx = flow[((size_t)n * 2 + 0) * HW + p], fy = flow[((size_t)n * 2 + 1) * HW + p];
   const Taps t = make_taps(j, i, fx, fy, H, W);
@@ -129,7 +131,7 @@ void warp_fwd_narrow_kernel(const T* __restrict__ x, const float* __restrict__ f
   const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
   const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f, w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
   for (int c = 0; c < C; ++c) {
-    const T* xc = x + ((size_t)n * C + c) * HW;
+    const T* xc = x + ((size_t)ns * C + c) * HW;
     const float r = ((Elem<T>::load(xc + o0) * w0 + Elem<T>::load(xc + o1) * w1) + Elem<T>::load(xc + o2) * w2) + Elem<T>::load(xc + o3) * w3;
     Elem<T>::store(y + ((size_t)n * C + c) * HW + p, valid ? r : 0.f);
   }
@@ -143,11 +145,12 @@ template <typename T>
 __global__ __launch_bounds__(THREADS)
 void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, const T* __restrict__ gy,
                      float* __restrict__ gx32, float* __restrict__ gflow,
-                     int C, int H, int W, int cpt, int mask_mode) {
+                     int C, int H, int W, int cpt, int mask_mode, int shift) {
   const int HW = H * W;
   const int p = blockIdx.x * THREADS + threadIdx.x;
   if (p >= HW) return;
   const int n = blockIdx.z;
+  const int ns = (n + shift) % (int)gridDim.z;
   const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
   const int i = p / W, j = p - i * W;
   const float fx = flow[((size_t)n * 2 + 0) * HW + p];
@@ -161,9 +164,9 @@ void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, co
   // d w / d ix, d w / d iy  for nw, ne, sw, se
   const float ax = (float)(t.x0 + 1) - t.ix, bx = t.ix - (float)t.x0;
   const float ay = (float)(t.y0 + 1) - t.iy, by = t.iy - (float)t.y0;
-  const T* xb = x + ((size_t)n * C + c_begin) * HW;
+  const T* xb = x + ((size_t)ns * C + c_begin) * HW;
   const T* gb = gy + ((size_t)n * C + c_begin) * HW + p;
-  float* gxb = gx32 + ((size_t)n * C + c_begin) * HW;
+  float* gxb = gx32 + ((size_t)ns * C + c_begin) * HW;
   float gix = 0.f, giy = 0.f;
   for (int c = c_begin; c < c_end; ++c, xb += HW, gb += HW, gxb += HW) {
     const float g = Elem<T>::load(gb);
@@ -193,16 +196,17 @@ static int pick_cpt(int B, int C, int HW) {
 }  // namespace upf
 
 extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B, int C, int H, int W,
-                                int dtype, int mask_mode, void* stream) {
+                                int dtype, int mask_mode, int batch_shift, void* stream) {
   using namespace upf;
   UPF_REQUIRE(x && flow && y, UPF_EINVAL, "warp_forward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_forward: bad mask_mode %d", mask_mode);
+  UPF_REQUIRE(batch_shift >= 0 && batch_shift < B, UPF_EINVAL, "warp_forward: batch_shift %d not in [0,%d)", batch_shift, B);
   const int HW = H * W;
   hipStream_t st = (hipStream_t)stream;
   if (W < 2) {
     UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((warp::warp_fwd_narrow_kernel<T>), dim3(cdiv(HW, warp::THREADS), 1, B), dim3(warp::THREADS), 0, st,
-                                              (const T*)x, flow, (T*)y, C, H, W, mask_mode));
+                                              (const T*)x, flow, (T*)y, C, H, W, mask_mode, batch_shift));
     return check_launch("warp_forward");
   }
   // two pixels per thread (4-byte stores) for 16-bit features when rows keep pixel pairs aligned
@@ -211,17 +215,18 @@ extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B
   const int cpt = warp::pick_cpt(B, C, HW / pxt);
   dim3 grid(cdiv(cdiv(HW, pxt), warp::THREADS), cdiv(C, cpt), B);
   UPF_DISPATCH(dtype, T,
-               if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode);
-               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode));
+               if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode, batch_shift);
+               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode, batch_shift));
   return check_launch("warp_forward");
 }
 
 extern "C" int upf_warp_backward(const void* x, const float* flow, const void* grad_y, float* gx32, float* gflow,
-                                 int B, int C, int H, int W, int dtype, int mask_mode, void* stream) {
+                                 int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream) {
   using namespace upf;
   UPF_REQUIRE(x && flow && grad_y && gx32 && gflow, UPF_EINVAL, "warp_backward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_backward: bad shape");
   UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_backward: bad mask_mode %d", mask_mode);
+  UPF_REQUIRE(batch_shift >= 0 && batch_shift < B, UPF_EINVAL, "warp_backward: batch_shift %d not in [0,%d)", batch_shift, B);
   const int HW = H * W;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(gx32, 0, (size_t)B * C * HW * sizeof(float), s);
@@ -231,6 +236,6 @@ extern "C" int upf_warp_backward(const void* x, const float* flow, const void* g
   dim3 grid(cdiv(HW, warp::THREADS), cdiv(C, cpt), B);
   UPF_DISPATCH(dtype, T,
                hipLaunchKernelGGL((warp::warp_bwd_kernel<T>), grid, dim3(warp::THREADS), 0, s,
-                                  (const T*)x, flow, (const T*)grad_y, gx32, gflow, C, H, W, cpt, mask_mode));
+                                  (const T*)x, flow, (const T*)grad_y, gx32, gflow, C, H, W, cpt, mask_mode, batch_shift));
   return check_launch("warp_backward");
 }

@@ -115,8 +115,8 @@ class WarpingLayer_no_div(nn.Module):
         super(WarpingLayer_no_div, self).__init__()
         self.mask_mode = mask_mode
 
-    def forward(self, x, flow):
-        return ops.warp(x, flow, self.mask_mode)
+    def forward(self, x, flow, batch_shift=0):
+        return ops.warp(x, flow, self.mask_mode, batch_shift)
 
 
 class WarpingLayer(nn.Module):

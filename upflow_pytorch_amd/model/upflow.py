@@ -46,11 +46,13 @@ class network_tools():
                                                       conv(16, 32, kernel_size=3, stride=1, dilation=1),
                                                       conv(32, 32, stride=2), )
 
-        def forward(self, flow_init, feature_1, feature_2, output_level_flow=None):
-            """-> (flow_init, flow_up, inter_flow, inter_mask), model/upflow.py:71-89."""
+        def forward(self, flow_init, feature_1, feature_2, output_level_flow=None, batch_shift=0):
+            """-> (flow_init, flow_up, inter_flow, inter_mask), model/upflow.py:71-89.
+            batch_shift (not in the reference): both flow directions stacked along the batch, feature_2 is
+            then feature_1 itself and item n's "other frame" is item (n + batch_shift) % B."""
             if flow_init.shape[2:] != feature_1.shape[2:]:
                 flow_init = upsample2d_flow_as(flow_init, feature_1, mode="bilinear", if_rate=True)
-            feature_2_warp = self.warping_layer(feature_2, flow_init)
+            feature_2_warp = self.warping_layer(feature_2, flow_init, batch_shift)
             est = self.dense_estimator_mask
             if _fast_conv_ok(feature_1):
                 # concat-free: both halves of the estimator input are written into its buffer slot
@@ -318,6 +320,8 @@ class UPFlow_net(tools.abstract_model):
         cdt = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype      # compute dtype of the convs
         x1_raw = x1_raw.to(cdt)
         x2_raw = x2_raw.to(cdt)
+        if not torch.is_grad_enabled():
+            return self._forward_stacked(x1_raw, x2_raw)
         x1_pyramid = self.feature_pyramid_extractor(x1_raw)
         x2_pyramid = self.feature_pyramid_extractor(x2_raw)
         B, _, h0, w0 = x1_pyramid[0].shape
@@ -340,6 +344,76 @@ class UPFlow_net(tools.abstract_model):
             flow_f_out = self.self_guided_upsample(flow_up_bilinear=flow_f, feature_1=g1, feature_2=g2, output_level_flow=flow_f_out)
             flow_b_out = self.self_guided_upsample(flow_up_bilinear=flow_b, feature_1=g2, feature_2=g1, output_level_flow=flow_b_out)
         return flow_f_out, flow_b_out, flows[::-1]
+
+    def _forward_stacked(self, x1_raw, x2_raw):
+        """Inference form of forward_2_frame_v3 (model/upflow.py:494-533), same arithmetic, different schedule:
+        the two frames are stacked along the batch, X = [im1; im2], so item n < B carries the forward direction
+        and item n >= B the backward one.  Every stage then runs ONCE on 2B items with shared weights — feature
+        pyramid, 1x1 convs, SGU, warp (batch_shift = B samples "the other frame" without a gather copy),
+        normalisation, cost volume, estimator, context network — halving the launch count and doubling every
+        grid, which is what the coarse levels need on a 256-CU chip."""
+        B = x1_raw.shape[0]
+        X = torch.cat([x1_raw, x2_raw], dim=0)
+        pyramid = self.feature_pyramid_extractor(X)
+        h0, w0 = pyramid[0].shape[2:]
+        flow = torch.zeros(2 * B, 2, h0, w0, dtype=torch.float32, device=X.device)
+        sgu = self.conf.if_sgu_upsample
+        flows = []
+        for level in range(self.output_level + 1):
+            Fm = pyramid[level]
+            A = self.conv_1x1[level](Fm)
+            flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
+            if level == 0:
+                Fw = torch.roll(Fm, shifts=B, dims=0)                        # no warp at the coarsest level (:539-541)
+            else:
+                if sgu:
+                    flow_up = self.sgi_model(flow_up, A, A, batch_shift=B)[1]
+                Fw = self.warping_layer(Fm, flow_up, batch_shift=B)
+            if self.conf.if_norm_before_cost_volume:
+                kw = dict(normalize=True, center=True, moments_across_channels=self.conf.norm_moments_across_channels,
+                          moments_across_images=self.conf.norm_moments_across_images)
+                if self.conf.norm_moments_across_images:                     # statistics shared inside each (f, f_warp) pair
+                    n1, n2w = network_tools.normalize_features((Fm[:B], Fw[:B]), **kw)
+                    n2, n1w = network_tools.normalize_features((Fm[B:], Fw[B:]), **kw)
+                    Fn, Fwn = torch.cat([n1, n2], 0), torch.cat([n2w, n1w], 0)
+                else:
+                    Fn, Fwn = network_tools.normalize_features((Fm, Fw), **kw)
+            else:
+                Fn, Fwn = Fm, Fw
+            total = self._level_update(Fn, Fwn, A, flow_up)
+            flow = flow_up + total
+            flows.append([flow[:B], flow[B:]])
+        flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
+        if sgu:
+            G = self.sgi_model.output_conv(X)
+            flow_out = self.sgi_model(flow, G, G, output_level_flow=flow_out, batch_shift=B)[1]
+        return flow_out[:B], flow_out[B:], flows[::-1]
+
+    def _level_update(self, Fn, Fwn, A, flow_up):
+        """res + fine for all 2B stacked items (model/upflow.py:557-572)."""
+        est = self.flow_estimators
+        nb, _, H, W = Fn.shape
+        nc = self.dim_corr
+        if _fast_conv_ok(Fn):
+            # one [2B, 565, H, W] buffer: corr81 (+LeakyReLU) -> 448..528, 1x1 features and flow -> 529..562, each
+            # dense conv reads a suffix and writes its slice, refined flow appended at 563..564 for the context net
+            buf, slot = est.alloc_buffer(nb, H, W, Fn.dtype, Fn.device, tail=2)
+            ops.corr81_forward_raw(Fn.contiguous(), Fwn.contiguous(), out=slot[:, :nc], leaky_slope=0.1)
+            slot[:, nc:nc + 32] = A
+            slot[:, nc + 32:] = flow_up
+            x5, res = est.forward_in_buffer(buf)
+            res = res.float()
+            buf[:, est._n_total:] = flow_up + res
+            fine = self.context_networks(buf).float()
+            return res + fine
+        x = torch.empty((nb, self.num_ch_in, H, W), dtype=Fn.dtype, device=Fn.device)
+        ops.corr81_forward_raw(Fn.contiguous(), Fwn.contiguous(), out=x[:, :nc], leaky_slope=0.1)
+        x[:, nc:nc + 32] = A
+        x[:, nc + 32:] = flow_up
+        feat, res = est(x)
+        res = res.float()
+        fine = self.context_networks(torch.cat([feat, (flow_up + res).to(feat.dtype)], dim=1)).float()
+        return res + fine
 
     def _estimator_input(self, f_a, f_b_warp, feat_1x1, flow):
         """cat[LeakyReLU(corr81(f_a, f_b_warp)), feat_1x1, flow]  (model/upflow.py:557-566).
@@ -372,8 +446,6 @@ class UPFlow_net(tools.abstract_model):
                       moments_across_images=self.conf.norm_moments_across_images)
             feature_1, feature_2_warp = network_tools.normalize_features((feature_1, feature_2_warp), **kw)
             feature_2, feature_1_warp = network_tools.normalize_features((feature_2, feature_1_warp), **kw)
-        if _fast_conv_ok(feature_1):
-            return self._decode_fast(feature_1, feature_2_warp, feature_1_1x1, flow_1_up, feature_2, feature_1_warp, feature_2_1x1, flow_2_up)
         in_1 = self._estimator_input(feature_1, feature_2_warp, feature_1_1x1, flow_1_up)
         in_2 = self._estimator_input(feature_2, feature_1_warp, feature_2_1x1, flow_2_up)
         feat_1, res_1 = self.flow_estimators(in_1)
@@ -382,31 +454,6 @@ class UPFlow_net(tools.abstract_model):
         fine_1 = self.context_networks(torch.cat([feat_1, (flow_1_up + res_1).to(feat_1.dtype)], dim=1)).float()
         fine_2 = self.context_networks(torch.cat([feat_2, (flow_2_up + res_2).to(feat_2.dtype)], dim=1)).float()
         return flow_1_up, flow_2_up, res_1 + fine_1, res_2 + fine_2
-
-    def _decode_fast(self, f1, f2w, a1, flow_1_up, f2, f1w, a2, flow_2_up):
-        """Inference fast path of decode_level_res (bf16/fp16): both directions share the weights, so they run
-        as ONE batch of 2B; the estimator input, its five dense outputs and the context input live in one
-        [2B, 565, H, W] buffer: corr81 writes channels 448..528 (LeakyReLU fused), the 1x1 features and the
-        flow go to 529..562, every conv reads a suffix and writes its slice, the refined flow is appended at
-        563..564 for the context network.  No torch.cat, no separate activation or bias kernels."""
-        est = self.flow_estimators
-        B, _, H, W = f1.shape
-        buf, slot = est.alloc_buffer(2 * B, H, W, f1.dtype, f1.device, tail=2)
-        nc = self.dim_corr
-        ops.corr81_forward_raw(f1.contiguous(), f2w.contiguous(), out=slot[:B, :nc], leaky_slope=0.1)
-        ops.corr81_forward_raw(f2.contiguous(), f1w.contiguous(), out=slot[B:, :nc], leaky_slope=0.1)
-        slot[:B, nc:nc + 32] = a1
-        slot[B:, nc:nc + 32] = a2
-        slot[:B, nc + 32:] = flow_1_up
-        slot[B:, nc + 32:] = flow_2_up
-        x5, res = est.forward_in_buffer(buf)
-        res = res.float()
-        flow_up = torch.cat([flow_1_up, flow_2_up], dim=0)
-        nt = est._n_total
-        buf[:, nt:] = flow_up + res
-        fine = self.context_networks(buf).float()
-        total = res + fine
-        return flow_1_up, flow_2_up, total[:B], total[B:]
 
     def froze_PWC(self):
         for part in (self.feature_pyramid_extractor, self.flow_estimators, self.context_networks, self.conv_1x1):

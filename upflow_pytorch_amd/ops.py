@@ -127,7 +127,7 @@ def correlation_forward_general(in1, in2, pad_size, kernel_size, max_displacemen
 # ------------------------------------------------------------------------------------------------
 class WarpFunction(Function):
     @staticmethod
-    def forward(ctx, x, flow, mask_mode):
+    def forward(ctx, x, flow, mask_mode, batch_shift=0):
         x = x.contiguous()
         flow = _f32(flow).contiguous()
         if x.dim() != 4 or flow.shape != (x.shape[0], 2, x.shape[2], x.shape[3]):
@@ -138,8 +138,9 @@ class WarpFunction(Function):
         y = torch.empty_like(x)
         with torch.cuda.device(dev):
             _lib.call('upf_warp_forward', _lib.ptr(x), _lib.ptr(flow), _lib.ptr(y), B, C, H, W,
-                      _lib.dtype_code(x), mask_mode, _lib.stream_ptr(dev))
+                      _lib.dtype_code(x), mask_mode, int(batch_shift), _lib.stream_ptr(dev))
         ctx.mask_mode = mask_mode
+        ctx.batch_shift = int(batch_shift)
         ctx.save_for_backward(x, flow)
         return y
 
@@ -153,14 +154,15 @@ class WarpFunction(Function):
         gflow = torch.empty_like(flow)
         with torch.cuda.device(dev):
             _lib.call('upf_warp_backward', _lib.ptr(x), _lib.ptr(flow), _lib.ptr(gy), _lib.ptr(gx32), _lib.ptr(gflow),
-                      B, C, H, W, _lib.dtype_code(x), ctx.mask_mode, _lib.stream_ptr(dev))
-        return gx32.to(x.dtype), gflow, None
+                      B, C, H, W, _lib.dtype_code(x), ctx.mask_mode, ctx.batch_shift, _lib.stream_ptr(dev))
+        return gx32.to(x.dtype), gflow, None, None
 
 
-def warp(x, flow, mask_mode='literal'):
+def warp(x, flow, mask_mode='literal', batch_shift=0):
     """mask_mode None/'none' = tools.torch_warp; 'literal' = WarpingLayer_no_div; 'robust' = exact
-    in-bounds predicate (non-default)."""
-    return WarpFunction.apply(x, flow, _MASKS[mask_mode])
+    in-bounds predicate (non-default).  batch_shift: output item n samples
+    x[(n + batch_shift) % B] (both frames of a pair stacked along the batch: shift B/2 = the other frame)."""
+    return WarpFunction.apply(x, flow, _MASKS[mask_mode], batch_shift)
 
 
 # ------------------------------------------------------------------------------------------------
