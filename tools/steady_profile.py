@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Per-kernel breakdown of ONE steady-state forward from a rocprofv3 kernel trace CSV (splits at occ_check)."""
+import csv, sys
+from collections import defaultdict
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+occ = [i for i, r in enumerate(rows) if 'occ_check' in r['Kernel_Name']]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else len(occ) - 2
+seg = rows[occ[k - 1] + 1:occ[k] + 1]
+agg = defaultdict(lambda: [0, 0.0, 1e18])
+for r in seg:
+    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    n = r['Kernel_Name'][:110]
+    agg[n][0] += 1; agg[n][1] += d; agg[n][2] = min(agg[n][2], d)
+tot = sum(v[1] for v in agg.values())
+print('# one steady-state forward: kernels %d, GPU time %.1f us, wall %.1f us' % (len(seg), tot, (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e3))
+print('%-110s %6s %10s %6s %9s %9s' % ('kernel', 'calls', 'total_us', 'pct', 'avg_us', 'min_us'))
+for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print('%-110s %6d %10.1f %6.2f %9.2f %9.2f' % (n, v[0], v[1], 100 * v[1] / tot, v[1] / v[0], v[2]))

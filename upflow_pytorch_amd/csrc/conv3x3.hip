@@ -69,8 +69,12 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
   }
 }
 
-// MT = number of 32-wide output-channel tiles (1..4)
-template <typename T, int MT>
+// MT = number of 32-wide output-channel tiles (1..4).
+// ALLTAPS (MT <= 2): the weight slices of all 9 taps of a channel chunk are staged together (9*MT*2 KB) and
+// the tap loop runs without barriers — with few output channels the MFMA phase of one tap is far too short
+// to hide the L2 latency of the next tap's weight prefetch, which then dominates (measured: 563->2 channels
+// spent 5.7 us per chunk in nine exposed prefetch+barrier rounds).  MT >= 3 keeps the per-tap double buffer.
+template <typename T, int MT, bool ALLTAPS = (MT <= 2)>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                     T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int d, int tiles_x, int tiles_y, float slope) {
@@ -79,7 +83,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   const int XS_E = 4 * rows * XW;                    // entries (16 B = 8 channels of one pixel) of the x tile
   constexpr int AS_E = 4 * MT * 32;                  // entries of one weight slice: [octet][co]
   uint4* xs = smem;                                  // [octet 4][rows][XW]
-  uint4* as = smem + XS_E;                           // [2][octet 4][MT*32]
+  uint4* as = smem + XS_E;                           // [2 (or 9 with ALLTAPS)][octet 4][MT*32]
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
@@ -132,19 +136,20 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
         dst[2 * pp + 1] = e1;
       }
     }
-    // ---- weight slice of tap 0 -> as[0]
-    for (int e = tid; e < AS_E; e += NTHREADS) {
-      const int oct = e / cop, co = e - oct * cop;
-      const uint32_t off = ((uint32_t)((0 * cop + co) * cip + cc * KC + oct * 8)) * 2u;
+    // ---- weight slices: tap 0 -> as[0]  (ALLTAPS: all 9 taps -> as[0..8])
+    for (int e = tid; e < (ALLTAPS ? 9 : 1) * AS_E; e += NTHREADS) {
+      const int tap0 = e / AS_E, r0 = e - tap0 * AS_E;
+      const int oct = r0 / cop, co = r0 - oct * cop;
+      const uint32_t off = ((uint32_t)((tap0 * cop + co) * cip + cc * KC + oct * 8)) * 2u;
       as[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
     }
     __syncthreads();
 
     for (int tap = 0; tap < 9; ++tap) {
-      const uint4* acur = as + (tap & 1) * AS_E;
+      const uint4* acur = as + (ALLTAPS ? tap : (tap & 1)) * AS_E;
       // prefetch the next tap's weight slice into the other buffer (consumed after the barrier below)
       u32x4 wpre[(AS_E + NTHREADS - 1) / NTHREADS];
-      if (tap + 1 < 9) {
+      if (!ALLTAPS && tap + 1 < 9) {
 #pragma unroll
         for (int j = 0; j < (AS_E + NTHREADS - 1) / NTHREADS; ++j) {
           const int e = tid + j * NTHREADS;
@@ -169,7 +174,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
           for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
         }
       }
-      if (tap + 1 < 9) {
+      if (!ALLTAPS && tap + 1 < 9) {
         uint4* anext = as + ((tap + 1) & 1) * AS_E;
 #pragma unroll
         for (int j = 0; j < (AS_E + NTHREADS - 1) / NTHREADS; ++j) {
@@ -209,7 +214,7 @@ int launch(const void* x, long long xbs, const void* wp, const float* bias, void
            int H, int W, int d, float slope, hipStream_t stream) {
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   const int rows = TH + 2 * d;
-  const size_t lds = (size_t)(4 * rows * XW + 2 * 4 * MT * 32) * 16;
+  const size_t lds = (size_t)(4 * rows * XW + (MT <= 2 ? 9 : 2) * 4 * MT * 32) * 16;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -97,8 +97,10 @@ class FeatureExtractor(nn.Module):
 
     def forward(self, x):
         pyramid = []
+        cache = self.__dict__.setdefault('_fast_cache', {})
         for stage in self.convs:
-            x = stage(x)
+            x = stage[0](x)                            # stride-2 conv: MIOpen
+            x = fast_conv_seq(stage[1], x, cache)      # stride-1 conv: matrix-core kernel when eligible
             pyramid.append(x)
         return pyramid[::-1]
 
@@ -158,6 +160,21 @@ class _PackedConv3x3(object):
     def __call__(self, x_view, y_view):
         packed, bias = self.get()
         return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, self.conv.dilation[0], self.slope)
+
+
+def fast_conv_seq(seq, x, cache):
+    """Run one `conv(...)` Sequential (Conv2d [+ LeakyReLU]) — through the matrix-core kernel when it is a
+    stride-1 3x3 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
+    that keeps the packed weights per Sequential."""
+    c = seq[0]
+    if (_fast_conv_ok(x) and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.groups == 1 and len(seq) <= 2
+            and ops.conv3x3_supported(x, c.out_channels, c.dilation[0])):
+        pc = cache.get(id(seq))
+        if pc is None:
+            pc = cache[id(seq)] = _PackedConv3x3(seq)
+        y = torch.empty((x.shape[0], c.out_channels) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        return pc(x, y)
+    return seq(x if x.is_contiguous() else x.contiguous())
 
 
 def _fast_conv_ok(t):
@@ -251,20 +268,13 @@ class ContextNetwork_v2_(nn.Module):
         dil = (1, 2, 4, 8, 16, 1, 1)
         chans = (ch_in,) + tuple(f_channels)
         self.convs = nn.Sequential(*[conv(chans[i], chans[i + 1], 3, 1, dil[i], isReLU=(i < 6)) for i in range(7)])
-        self._packed = None
 
     def forward(self, x):
         if not _fast_conv_ok(x):
             return self.convs(x)
-        if self._packed is None:
-            self._packed = [_PackedConv3x3(c) for c in self.convs]
-        for seq, pc in zip(self.convs, self._packed):
-            co = seq[0].out_channels
-            if ops.conv3x3_supported(x, co, seq[0].dilation[0]):
-                y = torch.empty((x.shape[0], co) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-                x = pc(x, y)
-            else:                                   # dilation 16: MIOpen
-                x = seq(x.contiguous())
+        cache = self.__dict__.setdefault('_fast_cache', {})
+        for seq in self.convs:                      # the dilation-16 layer falls back to MIOpen inside
+            x = fast_conv_seq(seq, x, cache)
         return x
 
 

@@ -23,7 +23,8 @@ from .. import ops
 from ..utils.tools import tools
 from ..utils.loss import loss_functions
 from .pwc_modules import (conv, initialize_msra, upsample2d_flow_as, upsample_flow, FlowEstimatorDense_v2,
-                          ContextNetwork_v2_, WarpingLayer_no_div, FeatureExtractor, _DenseStack, _fast_conv_ok)
+                          ContextNetwork_v2_, WarpingLayer_no_div, FeatureExtractor, _DenseStack, _fast_conv_ok,
+                          fast_conv_seq)
 from .correlation_package.correlation import Correlation
 
 
@@ -66,7 +67,10 @@ class network_tools():
             return ops.sgu_blend(flow_init, x_out, output_level_flow)
 
         def output_conv(self, x):
-            return self.upsample_output_conv(x)
+            cache = self.__dict__.setdefault('_fast_cache', {})
+            for seq in self.upsample_output_conv:       # stride-1 layers: matrix-core kernel when eligible
+                x = fast_conv_seq(seq, x, cache)
+            return x
 
     @classmethod
     def normalize_features(cls, feature_list, normalize, center, moments_across_channels=True, moments_across_images=True):
