@@ -32,7 +32,7 @@
 namespace upf {
 namespace conv {
 
-constexpr int TH = 8, TW = 32, NTHREADS = 256;
+constexpr int TW = 32, NTHREADS = 256;   // tile = (4*RPW) rows x 32 pixels; RPW = rows per wave (2, or 4 for Cout <= 64)
 constexpr int KC = 32;                    // input channels per chunk (4 octets, 2 MFMA k-steps)
 constexpr int XW = TW + 16;               // staged columns: [x0-8, x0+40) keeps 16-byte alignment of global loads
 constexpr int MAXD = 8;                   // dilation limit (halo rows); larger dilations fall back to MIOpen
@@ -74,11 +74,14 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
 // the tap loop runs without barriers — with few output channels the MFMA phase of one tap is far too short
 // to hide the L2 latency of the next tap's weight prefetch, which then dominates (measured: 563->2 channels
 // spent 5.7 us per chunk in nine exposed prefetch+barrier rounds).  MT >= 3 keeps the per-tap double buffer.
-template <typename T, int MT, bool ALLTAPS = (MT <= 2)>
+// RPW (rows per wave): Cout <= 32 uses 4 rows per wave = a 16x32 tile per workgroup — twice the pixels per
+// staged weight slice, halo row and barrier, which is what bounds the narrow layers.
+template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                     T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int d, int tiles_x, int tiles_y, float slope) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  constexpr int TH = 4 * RPW;
   const int rows = TH + 2 * d;                       // staged rows
   const int XS_E = 4 * rows * XW;                    // entries (16 B = 8 channels of one pixel) of the x tile
   constexpr int AS_E = 4 * MT * 32;                  // entries of one weight slice: [octet][co]
@@ -102,9 +105,9 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   const int ngroups = XW / 8;                        // 6
   const int ntasks = 4 * rows * ngroups;
 
-  f32x16 acc[2][MT];
+  f32x16 acc[RPW][MT];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -113,28 +116,54 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
   const int nchunks = cip / KC;
 
+  // x staging task t -> (channel octet, staged row, 8-pixel group): buffer-load offset of channel 0 of the
+  // octet in chunk 0 (0x80000000 = outside the image) and the LDS entry it fills
+  auto task_geom = [&](int t, uint32_t& off, int& dst) {
+    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
+    const int gy = y0 - d + r, gx = x0 - 8 + 8 * g;
+    const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // W % 8 == 0: a group is all in or all out
+    off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx) * 2u) : 0x80000000u;
+    dst = (oct * rows + r) * XW + 8 * g;
+  };
+  auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
+    const uint32_t o = off + (uint32_t)cc * KC * plane;                           // stays >= 2^31 for outside tasks
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
+  };
+  auto task_store = [&](int dsti, const u32x4 (&ch)[8]) {                         // 8 channel rows x 8 px -> 8 px x 8 channels
+    uint4* dst = xs + dsti;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
+      uint4 e0, e1;
+      e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
+      e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
+      e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
+      e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
+      dst[2 * pp] = e0;
+      dst[2 * pp + 1] = e1;
+    }
+  };
+  // PREFETCH (MT <= 3, where the register budget allows 32 more VGPRs): this thread's first x task of chunk
+  // cc+1 is loaded into registers BEFORE the tap loop of chunk cc and lands in LDS after it, so the HBM/L2
+  // latency of the staging hides under the matrix work instead of heading every chunk.
+  constexpr bool PREFETCH = (MT <= 3);
+  uint32_t off0 = 0x80000000u; int dst0 = 0;
+  u32x4 pre[8];
+  if constexpr (PREFETCH) {
+    task_geom(tid, off0, dst0);
+    task_load(off0, 0, pre);
+  }
+
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();                                 // previous chunk fully consumed
     // ---- stage the x tile (+halo) of channels [32cc, 32cc+32)
-    for (int t = tid; t < ntasks; t += NTHREADS) {
-      const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
-      const int gy = y0 - d + r, gx = x0 - 8 + 8 * g;
-      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;         // W % 8 == 0: a group is all in or all out
-      const uint32_t off = in ? ((uint32_t)((cc * KC + oct * 8) * HW + gy * W + gx) * 2u) : 0x80000000u;
+    if constexpr (PREFETCH) { if (tid < ntasks) task_store(dst0, pre); }
+    for (int t = tid + (PREFETCH ? NTHREADS : 0); t < ntasks; t += NTHREADS) {
+      uint32_t off; int dsti;
+      task_geom(t, off, dsti);
       u32x4 ch[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + k * plane, 0, 0);
-      uint4* dst = xs + (oct * rows + r) * XW + 8 * g;
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
-        uint4 e0, e1;                                // 8 channels of pixel 2pp / 2pp+1
-        e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
-        e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
-        e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
-        e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
-        dst[2 * pp] = e0;
-        dst[2 * pp + 1] = e1;
-      }
+      task_load(off, cc, ch);
+      task_store(dsti, ch);
     }
     // ---- weight slices: tap 0 -> as[0]  (ALLTAPS: all 9 taps -> as[0..8])
     for (int e = tid; e < (ALLTAPS ? 9 : 1) * AS_E; e += NTHREADS) {
@@ -144,6 +173,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       as[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
     }
     __syncthreads();
+    if constexpr (PREFETCH) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
 
     for (int tap = 0; tap < 9; ++tap) {
       const uint4* acur = as + (ALLTAPS ? tap : (tap & 1)) * AS_E;
@@ -168,8 +198,8 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[m] = acur[oct * cop + m * 32 + px];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const uint4 b = xs[(oct * rows + (2 * wave + r) + ky * d) * XW + col];
+        for (int r = 0; r < RPW; ++r) {
+          const uint4 b = xs[(oct * rows + (RPW * wave + r) + ky * d) * XW + col];
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
         }
@@ -190,8 +220,8 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   using st = uint16_t;
   st* yb = reinterpret_cast<st*>(y) + (size_t)n * ybs;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int gy = y0 + 2 * wave + r, gx = x0 + px;
+  for (int r = 0; r < RPW; ++r) {
+    const int gy = y0 + RPW * wave + r, gx = x0 + px;
     if (gy >= H || gx >= W) continue;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -209,20 +239,33 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   }
 }
 
-template <typename T, int MT>
-int launch(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
-           int H, int W, int d, float slope, hipStream_t stream) {
+template <typename T, int MT, int RPW>
+int launch_rpw(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
+               int H, int W, int d, float slope, hipStream_t stream) {
+  constexpr int TH = 4 * RPW;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   const int rows = TH + 2 * d;
   const size_t lds = (size_t)(4 * rows * XW + (MT <= 2 ? 9 : 2) * 4 * MT * 32) * 16;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(NTHREADS), lds, stream,
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(NTHREADS), lds, stream,
                      (const T*)x, xbs, (const T*)wp, bias, (T*)y, ybs, Cin, Cout, H, W, d, tiles_x, tiles_y, slope);
   return check_launch("conv3x3_forward");
+}
+
+template <typename T, int MT>
+int launch(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
+           int H, int W, int d, float slope, hipStream_t stream) {
+  if constexpr (MT == 1) {
+    // narrow layers: 16x32 tiles (4 rows per wave) halve the weight / halo / barrier cost per pixel, but only when
+    // the grid still fills the chip twice over (256 CUs x 2 resident workgroups)
+    if ((long long)B * cdiv(W, TW) * cdiv(H, 16) >= 512)
+      return launch_rpw<T, MT, 4>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
+  }
+  return launch_rpw<T, MT, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
 }
 
 }  // namespace conv
