@@ -92,14 +92,16 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
   const int x0 = tx * TW, y0 = ty * TH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cip = pad32(Cin), cop = MT * 32;
+  const int cip = pad32(Cin), cop = MT * 32;         // cop: output channels of THIS workgroup (one blockIdx.y slab)
+  const int copt = pad32(Cout);                      // packed weight rows
+  const int co0 = blockIdx.y * cop;                  // first output channel of the slab (Cout split over blockIdx.y)
   const int HW = H * W;
 
   // buffer descriptor over this image's Cin input planes: rows/cols outside the image get offset
   // 0x80000000, channel planes >= Cin fall off the end -> the hardware returns the zero padding
   const uint32_t plane = (uint32_t)HW * 2u;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
-  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, 9u * (uint32_t)cop * (uint32_t)cip * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, 9u * (uint32_t)copt * (uint32_t)cip * 2u, 0x00020000);
 
   // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
   const int ngroups = XW / 8;                        // 6
@@ -169,7 +171,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
     for (int e = tid; e < (ALLTAPS ? 9 : 1) * AS_E; e += NTHREADS) {
       const int tap0 = e / AS_E, r0 = e - tap0 * AS_E;
       const int oct = r0 / cop, co = r0 - oct * cop;
-      const uint32_t off = ((uint32_t)((tap0 * cop + co) * cip + cc * KC + oct * 8)) * 2u;
+      const uint32_t off = ((uint32_t)((tap0 * copt + co0 + co) * cip + cc * KC + oct * 8)) * 2u;
       as[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
     }
     __syncthreads();
@@ -184,7 +186,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
         for (int j = 0; j < (AS_E + NTHREADS - 1) / NTHREADS; ++j) {
           const int e = tid + j * NTHREADS;
           const int oct = e / cop, co = e - oct * cop;
-          const uint32_t off = (e < AS_E) ? ((uint32_t)(((tap + 1) * cop + co) * cip + cc * KC + oct * 8)) * 2u : 0x80000000u;
+          const uint32_t off = (e < AS_E) ? ((uint32_t)(((tap + 1) * copt + co0 + co) * cip + cc * KC + oct * 8)) * 2u : 0x80000000u;
           wpre[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0);
         }
       }
@@ -227,7 +229,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int co = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+        const int co = co0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
         if (co < Cout) {
           float v = acc[r][m][e] + bias[co];
           v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
@@ -241,7 +243,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 
 template <typename T, int MT, int RPW>
 int launch_rpw(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
-               int H, int W, int d, float slope, hipStream_t stream) {
+               int H, int W, int d, float slope, hipStream_t stream, int slabs = 1) {
   constexpr int TH = 4 * RPW;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   const int rows = TH + 2 * d;
@@ -251,7 +253,7 @@ int launch_rpw(const void* x, long long xbs, const void* wp, const float* bias, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(NTHREADS), lds, stream,
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW>), dim3((unsigned)(B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, stream,
                      (const T*)x, xbs, (const T*)wp, bias, (T*)y, ybs, Cin, Cout, H, W, d, tiles_x, tiles_y, slope);
   return check_launch("conv3x3_forward");
 }
@@ -264,6 +266,16 @@ int launch(const void* x, long long xbs, const void* wp, const float* bias, void
     // the grid still fills the chip twice over (256 CUs x 2 resident workgroups)
     if ((long long)B * cdiv(W, TW) * cdiv(H, 16) >= 512)
       return launch_rpw<T, MT, 4>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
+  }
+  if constexpr (MT > 1) {
+    // coarse pyramid levels: too few pixel tiles to fill 256 CUs -> split the OUTPUT CHANNELS over blockIdx.y
+    // (each slab re-stages the x tile, which is irrelevant when the grid is latency-bound)
+    const long long tiles = (long long)B * cdiv(W, TW) * cdiv(H, 8);
+    if (tiles * 2 <= 512) {
+      if (MT % 2 == 0 && tiles * (MT / 2) >= 384)
+        return launch_rpw<T, 2, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT / 2);
+      return launch_rpw<T, 1, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT);
+    }
   }
   return launch_rpw<T, MT, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
 }
