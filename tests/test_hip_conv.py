@@ -56,3 +56,20 @@ def test_conv3x3_rejects_unsupported():
     w = ops.conv3x3_pack(torch.zeros(8, 8, 3, 3, dtype=torch.bfloat16, device='cuda'))
     with pytest.raises(RuntimeError):
         ops.conv3x3_forward_raw(x, w, torch.zeros(8, device='cuda'), torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda'), dilation=16)
+
+
+@pytest.mark.parametrize('case', [(1, 3, 16, 64, 128), (2, 16, 32, 32, 64), (1, 32, 64, 24, 40), (1, 64, 96, 17, 24), (2, 16, 16, 48, 64)])
+def test_conv3x3_stride2(case):
+    from upflow_pytorch_amd import ops
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).bfloat16().cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    want = F.leaky_relu(F.conv2d(x.float(), w.float(), b, padding=1, stride=2), 0.1)
+    assert ops.conv3x3_supported(x, Cout, 1, 2)
+    ho, wo = ops.conv3x3_out_hw(H, W, 2)
+    assert (ho, wo) == tuple(want.shape[2:])
+    y = torch.empty(B, Cout, ho, wo, dtype=torch.bfloat16, device='cuda')
+    ops.conv3x3_forward_raw(x, ops.conv3x3_pack(w), b, y, dilation=1, leaky_slope=0.1, stride=2)
+    assert (y.float() - want).abs().max() <= 2.0 ** -8 * float(want.abs().max()) + 1e-3

@@ -34,7 +34,7 @@ namespace conv {
 
 constexpr int TW = 32, NTHREADS = 256;   // tile = (4*RPW) rows x 32 pixels; RPW = rows per wave (2, or 4 for Cout <= 64)
 constexpr int KC = 32;                    // input channels per chunk (4 octets, 2 MFMA k-steps)
-constexpr int XW = TW + 16;               // staged columns: [x0-8, x0+40) keeps 16-byte alignment of global loads
+constexpr int xw(int S) { return S * TW + 16; }  // staged columns [S*x0-8, S*x0+S*32+8): 16-byte aligned global loads
 constexpr int MAXD = 8;                   // dilation limit (halo rows); larger dilations fall back to MIOpen
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -76,14 +76,19 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
 // spent 5.7 us per chunk in nine exposed prefetch+barrier rounds).  MT >= 3 keeps the per-tap double buffer.
 // RPW (rows per wave): Cout <= 32 uses 4 rows per wave = a 16x32 tile per workgroup — twice the pixels per
 // staged weight slice, halo row and barrier, which is what bounds the narrow layers.
-template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2>
+// S = stride (1 or 2; the feature pyramid's down-sampling convs): output pixel (i,j) reads input
+// (S*i + (ky-1)d, S*j + (kx-1)d); only the staged window and the LDS read addresses change.
+template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2, int S = 1>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
-                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int d, int tiles_x, int tiles_y, float slope) {
+                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d,
+                    int tiles_x, int tiles_y, float slope) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   constexpr int TH = 4 * RPW;
-  const int rows = TH + 2 * d;                       // staged rows
-  const int XS_E = 4 * rows * XW;                    // entries (16 B = 8 channels of one pixel) of the x tile
+  constexpr int XW = xw(S);
+  const int rows = S * (TH - 1) + 2 * d + 1;         // staged input rows
+  const int nocts = (Cin <= 16) ? 2 : 4;             // channel octets staged per chunk (Cin <= 16: one k-step)
+  const int XS_E = nocts * rows * XW;                // entries (16 B = 8 channels of one pixel) of the x tile
   constexpr int AS_E = 4 * MT * 32;                  // entries of one weight slice: [octet][co]
   uint4* xs = smem;                                  // [octet 4][rows][XW]
   uint4* as = smem + XS_E;                           // [2 (or 9 with ALLTAPS)][octet 4][MT*32]
@@ -104,8 +109,8 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, 9u * (uint32_t)copt * (uint32_t)cip * 2u, 0x00020000);
 
   // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
-  const int ngroups = XW / 8;                        // 6
-  const int ntasks = 4 * rows * ngroups;
+  constexpr int ngroups = XW / 8;
+  const int ntasks = nocts * rows * ngroups;
 
   f32x16 acc[RPW][MT];
 #pragma unroll
@@ -122,7 +127,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   // octet in chunk 0 (0x80000000 = outside the image) and the LDS entry it fills
   auto task_geom = [&](int t, uint32_t& off, int& dst) {
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
-    const int gy = y0 - d + r, gx = x0 - 8 + 8 * g;
+    const int gy = S * y0 - d + r, gx = S * x0 - 8 + 8 * g;
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // W % 8 == 0: a group is all in or all out
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx) * 2u) : 0x80000000u;
     dst = (oct * rows + r) * XW + 8 * g;
@@ -192,16 +197,16 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       }
       const int ky = tap / 3, kx = tap - ky * 3;
       // shifted window: output pixel (row, px) reads staged entry (row + ky*d, 8 + px + (kx-1)*d)
-      const int col = 8 + px + (kx - 1) * d;
+      const int col = 8 + S * px + (kx - 1) * d;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {               // two k-steps of 16 channels
+      for (int ks = 0; ks < nocts / 2; ++ks) {       // k-steps of 16 channels
         const int oct = 2 * ks + kg;
         uint4 a[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[m] = acur[oct * cop + m * 32 + px];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-          const uint4 b = xs[(oct * rows + (RPW * wave + r) + ky * d) * XW + col];
+          const uint4 b = xs[(oct * rows + S * (RPW * wave + r) + ky * d) * XW + col];
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
         }
@@ -224,7 +229,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int gy = y0 + RPW * wave + r, gx = x0 + px;
-    if (gy >= H || gx >= W) continue;
+    if (gy >= Ho || gx >= Wo) continue;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -235,37 +240,40 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
           v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
           T tmp;
           Elem<T>::store(&tmp, v);
-          yb[(size_t)co * HW + gy * W + gx] = tmp.v;
+          yb[(size_t)co * (Ho * Wo) + gy * Wo + gx] = tmp.v;
         }
       }
   }
 }
 
-template <typename T, int MT, int RPW>
+template <typename T, int MT, int RPW, int S>
 int launch_rpw(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
                int H, int W, int d, float slope, hipStream_t stream, int slabs = 1) {
   constexpr int TH = 4 * RPW;
-  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
-  const int rows = TH + 2 * d;
-  const size_t lds = (size_t)(4 * rows * XW + (MT <= 2 ? 9 : 2) * 4 * MT * 32) * 16;
+  const int Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+  const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
+  const int rows = S * (TH - 1) + 2 * d + 1;
+  const size_t lds = (size_t)(((Cin <= 16) ? 2 : 4) * rows * xw(S) + (MT <= 2 ? 9 : 2) * 4 * MT * 32) * 16;
+  UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv3x3_forward: tile does not fit LDS (dilation %d, stride %d)", d, S);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW>), dim3((unsigned)(B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, stream,
-                     (const T*)x, xbs, (const T*)wp, bias, (T*)y, ybs, Cin, Cout, H, W, d, tiles_x, tiles_y, slope);
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW, S>), dim3((unsigned)(B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, stream,
+                     (const T*)x, xbs, (const T*)wp, bias, (T*)y, ybs, Cin, Cout, H, W, Ho, Wo, d, tiles_x, tiles_y, slope);
   return check_launch("conv3x3_forward");
 }
 
 template <typename T, int MT>
 int launch(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
-           int H, int W, int d, float slope, hipStream_t stream) {
+           int H, int W, int d, int stride, float slope, hipStream_t stream) {
+  if (stride == 2) return launch_rpw<T, MT, 2, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
   if constexpr (MT == 1) {
     // narrow layers: 16x32 tiles (4 rows per wave) halve the weight / halo / barrier cost per pixel, but only when
     // the grid still fills the chip twice over (256 CUs x 2 resident workgroups)
     if ((long long)B * cdiv(W, TW) * cdiv(H, 16) >= 512)
-      return launch_rpw<T, MT, 4>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
+      return launch_rpw<T, MT, 4, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
   }
   if constexpr (MT > 1) {
     // coarse pyramid levels: too few pixel tiles to fill 256 CUs -> split the OUTPUT CHANNELS over blockIdx.y
@@ -273,11 +281,11 @@ int launch(const void* x, long long xbs, const void* wp, const float* bias, void
     const long long tiles = (long long)B * cdiv(W, TW) * cdiv(H, 8);
     if (tiles * 2 <= 512) {
       if (MT % 2 == 0 && tiles * (MT / 2) >= 384)
-        return launch_rpw<T, 2, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT / 2);
-      return launch_rpw<T, 1, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT);
+        return launch_rpw<T, 2, 2, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT / 2);
+      return launch_rpw<T, 1, 2, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT);
     }
   }
-  return launch_rpw<T, MT, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
+  return launch_rpw<T, MT, 2, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
 }
 
 }  // namespace conv
@@ -302,23 +310,24 @@ extern "C" int upf_conv3x3_pack_weights(const void* w, void* w_packed, int Cin, 
 
 extern "C" int upf_conv3x3_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
                                    void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
-                                   int dilation, float leaky_slope, int dtype, void* stream) {
+                                   int dilation, int stride, float leaky_slope, int dtype, void* stream) {
   using namespace upf;
   UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv3x3_forward: null pointer");
   UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Cout <= 128 && H > 0 && W > 0, UPF_EINVAL,
               "conv3x3_forward: bad shape B=%d Cin=%d Cout=%d H=%d W=%d (Cout <= 128)", B, Cin, Cout, H, W);
   UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv3x3_forward: bf16 / fp16 only");
   UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv3x3_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
+  UPF_REQUIRE(stride == 1 || (stride == 2 && dilation == 1), UPF_EUNSUPPORTED, "conv3x3_forward: stride %d (1, or 2 with dilation 1)", stride);
   UPF_REQUIRE(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0, UPF_EALIGN, "conv3x3_forward: needs W %% 8 == 0 and 16-byte aligned x");
   UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv3x3_forward: image too large for one buffer descriptor");
   const int mt = (Cout + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
 #define UPF_CONV_CASE(T)                                                                                                        \
   switch (mt) {                                                                                                                 \
-    case 1: return conv::launch<T, 1>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
-    case 2: return conv::launch<T, 2>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
-    case 3: return conv::launch<T, 3>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
-    default: return conv::launch<T, 4>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, leaky_slope, s); \
+    case 1: return conv::launch<T, 1>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
+    case 2: return conv::launch<T, 2>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
+    case 3: return conv::launch<T, 3>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
+    default: return conv::launch<T, 4>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
   }
   if (dtype == UPF_BF16) { UPF_CONV_CASE(bf16_t) } else { UPF_CONV_CASE(f16_t) }
 #undef UPF_CONV_CASE

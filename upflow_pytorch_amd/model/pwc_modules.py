@@ -99,8 +99,8 @@ class FeatureExtractor(nn.Module):
         pyramid = []
         cache = self.__dict__.setdefault('_fast_cache', {})
         for stage in self.convs:
-            x = stage[0](x)                            # stride-2 conv: MIOpen
-            x = fast_conv_seq(stage[1], x, cache)      # stride-1 conv: matrix-core kernel when eligible
+            x = fast_conv_seq(stage[0], x, cache)      # stride-2 conv
+            x = fast_conv_seq(stage[1], x, cache)      # stride-1 conv  (matrix-core kernel when eligible, else MIOpen)
             pyramid.append(x)
         return pyramid[::-1]
 
@@ -159,7 +159,7 @@ class _PackedConv3x3(object):
 
     def __call__(self, x_view, y_view):
         packed, bias = self.get()
-        return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, self.conv.dilation[0], self.slope)
+        return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, self.conv.dilation[0], self.slope, self.conv.stride[0])
 
 
 def fast_conv_seq(seq, x, cache):
@@ -167,12 +167,13 @@ def fast_conv_seq(seq, x, cache):
     stride-1 3x3 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
     that keeps the packed weights per Sequential."""
     c = seq[0]
-    if (_fast_conv_ok(x) and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.groups == 1 and len(seq) <= 2
-            and ops.conv3x3_supported(x, c.out_channels, c.dilation[0])):
+    if (_fast_conv_ok(x) and c.kernel_size == (3, 3) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
+            and c.padding == c.dilation and ops.conv3x3_supported(x, c.out_channels, c.dilation[0], c.stride[0])):
         pc = cache.get(id(seq))
         if pc is None:
             pc = cache[id(seq)] = _PackedConv3x3(seq)
-        y = torch.empty((x.shape[0], c.out_channels) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        ho, wo = ops.conv3x3_out_hw(x.shape[2], x.shape[3], c.stride[0])
+        y = torch.empty((x.shape[0], c.out_channels, ho, wo), dtype=x.dtype, device=x.device)
         return pc(x, y)
     return seq(x if x.is_contiguous() else x.contiguous())
 

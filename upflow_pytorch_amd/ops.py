@@ -323,22 +323,29 @@ def conv3x3_pack(weight):
     return packed
 
 
-def conv3x3_supported(x_view, Cout, dilation):
+def conv3x3_supported(x_view, Cout, dilation, stride=1):
     """Shapes the matrix-core kernel takes; everything else stays with MIOpen."""
     return (x_view.is_cuda and x_view.dtype in (torch.bfloat16, torch.float16) and Cout <= 128 and 1 <= dilation <= 8
+            and (stride == 1 or (stride == 2 and dilation == 1))
             and x_view.shape[3] % 8 == 0 and x_view.stride(0) % 8 == 0 and x_view.data_ptr() % 16 == 0)
 
 
-def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=0.0):
-    """x_view / y_view: [B,Cin,H,W] / [B,Cout,H,W] channel slices of contiguous NCHW buffers."""
+def conv3x3_out_hw(H, W, stride=1):
+    return (H - 1) // stride + 1, (W - 1) // stride + 1
+
+
+def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=0.0, stride=1):
+    """x_view / y_view: [B,Cin,H,W] / [B,Cout,Ho,Wo] channel slices of contiguous NCHW buffers."""
     B, Cin, H, W = x_view.shape
     Cout = y_view.shape[1]
-    for v in (x_view, y_view):
-        if v.stride()[1:] != (H * W, W, 1):
-            raise UpflowHipError('conv3x3: operands must be channel slices of contiguous NCHW buffers')
+    Ho, Wo = conv3x3_out_hw(H, W, stride)
+    if tuple(y_view.shape) != (B, Cout, Ho, Wo):
+        raise UpflowHipError('conv3x3: output must be [%d,%d,%d,%d], got %s' % (B, Cout, Ho, Wo, tuple(y_view.shape)))
+    if x_view.stride()[1:] != (H * W, W, 1) or y_view.stride()[1:] != (Ho * Wo, Wo, 1):
+        raise UpflowHipError('conv3x3: operands must be channel slices of contiguous NCHW buffers')
     dev = x_view.device
     with torch.cuda.device(dev):
         _lib.call('upf_conv3x3_forward', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(packed), _lib.ptr(bias32),
-                  _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(dilation), float(leaky_slope),
+                  _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(dilation), int(stride), float(leaky_slope),
                   _lib.dtype_code(x_view), _lib.stream_ptr(dev))
     return y_view
