@@ -142,20 +142,21 @@ int upf_normalize_forward(const void* x, void* y, float* mean, float* rstd, void
 int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd, void* gx,
                            long long N, int HW, int dtype, void* stream);
 
-/* ---- 3x3 (dilated) convolution on the matrix cores   -----------------------
- * The dense flow-estimator / context / SGU-estimator convolutions (model/pwc_modules.py:250-286,
- * :396-412; model/upflow.py:24-60), bf16 / fp16 only (fp32 stays with MIOpen = the parity mode):
- *   y[n,co,i,j] = act(bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[n,ci, s*i+(ky-1)d, s*j+(kx-1)d]),  pad d,
- *   stride s = 1, or 2 with d = 1 (the pyramid's down-sampling convs); output (H-1)/s+1 x (W-1)/s+1
- * x / y point at the FIRST input / output channel of channel slices of larger contiguous NCHW buffers
- * (batch strides in elements), so the estimator's growing concatenation needs no copies.
- * w_packed: upf_conv3x3_pack_weights() output ([9][pad32(Cout)][pad32(Cin)], done once per layer).
- * Limits: Cout <= 128, 1 <= dilation <= 8, W % 8 == 0, 16-byte aligned x. */
-long long upf_conv3x3_packed_bytes(int Cin, int Cout);
-int upf_conv3x3_pack_weights(const void* w /* [Cout,Cin,3,3] */, void* w_packed, int Cin, int Cout, int dtype, void* stream);
-int upf_conv3x3_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
-                        void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
-                        int dilation, int stride, float leaky_slope, int dtype, void* stream);
+/* ---- convolution on the matrix cores   -------------------------------------
+ * The dense flow-estimator / context / SGU-estimator / pyramid convolutions (model/pwc_modules.py:122-142,
+ * :250-286, :396-412; model/upflow.py:24-60, :349-353), bf16 / fp16 only (fp32 stays with MIOpen = the
+ * parity mode), kernel_size 3 (dilation d <= 16, padding d; stride 1, or 2 with d = 1) or 1 (stride 1):
+ *   y[n,co,i,j] = act(bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[n,ci, s*i+(ky-1)d, s*j+(kx-1)d])
+ * output (H-1)/s+1 x (W-1)/s+1.  x / y point at the FIRST input / output channel of channel slices of larger
+ * contiguous NCHW buffers (batch strides in elements), so the estimator's growing concatenation needs no
+ * copies.  w_packed: upf_conv_pack_weights() output ([k*k][pad32(Cout)][pad32(Cin)], done once per layer).
+ * Limits: Cout <= 128, W % 8 == 0, 16-byte aligned x. */
+long long upf_conv_packed_bytes(int Cin, int Cout, int kernel_size);
+int upf_conv_pack_weights(const void* w /* [Cout,Cin,k,k] */, void* w_packed, int Cin, int Cout, int kernel_size,
+                          int dtype, void* stream);
+int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
+                     void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
+                     int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
 
 /* ---- occlusion check  (tools.occ_check_model(obj), utils/tools.py:519-588, 641-677) -------------
  * flow_f, flow_b : [B,2,H,W] fp32 -> occ_fw, occ_bw : [B,1,H,W] fp32 in {0,1}. */

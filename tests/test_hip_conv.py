@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = [  # B, Cin, Cout, H, W, dilation
     (1, 32, 32, 8, 32, 1), (2, 115, 128, 24, 40, 1), (1, 243, 128, 16, 64, 1), (1, 371, 96, 9, 24, 1), (1, 467, 64, 8, 8, 1),
-    (1, 563, 2, 12, 40, 1), (1, 565, 128, 16, 32, 1), (1, 128, 128, 24, 48, 2), (1, 128, 128, 24, 48, 4), (1, 128, 96, 40, 64, 8),
+    (1, 563, 2, 12, 40, 1), (1, 565, 128, 16, 32, 1), (1, 128, 128, 24, 48, 2), (1, 128, 128, 24, 48, 4), (1, 128, 96, 40, 64, 8), (1, 96, 64, 40, 64, 16), (2, 96, 64, 24, 80, 16),
     (2, 64, 32, 17, 56, 1), (1, 184, 3, 8, 16, 1), (1, 7, 5, 3, 8, 1), (4, 96, 32, 96, 320, 1)]
 
 
@@ -52,10 +52,10 @@ def test_conv3x3_rejects_unsupported():
     assert not ops.conv3x3_supported(x, 8, 1)
     assert not ops.conv3x3_supported(x.float(), 8, 1)
     x = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda')
-    assert not ops.conv3x3_supported(x, 8, 16) and not ops.conv3x3_supported(x, 200, 1)
+    assert not ops.conv3x3_supported(x, 8, 17) and not ops.conv3x3_supported(x, 200, 1)
     w = ops.conv3x3_pack(torch.zeros(8, 8, 3, 3, dtype=torch.bfloat16, device='cuda'))
     with pytest.raises(RuntimeError):
-        ops.conv3x3_forward_raw(x, w, torch.zeros(8, device='cuda'), torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda'), dilation=16)
+        ops.conv3x3_forward_raw(x, w, torch.zeros(8, device='cuda'), torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda'), dilation=17)
 
 
 @pytest.mark.parametrize('case', [(1, 3, 16, 64, 128), (2, 16, 32, 32, 64), (1, 32, 64, 24, 40), (1, 64, 96, 17, 24), (2, 16, 16, 48, 64)])
@@ -72,4 +72,19 @@ def test_conv3x3_stride2(case):
     assert (ho, wo) == tuple(want.shape[2:])
     y = torch.empty(B, Cout, ho, wo, dtype=torch.bfloat16, device='cuda')
     ops.conv3x3_forward_raw(x, ops.conv3x3_pack(w), b, y, dilation=1, leaky_slope=0.1, stride=2)
+    assert (y.float() - want).abs().max() <= 2.0 ** -8 * float(want.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 24, 40), (1, 64, 32, 16, 64), (1, 96, 32, 9, 16), (1, 128, 32, 12, 40), (4, 32, 32, 96, 320)])
+def test_conv1x1(case):
+    from upflow_pytorch_amd import ops
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).bfloat16().cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    want = F.leaky_relu(F.conv2d(x.float(), w.float(), b), 0.1)
+    assert ops.conv3x3_supported(x, Cout, 1, 1, 1)
+    y = torch.empty(B, Cout, H, W, dtype=torch.bfloat16, device='cuda')
+    ops.conv3x3_forward_raw(x, ops.conv3x3_pack(w), b, y, dilation=1, leaky_slope=0.1, stride=1, kernel_size=1)
     assert (y.float() - want).abs().max() <= 2.0 ** -8 * float(want.abs().max()) + 1e-3

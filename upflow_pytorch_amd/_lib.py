@@ -34,8 +34,8 @@ SIGNATURES = {
     'upf_sgu_blend_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_normalize_forward': [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
-    'upf_conv3x3_pack_weights': [_vp, _vp, _i, _i, _i, _vp],
-    'upf_conv3x3_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    'upf_conv_pack_weights': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'upf_conv_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_occ_check': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
 }
 
@@ -62,8 +62,8 @@ def lib():
             fn.restype = _i
         L.upf_normalize_workspace_bytes.argtypes = [_ll, _i]
         L.upf_normalize_workspace_bytes.restype = _ll
-        L.upf_conv3x3_packed_bytes.argtypes = [_i, _i]
-        L.upf_conv3x3_packed_bytes.restype = _ll
+        L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]
+        L.upf_conv_packed_bytes.restype = _ll
         L.upf_version.restype = _c.c_char_p
         L.upf_last_error.restype = _c.c_char_p
         _lib = L

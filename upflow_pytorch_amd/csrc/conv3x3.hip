@@ -33,9 +33,9 @@ namespace upf {
 namespace conv {
 
 constexpr int TW = 32, NTHREADS = 256;   // tile = (4*RPW) rows x 32 pixels; RPW = rows per wave (2, or 4 for Cout <= 64)
-constexpr int KC = 32;                    // input channels per chunk (4 octets, 2 MFMA k-steps)
-constexpr int xw(int S) { return S * TW + 16; }  // staged columns [S*x0-8, S*x0+S*32+8): 16-byte aligned global loads
-constexpr int MAXD = 8;                   // dilation limit (halo rows); larger dilations fall back to MIOpen
+// staged columns [S*x0 - marg, S*x0 + S*32 + marg), marg = 8 (d <= 8) or 16: 16-byte aligned global loads
+__host__ __device__ constexpr int xw(int S, int marg) { return S * TW + 2 * marg; }
+constexpr int MAXD = 16;                  // dilation limit (the context network's largest)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -56,15 +56,15 @@ template <> struct Mma32<f16_t> {
 
 __host__ __device__ constexpr int pad32(int v) { return (v + 31) / 32 * 32; }
 
-// w [Cout, Cin, 3, 3] -> packed [9][pad32(Cout)][pad32(Cin)], zero padded
+// w [Cout, Cin, k, k] (k*k = ntaps) -> packed [ntaps][pad32(Cout)][pad32(Cin)], zero padded
 template <typename T>
-__global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, int Cin, int Cout) {
+__global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps) {
   const int cip = pad32(Cin), cop = pad32(Cout);
-  const long long total = 9ll * cop * cip;
+  const long long total = (long long)ntaps * cop * cip;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % cip), co = (int)((i / cip) % cop), tap = (int)(i / ((long long)cip * cop));
     T v; v.v = 0;
-    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 9 + tap];
+    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ntaps + tap];
     wp[i] = v;
   }
 }
@@ -78,18 +78,26 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
 // staged weight slice, halo row and barrier, which is what bounds the narrow layers.
 // S = stride (1 or 2; the feature pyramid's down-sampling convs): output pixel (i,j) reads input
 // (S*i + (ky-1)d, S*j + (kx-1)d); only the staged window and the LDS read addresses change.
-template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2, int S = 1>
+// VAR: 0 = 3x3, 8-column margins (dilation <= 8); 1 = 3x3, 16-column margins (dilation 16); 2 = 1x1.
+// Compile-time so that the tap loop unrolls and the window addressing folds into immediates.
+template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2, int S = 1, int NOCTS = 4, int VAR = 0>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                     T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d,
                     int tiles_x, int tiles_y, float slope) {
+  constexpr int nocts = NOCTS;
+  constexpr int marg = (VAR == 1) ? 16 : 8;
+  constexpr int ntaps = (VAR == 2) ? 1 : 9;
+  // nocts: channel octets per chunk (4 = 32 channels; 2 when Cin <= 16 or when the dilation-16 halo would not
+  // fit LDS otherwise).  ntaps: 9, or 1 for a 1x1 convolution (then d = 0 and only the centre tap exists).
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   constexpr int TH = 4 * RPW;
-  constexpr int XW = xw(S);
+  constexpr int XW = xw(S, marg);
   const int rows = S * (TH - 1) + 2 * d + 1;         // staged input rows
-  const int nocts = (Cin <= 16) ? 2 : 4;             // channel octets staged per chunk (Cin <= 16: one k-step)
   const int XS_E = nocts * rows * XW;                // entries (16 B = 8 channels of one pixel) of the x tile
-  constexpr int AS_E = 4 * MT * 32;                  // entries of one weight slice: [octet][co]
+  constexpr int AS_MAX = nocts * MT * 32;
+  constexpr int AS_E = nocts * MT * 32;              // entries of one weight slice: [octet][co]
+  constexpr int KCH = nocts * 8;                     // input channels per chunk
   uint4* xs = smem;                                  // [octet 4][rows][XW]
   uint4* as = smem + XS_E;                           // [2 (or 9 with ALLTAPS)][octet 4][MT*32]
 
@@ -106,7 +114,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   // 0x80000000, channel planes >= Cin fall off the end -> the hardware returns the zero padding
   const uint32_t plane = (uint32_t)HW * 2u;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
-  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, 9u * (uint32_t)copt * (uint32_t)cip * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)copt * (uint32_t)cip * 2u, 0x00020000);
 
   // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
   constexpr int ngroups = XW / 8;
@@ -121,19 +129,19 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       for (int e = 0; e < 16; ++e) acc[r][m][e] = 0.f;
 
   const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
-  const int nchunks = cip / KC;
+  const int nchunks = cip / KCH;
 
   // x staging task t -> (channel octet, staged row, 8-pixel group): buffer-load offset of channel 0 of the
   // octet in chunk 0 (0x80000000 = outside the image) and the LDS entry it fills
   auto task_geom = [&](int t, uint32_t& off, int& dst) {
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
-    const int gy = S * y0 - d + r, gx = S * x0 - 8 + 8 * g;
+    const int gy = S * y0 - d + r, gx = S * x0 - marg + 8 * g;
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // W % 8 == 0: a group is all in or all out
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx) * 2u) : 0x80000000u;
     dst = (oct * rows + r) * XW + 8 * g;
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
-    const uint32_t o = off + (uint32_t)cc * KC * plane;                           // stays >= 2^31 for outside tasks
+    const uint32_t o = off + (uint32_t)cc * KCH * plane;                           // stays >= 2^31 for outside tasks
 #pragma unroll
     for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
   };
@@ -173,31 +181,31 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       task_store(dsti, ch);
     }
     // ---- weight slices: tap 0 -> as[0]  (ALLTAPS: all 9 taps -> as[0..8])
-    for (int e = tid; e < (ALLTAPS ? 9 : 1) * AS_E; e += NTHREADS) {
+    for (int e = tid; e < (ALLTAPS ? ntaps : 1) * AS_E; e += NTHREADS) {
       const int tap0 = e / AS_E, r0 = e - tap0 * AS_E;
       const int oct = r0 / cop, co = r0 - oct * cop;
-      const uint32_t off = ((uint32_t)((tap0 * copt + co0 + co) * cip + cc * KC + oct * 8)) * 2u;
+      const uint32_t off = ((uint32_t)((tap0 * copt + co0 + co) * cip + cc * KCH + oct * 8)) * 2u;
       as[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
     }
     __syncthreads();
     if constexpr (PREFETCH) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
 
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < ntaps; ++tap) {
       const uint4* acur = as + (ALLTAPS ? tap : (tap & 1)) * AS_E;
       // prefetch the next tap's weight slice into the other buffer (consumed after the barrier below)
-      u32x4 wpre[(AS_E + NTHREADS - 1) / NTHREADS];
-      if (!ALLTAPS && tap + 1 < 9) {
+      u32x4 wpre[(AS_MAX + NTHREADS - 1) / NTHREADS];
+      if (!ALLTAPS && tap + 1 < ntaps) {
 #pragma unroll
-        for (int j = 0; j < (AS_E + NTHREADS - 1) / NTHREADS; ++j) {
+        for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
           const int e = tid + j * NTHREADS;
           const int oct = e / cop, co = e - oct * cop;
-          const uint32_t off = (e < AS_E) ? ((uint32_t)(((tap + 1) * copt + co0 + co) * cip + cc * KC + oct * 8)) * 2u : 0x80000000u;
+          const uint32_t off = (e < AS_E) ? ((uint32_t)(((tap + 1) * copt + co0 + co) * cip + cc * KCH + oct * 8)) * 2u : 0x80000000u;
           wpre[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0);
         }
       }
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
       // shifted window: output pixel (row, px) reads staged entry (row + ky*d, 8 + px + (kx-1)*d)
-      const int col = 8 + S * px + (kx - 1) * d;
+      const int col = marg + S * px + (kx - 1) * d;
 #pragma unroll
       for (int ks = 0; ks < nocts / 2; ++ks) {       // k-steps of 16 channels
         const int oct = 2 * ks + kg;
@@ -211,10 +219,10 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
           for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
         }
       }
-      if (!ALLTAPS && tap + 1 < 9) {
+      if (!ALLTAPS && tap + 1 < ntaps) {
         uint4* anext = as + ((tap + 1) & 1) * AS_E;
 #pragma unroll
-        for (int j = 0; j < (AS_E + NTHREADS - 1) / NTHREADS; ++j) {
+        for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
           const int e = tid + j * NTHREADS;
           if (e < AS_E) anext[e] = __builtin_bit_cast(uint4, wpre[j]);
         }
@@ -246,88 +254,109 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   }
 }
 
+struct Args {
+  const void* x; long long xbs; const void* wp; const float* bias; void* y; long long ybs;
+  int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
+};
+
 template <typename T, int MT, int RPW, int S>
-int launch_rpw(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
-               int H, int W, int d, float slope, hipStream_t stream, int slabs = 1) {
+int launch_rpw(const Args& a, int slabs = 1) {
   constexpr int TH = 4 * RPW;
-  const int Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+  const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
-  const int rows = S * (TH - 1) + 2 * d + 1;
-  const size_t lds = (size_t)(((Cin <= 16) ? 2 : 4) * rows * xw(S) + (MT <= 2 ? 9 : 2) * 4 * MT * 32) * 16;
-  UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv3x3_forward: tile does not fit LDS (dilation %d, stride %d)", d, S);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_lds = lds;
+  const int rows = S * (TH - 1) + 2 * a.d + 1;
+  const int marg = (a.d <= 8) ? 8 : 16;
+  const int wslices = (MT <= 2) ? a.ntaps : 2;
+  auto lds_for = [&](int nocts) { return (size_t)(nocts * rows * xw(S, marg) + wslices * nocts * MT * 32) * 16; };
+  int nocts = (a.Cin <= 16 || marg == 16) ? 2 : 4;
+  const size_t lds = lds_for(nocts);
+  UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
+  const dim3 grid((unsigned)(a.B * tiles_x * tiles_y), slabs);
+#define UPF_CONV_LAUNCH(NO, VAR)                                                                                                   \
+  {                                                                                                                                \
+    static size_t attr_lds = 0;                                                                                                    \
+    if (lds > attr_lds) {                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
+      attr_lds = lds;                                                                                                              \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR>), grid, dim3(NTHREADS), lds, a.stream, (const T*)a.x,     \
+                       a.xbs, (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, a.d, tiles_x, tiles_y,      \
+                       a.slope);                                                                                                   \
   }
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW, S>), dim3((unsigned)(B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, stream,
-                     (const T*)x, xbs, (const T*)wp, bias, (T*)y, ybs, Cin, Cout, H, W, Ho, Wo, d, tiles_x, tiles_y, slope);
-  return check_launch("conv3x3_forward");
+  if constexpr (S == 1 && RPW == 2) {
+    if (a.ntaps == 1) { if (nocts == 4) UPF_CONV_LAUNCH(4, 2) else UPF_CONV_LAUNCH(2, 2) return check_launch("conv_forward"); }
+    if (marg == 16) { UPF_CONV_LAUNCH(2, 1) return check_launch("conv_forward"); }
+  }
+  if (nocts == 4) UPF_CONV_LAUNCH(4, 0) else UPF_CONV_LAUNCH(2, 0)
+#undef UPF_CONV_LAUNCH
+  return check_launch("conv_forward");
 }
 
 template <typename T, int MT>
-int launch(const void* x, long long xbs, const void* wp, const float* bias, void* y, long long ybs, int B, int Cin, int Cout,
-           int H, int W, int d, int stride, float slope, hipStream_t stream) {
-  if (stride == 2) return launch_rpw<T, MT, 2, 2>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
+int launch(const Args& a) {
+  if (a.stride == 2) return launch_rpw<T, MT, 2, 2>(a);
   if constexpr (MT == 1) {
     // narrow layers: 16x32 tiles (4 rows per wave) halve the weight / halo / barrier cost per pixel, but only when
     // the grid still fills the chip twice over (256 CUs x 2 resident workgroups)
-    if ((long long)B * cdiv(W, TW) * cdiv(H, 16) >= 512)
-      return launch_rpw<T, MT, 4, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
+    if ((long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 16) >= 512 && a.d <= 8 && a.ntaps == 9) return launch_rpw<T, MT, 4, 1>(a);
   }
   if constexpr (MT > 1) {
     // coarse pyramid levels: too few pixel tiles to fill 256 CUs -> split the OUTPUT CHANNELS over blockIdx.y
     // (each slab re-stages the x tile, which is irrelevant when the grid is latency-bound)
-    const long long tiles = (long long)B * cdiv(W, TW) * cdiv(H, 8);
+    const long long tiles = (long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 8);
     if (tiles * 2 <= 512) {
-      if (MT % 2 == 0 && tiles * (MT / 2) >= 384)
-        return launch_rpw<T, 2, 2, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT / 2);
-      return launch_rpw<T, 1, 2, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream, MT);
+      if (MT % 2 == 0 && tiles * (MT / 2) >= 384) return launch_rpw<T, 2, 2, 1>(a, MT / 2);
+      return launch_rpw<T, 1, 2, 1>(a, MT);
     }
   }
-  return launch_rpw<T, MT, 2, 1>(x, xbs, wp, bias, y, ybs, B, Cin, Cout, H, W, d, slope, stream);
+  return launch_rpw<T, MT, 2, 1>(a);
 }
 
 }  // namespace conv
 }  // namespace upf
 
-extern "C" long long upf_conv3x3_packed_bytes(int Cin, int Cout) {
-  return 9ll * upf::conv::pad32(Cout) * upf::conv::pad32(Cin) * 2;
+extern "C" long long upf_conv_packed_bytes(int Cin, int Cout, int kernel_size) {
+  return (long long)kernel_size * kernel_size * upf::conv::pad32(Cout) * upf::conv::pad32(Cin) * 2;
 }
 
-extern "C" int upf_conv3x3_pack_weights(const void* w, void* w_packed, int Cin, int Cout, int dtype, void* stream) {
+extern "C" int upf_conv_pack_weights(const void* w, void* w_packed, int Cin, int Cout, int kernel_size, int dtype, void* stream) {
   using namespace upf;
-  UPF_REQUIRE(w && w_packed && Cin > 0 && Cout > 0, UPF_EINVAL, "conv3x3_pack_weights: bad arguments");
-  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv3x3: bf16 / fp16 only (fp32 convolutions stay with MIOpen)");
-  const long long total = 9ll * conv::pad32(Cout) * conv::pad32(Cin);
+  UPF_REQUIRE(w && w_packed && Cin > 0 && Cout > 0, UPF_EINVAL, "conv_pack_weights: bad arguments");
+  UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_pack_weights: kernel_size %d (1 or 3)", kernel_size);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv: bf16 / fp16 only (fp32 convolutions stay with MIOpen)");
+  const int ntaps = kernel_size * kernel_size;
+  const long long total = (long long)ntaps * conv::pad32(Cout) * conv::pad32(Cin);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == UPF_BF16)
-    hipLaunchKernelGGL((conv::pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)w_packed, Cin, Cout);
+    hipLaunchKernelGGL((conv::pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)w_packed, Cin, Cout, ntaps);
   else
-    hipLaunchKernelGGL((conv::pack_weights_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)w, (f16_t*)w_packed, Cin, Cout);
-  return check_launch("conv3x3_pack_weights");
+    hipLaunchKernelGGL((conv::pack_weights_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)w, (f16_t*)w_packed, Cin, Cout, ntaps);
+  return check_launch("conv_pack_weights");
 }
 
-extern "C" int upf_conv3x3_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
-                                   void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
-                                   int dilation, int stride, float leaky_slope, int dtype, void* stream) {
+extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
+                                void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
+                                int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream) {
   using namespace upf;
-  UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv3x3_forward: null pointer");
+  UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv_forward: null pointer");
   UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Cout <= 128 && H > 0 && W > 0, UPF_EINVAL,
-              "conv3x3_forward: bad shape B=%d Cin=%d Cout=%d H=%d W=%d (Cout <= 128)", B, Cin, Cout, H, W);
-  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv3x3_forward: bf16 / fp16 only");
-  UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv3x3_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
-  UPF_REQUIRE(stride == 1 || (stride == 2 && dilation == 1), UPF_EUNSUPPORTED, "conv3x3_forward: stride %d (1, or 2 with dilation 1)", stride);
-  UPF_REQUIRE(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0, UPF_EALIGN, "conv3x3_forward: needs W %% 8 == 0 and 16-byte aligned x");
-  UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv3x3_forward: image too large for one buffer descriptor");
+              "conv_forward: bad shape B=%d Cin=%d Cout=%d H=%d W=%d (Cout <= 128)", B, Cin, Cout, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward: bf16 / fp16 only");
+  UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_forward: kernel_size %d (1 or 3)", kernel_size);
+  UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
+  UPF_REQUIRE(stride == 1 || (stride == 2 && dilation == 1 && kernel_size == 3), UPF_EUNSUPPORTED, "conv_forward: stride %d (1, or 2 for a 3x3 with dilation 1)", stride);
+  UPF_REQUIRE(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0, UPF_EALIGN, "conv_forward: needs W %% 8 == 0 and 16-byte aligned x");
+  UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: image too large for one buffer descriptor");
+  conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W,
+               kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope, (hipStream_t)stream};
   const int mt = (Cout + 31) / 32;
-  hipStream_t s = (hipStream_t)stream;
-#define UPF_CONV_CASE(T)                                                                                                        \
-  switch (mt) {                                                                                                                 \
-    case 1: return conv::launch<T, 1>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
-    case 2: return conv::launch<T, 2>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
-    case 3: return conv::launch<T, 3>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
-    default: return conv::launch<T, 4>(x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, leaky_slope, s); \
+#define UPF_CONV_CASE(T)                          \
+  switch (mt) {                                   \
+    case 1: return conv::launch<T, 1>(a);         \
+    case 2: return conv::launch<T, 2>(a);         \
+    case 3: return conv::launch<T, 3>(a);         \
+    default: return conv::launch<T, 4>(a);        \
   }
   if (dtype == UPF_BF16) { UPF_CONV_CASE(bf16_t) } else { UPF_CONV_CASE(f16_t) }
 #undef UPF_CONV_CASE

@@ -159,16 +159,19 @@ class _PackedConv3x3(object):
 
     def __call__(self, x_view, y_view):
         packed, bias = self.get()
-        return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, self.conv.dilation[0], self.slope, self.conv.stride[0])
+        return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, self.conv.dilation[0], self.slope, self.conv.stride[0],
+                                       self.conv.kernel_size[0])
 
 
 def fast_conv_seq(seq, x, cache):
     """Run one `conv(...)` Sequential (Conv2d [+ LeakyReLU]) — through the matrix-core kernel when it is a
-    stride-1 3x3 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
+    3x3 (stride 1/2, dilation <= 16) or 1x1 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
     that keeps the packed weights per Sequential."""
     c = seq[0]
-    if (_fast_conv_ok(x) and c.kernel_size == (3, 3) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
-            and c.padding == c.dilation and ops.conv3x3_supported(x, c.out_channels, c.dilation[0], c.stride[0])):
+    k = c.kernel_size[0]
+    if (_fast_conv_ok(x) and c.kernel_size in ((3, 3), (1, 1)) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
+            and c.padding == (((k - 1) * c.dilation[0]) // 2,) * 2
+            and ops.conv3x3_supported(x, c.out_channels, c.dilation[0], c.stride[0], k)):
         pc = cache.get(id(seq))
         if pc is None:
             pc = cache[id(seq)] = _PackedConv3x3(seq)

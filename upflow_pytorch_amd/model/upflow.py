@@ -365,7 +365,7 @@ class UPFlow_net(tools.abstract_model):
         flows = []
         for level in range(self.output_level + 1):
             Fm = pyramid[level]
-            A = self.conv_1x1[level](Fm)
+            A = fast_conv_seq(self.conv_1x1[level], Fm, self.__dict__.setdefault('_fast_cache', {}))
             flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
             if level == 0:
                 Fw = torch.roll(Fm, shifts=B, dims=0)                        # no warp at the coarsest level (:539-541)

@@ -310,23 +310,23 @@ def occ_check(flow_f, flow_b, alpha1=0.1, alpha2=0.5):
 # 3x3 convolution on the matrix cores (inference, bf16 / fp16)
 # ------------------------------------------------------------------------------------------------
 def conv3x3_pack(weight):
-    """[Cout,Cin,3,3] bf16/fp16 -> the kernel's packed layout (done once per layer)."""
+    """[Cout,Cin,k,k] (k = 3 or 1) bf16/fp16 -> the kernel's packed layout (done once per layer)."""
     w = weight.detach().contiguous()
     Cout, Cin, kh, kw = w.shape
-    if (kh, kw) != (3, 3):
-        raise UpflowHipError('conv3x3_pack: 3x3 kernels only')
+    if kh != kw or kh not in (1, 3):
+        raise UpflowHipError('conv pack: 3x3 or 1x1 kernels only')
     dev = _lib.check_gpu(w)
-    nbytes = _lib.lib().upf_conv3x3_packed_bytes(Cin, Cout)
+    nbytes = _lib.lib().upf_conv_packed_bytes(Cin, Cout, kh)
     packed = torch.empty((nbytes // 2,), dtype=w.dtype, device=w.device)
     with torch.cuda.device(dev):
-        _lib.call('upf_conv3x3_pack_weights', _lib.ptr(w), _lib.ptr(packed), Cin, Cout, _lib.dtype_code(w), _lib.stream_ptr(dev))
+        _lib.call('upf_conv_pack_weights', _lib.ptr(w), _lib.ptr(packed), Cin, Cout, kh, _lib.dtype_code(w), _lib.stream_ptr(dev))
     return packed
 
 
-def conv3x3_supported(x_view, Cout, dilation, stride=1):
+def conv3x3_supported(x_view, Cout, dilation, stride=1, kernel_size=3):
     """Shapes the matrix-core kernel takes; everything else stays with MIOpen."""
-    return (x_view.is_cuda and x_view.dtype in (torch.bfloat16, torch.float16) and Cout <= 128 and 1 <= dilation <= 8
-            and (stride == 1 or (stride == 2 and dilation == 1))
+    return (x_view.is_cuda and x_view.dtype in (torch.bfloat16, torch.float16) and Cout <= 128 and kernel_size in (1, 3)
+            and 1 <= dilation <= 16 and (stride == 1 or (stride == 2 and dilation == 1 and kernel_size == 3))
             and x_view.shape[3] % 8 == 0 and x_view.stride(0) % 8 == 0 and x_view.data_ptr() % 16 == 0)
 
 
@@ -334,18 +334,18 @@ def conv3x3_out_hw(H, W, stride=1):
     return (H - 1) // stride + 1, (W - 1) // stride + 1
 
 
-def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=0.0, stride=1):
+def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=0.0, stride=1, kernel_size=3):
     """x_view / y_view: [B,Cin,H,W] / [B,Cout,Ho,Wo] channel slices of contiguous NCHW buffers."""
     B, Cin, H, W = x_view.shape
     Cout = y_view.shape[1]
     Ho, Wo = conv3x3_out_hw(H, W, stride)
     if tuple(y_view.shape) != (B, Cout, Ho, Wo):
-        raise UpflowHipError('conv3x3: output must be [%d,%d,%d,%d], got %s' % (B, Cout, Ho, Wo, tuple(y_view.shape)))
+        raise UpflowHipError('conv: output must be [%d,%d,%d,%d], got %s' % (B, Cout, Ho, Wo, tuple(y_view.shape)))
     if x_view.stride()[1:] != (H * W, W, 1) or y_view.stride()[1:] != (Ho * Wo, Wo, 1):
-        raise UpflowHipError('conv3x3: operands must be channel slices of contiguous NCHW buffers')
+        raise UpflowHipError('conv: operands must be channel slices of contiguous NCHW buffers')
     dev = x_view.device
     with torch.cuda.device(dev):
-        _lib.call('upf_conv3x3_forward', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(packed), _lib.ptr(bias32),
-                  _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(dilation), int(stride), float(leaky_slope),
-                  _lib.dtype_code(x_view), _lib.stream_ptr(dev))
+        _lib.call('upf_conv_forward', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(packed), _lib.ptr(bias32),
+                  _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
+                  float(leaky_slope), _lib.dtype_code(x_view), _lib.stream_ptr(dev))
     return y_view
