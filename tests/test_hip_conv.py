@@ -9,7 +9,10 @@ pytestmark = pytest.mark.gpu
 CASES = [  # B, Cin, Cout, H, W, dilation
     (1, 32, 32, 8, 32, 1), (2, 115, 128, 24, 40, 1), (1, 243, 128, 16, 64, 1), (1, 371, 96, 9, 24, 1), (1, 467, 64, 8, 8, 1),
     (1, 563, 2, 12, 40, 1), (1, 565, 128, 16, 32, 1), (1, 128, 128, 24, 48, 2), (1, 128, 128, 24, 48, 4), (1, 128, 96, 40, 64, 8), (1, 96, 64, 40, 64, 16), (2, 96, 64, 24, 80, 16),
-    (2, 64, 32, 17, 56, 1), (1, 184, 3, 8, 16, 1), (1, 7, 5, 3, 8, 1), (4, 96, 32, 96, 320, 1)]
+    (2, 64, 32, 17, 56, 1), (1, 184, 3, 8, 16, 1), (1, 7, 5, 3, 8, 1), (4, 96, 32, 96, 320, 1),
+    # rows that are not 16-byte aligned (W % 8 != 0, odd W, odd channel-slice offsets) and Cout > 128
+    (2, 115, 128, 6, 20, 1), (1, 565, 96, 6, 20, 1), (2, 64, 196, 6, 20, 1), (1, 96, 64, 6, 20, 16), (1, 128, 128, 12, 26, 4),
+    (1, 40, 33, 7, 13, 1), (1, 35, 2, 5, 9, 1), (2, 48, 64, 24, 52, 2), (1, 16, 160, 9, 75, 1), (1, 196, 196, 8, 24, 1)]
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -26,13 +29,8 @@ def test_conv3x3_matches_conv2d(case, dtype):
     xbuf = torch.zeros(B, Cin + 5, H, W, dtype=dtype, device='cuda')
     xbuf[:, 5:] = x
     ybuf = torch.full((B, Cout + 3, H, W), 7.0, dtype=dtype, device='cuda')
-    assert ops.conv3x3_supported(xbuf[:, 5:], Cout, d) or (5 * H * W * 2) % 16 != 0
-    if not ops.conv3x3_supported(xbuf[:, 5:], Cout, d):
-        xbuf = torch.zeros(B, Cin + 8, H, W, dtype=dtype, device='cuda')
-        xbuf[:, 8:] = x
-        xv = xbuf[:, 8:]
-    else:
-        xv = xbuf[:, 5:]
+    xv = xbuf[:, 5:]                        # 5*H*W elements in: 16-byte aligned for some cases, not for others
+    assert ops.conv3x3_supported(xv, Cout, d)
     packed = ops.conv3x3_pack(w)
     ops.conv3x3_forward_raw(xv, packed, b, ybuf[:, 2:2 + Cout], dilation=d, leaky_slope=0.1)
     got = ybuf[:, 2:2 + Cout].float()
@@ -48,17 +46,18 @@ def test_conv3x3_matches_conv2d(case, dtype):
 
 def test_conv3x3_rejects_unsupported():
     from upflow_pytorch_amd import ops
-    x = torch.zeros(1, 8, 8, 12, dtype=torch.bfloat16, device='cuda')       # W % 8 != 0
+    x = torch.zeros(1, 8, 8, 6, dtype=torch.bfloat16, device='cuda')        # rows shorter than one 8-pixel group
     assert not ops.conv3x3_supported(x, 8, 1)
-    assert not ops.conv3x3_supported(x.float(), 8, 1)
     x = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda')
-    assert not ops.conv3x3_supported(x, 8, 17) and not ops.conv3x3_supported(x, 200, 1)
+    assert not ops.conv3x3_supported(x.float(), 8, 1)
+    assert not ops.conv3x3_supported(x, 8, 17) and not ops.conv3x3_supported(x, 8, 2, 2)
     w = ops.conv3x3_pack(torch.zeros(8, 8, 3, 3, dtype=torch.bfloat16, device='cuda'))
     with pytest.raises(RuntimeError):
         ops.conv3x3_forward_raw(x, w, torch.zeros(8, device='cuda'), torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda'), dilation=17)
 
 
-@pytest.mark.parametrize('case', [(1, 3, 16, 64, 128), (2, 16, 32, 32, 64), (1, 32, 64, 24, 40), (1, 64, 96, 17, 24), (2, 16, 16, 48, 64)])
+@pytest.mark.parametrize('case', [(1, 3, 16, 64, 128), (2, 16, 32, 32, 64), (1, 32, 64, 24, 40), (1, 64, 96, 17, 24), (2, 16, 16, 48, 64),
+                                  (2, 128, 196, 12, 40), (1, 96, 128, 24, 52), (1, 128, 196, 12, 26), (1, 32, 64, 13, 27)])
 def test_conv3x3_stride2(case):
     from upflow_pytorch_amd import ops
     B, Cin, Cout, H, W = case
@@ -75,7 +74,8 @@ def test_conv3x3_stride2(case):
     assert (y.float() - want).abs().max() <= 2.0 ** -8 * float(want.abs().max()) + 1e-3
 
 
-@pytest.mark.parametrize('case', [(2, 32, 32, 24, 40), (1, 64, 32, 16, 64), (1, 96, 32, 9, 16), (1, 128, 32, 12, 40), (4, 32, 32, 96, 320)])
+@pytest.mark.parametrize('case', [(2, 32, 32, 24, 40), (1, 64, 32, 16, 64), (1, 96, 32, 9, 16), (1, 128, 32, 12, 40), (4, 32, 32, 96, 320),
+                                  (2, 196, 32, 6, 20), (1, 128, 32, 12, 26), (1, 16, 32, 7, 13), (1, 64, 200, 6, 20)])
 def test_conv1x1(case):
     from upflow_pytorch_amd import ops
     B, Cin, Cout, H, W = case

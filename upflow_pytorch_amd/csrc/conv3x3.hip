@@ -80,7 +80,11 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
 // (S*i + (ky-1)d, S*j + (kx-1)d); only the staged window and the LDS read addresses change.
 // VAR: 0 = 3x3, 8-column margins (dilation <= 8); 1 = 3x3, 16-column margins (dilation 16); 2 = 1x1.
 // Compile-time so that the tap loop unrolls and the window addressing folds into immediates.
-template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2, int S = 1, int NOCTS = 4, int VAR = 0>
+// GEN: the staged rows need not be 16-byte aligned (W % 8 != 0, or x is an odd channel slice): the 8-pixel group
+// that would cross the end of its image row is loaded SHIFTED LEFT so that it ends at the row end (gfx950 executes
+// the 2-byte-aligned 16-byte load; tools/unaligned_b128_probe.hip), and the shift is undone by the LDS entry index
+// each transposed pixel is written to — no load ever leaves its row, so nothing depends on what follows the buffer.
+template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2, int S = 1, int NOCTS = 4, int VAR = 0, bool GEN = false>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                     T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d,
@@ -133,11 +137,13 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 
   // x staging task t -> (channel octet, staged row, 8-pixel group): buffer-load offset of channel 0 of the
   // octet in chunk 0 (0x80000000 = outside the image) and the LDS entry it fills
-  auto task_geom = [&](int t, uint32_t& off, int& dst) {
+  // sh (GEN only): pixels by which the load window is shifted left so that it ends at the row end
+  auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
     const int gy = S * y0 - d + r, gx = S * x0 - marg + 8 * g;
-    const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // W % 8 == 0: a group is all in or all out
-    off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx) * 2u) : 0x80000000u;
+    const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // !GEN: W % 8 == 0, a group is all in or all out
+    sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
+    off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
     dst = (oct * rows + r) * XW + 8 * g;
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
@@ -145,7 +151,7 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
   };
-  auto task_store = [&](int dsti, const u32x4 (&ch)[8]) {                         // 8 channel rows x 8 px -> 8 px x 8 channels
+  auto task_store = [&](int dsti, int sh, const u32x4 (&ch)[8]) {                 // 8 channel rows x 8 px -> 8 px x 8 channels
     uint4* dst = xs + dsti;
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
@@ -154,31 +160,37 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
       e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
       e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
-      dst[2 * pp] = e0;
-      dst[2 * pp + 1] = e1;
+      if constexpr (GEN) {                           // loaded pixel q is column q - sh of the group; columns >= 8 - sh are past the row end
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        dst[(2 * pp - sh) & 7] = (2 * pp >= sh) ? e0 : z;
+        dst[(2 * pp + 1 - sh) & 7] = (2 * pp + 1 >= sh) ? e1 : z;
+      } else {
+        dst[2 * pp] = e0;
+        dst[2 * pp + 1] = e1;
+      }
     }
   };
   // PREFETCH (MT <= 3, where the register budget allows 32 more VGPRs): this thread's first x task of chunk
   // cc+1 is loaded into registers BEFORE the tap loop of chunk cc and lands in LDS after it, so the HBM/L2
   // latency of the staging hides under the matrix work instead of heading every chunk.
   constexpr bool PREFETCH = (MT <= 3);
-  uint32_t off0 = 0x80000000u; int dst0 = 0;
+  uint32_t off0 = 0x80000000u; int dst0 = 0, sh0 = 0;
   u32x4 pre[8];
   if constexpr (PREFETCH) {
-    task_geom(tid, off0, dst0);
+    task_geom(tid, off0, dst0, sh0);
     task_load(off0, 0, pre);
   }
 
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();                                 // previous chunk fully consumed
     // ---- stage the x tile (+halo) of channels [32cc, 32cc+32)
-    if constexpr (PREFETCH) { if (tid < ntasks) task_store(dst0, pre); }
+    if constexpr (PREFETCH) { if (tid < ntasks) task_store(dst0, sh0, pre); }
     for (int t = tid + (PREFETCH ? NTHREADS : 0); t < ntasks; t += NTHREADS) {
-      uint32_t off; int dsti;
-      task_geom(t, off, dsti);
+      uint32_t off; int dsti, sh;
+      task_geom(t, off, dsti, sh);
       u32x4 ch[8];
       task_load(off, cc, ch);
-      task_store(dsti, ch);
+      task_store(dsti, sh, ch);
     }
     // ---- weight slices: tap 0 -> as[0]  (ALLTAPS: all 9 taps -> as[0..8])
     for (int e = tid; e < (ALLTAPS ? ntaps : 1) * AS_E; e += NTHREADS) {
@@ -259,7 +271,7 @@ struct Args {
   int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
 };
 
-template <typename T, int MT, int RPW, int S>
+template <typename T, int MT, int RPW, int S, bool GEN = false>
 int launch_rpw(const Args& a, int slabs = 1) {
   constexpr int TH = 4 * RPW;
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
@@ -276,11 +288,11 @@ int launch_rpw(const Args& a, int slabs = 1) {
   {                                                                                                                                \
     static size_t attr_lds = 0;                                                                                                    \
     if (lds > attr_lds) {                                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR>),                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR, GEN>),            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
       attr_lds = lds;                                                                                                              \
     }                                                                                                                              \
-    hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR>), grid, dim3(NTHREADS), lds, a.stream, (const T*)a.x,     \
+    hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR, GEN>), grid, dim3(NTHREADS), lds, a.stream, (const T*)a.x, \
                        a.xbs, (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, a.d, tiles_x, tiles_y,      \
                        a.slope);                                                                                                   \
   }
@@ -313,6 +325,18 @@ int launch(const Args& a) {
   return launch_rpw<T, MT, 2, 1>(a);
 }
 
+// Output-channel slabs of 32 or 64 over blockIdx.y: any Cout (the pyramid's 196-channel level), and the GEN
+// (unaligned-row) variant, which only the small pyramid levels of inputs that are not multiples of 512 reach.
+template <typename T, bool GEN>
+int launch_slabs(const Args& a) {
+  const int mt = cdiv(a.Cout, 32);
+  const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
+  const long long tiles = (long long)a.B * cdiv(Wo, TW) * cdiv(Ho, 8);
+  const bool two = mt >= 2 && tiles * ((mt + 1) / 2) >= 384;     // 64-wide slabs once they still fill the chip
+  if (a.stride == 2) return two ? launch_rpw<T, 2, 2, 2, GEN>(a, (mt + 1) / 2) : launch_rpw<T, 1, 2, 2, GEN>(a, mt);
+  return two ? launch_rpw<T, 2, 2, 1, GEN>(a, (mt + 1) / 2) : launch_rpw<T, 1, 2, 1, GEN>(a, mt);
+}
+
 }  // namespace conv
 }  // namespace upf
 
@@ -340,17 +364,20 @@ extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const v
                                 int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream) {
   using namespace upf;
   UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv_forward: null pointer");
-  UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Cout <= 128 && H > 0 && W > 0, UPF_EINVAL,
-              "conv_forward: bad shape B=%d Cin=%d Cout=%d H=%d W=%d (Cout <= 128)", B, Cin, Cout, H, W);
+  UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL,
+              "conv_forward: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
   UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward: bf16 / fp16 only");
   UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_forward: kernel_size %d (1 or 3)", kernel_size);
   UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
   UPF_REQUIRE(stride == 1 || (stride == 2 && dilation == 1 && kernel_size == 3), UPF_EUNSUPPORTED, "conv_forward: stride %d (1, or 2 for a 3x3 with dilation 1)", stride);
-  UPF_REQUIRE(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0, UPF_EALIGN, "conv_forward: needs W %% 8 == 0 and 16-byte aligned x");
+  const bool gen = !(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0);   // rows not 16-byte aligned
+  UPF_REQUIRE(!gen || W >= 8, UPF_EUNSUPPORTED, "conv_forward: W = %d < 8 with unaligned rows", W);
   UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: image too large for one buffer descriptor");
   conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W,
                kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope, (hipStream_t)stream};
   const int mt = (Cout + 31) / 32;
+  if (gen) return dtype == UPF_BF16 ? conv::launch_slabs<bf16_t, true>(a) : conv::launch_slabs<f16_t, true>(a);
+  if (mt > 4) return dtype == UPF_BF16 ? conv::launch_slabs<bf16_t, false>(a) : conv::launch_slabs<f16_t, false>(a);
 #define UPF_CONV_CASE(T)                          \
   switch (mt) {                                   \
     case 1: return conv::launch<T, 1>(a);         \

@@ -182,9 +182,9 @@ def fast_conv_seq(seq, x, cache):
 
 
 def _fast_conv_ok(t):
-    """Inference in bf16/fp16 on the GPU with 8-pixel aligned rows: the hand-written MFMA convolution and
+    """Inference in bf16/fp16 on the GPU (rows of at least 8 pixels): the hand-written MFMA convolution and
     the copy-free concat buffer apply; otherwise the same arithmetic runs through MIOpen + torch.cat."""
-    return (not torch.is_grad_enabled()) and t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.shape[3] % 8 == 0
+    return (not torch.is_grad_enabled()) and t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.shape[3] >= 8
 
 
 class _DenseStack(tools.abstract_model):

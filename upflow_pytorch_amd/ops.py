@@ -325,9 +325,9 @@ def conv3x3_pack(weight):
 
 def conv3x3_supported(x_view, Cout, dilation, stride=1, kernel_size=3):
     """Shapes the matrix-core kernel takes; everything else stays with MIOpen."""
-    return (x_view.is_cuda and x_view.dtype in (torch.bfloat16, torch.float16) and Cout <= 128 and kernel_size in (1, 3)
+    return (x_view.is_cuda and x_view.dtype in (torch.bfloat16, torch.float16) and kernel_size in (1, 3)
             and 1 <= dilation <= 16 and (stride == 1 or (stride == 2 and dilation == 1 and kernel_size == 3))
-            and x_view.shape[3] % 8 == 0 and x_view.stride(0) % 8 == 0 and x_view.data_ptr() % 16 == 0)
+            and x_view.shape[3] >= 8)
 
 
 def conv3x3_out_hw(H, W, stride=1):
