@@ -28,6 +28,7 @@
 //     current tap's MFMAs run;
 //   * epilogue: + bias, LeakyReLU, convert, store.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace upf {
 namespace conv {
@@ -56,13 +57,19 @@ template <> struct Mma32<f16_t> {
 
 __host__ __device__ constexpr int pad32(int v) { return (v + 31) / 32 * 32; }
 
-// w [Cout, Cin, k, k] (k*k = ntaps) -> packed [ntaps][pad32(Cout)][pad32(Cin)], zero padded
+// w [Cout, Cin, k, k] (k*k = ntaps) -> packed [slab = co/32][k-step = ci/16][tap][kg = (ci/8)%2][px = co%32][ci%8],
+// zero padded to pad32(Cout) x pad32(Cin): the 1 KB block of one (slab, k-step, tap) is exactly the A operand of one
+// v_mfma_f32_32x32x16 in lane order (lane = kg*32 + px holds 8 consecutive input channels of output channel px),
+// so a wave fetches it with ONE fully coalesced 16-byte-per-lane load, and an LDS weight slice is 512-byte runs.
 template <typename T>
 __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps) {
-  const int cip = pad32(Cin), cop = pad32(Cout);
+  const int cip = pad32(Cin), cop = pad32(Cout), nk = cip / 16;
   const long long total = (long long)ntaps * cop * cip;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % cip), co = (int)((i / cip) % cop), tap = (int)(i / ((long long)cip * cop));
+    const int j = (int)(i & 7), px = (int)((i >> 3) & 31), kg = (int)((i >> 8) & 1);
+    const long long b = i >> 9;                      // (slab * nk + kstep) * ntaps + tap
+    const int tap = (int)(b % ntaps), kstep = (int)((b / ntaps) % nk), slab = (int)(b / ((long long)ntaps * nk));
+    const int co = slab * 32 + px, ci = kstep * 16 + kg * 8 + j;
     T v; v.v = 0;
     if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ntaps + tap];
     wp[i] = v;
@@ -78,8 +85,17 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
 // staged weight slice, halo row and barrier, which is what bounds the narrow layers.
 // S = stride (1 or 2; the feature pyramid's down-sampling convs): output pixel (i,j) reads input
 // (S*i + (ky-1)d, S*j + (kx-1)d); only the staged window and the LDS read addresses change.
-// VAR: 0 = 3x3, 8-column margins (dilation <= 8); 1 = 3x3, 16-column margins (dilation 16); 2 = 1x1.
-// Compile-time so that the tap loop unrolls and the window addressing folds into immediates.
+// VAR: 0 = 3x3, 8-column margins (dilation <= 8); 1 = 3x3, 16-column margins (dilation 16); 2 = 1x1;
+// 3 = 3x3 with dilation exactly 1.  Compile-time so that the tap loop unrolls and the window addressing folds
+// into immediates.
+// MT == 1 (Cout <= 32 per workgroup — the narrow layers, which are most of the launches): with one 32-channel tile
+// the LDS pipe, not the matrix core, is the bound (1 A + RPW B reads of 1 KB per RPW MFMAs, four waves on one
+// pipe), and the per-chunk weight staging (L2 latency + a barrier) heads every chunk.  So the weights skip LDS:
+// each lane keeps its A operand of all 9 taps x 2 k-steps of the current chunk in 72 registers, loaded straight
+// from the packed weights (L2-resident, identical for every workgroup) and RE-loaded for the next chunk tap by tap
+// right after the tap's last use — the L2 latency hides under the remaining taps and the next chunk's staging.
+// With dilation 1 / stride 1 (VAR 3) a staged row s feeds output rows r = s-ky, so each B window is read once
+// per (s, kx) instead of once per (r, ky, kx): (RPW+2)*3 reads for 9*RPW MFMAs per k-step.
 // GEN: the staged rows need not be 16-byte aligned (W % 8 != 0, or x is an odd channel slice): the 8-pixel group
 // that would cross the end of its image row is loaded SHIFTED LEFT so that it ends at the row end (gfx950 executes
 // the 2-byte-aligned 16-byte load; tools/unaligned_b128_probe.hip), and the shift is undone by the LDS entry index
@@ -92,6 +108,9 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   constexpr int nocts = NOCTS;
   constexpr int marg = (VAR == 1) ? 16 : 8;
   constexpr int ntaps = (VAR == 2) ? 1 : 9;
+  constexpr bool WREG = (MT == 1);                   // weights live in registers, not LDS (see the tap loops)
+  constexpr int KS = nocts / 2;                      // k-steps of 16 channels per chunk
+  if constexpr (VAR == 3) d = 1;                     // compile-time dilation 1: the window addressing folds
   // nocts: channel octets per chunk (4 = 32 channels; 2 when Cin <= 16 or when the dilation-16 halo would not
   // fit LDS otherwise).  ntaps: 9, or 1 for a 1x1 convolution (then d = 0 and only the centre tap exists).
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -134,6 +153,9 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 
   const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
   const int nchunks = cip / KCH;
+  // byte offset of the 1 KB packed block (slab m of this workgroup, global k-step, tap)
+  const int nksteps = cip / 16;
+  auto woff = [&](int m, int kstep, int tap) { return (uint32_t)((((int)blockIdx.y * MT + m) * nksteps + kstep) * ntaps + tap) * 1024u; };
 
   // x staging task t -> (channel octet, staged row, 8-pixel group): buffer-load offset of channel 0 of the
   // octet in chunk 0 (0x80000000 = outside the image) and the LDS entry it fills
@@ -161,9 +183,11 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
       e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
       if constexpr (GEN) {                           // loaded pixel q is column q - sh of the group; columns >= 8 - sh are past the row end
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        dst[(2 * pp - sh) & 7] = (2 * pp >= sh) ? e0 : z;
-        dst[(2 * pp + 1 - sh) & 7] = (2 * pp + 1 >= sh) ? e1 : z;
+        const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
+        e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
+        e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
+        dst[(2 * pp - sh) & 7] = e0;
+        dst[(2 * pp + 1 - sh) & 7] = e1;
       } else {
         dst[2 * pp] = e0;
         dst[2 * pp + 1] = e1;
@@ -173,12 +197,25 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   // PREFETCH (MT <= 3, where the register budget allows 32 more VGPRs): this thread's first x task of chunk
   // cc+1 is loaded into registers BEFORE the tap loop of chunk cc and lands in LDS after it, so the HBM/L2
   // latency of the staging hides under the matrix work instead of heading every chunk.
-  constexpr bool PREFETCH = (MT <= 3);
+  constexpr bool PREFETCH = (MT <= 3) && !(MT == 1 && RPW == 4 && NOCTS == 4);   // (that one holds 72 weight registers)
   uint32_t off0 = 0x80000000u; int dst0 = 0, sh0 = 0;
   u32x4 pre[8];
   if constexpr (PREFETCH) {
     task_geom(tid, off0, dst0, sh0);
     task_load(off0, 0, pre);
+  }
+
+  // WREG: this lane's A operands (row px of the weight tile, k-octet kg of each k-step) for every tap of a chunk
+  uint4 wa[WREG ? ntaps : 1][KS];
+  auto wload = [&](int cc, int tap, int ks) {
+    const uint32_t off = (cc < nchunks) ? woff(0, cc * KS + ks, tap) + (uint32_t)lane * 16u : 0x80000000u;
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+  };
+  if constexpr (WREG) {
+#pragma unroll
+    for (int tap = 0; tap < ntaps; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(0, tap, ks);
   }
 
   for (int cc = 0; cc < nchunks; ++cc) {
@@ -192,54 +229,93 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       task_load(off, cc, ch);
       task_store(dsti, sh, ch);
     }
-    // ---- weight slices: tap 0 -> as[0]  (ALLTAPS: all 9 taps -> as[0..8])
-    for (int e = tid; e < (ALLTAPS ? ntaps : 1) * AS_E; e += NTHREADS) {
+    // ---- weight slices: tap 0 -> as[0]  (ALLTAPS: all 9 taps -> as[0..8]);  WREG: nothing to stage
+    for (int e = tid; !WREG && e < (ALLTAPS ? ntaps : 1) * AS_E; e += NTHREADS) {
       const int tap0 = e / AS_E, r0 = e - tap0 * AS_E;
       const int oct = r0 / cop, co = r0 - oct * cop;
-      const uint32_t off = ((uint32_t)((tap0 * copt + co0 + co) * cip + cc * KCH + oct * 8)) * 2u;
+      const uint32_t off = woff(co >> 5, cc * KS + (oct >> 1), tap0) + (uint32_t)(((oct & 1) * 32 + (co & 31)) * 16);
       as[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
     }
     __syncthreads();
     if constexpr (PREFETCH) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
 
-    for (int tap = 0; tap < ntaps; ++tap) {
-      const uint4* acur = as + (ALLTAPS ? tap : (tap & 1)) * AS_E;
-      // prefetch the next tap's weight slice into the other buffer (consumed after the barrier below)
-      u32x4 wpre[(AS_MAX + NTHREADS - 1) / NTHREADS];
-      if (!ALLTAPS && tap + 1 < ntaps) {
+    if constexpr (WREG) {
+      if constexpr (VAR == 3 && S == 1) {
 #pragma unroll
-        for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
-          const int e = tid + j * NTHREADS;
-          const int oct = e / cop, co = e - oct * cop;
-          const uint32_t off = (e < AS_E) ? ((uint32_t)(((tap + 1) * copt + co0 + co) * cip + cc * KCH + oct * 8)) * 2u : 0x80000000u;
-          wpre[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0);
+        for (int sr = 0; sr < RPW + 2; ++sr) {       // staged row sr of this wave's strip feeds output rows r = sr - ky
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              const uint4 b = xs[((2 * ks + kg) * rows + RPW * wave + sr) * XW + marg + px + kx - 1];
+#pragma unroll
+              for (int r = 0; r < RPW; ++r)
+                if (sr - r >= 0 && sr - r <= 2) acc[r][0] = Mma32<T>::mma(wa[(sr - r) * 3 + kx][ks], b, acc[r][0]);
+            }
+          if (sr - (RPW - 1) >= 0 && sr - (RPW - 1) <= 2) {   // kernel row ky = sr-(RPW-1) is finished: fetch the next chunk's
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+              for (int ks = 0; ks < KS; ++ks) wa[(sr - (RPW - 1)) * 3 + kx][ks] = wload(cc + 1, (sr - (RPW - 1)) * 3 + kx, ks);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < ntaps; ++tap) {
+          const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
+          const int col = marg + S * px + (kx - 1) * d;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+              const uint4 b = xs[((2 * ks + kg) * rows + S * (RPW * wave + r) + ky * d) * XW + col];
+              acc[r][0] = Mma32<T>::mma(wa[tap][ks], b, acc[r][0]);
+            }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(cc + 1, tap, ks);
         }
       }
-      const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
-      // shifted window: output pixel (row, px) reads staged entry (row + ky*d, 8 + px + (kx-1)*d)
-      const int col = marg + S * px + (kx - 1) * d;
+    } else {
+      for (int tap = 0; tap < ntaps; ++tap) {
+        const uint4* acur = as + (ALLTAPS ? tap : (tap & 1)) * AS_E;
+        // prefetch the next tap's weight slice into the other buffer (consumed after the barrier below)
+        u32x4 wpre[(AS_MAX + NTHREADS - 1) / NTHREADS];
+        if (!ALLTAPS && tap + 1 < ntaps) {
 #pragma unroll
-      for (int ks = 0; ks < nocts / 2; ++ks) {       // k-steps of 16 channels
-        const int oct = 2 * ks + kg;
-        uint4 a[MT];
+          for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
+            const int e = tid + j * NTHREADS;
+            const int oct = e / cop, co = e - oct * cop;
+            const uint32_t off = (e < AS_E) ? woff(co >> 5, cc * KS + (oct >> 1), tap + 1) + (uint32_t)(((oct & 1) * 32 + (co & 31)) * 16) : 0x80000000u;
+            wpre[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0);
+          }
+        }
+        const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
+        // shifted window: output pixel (row, px) reads staged entry (row + ky*d, 8 + px + (kx-1)*d)
+        const int col = marg + S * px + (kx - 1) * d;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = acur[oct * cop + m * 32 + px];
+        for (int ks = 0; ks < nocts / 2; ++ks) {       // k-steps of 16 channels
+          const int oct = 2 * ks + kg;
+          uint4 a[MT];
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-          const uint4 b = xs[(oct * rows + S * (RPW * wave + r) + ky * d) * XW + col];
+          for (int m = 0; m < MT; ++m) a[m] = acur[oct * cop + m * 32 + px];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
+          for (int r = 0; r < RPW; ++r) {
+            const uint4 b = xs[(oct * rows + S * (RPW * wave + r) + ky * d) * XW + col];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
+          }
+        }
+        if (!ALLTAPS && tap + 1 < ntaps) {
+          uint4* anext = as + ((tap + 1) & 1) * AS_E;
+#pragma unroll
+          for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
+            const int e = tid + j * NTHREADS;
+            if (e < AS_E) anext[e] = __builtin_bit_cast(uint4, wpre[j]);
+          }
+          __syncthreads();
         }
       }
-      if (!ALLTAPS && tap + 1 < ntaps) {
-        uint4* anext = as + ((tap + 1) & 1) * AS_E;
-#pragma unroll
-        for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
-          const int e = tid + j * NTHREADS;
-          if (e < AS_E) anext[e] = __builtin_bit_cast(uint4, wpre[j]);
-        }
-        __syncthreads();
-      }
+  
     }
   }
 
@@ -278,7 +354,7 @@ int launch_rpw(const Args& a, int slabs = 1) {
   const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
   const int rows = S * (TH - 1) + 2 * a.d + 1;
   const int marg = (a.d <= 8) ? 8 : 16;
-  const int wslices = (MT <= 2) ? a.ntaps : 2;
+  const int wslices = (MT == 1) ? 0 : (MT <= 2) ? a.ntaps : 2;      // MT == 1 keeps its weights in registers
   auto lds_for = [&](int nocts) { return (size_t)(nocts * rows * xw(S, marg) + wslices * nocts * MT * 32) * 16; };
   int nocts = (a.Cin <= 16 || marg == 16) ? 2 : 4;
   const size_t lds = lds_for(nocts);
@@ -300,6 +376,9 @@ int launch_rpw(const Args& a, int slabs = 1) {
     if (a.ntaps == 1) { if (nocts == 4) UPF_CONV_LAUNCH(4, 2) else UPF_CONV_LAUNCH(2, 2) return check_launch("conv_forward"); }
     if (marg == 16) { UPF_CONV_LAUNCH(2, 1) return check_launch("conv_forward"); }
   }
+  if constexpr (MT == 1) {
+    if (a.d == 1 && a.ntaps == 9) { if (nocts == 4) UPF_CONV_LAUNCH(4, 3) else UPF_CONV_LAUNCH(2, 3) return check_launch("conv_forward"); }
+  }
   if (nocts == 4) UPF_CONV_LAUNCH(4, 0) else UPF_CONV_LAUNCH(2, 0)
 #undef UPF_CONV_LAUNCH
   return check_launch("conv_forward");
@@ -311,7 +390,8 @@ int launch(const Args& a) {
   if constexpr (MT == 1) {
     // narrow layers: 16x32 tiles (4 rows per wave) halve the weight / halo / barrier cost per pixel, but only when
     // the grid still fills the chip twice over (256 CUs x 2 resident workgroups)
-    if ((long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 16) >= 512 && a.d <= 8 && a.ntaps == 9) return launch_rpw<T, MT, 4, 1>(a);
+    static const int rpw4_min = getenv("UPF_CONV_RPW4_MIN") ? atoi(getenv("UPF_CONV_RPW4_MIN")) : 256;
+    if ((long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 16) >= rpw4_min && a.d <= 8 && a.ntaps == 9) return launch_rpw<T, MT, 4, 1>(a);
   }
   if constexpr (MT > 1) {
     // coarse pyramid levels: too few pixel tiles to fill 256 CUs -> split the OUTPUT CHANNELS over blockIdx.y
