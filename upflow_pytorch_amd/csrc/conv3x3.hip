@@ -1,42 +1,49 @@
-// 3x3 (dilated) convolution as an implicit GEMM on the bf16/fp16 matrix cores — gfx950.
+// 3x3 (dilated / strided) and 1x1 convolution as an implicit GEMM on the bf16/fp16 matrix cores — gfx950.
 //
-// the dense flow-estimator / context / SGU-estimator convolutions
-// (/root/reference/model/pwc_modules.py:250-286, :396-412, model/upflow.py:24-60) are where an
-// inference step actually spends its time (≈1.5 TFLOP per 384x1280 batch-4 step; MIOpen reaches ≈55
-// TFLOP/s on them through im2col + GEMM + NCHW<->NHWC transposes + separate bias / LeakyReLU / concat
-// kernels).  BASELINE.json's north star allows MFMA exactly here ("a real contraction").
+// the dense flow-estimator / context / SGU-estimator / feature-pyramid convolutions
+// (/root/reference/model/pwc_modules.py:250-286, :396-412, :172-199, model/upflow.py:24-60) are where an
+// inference step actually spends its time (≈1.5 TFLOP per 384x1280 batch-4 step; MIOpen reaches ≈55 TFLOP/s on
+// them through im2col + GEMM + NCHW<->NHWC transposes + separate bias / LeakyReLU / concat kernels).
+// BASELINE.json's north star allows MFMA exactly here ("a real contraction").
 //
-//   y[n, co, i, j] = act( bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[n, ci, i+(ky-1)d, j+(kx-1)d] )
-//   stride 1, padding = dilation d (same-size output), zero padding, act = LeakyReLU(slope) or identity.
+//   y[n, co, i, j] = act( bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[n, ci, S*i+(ky-1)d, S*j+(kx-1)d] )
+//   padding = dilation d (zero padding), stride S in {1,2}, act = LeakyReLU(slope) or identity.
 //
-// x and y are CHANNEL SLICES of larger contiguous NCHW buffers (batch strides given): the dense
-// estimator's growing concatenation (`x1 = cat([conv1(x), x])`, pwc_modules.py:280-285) becomes one
-// 565-channel buffer that every conv reads a suffix of and writes its own slice of — no concat copy,
-// no separate bias or activation pass, no layout transposes, no im2col buffer.
+// x and y are CHANNEL SLICES of larger contiguous NCHW buffers (batch strides given): the dense estimator's
+// growing concatenation (`x1 = cat([conv1(x), x])`, pwc_modules.py:280-285) becomes one 565-channel buffer that
+// every conv reads a suffix of and writes its own slice of — no concat copy, no separate bias or activation
+// pass, no layout transposes, no im2col buffer.
 //
 // GEMM view per image: D[co][pixel] = sum_tap sum_ci W[tap][co][ci] * X[ci][pixel + shift(tap)],
 // v_mfma_f32_32x32x16_{bf16,f16}: A = 32 output channels x 16 k, B = 16 k x 32 pixels (one tile row).
-//   * workgroup = 4 waves = an 8x32 pixel tile of one image, ALL output channels (<= 128, MT tiles of 32);
-//     wave w owns tile rows 2w, 2w+1 -> 2*MT accumulator tiles of 16 fp32 registers;
-//   * per chunk of 32 input channels the x tile + halo is staged ONCE into LDS, transposed in registers
+//   * workgroup = 4 waves = a TH x 32 pixel tile of one image and MTW*32 output channels.  The waves split the
+//     OUTPUT CHANNELS first (wave -> 32-channel block cb = wave % MTW) and the tile rows second
+//     (row group rg = wave / MTW, RPW rows each): MTW=4 -> every wave owns all 8 rows of its 32 channels.
+//   * the x tile + halo of a chunk of 32 (16) input channels is staged ONCE into LDS, transposed in registers
 //     (8 channel rows x 8 pixels -> 8 pixels x 8 channels, 32 v_perm) into 16-byte entries
-//     [channel-octet][row][col]; the 9 taps then read SHIFTED windows of it (per-lane LDS addresses), so
-//     the im2col expansion exists only as LDS read addresses;  halo zeros and channels >= Cin come from
-//     the buffer descriptor's bounds check;
-//   * weights are pre-packed once ([tap][co][ci], ci padded to 32, co to 32) so that a wave's A operand
-//     is a 16-byte LDS read; the 8 KB weight slice of the next tap is staged (double-buffered) while the
-//     current tap's MFMAs run;
-//   * epilogue: + bias, LeakyReLU, convert, store.
+//     [channel-octet][row][col]; taps read SHIFTED windows of it, so the im2col expansion exists only as LDS read
+//     addresses.  Halo zeros and channels >= Cin come from the buffer descriptor's bounds check.  The first
+//     staging task of the NEXT chunk is loaded into registers before the matrix phase (HBM latency hides under it).
+//   * the WEIGHTS never touch LDS: they are pre-packed in MFMA lane order (pack_weights_kernel), each lane keeps
+//     its A operand of all 9 taps x 2 k-steps of the current chunk in 72 registers, loaded straight from the
+//     packed buffer (L2-resident, identical for every workgroup), and re-loads a kernel row for the next chunk
+//     right after that row's last use.  (The first version staged weights per tap through LDS: one barrier and one
+//     exposed L2 round trip per tap, and 1 A + 0.5 B LDS reads per MFMA — LDS-pipe bound at ~30 % of the MFMA peak.)
+//   * compile-time dilation D (1,2,4,8): staged row s feeds output rows r = s - ky*D, so each B window is read
+//     once per (s, kx) and used by up to three MFMAs: (RPW+2D)*3 LDS reads instead of 9*RPW per k-step.
+//   * epilogue: + bias, LeakyReLU, convert, lane pairs exchange so that every lane stores two adjacent pixels.
 #include "common.hpp"
 #include <cstdlib>
 
 namespace upf {
 namespace conv {
 
-constexpr int TW = 32, NTHREADS = 256;   // tile = (4*RPW) rows x 32 pixels; RPW = rows per wave (2, or 4 for Cout <= 64)
-// staged columns [S*x0 - marg, S*x0 + S*32 + marg), marg = 8 (d <= 8) or 16: 16-byte aligned global loads
-__host__ __device__ constexpr int xw(int S, int marg) { return S * TW + 2 * marg; }
+constexpr int TW = 32, NTHREADS = 256;
 constexpr int MAXD = 16;                  // dilation limit (the context network's largest)
+// D template values: 0 = 1x1; 1,2,4,8,16 = 3x3 with that dilation; -1 = 3x3, run-time dilation (1..16)
+__host__ __device__ constexpr int margin_of(int D) { return (D == 16 || D < 0) ? 16 : 8; }
+// staged columns [S*x0 - marg, S*x0 + S*32 + marg): whole 8-pixel groups -> 16-byte global loads
+__host__ __device__ constexpr int xw(int S, int marg) { return S * TW + 2 * marg; }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -60,7 +67,7 @@ __host__ __device__ constexpr int pad32(int v) { return (v + 31) / 32 * 32; }
 // w [Cout, Cin, k, k] (k*k = ntaps) -> packed [slab = co/32][k-step = ci/16][tap][kg = (ci/8)%2][px = co%32][ci%8],
 // zero padded to pad32(Cout) x pad32(Cin): the 1 KB block of one (slab, k-step, tap) is exactly the A operand of one
 // v_mfma_f32_32x32x16 in lane order (lane = kg*32 + px holds 8 consecutive input channels of output channel px),
-// so a wave fetches it with ONE fully coalesced 16-byte-per-lane load, and an LDS weight slice is 512-byte runs.
+// so a wave fetches it with ONE fully coalesced 16-byte-per-lane load.
 template <typename T>
 __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps) {
   const int cip = pad32(Cin), cop = pad32(Cout), nk = cip / 16;
@@ -76,90 +83,55 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
   }
 }
 
-// MT = number of 32-wide output-channel tiles (1..4).
-// ALLTAPS (MT <= 2): the weight slices of all 9 taps of a channel chunk are staged together (9*MT*2 KB) and
-// the tap loop runs without barriers — with few output channels the MFMA phase of one tap is far too short
-// to hide the L2 latency of the next tap's weight prefetch, which then dominates (measured: 563->2 channels
-// spent 5.7 us per chunk in nine exposed prefetch+barrier rounds).  MT >= 3 keeps the per-tap double buffer.
-// RPW (rows per wave): Cout <= 32 uses 4 rows per wave = a 16x32 tile per workgroup — twice the pixels per
-// staged weight slice, halo row and barrier, which is what bounds the narrow layers.
-// S = stride (1 or 2; the feature pyramid's down-sampling convs): output pixel (i,j) reads input
-// (S*i + (ky-1)d, S*j + (kx-1)d); only the staged window and the LDS read addresses change.
-// VAR: 0 = 3x3, 8-column margins (dilation <= 8); 1 = 3x3, 16-column margins (dilation 16); 2 = 1x1;
-// 3 = 3x3 with dilation exactly 1.  Compile-time so that the tap loop unrolls and the window addressing folds
-// into immediates.
-// MT == 1 (Cout <= 32 per workgroup — the narrow layers, which are most of the launches): with one 32-channel tile
-// the LDS pipe, not the matrix core, is the bound (1 A + RPW B reads of 1 KB per RPW MFMAs, four waves on one
-// pipe), and the per-chunk weight staging (L2 latency + a barrier) heads every chunk.  So the weights skip LDS:
-// each lane keeps its A operand of all 9 taps x 2 k-steps of the current chunk in 72 registers, loaded straight
-// from the packed weights (L2-resident, identical for every workgroup) and RE-loaded for the next chunk tap by tap
-// right after the tap's last use — the L2 latency hides under the remaining taps and the next chunk's staging.
-// With dilation 1 / stride 1 (VAR 3) a staged row s feeds output rows r = s-ky, so each B window is read once
-// per (s, kx) instead of once per (r, ky, kx): (RPW+2)*3 reads for 9*RPW MFMAs per k-step.
-// GEN: the staged rows need not be 16-byte aligned (W % 8 != 0, or x is an odd channel slice): the 8-pixel group
-// that would cross the end of its image row is loaded SHIFTED LEFT so that it ends at the row end (gfx950 executes
-// the 2-byte-aligned 16-byte load; tools/unaligned_b128_probe.hip), and the shift is undone by the LDS entry index
-// each transposed pixel is written to — no load ever leaves its row, so nothing depends on what follows the buffer.
-template <typename T, int MT, bool ALLTAPS = (MT <= 2), int RPW = 2, int S = 1, int NOCTS = 4, int VAR = 0, bool GEN = false>
+// MTW: 32-channel output blocks per workgroup (1, 2, 4) = waves along Cout;  RPW: tile rows per wave
+// (tile height TH = (4/MTW)*RPW);  S: stride;  NOCTS: channel octets per chunk (4 = 32 channels, 2 = 16);
+// D: compile-time dilation (see margin_of);  GEN: the staged rows need not be 16-byte aligned (W % 8 != 0, or x is an
+// odd channel slice): the 8-pixel group that would cross the end of its image row is loaded SHIFTED LEFT so that it
+// ends at the row end (gfx950 executes the 2-byte-aligned 16-byte load; tools/unaligned_b128_probe.hip), and the
+// shift is undone by the LDS entry index each transposed pixel is written to — no load ever leaves its row, so
+// nothing depends on what follows the buffer.
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN>
 __global__ __launch_bounds__(NTHREADS, 2)
-void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
-                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d,
-                    int tiles_x, int tiles_y, float slope) {
-  constexpr int nocts = NOCTS;
-  constexpr int marg = (VAR == 1) ? 16 : 8;
-  constexpr int ntaps = (VAR == 2) ? 1 : 9;
-  constexpr bool WREG = (MT == 1);                   // weights live in registers, not LDS (see the tap loops)
-  constexpr int KS = nocts / 2;                      // k-steps of 16 channels per chunk
-  if constexpr (VAR == 3) d = 1;                     // compile-time dilation 1: the window addressing folds
-  // nocts: channel octets per chunk (4 = 32 channels; 2 when Cin <= 16 or when the dilation-16 halo would not
-  // fit LDS otherwise).  ntaps: 9, or 1 for a 1x1 convolution (then d = 0 and only the centre tap exists).
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  constexpr int TH = 4 * RPW;
+void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
+                 T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
+                 int tiles_x, int tiles_y, float slope) {
+  constexpr int ntaps = (D == 0) ? 1 : 9;
+  constexpr int marg = margin_of(D);
+  constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
+  constexpr int RG = 4 / MTW, TH = RG * RPW;
   constexpr int XW = xw(S, marg);
+  const int d = (D >= 0) ? D : d_rt;
   const int rows = S * (TH - 1) + 2 * d + 1;         // staged input rows
-  const int XS_E = nocts * rows * XW;                // entries (16 B = 8 channels of one pixel) of the x tile
-  constexpr int AS_MAX = nocts * MT * 32;
-  constexpr int AS_E = nocts * MT * 32;              // entries of one weight slice: [octet][co]
-  constexpr int KCH = nocts * 8;                     // input channels per chunk
-  uint4* xs = smem;                                  // [octet 4][rows][XW]
-  uint4* as = smem + XS_E;                           // [2 (or 9 with ALLTAPS)][octet 4][MT*32]
+  extern __shared__ __attribute__((aligned(16))) uint4 xs[];   // [octet][rows][XW] entries of 8 channels x 1 pixel
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
   const int x0 = tx * TW, y0 = ty * TH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cip = pad32(Cin), cop = MT * 32;         // cop: output channels of THIS workgroup (one blockIdx.y slab)
-  const int copt = pad32(Cout);                      // packed weight rows
-  const int co0 = blockIdx.y * cop;                  // first output channel of the slab (Cout split over blockIdx.y)
+  const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
+  const int cb = wave % MTW, rg = wave / MTW;
+  const int slab = blockIdx.y * MTW + cb;            // this wave's 32-channel output block
+  const int cip = pad32(Cin);
+  const int nchunks = cip / KCH, nksteps = cip / 16;
   const int HW = H * W;
 
   // buffer descriptor over this image's Cin input planes: rows/cols outside the image get offset
   // 0x80000000, channel planes >= Cin fall off the end -> the hardware returns the zero padding
   const uint32_t plane = (uint32_t)HW * 2u;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
-  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)copt * (uint32_t)cip * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 2u, 0x00020000);
 
-  // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
-  constexpr int ngroups = XW / 8;
-  const int ntasks = nocts * rows * ngroups;
-
-  f32x16 acc[RPW][MT];
+  f32x16 acc[RPW];
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[r][m][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
-  const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
-  const int nchunks = cip / KCH;
-  // byte offset of the 1 KB packed block (slab m of this workgroup, global k-step, tap)
-  const int nksteps = cip / 16;
-  auto woff = [&](int m, int kstep, int tap) { return (uint32_t)((((int)blockIdx.y * MT + m) * nksteps + kstep) * ntaps + tap) * 1024u; };
-
-  // x staging task t -> (channel octet, staged row, 8-pixel group): buffer-load offset of channel 0 of the
-  // octet in chunk 0 (0x80000000 = outside the image) and the LDS entry it fills
-  // sh (GEN only): pixels by which the load window is shifted left so that it ends at the row end
+  // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
+  constexpr int ngroups = XW / 8;
+  const int ntasks = NOCTS * rows * ngroups;
+  // task t -> buffer-load offset of channel 0 of its octet in chunk 0 (0x80000000 = outside the image), the LDS
+  // entry it fills, and (GEN) the pixels by which the load window is shifted left to end at the row end
   auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
     const int gy = S * y0 - d + r, gx = S * x0 - marg + 8 * g;
@@ -194,151 +166,110 @@ void conv3x3_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
       }
     }
   };
-  // PREFETCH (MT <= 3, where the register budget allows 32 more VGPRs): this thread's first x task of chunk
-  // cc+1 is loaded into registers BEFORE the tap loop of chunk cc and lands in LDS after it, so the HBM/L2
-  // latency of the staging hides under the matrix work instead of heading every chunk.
-  constexpr bool PREFETCH = (MT <= 3) && !(MT == 1 && RPW == 4 && NOCTS == 4);   // (that one holds 72 weight registers)
+  // this thread's first x task of chunk cc+1 is loaded into registers BEFORE the matrix phase of chunk cc and
+  // lands in LDS after it
+  constexpr bool PRE = !(MTW == 1 && RPW == 4 && NOCTS == 4);     // (that one would spill)
   uint32_t off0 = 0x80000000u; int dst0 = 0, sh0 = 0;
   u32x4 pre[8];
-  if constexpr (PREFETCH) {
+  if constexpr (PRE) {
     task_geom(tid, off0, dst0, sh0);
     task_load(off0, 0, pre);
   }
 
-  // WREG: this lane's A operands (row px of the weight tile, k-octet kg of each k-step) for every tap of a chunk
-  uint4 wa[WREG ? ntaps : 1][KS];
+  // this lane's A operands (row px of the weight tile, k-octet kg of each k-step) for every tap of a chunk
+  uint4 wa[ntaps][KS];
   auto wload = [&](int cc, int tap, int ks) {
-    const uint32_t off = (cc < nchunks) ? woff(0, cc * KS + ks, tap) + (uint32_t)lane * 16u : 0x80000000u;
+    const uint32_t off = (cc < nchunks) ? (uint32_t)(((slab * nksteps + cc * KS + ks) * ntaps + tap) * 1024 + lane * 16) : 0x80000000u;
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
   };
-  if constexpr (WREG) {
 #pragma unroll
-    for (int tap = 0; tap < ntaps; ++tap)
+  for (int tap = 0; tap < ntaps; ++tap)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(0, tap, ks);
-  }
+    for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(0, tap, ks);
+
+  constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * D) * 3 < 9 * RPW);
 
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();                                 // previous chunk fully consumed
-    // ---- stage the x tile (+halo) of channels [32cc, 32cc+32)
-    if constexpr (PREFETCH) { if (tid < ntasks) task_store(dst0, sh0, pre); }
-    for (int t = tid + (PREFETCH ? NTHREADS : 0); t < ntasks; t += NTHREADS) {
+    // ---- stage the x tile (+halo) of channels [KCH*cc, KCH*cc + KCH)
+    if constexpr (PRE) { if (tid < ntasks) task_store(dst0, sh0, pre); }
+    for (int t = tid + (PRE ? NTHREADS : 0); t < ntasks; t += NTHREADS) {
       uint32_t off; int dsti, sh;
       task_geom(t, off, dsti, sh);
       u32x4 ch[8];
       task_load(off, cc, ch);
       task_store(dsti, sh, ch);
     }
-    // ---- weight slices: tap 0 -> as[0]  (ALLTAPS: all 9 taps -> as[0..8]);  WREG: nothing to stage
-    for (int e = tid; !WREG && e < (ALLTAPS ? ntaps : 1) * AS_E; e += NTHREADS) {
-      const int tap0 = e / AS_E, r0 = e - tap0 * AS_E;
-      const int oct = r0 / cop, co = r0 - oct * cop;
-      const uint32_t off = woff(co >> 5, cc * KS + (oct >> 1), tap0) + (uint32_t)(((oct & 1) * 32 + (co & 31)) * 16);
-      as[e] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
-    }
     __syncthreads();
-    if constexpr (PREFETCH) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
+    if constexpr (PRE) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
 
-    if constexpr (WREG) {
-      if constexpr (VAR == 3 && S == 1) {
+    if constexpr (REUSE) {
 #pragma unroll
-        for (int sr = 0; sr < RPW + 2; ++sr) {       // staged row sr of this wave's strip feeds output rows r = sr - ky
+      for (int sr = 0; sr < RPW + 2 * D; ++sr) {     // staged row sr of this wave's strip feeds output rows r = sr - ky*D
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              const uint4 b = xs[((2 * ks + kg) * rows + RPW * wave + sr) * XW + marg + px + kx - 1];
+          for (int ks = 0; ks < KS; ++ks) {
+            const uint4 b = xs[((2 * ks + kg) * rows + RPW * rg + sr) * XW + marg + px + (kx - 1) * D];
 #pragma unroll
-              for (int r = 0; r < RPW; ++r)
-                if (sr - r >= 0 && sr - r <= 2) acc[r][0] = Mma32<T>::mma(wa[(sr - r) * 3 + kx][ks], b, acc[r][0]);
-            }
-          if (sr - (RPW - 1) >= 0 && sr - (RPW - 1) <= 2) {   // kernel row ky = sr-(RPW-1) is finished: fetch the next chunk's
+            for (int ky = 0; ky < 3; ++ky)
+              if (sr - ky * D >= 0 && sr - ky * D < RPW) acc[sr - ky * D] = Mma32<T>::mma(wa[ky * 3 + kx][ks], b, acc[sr - ky * D]);
+          }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+          if (sr == ky * D + RPW - 1) {              // kernel row ky is finished: fetch the next chunk's
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-              for (int ks = 0; ks < KS; ++ks) wa[(sr - (RPW - 1)) * 3 + kx][ks] = wload(cc + 1, (sr - (RPW - 1)) * 3 + kx, ks);
+              for (int ks = 0; ks < KS; ++ks) wa[ky * 3 + kx][ks] = wload(cc + 1, ky * 3 + kx, ks);
           }
-        }
-      } else {
-#pragma unroll
-        for (int tap = 0; tap < ntaps; ++tap) {
-          const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
-          const int col = marg + S * px + (kx - 1) * d;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-              const uint4 b = xs[((2 * ks + kg) * rows + S * (RPW * wave + r) + ky * d) * XW + col];
-              acc[r][0] = Mma32<T>::mma(wa[tap][ks], b, acc[r][0]);
-            }
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(cc + 1, tap, ks);
-        }
       }
     } else {
-      for (int tap = 0; tap < ntaps; ++tap) {
-        const uint4* acur = as + (ALLTAPS ? tap : (tap & 1)) * AS_E;
-        // prefetch the next tap's weight slice into the other buffer (consumed after the barrier below)
-        u32x4 wpre[(AS_MAX + NTHREADS - 1) / NTHREADS];
-        if (!ALLTAPS && tap + 1 < ntaps) {
 #pragma unroll
-          for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
-            const int e = tid + j * NTHREADS;
-            const int oct = e / cop, co = e - oct * cop;
-            const uint32_t off = (e < AS_E) ? woff(co >> 5, cc * KS + (oct >> 1), tap + 1) + (uint32_t)(((oct & 1) * 32 + (co & 31)) * 16) : 0x80000000u;
-            wpre[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0);
-          }
-        }
+      for (int tap = 0; tap < ntaps; ++tap) {
         const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
-        // shifted window: output pixel (row, px) reads staged entry (row + ky*d, 8 + px + (kx-1)*d)
+        // shifted window: output pixel (row, px) reads staged entry (S*row + ky*d, marg + S*px + (kx-1)*d)
         const int col = marg + S * px + (kx - 1) * d;
 #pragma unroll
-        for (int ks = 0; ks < nocts / 2; ++ks) {       // k-steps of 16 channels
-          const int oct = 2 * ks + kg;
-          uint4 a[MT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) a[m] = acur[oct * cop + m * 32 + px];
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int r = 0; r < RPW; ++r) {
-            const uint4 b = xs[(oct * rows + S * (RPW * wave + r) + ky * d) * XW + col];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[r][m] = Mma32<T>::mma(a[m], b, acc[r][m]);
+            const uint4 b = xs[((2 * ks + kg) * rows + S * (RPW * rg + r) + ky * d) * XW + col];
+            acc[r] = Mma32<T>::mma(wa[tap][ks], b, acc[r]);
           }
-        }
-        if (!ALLTAPS && tap + 1 < ntaps) {
-          uint4* anext = as + ((tap + 1) & 1) * AS_E;
 #pragma unroll
-          for (int j = 0; j < (AS_MAX + NTHREADS - 1) / NTHREADS; ++j) {
-            const int e = tid + j * NTHREADS;
-            if (e < AS_E) anext[e] = __builtin_bit_cast(uint4, wpre[j]);
-          }
-          __syncthreads();
-        }
+        for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(cc + 1, tap, ks);
       }
-  
     }
   }
 
-  // ---- epilogue: D[co][pixel]; lane -> pixel column px, regs -> co = (e&3) + 8*(e>>2) + 4*kg
-  using st = uint16_t;
-  st* yb = reinterpret_cast<st*>(y) + (size_t)n * ybs;
+  // ---- epilogue: D[co][pixel]; lane -> pixel column px, regs -> co = (e&3) + 8*(e>>2) + 4*kg.
+  // Lane pairs (px, px^1) swap halves: the even lane stores pixels (px, px+1) of the even registers' channels,
+  // the odd lane pixels (px-1, px) of the odd registers' — 4-byte stores, half as many.
+  uint16_t* yb = reinterpret_cast<uint16_t*>(y) + (size_t)n * ybs;
+  const bool odd = px & 1;
+  const int gx = x0 + (px & ~1);
+  const size_t HoWo = (size_t)Ho * Wo;
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
-    const int gy = y0 + RPW * wave + r, gx = x0 + px;
-    if (gy >= Ho || gx >= Wo) continue;
+    const int gy = y0 + RPW * rg + r;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int co = co0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-        if (co < Cout) {
-          float v = acc[r][m][e] + bias[co];
-          v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
-          T tmp;
-          Elem<T>::store(&tmp, v);
-          yb[(size_t)co * (Ho * Wo) + gy * Wo + gx] = tmp.v;
-        }
+    for (int j = 0; j < 8; ++j) {
+      const int e0 = 2 * j, e1 = 2 * j + 1;
+      const int c0 = slab * 32 + (e0 & 3) + 8 * (e0 >> 2) + 4 * kg, c1 = c0 + 1;
+      float v0 = acc[r][e0] + (c0 < Cout ? bias[c0] : 0.f), v1 = acc[r][e1] + (c1 < Cout ? bias[c1] : 0.f);
+      if (slope != 0.f) { v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope); }
+      const uint32_t p = pack2<T>(v0, v1);                                   // lo = channel c0, hi = channel c1 of pixel px
+      const uint32_t send = odd ? (p & 0xffffu) : (p >> 16);
+      const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+      const uint32_t out = odd ? (recv | (p & 0xffff0000u)) : ((p & 0xffffu) | (recv << 16));
+      const int co = odd ? c1 : c0;
+      if (gy < Ho && co < Cout && gx < Wo) {
+        uint16_t* dst = yb + (size_t)co * HoWo + (size_t)gy * Wo + gx;
+        if (gx + 1 < Wo) *reinterpret_cast<uint32_t*>(dst) = out;           // (2-byte aligned is enough on gfx950)
+        else *dst = (uint16_t)out;
       }
+    }
   }
 }
 
@@ -347,74 +278,83 @@ struct Args {
   int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
 };
 
-template <typename T, int MT, int RPW, int S, bool GEN = false>
-int launch_rpw(const Args& a, int slabs = 1) {
-  constexpr int TH = 4 * RPW;
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN>
+int launch_one(const Args& a, int slabs) {
+  constexpr int TH = (4 / MTW) * RPW;
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
   const int rows = S * (TH - 1) + 2 * a.d + 1;
-  const int marg = (a.d <= 8) ? 8 : 16;
-  const int wslices = (MT == 1) ? 0 : (MT <= 2) ? a.ntaps : 2;      // MT == 1 keeps its weights in registers
-  auto lds_for = [&](int nocts) { return (size_t)(nocts * rows * xw(S, marg) + wslices * nocts * MT * 32) * 16; };
-  int nocts = (a.Cin <= 16 || marg == 16) ? 2 : 4;
-  const size_t lds = lds_for(nocts);
+  const size_t lds = (size_t)NOCTS * rows * xw(S, margin_of(D)) * 16;
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
-  const dim3 grid((unsigned)(a.B * tiles_x * tiles_y), slabs);
-#define UPF_CONV_LAUNCH(NO, VAR)                                                                                                   \
-  {                                                                                                                                \
-    static size_t attr_lds = 0;                                                                                                    \
-    if (lds > attr_lds) {                                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR, GEN>),            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
-      attr_lds = lds;                                                                                                              \
-    }                                                                                                                              \
-    hipLaunchKernelGGL((conv3x3_kernel<T, MT, (MT <= 2), RPW, S, NO, VAR, GEN>), grid, dim3(NTHREADS), lds, a.stream, (const T*)a.x, \
-                       a.xbs, (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, a.d, tiles_x, tiles_y,      \
-                       a.slope);                                                                                                   \
+  static size_t attr_lds = 0;
+  auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN>;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
   }
-  if constexpr (S == 1 && RPW == 2) {
-    if (a.ntaps == 1) { if (nocts == 4) UPF_CONV_LAUNCH(4, 2) else UPF_CONV_LAUNCH(2, 2) return check_launch("conv_forward"); }
-    if (marg == 16) { UPF_CONV_LAUNCH(2, 1) return check_launch("conv_forward"); }
-  }
-  if constexpr (MT == 1) {
-    if (a.d == 1 && a.ntaps == 9) { if (nocts == 4) UPF_CONV_LAUNCH(4, 3) else UPF_CONV_LAUNCH(2, 3) return check_launch("conv_forward"); }
-  }
-  if (nocts == 4) UPF_CONV_LAUNCH(4, 0) else UPF_CONV_LAUNCH(2, 0)
-#undef UPF_CONV_LAUNCH
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, a.d, tiles_x, tiles_y, a.slope);
   return check_launch("conv_forward");
 }
 
-template <typename T, int MT>
-int launch(const Args& a) {
-  if (a.stride == 2) return launch_rpw<T, MT, 2, 2>(a);
-  if constexpr (MT == 1) {
-    // narrow layers: 16x32 tiles (4 rows per wave) halve the weight / halo / barrier cost per pixel, but only when
-    // the grid still fills the chip twice over (256 CUs x 2 resident workgroups)
-    static const int rpw4_min = getenv("UPF_CONV_RPW4_MIN") ? atoi(getenv("UPF_CONV_RPW4_MIN")) : 256;
-    if ((long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 16) >= rpw4_min && a.d <= 8 && a.ntaps == 9) return launch_rpw<T, MT, 4, 1>(a);
-  }
-  if constexpr (MT > 1) {
-    // coarse pyramid levels: too few pixel tiles to fill 256 CUs -> split the OUTPUT CHANNELS over blockIdx.y
-    // (each slab re-stages the x tile, which is irrelevant when the grid is latency-bound)
-    const long long tiles = (long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 8);
-    if (tiles * 2 <= 512) {
-      if (MT % 2 == 0 && tiles * (MT / 2) >= 384) return launch_rpw<T, 2, 2, 1>(a, MT / 2);
-      return launch_rpw<T, 1, 2, 1>(a, MT);
+// run-time (kernel size, dilation, Cin) -> compile-time (D, NOCTS).  16-channel chunks (NOCTS = 2) where 72 weight
+// registers + the accumulators would spill (four channel blocks per workgroup: 128 accumulator registers per wave),
+// where the halo of the dilation would not fit LDS, and for the RGB / 16-channel layers (half the staging).
+template <int MTW, int D> constexpr int wide_nocts() { return (MTW == 4 || D == 16 || D < 0 || (MTW == 2 && D == 2)) ? 2 : 4; }
+
+template <typename T, int MTW, int RPW, int S, bool GEN>
+int launch_shape(const Args& a, int slabs) {
+  const bool narrow = a.Cin <= 16;
+#define UPF_CONV_D(DD) return narrow ? launch_one<T, MTW, RPW, S, 2, DD, GEN>(a, slabs) : launch_one<T, MTW, RPW, S, wide_nocts<MTW, DD>(), DD, GEN>(a, slabs);
+  if constexpr (S == 2) {
+    UPF_CONV_D(1)
+  } else {
+    if (a.ntaps == 1) { UPF_CONV_D(0) }
+    switch (a.d) {
+      case 1: UPF_CONV_D(1)
+      case 2: UPF_CONV_D(2)
+      case 4: UPF_CONV_D(4)
     }
+    if constexpr (MTW < 4) {                         // (launch() never sends these to four-block workgroups)
+      if (a.d == 8) { UPF_CONV_D(8) }
+      if (a.d == 16) { UPF_CONV_D(16) }
+      UPF_CONV_D(-1)
+    }
+    set_error("conv_forward: internal routing error (dilation %d, MTW %d)", a.d, MTW);
+    return UPF_EUNSUPPORTED;
   }
-  return launch_rpw<T, MT, 2, 1>(a);
+#undef UPF_CONV_D
 }
 
-// Output-channel slabs of 32 or 64 over blockIdx.y: any Cout (the pyramid's 196-channel level), and the GEN
-// (unaligned-row) variant, which only the small pyramid levels of inputs that are not multiples of 512 reach.
+// Cout and the grid size -> (MTW, RPW, slabs over blockIdx.y)
 template <typename T, bool GEN>
-int launch_slabs(const Args& a) {
+int launch(const Args& a) {
   const int mt = cdiv(a.Cout, 32);
   const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
   const long long tiles = (long long)a.B * cdiv(Wo, TW) * cdiv(Ho, 8);
-  const bool two = mt >= 2 && tiles * ((mt + 1) / 2) >= 384;     // 64-wide slabs once they still fill the chip
-  if (a.stride == 2) return two ? launch_rpw<T, 2, 2, 2, GEN>(a, (mt + 1) / 2) : launch_rpw<T, 1, 2, 2, GEN>(a, mt);
-  return two ? launch_rpw<T, 2, 2, 1, GEN>(a, (mt + 1) / 2) : launch_rpw<T, 1, 2, 1, GEN>(a, mt);
+  static const int small_grid = getenv("UPF_CONV_SMALL_GRID") ? atoi(getenv("UPF_CONV_SMALL_GRID")) : 256;
+  static const int rpw4_min = getenv("UPF_CONV_RPW4_MIN") ? atoi(getenv("UPF_CONV_RPW4_MIN")) : 256;
+  int mtw = mt >= 3 ? 4 : mt;
+  if (tiles <= small_grid && mt > 1) {
+    // coarse pyramid levels: too few pixel tiles to fill 256 CUs -> more, narrower workgroups over blockIdx.y
+    // (each re-stages the x tile, which is irrelevant when the grid is latency-bound)
+    mtw = (tiles * cdiv(mt, 2) >= 384) ? 2 : 1;
+  }
+  // four-block workgroups keep 128 accumulator registers per wave: only the window-reuse loops fit beside them
+  const bool reuse_d = a.ntaps == 1 || a.d == 1 || a.d == 2 || a.d == 4;
+  if (mtw == 4 && (a.stride == 2 || !reuse_d)) mtw = 2;
+  const int slabs = cdiv(mt, mtw);
+  if (a.stride == 2) {
+    if (mtw == 2) return launch_shape<T, 2, 4, 2, GEN>(a, slabs);
+    return launch_shape<T, 1, 2, 2, GEN>(a, slabs);
+  }
+  if (mtw == 4) return launch_shape<T, 4, 8, 1, GEN>(a, slabs);
+  if (mtw == 2) return launch_shape<T, 2, 4, 1, GEN>(a, slabs);
+  if constexpr (!GEN) {
+    // narrow layers on large grids: 16x32 tiles (4 rows per wave) halve the halo rows and barriers per pixel
+    if ((long long)a.B * cdiv(Wo, TW) * cdiv(Ho, 16) >= rpw4_min && a.d <= 2 && a.ntaps == 9) return launch_shape<T, 1, 4, 1, false>(a, slabs);
+  }
+  return launch_shape<T, 1, 2, 1, GEN>(a, slabs);
 }
 
 }  // namespace conv
@@ -455,16 +395,6 @@ extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const v
   UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: image too large for one buffer descriptor");
   conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W,
                kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope, (hipStream_t)stream};
-  const int mt = (Cout + 31) / 32;
-  if (gen) return dtype == UPF_BF16 ? conv::launch_slabs<bf16_t, true>(a) : conv::launch_slabs<f16_t, true>(a);
-  if (mt > 4) return dtype == UPF_BF16 ? conv::launch_slabs<bf16_t, false>(a) : conv::launch_slabs<f16_t, false>(a);
-#define UPF_CONV_CASE(T)                          \
-  switch (mt) {                                   \
-    case 1: return conv::launch<T, 1>(a);         \
-    case 2: return conv::launch<T, 2>(a);         \
-    case 3: return conv::launch<T, 3>(a);         \
-    default: return conv::launch<T, 4>(a);        \
-  }
-  if (dtype == UPF_BF16) { UPF_CONV_CASE(bf16_t) } else { UPF_CONV_CASE(f16_t) }
-#undef UPF_CONV_CASE
+  if (dtype == UPF_BF16) return gen ? conv::launch<bf16_t, true>(a) : conv::launch<bf16_t, false>(a);
+  return gen ? conv::launch<f16_t, true>(a) : conv::launch<f16_t, false>(a);
 }
