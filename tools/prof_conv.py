@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Profile target: one convolution shape launched N times (for rocprofv3 --kernel-trace / --pmc passes).
+  python tools/prof_conv.py Cin Cout H W dilation [B=8] [N=20]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from upflow_pytorch_amd import ops
+a = [int(v) for v in sys.argv[1:]]
+Cin, Cout, H, W, d = a[:5]
+B = a[5] if len(a) > 5 else 8
+N = a[6] if len(a) > 6 else 20
+x = torch.randn(B, Cin, H, W, device='cuda').bfloat16()
+w = (torch.randn(Cout, Cin, 3, 3, device='cuda') * 0.02).bfloat16()
+b = torch.randn(Cout, device='cuda')
+y = torch.empty(B, Cout, H, W, device='cuda', dtype=torch.bfloat16)
+packed = ops.conv3x3_pack(w)
+for _ in range(N):
+    ops.conv3x3_forward_raw(x, packed, b, y, d, 0.1)
+torch.cuda.synchronize()

@@ -100,9 +100,11 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
   constexpr int RG = 4 / MTW, TH = RG * RPW;
   constexpr int XW = xw(S, marg);
+  constexpr int XWP = XW + 1;                        // LDS row pitch in entries: +1 so that the staging writes of 16 lanes
+                                                     // (one staged row each, 16 B at the same column) hit 16 different bank quads
   const int d = (D >= 0) ? D : d_rt;
   const int rows = S * (TH - 1) + 2 * d + 1;         // staged input rows
-  extern __shared__ __attribute__((aligned(16))) uint4 xs[];   // [octet][rows][XW] entries of 8 channels x 1 pixel
+  extern __shared__ __attribute__((aligned(16))) uint4 xs[];   // [octet][rows][XWP] entries of 8 channels x 1 pixel
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
@@ -133,12 +135,12 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   // task t -> buffer-load offset of channel 0 of its octet in chunk 0 (0x80000000 = outside the image), the LDS
   // entry it fills, and (GEN) the pixels by which the load window is shifted left to end at the row end
   auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
-    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;
+    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), g = rem / rows, r = rem - g * rows;   // row fastest
     const int gy = S * y0 - d + r, gx = S * x0 - marg + 8 * g;
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // !GEN: W % 8 == 0, a group is all in or all out
     sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
-    dst = (oct * rows + r) * XW + 8 * g;
+    dst = (oct * rows + r) * XWP + 8 * g;
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
     const uint32_t o = off + (uint32_t)cc * KCH * plane;                           // stays >= 2^31 for outside tasks
@@ -204,17 +206,30 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     if constexpr (PRE) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
 
     if constexpr (REUSE) {
-#pragma unroll
-      for (int sr = 0; sr < RPW + 2 * D; ++sr) {     // staged row sr of this wave's strip feeds output rows r = sr - ky*D
+      // staged row sr of this wave's strip feeds output rows r = sr - ky*D.  The three windows (kx) of row sr+1 are
+      // read from LDS while the (up to 9*KS) MFMAs of row sr run: left to itself hipcc issues each ds_read right
+      // before its first use and the ~130-cycle LDS latency stalls the matrix pipe twice per row.
+      constexpr int NR = RPW + 2 * D;
+      uint4 bq[2][3 * KS];
+      auto bload = [&](int sr, uint4 (&b)[3 * KS]) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const uint4 b = xs[((2 * ks + kg) * rows + RPW * rg + sr) * XW + marg + px + (kx - 1) * D];
+          for (int ks = 0; ks < KS; ++ks) b[kx * KS + ks] = xs[((2 * ks + kg) * rows + RPW * rg + sr) * XWP + marg + px + (kx - 1) * D];
+      };
+      bload(0, bq[0]);
+#pragma unroll
+      for (int sr = 0; sr < NR; ++sr) {
+        if (sr + 1 < NR) bload(sr + 1, bq[(sr + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
-              if (sr - ky * D >= 0 && sr - ky * D < RPW) acc[sr - ky * D] = Mma32<T>::mma(wa[ky * 3 + kx][ks], b, acc[sr - ky * D]);
-          }
+              if (sr - ky * D >= 0 && sr - ky * D < RPW)
+                acc[sr - ky * D] = Mma32<T>::mma(wa[ky * 3 + kx][ks], bq[sr & 1][kx * KS + ks], acc[sr - ky * D]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
           if (sr == ky * D + RPW - 1) {              // kernel row ky is finished: fetch the next chunk's
@@ -223,6 +238,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 #pragma unroll
               for (int ks = 0; ks < KS; ++ks) wa[ky * 3 + kx][ks] = wload(cc + 1, ky * 3 + kx, ks);
           }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
@@ -234,7 +250,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int r = 0; r < RPW; ++r) {
-            const uint4 b = xs[((2 * ks + kg) * rows + S * (RPW * rg + r) + ky * d) * XW + col];
+            const uint4 b = xs[((2 * ks + kg) * rows + S * (RPW * rg + r) + ky * d) * XWP + col];
             acc[r] = Mma32<T>::mma(wa[tap][ks], b, acc[r]);
           }
 #pragma unroll
@@ -284,7 +300,7 @@ int launch_one(const Args& a, int slabs) {
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
   const int rows = S * (TH - 1) + 2 * a.d + 1;
-  const size_t lds = (size_t)NOCTS * rows * xw(S, margin_of(D)) * 16;
+  const size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + 1) * 16;
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
   static size_t attr_lds = 0;
   auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN>;
