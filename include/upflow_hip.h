@@ -149,14 +149,21 @@ int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd,
  *   y[n,co,i,j] = act(bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[n,ci, s*i+(ky-1)d, s*j+(kx-1)d])
  * output (H-1)/s+1 x (W-1)/s+1.  x / y point at the FIRST input / output channel of channel slices of larger
  * contiguous NCHW buffers (batch strides in elements), so the estimator's growing concatenation needs no
- * copies.  w_packed: upf_conv_pack_weights() output ([k*k][pad32(Cout)][pad32(Cin)], done once per layer).
- * Limits: Cout <= 128, W % 8 == 0, 16-byte aligned x. */
+ * copies.  w_packed: upf_conv_pack_weights() output (MFMA lane order, zero padded to pad32(Cout) x pad32(Cin),
+ * done once per layer).  Any Cout; any W >= 8 (rows that are not 16-byte aligned take a slightly slower
+ * staging path); Cin*H*W*2 < 2^31.
+ * upf_conv_set_option: launch heuristics, for tuning and for the tests to reach every kernel variant:
+ *   "sk_grid"    (96)  grids of at most this many 8x32 pixel tiles use the split-K kernel (0 = never)
+ *   "small_grid" (256) at most this many tiles: narrower workgroups, output channels over blockIdx.y
+ *   "rpw4_min"   (256) at least this many 16x32 tiles: Cout <= 32 layers use 16-row tiles
+ * returns the previous value, or -1 for an unknown name. */
 long long upf_conv_packed_bytes(int Cin, int Cout, int kernel_size);
 int upf_conv_pack_weights(const void* w /* [Cout,Cin,k,k] */, void* w_packed, int Cin, int Cout, int kernel_size,
                           int dtype, void* stream);
 int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
                      void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
                      int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
+int upf_conv_set_option(const char* name, int value);
 
 /* ---- occlusion check  (tools.occ_check_model(obj), utils/tools.py:519-588, 641-677) -------------
  * flow_f, flow_b : [B,2,H,W] fp32 -> occ_fw, occ_bw : [B,1,H,W] fp32 in {0,1}. */

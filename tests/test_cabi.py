@@ -22,7 +22,8 @@ def test_header_symbols_exported():
     assert len(names) >= 15
     for n in names:
         assert hasattr(L, n), 'missing symbol %s' % n
-    bound = set(_lib.SIGNATURES) | {'upf_version', 'upf_last_error', 'upf_normalize_workspace_bytes', 'upf_conv_packed_bytes'}
+    bound = set(_lib.SIGNATURES) | {'upf_version', 'upf_last_error', 'upf_normalize_workspace_bytes', 'upf_conv_packed_bytes',
+             'upf_conv_set_option'}
     assert bound == set(names), (bound ^ set(names))
 
 

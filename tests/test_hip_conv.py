@@ -15,9 +15,24 @@ CASES = [  # B, Cin, Cout, H, W, dilation
     (1, 40, 33, 7, 13, 1), (1, 35, 2, 5, 9, 1), (2, 48, 64, 24, 52, 2), (1, 16, 160, 9, 75, 1), (1, 196, 196, 8, 24, 1)]
 
 
+# launch heuristics under which every case runs: the defaults (coarse grids -> split-K kernel), every grid
+# through the tiled kernel with 4 / 2 / 1 channel blocks per workgroup by Cout (and 16-row tiles for Cout <= 32),
+# and every grid through 32-channel slabs over blockIdx.y
+MODES = {'auto': {}, 'tiled': {'sk_grid': 0, 'small_grid': 0, 'rpw4_min': 0}, 'slabs': {'sk_grid': 0, 'small_grid': 1 << 30, 'rpw4_min': 1 << 30}}
+
+
+@pytest.fixture(params=sorted(MODES))
+def conv_mode(request):
+    from upflow_pytorch_amd import ops
+    prev = {k: ops.conv_set_option(k, v) for k, v in MODES[request.param].items()}
+    yield request.param
+    for k, v in prev.items():
+        ops.conv_set_option(k, v)
+
+
 @pytest.mark.parametrize('case', CASES)
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-def test_conv3x3_matches_conv2d(case, dtype):
+def test_conv3x3_matches_conv2d(case, dtype, conv_mode):
     from upflow_pytorch_amd import ops
     B, Cin, Cout, H, W, d = case
     g = torch.Generator().manual_seed(sum(case))
@@ -58,7 +73,7 @@ def test_conv3x3_rejects_unsupported():
 
 @pytest.mark.parametrize('case', [(1, 3, 16, 64, 128), (2, 16, 32, 32, 64), (1, 32, 64, 24, 40), (1, 64, 96, 17, 24), (2, 16, 16, 48, 64),
                                   (2, 128, 196, 12, 40), (1, 96, 128, 24, 52), (1, 128, 196, 12, 26), (1, 32, 64, 13, 27)])
-def test_conv3x3_stride2(case):
+def test_conv3x3_stride2(case, conv_mode):
     from upflow_pytorch_amd import ops
     B, Cin, Cout, H, W = case
     g = torch.Generator().manual_seed(sum(case))
@@ -76,7 +91,7 @@ def test_conv3x3_stride2(case):
 
 @pytest.mark.parametrize('case', [(2, 32, 32, 24, 40), (1, 64, 32, 16, 64), (1, 96, 32, 9, 16), (1, 128, 32, 12, 40), (4, 32, 32, 96, 320),
                                   (2, 196, 32, 6, 20), (1, 128, 32, 12, 26), (1, 16, 32, 7, 13), (1, 64, 200, 6, 20)])
-def test_conv1x1(case):
+def test_conv1x1(case, conv_mode):
     from upflow_pytorch_amd import ops
     B, Cin, Cout, H, W = case
     g = torch.Generator().manual_seed(sum(case))

@@ -64,6 +64,8 @@ def lib():
         L.upf_normalize_workspace_bytes.restype = _ll
         L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]
         L.upf_conv_packed_bytes.restype = _ll
+        L.upf_conv_set_option.argtypes = [_c.c_char_p, _i]
+        L.upf_conv_set_option.restype = _i
         L.upf_version.restype = _c.c_char_p
         L.upf_last_error.restype = _c.c_char_p
         _lib = L

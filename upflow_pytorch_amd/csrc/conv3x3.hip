@@ -33,7 +33,7 @@
 //     once per (s, kx) and used by up to three MFMAs: (RPW+2D)*3 LDS reads instead of 9*RPW per k-step.
 //   * epilogue: + bias, LeakyReLU, convert, lane pairs exchange so that every lane stores two adjacent pixels.
 #include "common.hpp"
-#include <cstdlib>
+#include <cstring>
 
 namespace upf {
 namespace conv {
@@ -289,6 +289,198 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   }
 }
 
+// Split-K variant for the COARSE pyramid levels (a handful of pixel tiles on 256 CUs: the kernel above is then a
+// serial chain of Cin/32 chunks, ~1.5 us each, on a few dozen workgroups).  Here a workgroup owns a 2 x 32 pixel
+// tile and 32 output channels, and its four waves split the INPUT-CHANNEL chunks (wave w takes chunks w, w+4, ...):
+// every wave stages its own chunk into a private LDS region — no workgroup barrier in the loop — and the four
+// partial accumulators are summed through LDS at the end in a fixed order (deterministic).  4x the workgroups,
+// a quarter of the chain each.
+template <typename T, int NOCTS, int D, bool GEN>
+__global__ __launch_bounds__(NTHREADS, 2)
+void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
+                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, float slope) {
+  constexpr int ntaps = (D == 0) ? 1 : 9;
+  constexpr int marg = margin_of(D);
+  constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;
+  constexpr int RPW = 2, TH = 2;
+  constexpr int XW = xw(1, marg), XWP = XW + 1;
+  constexpr int rows = TH + 2 * D;                   // staged input rows
+  constexpr int ngroups = XW / 8;
+  constexpr int ntasks = NOCTS * rows * ngroups;     // per wave and chunk
+  constexpr int NT = (ntasks + 63) / 64;             // staging tasks per lane
+  constexpr int NPF = NT < 2 ? NT : 2;               // of which prefetched a chunk ahead
+  constexpr int WAVE_ENTRIES = NOCTS * rows * XWP;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint4* xs = smem + wave * WAVE_ENTRIES;            // this wave's private x tile
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int px = lane & 31, kg = lane >> 5;
+  const int slab = blockIdx.y;
+  const int cip = pad32(Cin);
+  const int nchunks = cip / KCH, nksteps = cip / 16;
+  const int HW = H * W;
+  const uint32_t plane = (uint32_t)HW * 2u;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 2u, 0x00020000);
+
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+  auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
+    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), g = rem / rows, r = rem - g * rows;   // row fastest
+    const int gy = y0 - D + r, gx = x0 - marg + 8 * g;
+    const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
+    off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
+    dst = (oct * rows + r) * XWP + 8 * g;
+  };
+  auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
+    const uint32_t o = (cc < nchunks) ? off + (uint32_t)cc * KCH * plane : 0x80000000u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
+  };
+  auto task_store = [&](int dsti, int sh, const u32x4 (&ch)[8]) {
+    uint4* dst = xs + dsti;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      uint4 e0, e1;
+      e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
+      e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
+      e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
+      e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
+      if constexpr (GEN) {
+        const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
+        e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
+        e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
+        dst[(2 * pp - sh) & 7] = e0;
+        dst[(2 * pp + 1 - sh) & 7] = e1;
+      } else {
+        dst[2 * pp] = e0;
+        dst[2 * pp + 1] = e1;
+      }
+    }
+  };
+
+  // geometry of this lane's staging tasks (the same for every chunk) and the prefetch registers of the first NPF
+  uint32_t toff[NT]; int tdst[NT], tsh[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) task_geom(lane + 64 * i, toff[i], tdst[i], tsh[i]);
+  u32x4 pre[NPF][8];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) task_load(toff[i], wave, pre[i]);
+
+  uint4 wa[ntaps][KS];
+  auto wload = [&](int cc, int tap, int ks) {
+    const uint32_t off = (cc < nchunks) ? (uint32_t)(((slab * nksteps + cc * KS + ks) * ntaps + tap) * 1024 + lane * 16) : 0x80000000u;
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+  };
+#pragma unroll
+  for (int tap = 0; tap < ntaps; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(wave, tap, ks);
+
+  constexpr bool REUSE = (D >= 1 && (RPW + 2 * D) * 3 < 9 * RPW);
+
+  for (int cc = wave; cc < nchunks; cc += 4) {
+    // ---- stage this wave's chunk (LDS operations of one wave execute in order: no barrier against its own reads)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      if (i < NPF) {
+        if (lane + 64 * i < ntasks) task_store(tdst[i], tsh[i], pre[i < NPF ? i : 0]);
+      } else if (lane + 64 * i < ntasks) {
+        u32x4 ch[8];
+        task_load(toff[i], cc, ch);
+        task_store(tdst[i], tsh[i], ch);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) task_load(toff[i], cc + 4, pre[i]);
+
+    if constexpr (REUSE) {
+      constexpr int NR = RPW + 2 * D;
+#pragma unroll
+      for (int sr = 0; sr < NR; ++sr) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const uint4 b = xs[((2 * ks + kg) * rows + sr) * XWP + marg + px + (kx - 1) * D];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+              if (sr - ky * D >= 0 && sr - ky * D < RPW) acc[sr - ky * D] = Mma32<T>::mma(wa[ky * 3 + kx][ks], b, acc[sr - ky * D]);
+          }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+          if (sr == ky * D + RPW - 1) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+              for (int ks = 0; ks < KS; ++ks) wa[ky * 3 + kx][ks] = wload(cc + 4, ky * 3 + kx, ks);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < ntaps; ++tap) {
+        const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
+        const int col = marg + px + (kx - 1) * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            const uint4 b = xs[((2 * ks + kg) * rows + r + ky * D) * XWP + col];
+            acc[r] = Mma32<T>::mma(wa[tap][ks], b, acc[r]);
+          }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(cc + 4, tap, ks);
+      }
+    }
+  }
+
+  // ---- sum the four partial tiles in wave order: part[(w*2 + r)*16 + e][lane]
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[((wave * 2 + r) * 16 + e) * 64 + lane] = acc[r][e];
+  __syncthreads();
+  // wave w finishes output row r = w/2, accumulator registers [8*(w%2), 8*(w%2)+8)
+  const int r = wave >> 1, ebase = 8 * (wave & 1);
+  uint16_t* yb = reinterpret_cast<uint16_t*>(y) + (size_t)n * ybs;
+  const bool odd = px & 1;
+  const int gx = x0 + (px & ~1), gy = y0 + r;
+  const size_t HWo = (size_t)H * W;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = ebase + 2 * j, e1 = e0 + 1;
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      v0 += part[((w * 2 + r) * 16 + e0) * 64 + lane];
+      v1 += part[((w * 2 + r) * 16 + e1) * 64 + lane];
+    }
+    const int c0 = slab * 32 + (e0 & 3) + 8 * (e0 >> 2) + 4 * kg, c1 = c0 + 1;
+    v0 += (c0 < Cout ? bias[c0] : 0.f); v1 += (c1 < Cout ? bias[c1] : 0.f);
+    if (slope != 0.f) { v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope); }
+    const uint32_t p = pack2<T>(v0, v1);
+    const uint32_t send = odd ? (p & 0xffffu) : (p >> 16);
+    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
+    const uint32_t out = odd ? (recv | (p & 0xffff0000u)) : ((p & 0xffffu) | (recv << 16));
+    const int co = odd ? c1 : c0;
+    if (gy < H && co < Cout && gx < W) {
+      uint16_t* dst = yb + (size_t)co * HWo + (size_t)gy * W + gx;
+      if (gx + 1 < W) *reinterpret_cast<uint32_t*>(dst) = out;
+      else *dst = (uint16_t)out;
+    }
+  }
+}
+
 struct Args {
   const void* x; long long xbs; const void* wp; const float* bias; void* y; long long ybs;
   int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
@@ -342,14 +534,44 @@ int launch_shape(const Args& a, int slabs) {
 #undef UPF_CONV_D
 }
 
+template <typename T, int NOCTS, int D, bool GEN>
+int launch_sk_one(const Args& a) {
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, 2);
+  constexpr int rows = 2 + 2 * D;
+  size_t lds = (size_t)4 * NOCTS * rows * (xw(1, margin_of(D)) + 1) * 16;
+  if (lds < 4 * 2 * 16 * 64 * 4) lds = 4 * 2 * 16 * 64 * 4;       // the partial-sum exchange reuses the region
+  static bool attr_set = false;
+  auto kern = &conv_sk_kernel<T, NOCTS, D, GEN>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), cdiv(a.Cout, 32)), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope);
+  return check_launch("conv_forward");
+}
+
+// split-K applies to stride 1, kernel 1x1 or dilation 1/2/4, at least 3 chunks of 32 input channels
+template <typename T, bool GEN>
+int launch_sk(const Args& a) {
+  if (a.ntaps == 1) return launch_sk_one<T, 4, 0, GEN>(a);
+  if (a.d == 1) return launch_sk_one<T, 4, 1, GEN>(a);
+  if (a.d == 2) return launch_sk_one<T, 4, 2, GEN>(a);
+  return launch_sk_one<T, 4, 4, GEN>(a);
+}
+
+// launch heuristics (upf_conv_set_option)
+static int g_sk_grid = 96, g_small_grid = 256, g_rpw4_min = 256;
+
 // Cout and the grid size -> (MTW, RPW, slabs over blockIdx.y)
 template <typename T, bool GEN>
 int launch(const Args& a) {
   const int mt = cdiv(a.Cout, 32);
   const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
   const long long tiles = (long long)a.B * cdiv(Wo, TW) * cdiv(Ho, 8);
-  static const int small_grid = getenv("UPF_CONV_SMALL_GRID") ? atoi(getenv("UPF_CONV_SMALL_GRID")) : 256;
-  static const int rpw4_min = getenv("UPF_CONV_RPW4_MIN") ? atoi(getenv("UPF_CONV_RPW4_MIN")) : 256;
+  const int small_grid = g_small_grid, sk_grid = g_sk_grid, rpw4_min = g_rpw4_min;
+  if (tiles <= (a.d == 4 ? sk_grid / 2 : sk_grid) && a.stride == 1 && a.Cin > 64 && (a.ntaps == 1 || a.d == 1 || a.d == 2 || a.d == 4))
+    return launch_sk<T, GEN>(a);       // (dilation 4 stages 10 rows per wave for 2 output rows: only the coarsest grids gain)
   int mtw = mt >= 3 ? 4 : mt;
   if (tiles <= small_grid && mt > 1) {
     // coarse pyramid levels: too few pixel tiles to fill 256 CUs -> more, narrower workgroups over blockIdx.y
@@ -375,6 +597,18 @@ int launch(const Args& a) {
 
 }  // namespace conv
 }  // namespace upf
+
+extern "C" int upf_conv_set_option(const char* name, int value) {
+  using namespace upf::conv;
+  int* slot = nullptr;
+  if (name && !strcmp(name, "sk_grid")) slot = &g_sk_grid;
+  else if (name && !strcmp(name, "small_grid")) slot = &g_small_grid;
+  else if (name && !strcmp(name, "rpw4_min")) slot = &g_rpw4_min;
+  if (!slot) return -1;
+  const int prev = *slot;
+  *slot = value;
+  return prev;
+}
 
 extern "C" long long upf_conv_packed_bytes(int Cin, int Cout, int kernel_size) {
   return (long long)kernel_size * kernel_size * upf::conv::pad32(Cout) * upf::conv::pad32(Cin) * 2;

@@ -330,6 +330,15 @@ def conv3x3_supported(x_view, Cout, dilation, stride=1, kernel_size=3):
             and x_view.shape[3] >= 8)
 
 
+def conv_set_option(name, value):
+    """Launch heuristics of the convolution (include/upflow_hip.h: "sk_grid", "small_grid", "rpw4_min");
+    returns the previous value."""
+    prev = _lib.lib().upf_conv_set_option(name.encode(), int(value))
+    if prev < 0:
+        raise UpflowHipError('unknown convolution option %r' % name)
+    return prev
+
+
 def conv3x3_out_hw(H, W, stride=1):
     return (H - 1) // stride + 1, (W - 1) // stride + 1
 
