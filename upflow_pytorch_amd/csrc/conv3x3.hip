@@ -83,6 +83,42 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
   }
 }
 
+// ---- epilogue: accumulators -> LeakyReLU -> 16-bit -> y.  D[co][pixel]: lane -> pixel column px, register e ->
+// output channel (e&3) + 8*(e>>2) + 4*kg of the 32-channel block.  Lane pairs (px, px^1) swap halves (one DPP move +
+// one v_perm): the even lane stores pixels (px, px+1) of the even registers' channels, the odd lane pixels (px-1, px) of
+// the odd registers' — 4-byte stores, half as many.  Stores go through a buffer descriptor over the image's Cout output
+// planes, so channels >= Cout and columns >= Wo are dropped by the bounds check instead of by branches.
+struct Epilogue {
+  __amdgpu_buffer_rsrc_t yr;
+  uint32_t off32, off16;   // this lane's byte offset at (first channel of its pair set, row 0, its pixel pair) or 0x80000000
+  uint32_t sel;            // v_perm selector merging own and partner halves
+  uint32_t plane2;         // bytes per output plane
+};
+template <typename T, bool GEN>
+__device__ __forceinline__ void epilogue_init(Epilogue& ep, T* y_img, int Cout, int Ho, int Wo, int slab, int lane, int x0) {
+  const int px = lane & 31, kg = lane >> 5;
+  const bool odd = px & 1;
+  const int gx = x0 + (px & ~1);
+  ep.plane2 = (uint32_t)(Ho * Wo) * 2u;
+  ep.yr = __builtin_amdgcn_make_buffer_rsrc(y_img, 0, (uint32_t)Cout * ep.plane2, 0x00020000);
+  const uint32_t off = (uint32_t)(slab * 32 + 4 * kg + (odd ? 1 : 0)) * ep.plane2 + (uint32_t)gx * 2u;
+  ep.off32 = (gx + 1 < Wo) ? off : 0x80000000u;
+  ep.off16 = (GEN && gx + 1 == Wo) ? off : 0x80000000u;     // odd Wo: the last column is a 2-byte store
+  ep.sel = odd ? 0x03020706u : 0x05040100u;
+}
+// v0, v1: channels c and c+1 of this lane's pixel (registers e = 2j, 2j+1); soff: uniform byte offset of
+// (channel offset of register 2j, output row) = ({0,2,8,10,16,18,24,26}[j] * Ho*Wo + gy*Wo) * 2
+template <typename T, bool GEN>
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, float v0, float v1, uint32_t soff, float slope) {
+  v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);                  // slope = 1 -> identity
+  const uint32_t p = pack2<T>(v0, v1);                                     // lo = channel c, hi = channel c+1 of pixel px
+  const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  const uint32_t out = __builtin_amdgcn_perm(recv, p, ep.sel);
+  __builtin_amdgcn_raw_buffer_store_b32(out, ep.yr, ep.off32 + soff, 0, 0);
+  if constexpr (GEN) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)out, ep.yr, ep.off16 + soff, 0, 0);
+}
+__device__ __forceinline__ uint32_t epilogue_choff(int j) { return (uint32_t)((2 * j & 3) + 8 * (2 * j >> 2)); }   // channel offset of register 2j
+
 // MTW: 32-channel output blocks per workgroup (1, 2, 4) = waves along Cout;  RPW: tile rows per wave
 // (tile height TH = (4/MTW)*RPW);  S: stride;  NOCTS: channel octets per chunk (4 = 32 channels, 2 = 16);
 // D: compile-time dilation (see margin_of);  GEN: the staged rows need not be 16-byte aligned (W % 8 != 0, or x is an
@@ -123,11 +159,15 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
   __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 2u, 0x00020000);
 
+  // accumulators start at the bias (channels >= Cout read 0 through the descriptor)
+  __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, (uint32_t)Cout * 4u, 0x00020000);
   f32x16 acc[RPW];
 #pragma unroll
-  for (int r = 0; r < RPW; ++r)
+  for (int e = 0; e < 16; ++e) {
+    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+    for (int r = 0; r < RPW; ++r) acc[r][e] = bv;
+  }
 
   // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
   constexpr int ngroups = XW / 8;
@@ -259,32 +299,16 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     }
   }
 
-  // ---- epilogue: D[co][pixel]; lane -> pixel column px, regs -> co = (e&3) + 8*(e>>2) + 4*kg.
-  // Lane pairs (px, px^1) swap halves: the even lane stores pixels (px, px+1) of the even registers' channels,
-  // the odd lane pixels (px-1, px) of the odd registers' — 4-byte stores, half as many.
-  uint16_t* yb = reinterpret_cast<uint16_t*>(y) + (size_t)n * ybs;
-  const bool odd = px & 1;
-  const int gx = x0 + (px & ~1);
-  const size_t HoWo = (size_t)Ho * Wo;
+  // ---- epilogue (bias is already in the accumulators)
+  Epilogue ep;
+  epilogue_init<T, GEN>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0);
+  const int gy0 = __builtin_amdgcn_readfirstlane(y0 + RPW * rg);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
-    const int gy = y0 + RPW * rg + r;
+    if (gy0 + r < Ho) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e0 = 2 * j, e1 = 2 * j + 1;
-      const int c0 = slab * 32 + (e0 & 3) + 8 * (e0 >> 2) + 4 * kg, c1 = c0 + 1;
-      float v0 = acc[r][e0] + (c0 < Cout ? bias[c0] : 0.f), v1 = acc[r][e1] + (c1 < Cout ? bias[c1] : 0.f);
-      if (slope != 0.f) { v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope); }
-      const uint32_t p = pack2<T>(v0, v1);                                   // lo = channel c0, hi = channel c1 of pixel px
-      const uint32_t send = odd ? (p & 0xffffu) : (p >> 16);
-      const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-      const uint32_t out = odd ? (recv | (p & 0xffff0000u)) : ((p & 0xffffu) | (recv << 16));
-      const int co = odd ? c1 : c0;
-      if (gy < Ho && co < Cout && gx < Wo) {
-        uint16_t* dst = yb + (size_t)co * HoWo + (size_t)gy * Wo + gx;
-        if (gx + 1 < Wo) *reinterpret_cast<uint32_t*>(dst) = out;           // (2-byte aligned is enough on gfx950)
-        else *dst = (uint16_t)out;
-      }
+      for (int j = 0; j < 8; ++j)
+        epilogue_store<T, GEN>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r) * Wo) * 2u, slope);
     }
   }
 }
@@ -326,11 +350,15 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
   __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 2u, 0x00020000);
 
+  // wave 0's partial tile starts at the bias (channels >= Cout read 0 through the descriptor)
+  __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, wave == 0 ? (uint32_t)Cout * 4u : 0u, 0x00020000);
   f32x16 acc[RPW];
 #pragma unroll
-  for (int r = 0; r < RPW; ++r)
+  for (int e = 0; e < 16; ++e) {
+    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+    for (int r = 0; r < RPW; ++r) acc[r][e] = bv;
+  }
 
   auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), g = rem / rows, r = rem - g * rows;   // row fastest
@@ -451,32 +479,20 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
     for (int e = 0; e < 16; ++e) part[((wave * 2 + r) * 16 + e) * 64 + lane] = acc[r][e];
   __syncthreads();
   // wave w finishes output row r = w/2, accumulator registers [8*(w%2), 8*(w%2)+8)
-  const int r = wave >> 1, ebase = 8 * (wave & 1);
-  uint16_t* yb = reinterpret_cast<uint16_t*>(y) + (size_t)n * ybs;
-  const bool odd = px & 1;
-  const int gx = x0 + (px & ~1), gy = y0 + r;
-  const size_t HWo = (size_t)H * W;
+  const int r = wave >> 1, jbase = 4 * (wave & 1);
+  Epilogue ep;
+  epilogue_init<T, GEN>(ep, y + (size_t)n * ybs, Cout, H, W, slab, lane, x0);
+  if (y0 + r < H) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e0 = ebase + 2 * j, e1 = e0 + 1;
-    float v0 = 0.f, v1 = 0.f;
+    for (int jj = 0; jj < 4; ++jj) {
+      const int e0 = 2 * (jbase + jj), e1 = e0 + 1;
+      float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      v0 += part[((w * 2 + r) * 16 + e0) * 64 + lane];
-      v1 += part[((w * 2 + r) * 16 + e1) * 64 + lane];
-    }
-    const int c0 = slab * 32 + (e0 & 3) + 8 * (e0 >> 2) + 4 * kg, c1 = c0 + 1;
-    v0 += (c0 < Cout ? bias[c0] : 0.f); v1 += (c1 < Cout ? bias[c1] : 0.f);
-    if (slope != 0.f) { v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope); }
-    const uint32_t p = pack2<T>(v0, v1);
-    const uint32_t send = odd ? (p & 0xffffu) : (p >> 16);
-    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
-    const uint32_t out = odd ? (recv | (p & 0xffff0000u)) : ((p & 0xffffu) | (recv << 16));
-    const int co = odd ? c1 : c0;
-    if (gy < H && co < Cout && gx < W) {
-      uint16_t* dst = yb + (size_t)co * HWo + (size_t)gy * W + gx;
-      if (gx + 1 < W) *reinterpret_cast<uint32_t*>(dst) = out;
-      else *dst = (uint16_t)out;
+      for (int w = 0; w < 4; ++w) {
+        v0 += part[((w * 2 + r) * 16 + e0) * 64 + lane];
+        v1 += part[((w * 2 + r) * 16 + e1) * 64 + lane];
+      }
+      epilogue_store<T, GEN>(ep, v0, v1, epilogue_choff(jbase + jj) * ep.plane2 + (uint32_t)((y0 + r) * W) * 2u, slope);
     }
   }
 }
@@ -643,8 +659,11 @@ extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const v
   const bool gen = !(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0);   // rows not 16-byte aligned
   UPF_REQUIRE(!gen || W >= 8, UPF_EUNSUPPORTED, "conv_forward: W = %d < 8 with unaligned rows", W);
   UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: image too large for one buffer descriptor");
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  UPF_REQUIRE((long long)Cout * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: output too large for one buffer descriptor");
+  // the kernels compute max(v, v*slope): "no activation" (0) becomes slope 1
   conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W,
-               kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope, (hipStream_t)stream};
+               kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};
   if (dtype == UPF_BF16) return gen ? conv::launch<bf16_t, true>(a) : conv::launch<bf16_t, false>(a);
   return gen ? conv::launch<f16_t, true>(a) : conv::launch<f16_t, false>(a);
 }
