@@ -99,6 +99,10 @@ int upf_correlation_out_shape(int H, int W, int pad_size, int kernel_size, int m
  *   directions in one launch, no gather copy.  0 = plain. */
 int upf_warp_forward(const void* x, const float* flow, void* y,
                      int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
+/* same, x / y being channel slices of wider contiguous NCHW buffers (batch strides in elements, 0 = C*H*W): the
+ * inference path warps straight out of / into the concatenation buffers the convolutions read (no slot copies). */
+int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
+                             int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
 /* grad wrt x (scatter-add, fp32 buffer gx32 [B,C,H,W] that the CALLER has zero-filled) and wrt
  * flow (gflow [B,2,H,W] fp32, fully written).  grad_y : [B,C,H,W] of `dtype`. */
 int upf_warp_backward(const void* x, const float* flow, const void* grad_y,
@@ -164,6 +168,14 @@ int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_pack
                      void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
                      int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
+
+/* ---- flow bookkeeping of a pyramid level  (model/upflow.py:566-572) -------------------------------
+ * out[n,:] = cast(a + (b + c)) in fp32, b and c optional: `flow_up + res` into the context network's input,
+ * `flow_up + (res + fine)` for the next level, or a plain fp32 -> 16-bit copy of a flow into an estimator slot.
+ * a : [N,per_item] fp32;  b, c : [N,per_item] of `dtype` (bf16 / fp16) or NULL;  out : fp32 (out_is_f32) or `dtype`,
+ * rows out_batch_stride elements apart (0 = per_item). */
+int upf_flow_update(const float* a, const void* b, const void* c, void* out, long long out_batch_stride,
+                    int out_is_f32, int N, int per_item, int dtype, void* stream);
 
 /* ---- occlusion check  (tools.occ_check_model(obj), utils/tools.py:519-588, 641-677) -------------
  * flow_f, flow_b : [B,2,H,W] fp32 -> occ_fw, occ_bw : [B,1,H,W] fp32 in {0,1}. */

@@ -106,3 +106,34 @@ def test_batch_independence_and_repeatability():
     print('bit-identical repeat:', bool(torch.equal(a, b)))
     assert oracle.epe(a.cpu(), b.cpu()) <= 1e-4
     assert oracle.epe(a[1:2].cpu(), c.cpu()) <= 1e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('mask_mode', ['robust', 'literal'])
+def test_in_buffer_schedule_is_the_same_arithmetic(dtype, mask_mode):
+    """The 16-bit inference schedule that produces every intermediate in its consumer's buffer
+    (UPFlow_net._forward_stacked_fast: strided warps, one normalisation launch pair per level, fused flow
+    bookkeeping) must give the SAME BITS as the generic stacked schedule (separate tensors + torch glue):
+    only data placement differs.  128x512: the coarsest level is 2x8, every convolution takes the HIP kernel."""
+    net = build(mask_mode, dtype)
+    im1, im2 = _weights.make_smooth_images(3, 2, 128, 512)
+    with torch.no_grad():
+        fast = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        net._no_fast_stacked = True
+        slow = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    for k in ('flow_f_out', 'flow_b_out'):
+        assert torch.equal(fast[k], slow[k]), (k, float((fast[k] - slow[k]).abs().max()))
+
+
+def test_16bit_all_hip_path_vs_fp32():
+    """At 192x512 every level of the 16-bit path runs the hand-written convolution (coarsest level 3x8); its flow
+    must stay within the 16-bit rounding envelope of the fp32 (parity-mode) forward of the same network."""
+    im1, im2 = _weights.make_smooth_images(5, 1, 192, 512)
+    with torch.no_grad():
+        ref = build('robust', torch.float32)({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})['flow_f_out']
+        mag = float(ref.pow(2).sum(1).sqrt().mean())
+        for dtype, tol in ((torch.float16, 0.05), (torch.bfloat16, 0.25)):
+            out = build('robust', dtype)({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})['flow_f_out']
+            e = oracle.epe(out.cpu(), ref.cpu())
+            print('%s all-HIP path EPE vs fp32 %.3g px (mean |flow| %.3g px)' % (dtype, e, mag))
+            assert e <= tol * max(mag, 1.0)

@@ -178,6 +178,27 @@ void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, i
   atomicAdd(d + ly.i1 * w + lx.i1, g * ly.l1 * lx.l1);
 }
 
+// out[n, :] = cast(a + (b + c))  — the flow bookkeeping of one pyramid level (model/upflow.py:566-572:
+// `flow_up + res` fed to the context network, `flow_up + (res + fine)` handed to the next level) and the fp32 -> 16-bit
+// copies of the flow into estimator-input slots, each ONE launch instead of a convert / add / convert chain of ATen
+// kernels.  a: fp32 [N, per]; b, c: optional 16-bit [N, per] (conv outputs); the additions happen in fp32 in exactly
+// this association.  out: fp32 or 16-bit, rows `obs` elements apart (a channel slice of a wider buffer).
+template <typename T, typename TO>
+__global__ void flow_update_kernel(const float* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                   TO* __restrict__ out, long long obs, int per, long long total) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long n = i / per;
+  const int r = (int)(i - n * per);
+  float v = a[i];
+  if (b) {
+    float t = Elem<T>::load(b + i);
+    if (c) t = t + Elem<T>::load(c + i);
+    v = v + t;
+  }
+  Elem<TO>::store(out + n * obs + r, v);
+}
+
 }  // namespace sgu
 }  // namespace upf
 
@@ -233,4 +254,23 @@ extern "C" int upf_flow_upsample_backward(const float* grad_y, float* gx, int B,
   dim3 grid(cdiv(H * W, sgu::THREADS), B * C);
   hipLaunchKernelGGL(sgu::upsample_bwd_kernel, grid, dim3(sgu::THREADS), 0, (hipStream_t)stream, grad_y, gx, C, h, w, H, W, if_rate);
   return check_launch("flow_upsample_backward");
+}
+
+extern "C" int upf_flow_update(const float* a, const void* b, const void* c, void* out, long long out_batch_stride,
+                               int out_is_f32, int N, int per_item, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(a && out && N > 0 && per_item > 0, UPF_EINVAL, "flow_update: bad arguments");
+  UPF_REQUIRE(b || !c, UPF_EINVAL, "flow_update: c without b");
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "flow_update: b, c and a 16-bit out are bf16 / fp16");
+  const long long obs = out_batch_stride ? out_batch_stride : per_item;
+  UPF_REQUIRE(obs >= per_item, UPF_EINVAL, "flow_update: out_batch_stride smaller than a row");
+  const long long total = (long long)N * per_item;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define UPF_FU(T)                                                                                                                     \
+  if (out_is_f32) hipLaunchKernelGGL((sgu::flow_update_kernel<T, float>), grid, block, 0, st, a, (const T*)b, (const T*)c, (float*)out, obs, per_item, total); \
+  else hipLaunchKernelGGL((sgu::flow_update_kernel<T, T>), grid, block, 0, st, a, (const T*)b, (const T*)c, (T*)out, obs, per_item, total);
+  if (dtype == UPF_BF16) { UPF_FU(bf16_t) } else { UPF_FU(f16_t) }
+#undef UPF_FU
+  return check_launch("flow_update");
 }

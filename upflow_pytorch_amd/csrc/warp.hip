@@ -84,7 +84,7 @@ __device__ __forceinline__ float sample(const T* __restrict__ plane, const Pixel
 // PXT pixels per thread (2 for 16-bit types when W is even: 4-byte stores), W >= 2.
 template <typename T, int PXT>
 __global__ __launch_bounds__(THREADS)
-void warp_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, T* __restrict__ y,
+void warp_fwd_kernel(const T* __restrict__ x, long long xbs, const float* __restrict__ flow, T* __restrict__ y, long long ybs,
                      int C, int H, int W, int cpt, int mask_mode, int shift) {
   const int HW = H * W;
   const int p0 = (blockIdx.x * THREADS + threadIdx.x) * PXT;
@@ -96,8 +96,8 @@ void warp_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, T*
   PixelTaps s[PXT];
 #pragma unroll
   for (int k = 0; k < PXT; ++k) s[k] = make_pixel(fl, p0 + k, H, W, mask_mode);
-  const T* xb = x + ((size_t)ns * C + c_begin) * HW;
-  T* yb = y + ((size_t)n * C + c_begin) * HW + p0;
+  const T* xb = x + (size_t)ns * xbs + (size_t)c_begin * HW;          // x / y may be channel slices of wider buffers
+  T* yb = y + (size_t)n * ybs + (size_t)c_begin * HW + p0;
 #pragma unroll 4
   for (int c = c_begin; c < c_end; ++c, xb += HW, yb += HW) {
     float r[PXT];
@@ -115,7 +115,7 @@ void warp_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, T*
 // W == 1 (no pair exists): plain four-tap version
 template <typename T>
 __global__ __launch_bounds__(THREADS)
-void warp_fwd_narrow_kernel(const T* __restrict__ x, const float* __restrict__ flow, T* __restrict__ y,
+void warp_fwd_narrow_kernel(const T* __restrict__ x, long long xbs, const float* __restrict__ flow, T* __restrict__ y, long long ybs,
                             int C, int H, int W, int mask_mode, int shift) {
   const int HW = H * W;
   const int p = blockIdx.x * THREADS + threadIdx.x;
@@ -131,9 +131,9 @@ void warp_fwd_narrow_kernel(const T* __restrict__ x, const float* __restrict__ f
   const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
   const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f, w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
   for (int c = 0; c < C; ++c) {
-    const T* xc = x + ((size_t)ns * C + c) * HW;
+    const T* xc = x + (size_t)ns * xbs + (size_t)c * HW;
     const float r = ((Elem<T>::load(xc + o0) * w0 + Elem<T>::load(xc + o1) * w1) + Elem<T>::load(xc + o2) * w2) + Elem<T>::load(xc + o3) * w3;
-    Elem<T>::store(y + ((size_t)n * C + c) * HW + p, valid ? r : 0.f);
+    Elem<T>::store(y + (size_t)n * ybs + (size_t)c * HW + p, valid ? r : 0.f);
   }
 }
 
@@ -195,29 +195,36 @@ static int pick_cpt(int B, int C, int HW) {
 }  // namespace warp
 }  // namespace upf
 
-extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B, int C, int H, int W,
-                                int dtype, int mask_mode, int batch_shift, void* stream) {
+extern "C" int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
+                                        int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream) {
   using namespace upf;
   UPF_REQUIRE(x && flow && y, UPF_EINVAL, "warp_forward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_forward: bad mask_mode %d", mask_mode);
   UPF_REQUIRE(batch_shift >= 0 && batch_shift < B, UPF_EINVAL, "warp_forward: batch_shift %d not in [0,%d)", batch_shift, B);
   const int HW = H * W;
+  const long long xbs = x_batch_stride ? x_batch_stride : (long long)C * HW, ybs = y_batch_stride ? y_batch_stride : (long long)C * HW;
+  UPF_REQUIRE(xbs >= (long long)C * HW && ybs >= (long long)C * HW, UPF_EINVAL, "warp_forward: batch stride smaller than C*H*W");
   hipStream_t st = (hipStream_t)stream;
   if (W < 2) {
     UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((warp::warp_fwd_narrow_kernel<T>), dim3(cdiv(HW, warp::THREADS), 1, B), dim3(warp::THREADS), 0, st,
-                                              (const T*)x, flow, (T*)y, C, H, W, mask_mode, batch_shift));
+                                              (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, mask_mode, batch_shift));
     return check_launch("warp_forward");
   }
   // two pixels per thread (4-byte stores) for 16-bit features when rows keep pixel pairs aligned
-  const bool two = (dtype != UPF_F32) && (W % 2 == 0) && aligned_to(y, 4);
+  const bool two = (dtype != UPF_F32) && (W % 2 == 0) && aligned_to(y, 4) && ybs % 2 == 0;
   const int pxt = two ? 2 : 1;
   const int cpt = warp::pick_cpt(B, C, HW / pxt);
   dim3 grid(cdiv(cdiv(HW, pxt), warp::THREADS), cdiv(C, cpt), B);
   UPF_DISPATCH(dtype, T,
-               if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode, batch_shift);
-               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, flow, (T*)y, C, H, W, cpt, mask_mode, batch_shift));
+               if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift);
+               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift));
   return check_launch("warp_forward");
+}
+
+extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B, int C, int H, int W,
+                                int dtype, int mask_mode, int batch_shift, void* stream) {
+  return upf_warp_forward_strided(x, 0, flow, y, 0, B, C, H, W, dtype, mask_mode, batch_shift, stream);
 }
 
 extern "C" int upf_warp_backward(const void* x, const float* flow, const void* grad_y, float* gx32, float* gflow,

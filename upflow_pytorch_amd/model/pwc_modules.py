@@ -95,14 +95,23 @@ class FeatureExtractor(nn.Module):
             nn.Sequential(conv(ci, co, stride=2), conv(co, co, isReLU=if_end_relu, if_IN=if_end_norm))
             for ci, co in zip(num_chs[:-1], num_chs[1:]))
 
-    def forward(self, x):
+    def forward(self, x, outs=None):
+        """outs (inference fast path): per stage, None or the [B, C, H, W] view the stage's output is written to."""
         pyramid = []
         cache = self.__dict__.setdefault('_fast_cache', {})
-        for stage in self.convs:
+        for i, stage in enumerate(self.convs):
             x = fast_conv_seq(stage[0], x, cache)      # stride-2 conv
-            x = fast_conv_seq(stage[1], x, cache)      # stride-1 conv  (matrix-core kernel when eligible, else MIOpen)
+            x = fast_conv_seq(stage[1], x, cache, out=None if outs is None else outs[i])   # stride-1 conv
             pyramid.append(x)
         return pyramid[::-1]
+
+    def out_shapes(self, H, W):
+        """[(C, H, W)] of the stage outputs, finest first."""
+        shapes = []
+        for c in self.num_chs[1:]:
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            shapes.append((c, H, W))
+        return shapes
 
 
 class WarpingLayer_no_div(nn.Module):
@@ -163,10 +172,10 @@ class _PackedConv3x3(object):
                                        self.conv.kernel_size[0])
 
 
-def fast_conv_seq(seq, x, cache):
+def fast_conv_seq(seq, x, cache, out=None):
     """Run one `conv(...)` Sequential (Conv2d [+ LeakyReLU]) — through the matrix-core kernel when it is a
     3x3 (stride 1/2, dilation <= 16) or 1x1 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
-    that keeps the packed weights per Sequential."""
+    that keeps the packed weights per Sequential.  `out`: optional destination (a channel slice of a wider NCHW buffer)."""
     c = seq[0]
     k = c.kernel_size[0]
     if (_fast_conv_ok(x) and c.kernel_size in ((3, 3), (1, 1)) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
@@ -176,9 +185,13 @@ def fast_conv_seq(seq, x, cache):
         if pc is None:
             pc = cache[id(seq)] = _PackedConv3x3(seq)
         ho, wo = ops.conv3x3_out_hw(x.shape[2], x.shape[3], c.stride[0])
-        y = torch.empty((x.shape[0], c.out_channels, ho, wo), dtype=x.dtype, device=x.device)
+        y = out if out is not None else torch.empty((x.shape[0], c.out_channels, ho, wo), dtype=x.dtype, device=x.device)
         return pc(x, y)
-    return seq(x if x.is_contiguous() else x.contiguous())
+    y = seq(x if x.is_contiguous() else x.contiguous())
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def _fast_conv_ok(t):

@@ -66,10 +66,20 @@ class network_tools():
             # slice + sigmoid + (up-sampling) + torch_warp + blend: ONE launch (csrc/sgu_blend.hip)
             return ops.sgu_blend(flow_init, x_out, output_level_flow)
 
-        def output_conv(self, x):
+        def forward_in_buffer(self, flow_init, buf, slot, output_level_flow=None, batch_shift=0):
+            """Inference fast path of forward(): `slot` (the estimator's input slot of `buf`, from
+            dense_estimator_mask.alloc_buffer) already holds feature_1 in its first half — written there by the conv
+            that produced it; the other frame's features are warped straight into the second half."""
+            c1 = slot.shape[1] // 2
+            ops.warp_into(slot[:, :c1], flow_init, slot[:, c1:], self.warping_layer.mask_mode, batch_shift)
+            _, x_out = self.dense_estimator_mask.forward_in_buffer(buf)
+            return ops.sgu_blend(flow_init, x_out, output_level_flow)
+
+        def output_conv(self, x, out=None):
             cache = self.__dict__.setdefault('_fast_cache', {})
-            for seq in self.upsample_output_conv:       # stride-1 layers: matrix-core kernel when eligible
-                x = fast_conv_seq(seq, x, cache)
+            n = len(self.upsample_output_conv)
+            for i, seq in enumerate(self.upsample_output_conv):       # matrix-core kernel when eligible
+                x = fast_conv_seq(seq, x, cache, out=out if i == n - 1 else None)
             return x
 
     @classmethod
@@ -358,6 +368,10 @@ class UPFlow_net(tools.abstract_model):
         grid, which is what the coarse levels need on a 256-CU chip."""
         B = x1_raw.shape[0]
         X = torch.cat([x1_raw, x2_raw], dim=0)
+        if (_fast_conv_ok(X) and self.conf.if_norm_before_cost_volume and not self.conf.norm_moments_across_channels
+                and not self.conf.norm_moments_across_images and not getattr(self, '_no_fast_stacked', False)
+                and self.feature_pyramid_extractor.out_shapes(X.shape[2], X.shape[3])[-1][2] >= 8):   # every level takes the conv kernel
+            return self._forward_stacked_fast(X, B)
         pyramid = self.feature_pyramid_extractor(X)
         h0, w0 = pyramid[0].shape[2:]
         flow = torch.zeros(2 * B, 2, h0, w0, dtype=torch.float32, device=X.device)
@@ -391,6 +405,62 @@ class UPFlow_net(tools.abstract_model):
         if sgu:
             G = self.sgi_model.output_conv(X)
             flow_out = self.sgi_model(flow, G, G, output_level_flow=flow_out, batch_shift=B)[1]
+        return flow_out[:B], flow_out[B:], flows[::-1]
+
+    def _forward_stacked_fast(self, X, B):
+        """_forward_stacked for bf16/fp16 with the published normalisation flags: same arithmetic, and every
+        intermediate is produced IN the buffer its consumer reads — the pyramid's convs write the per-level
+        [features; warped other frame] pair buffers that one normalisation launch pair covers, the 1x1 convs write
+        the estimator / SGU input slots, the warps write their slots, and the per-level flow bookkeeping is one
+        launch per sum (ops.flow_update).  No slot copies, no convert/add chains: ~40 fewer launches per step."""
+        nb = 2 * B
+        dev, dt = X.device, X.dtype
+        cache = self.__dict__.setdefault('_fast_cache', {})
+        fpe, est, sgi = self.feature_pyramid_extractor, self.flow_estimators, self.sgi_model
+        sgu = self.conf.if_sgu_upsample
+        nlev = self.output_level + 1
+        nc = self.dim_corr
+        shapes = fpe.out_shapes(X.shape[2], X.shape[3])[::-1]                 # coarsest first, like the pyramid
+        pairs = [torch.empty((2, nb) + shp, dtype=dt, device=dev) for shp in shapes[:nlev]]
+        outs = ([p[0] for p in pairs] + [None] * (len(shapes) - nlev))[::-1]   # stage order: finest first
+        pyramid = fpe(X, outs=outs)
+        flow = torch.zeros((nb, 2) + shapes[0][1:], dtype=torch.float32, device=dev)
+        flows = []
+        for level in range(nlev):
+            Fm, pair = pyramid[level], pairs[level]
+            C, H, W = shapes[level]
+            buf, slot = est.alloc_buffer(nb, H, W, dt, dev, tail=2)
+            use_sgu = sgu and level > 0
+            if use_sgu:
+                sbuf, sslot = sgi.dense_estimator_mask.alloc_buffer(nb, H, W, dt, dev)
+                A = fast_conv_seq(self.conv_1x1[level], Fm, cache, out=sslot[:, :32])
+                slot[:, nc:nc + 32].copy_(A)
+            else:
+                fast_conv_seq(self.conv_1x1[level], Fm, cache, out=slot[:, nc:nc + 32])
+            flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
+            if level == 0:                                                    # no warp at the coarsest level (:539-541)
+                pair[1, :B].copy_(Fm[B:])
+                pair[1, B:].copy_(Fm[:B])
+            else:
+                if use_sgu:
+                    flow_up = sgi.forward_in_buffer(flow_up, sbuf, sslot, batch_shift=B)[1]
+                ops.warp_into(Fm, flow_up, pair[1], self.warping_layer.mask_mode, B)
+            normed = ops.normalize(pair.view(2 * nb, C, H, W))                # rows are (item, channel): one launch pair
+            ops.corr81_forward_raw(normed[:nb], normed[nb:], out=slot[:, :nc], leaky_slope=0.1)
+            ops.flow_update(flow_up, out=slot[:, nc + 32:])
+            _, res = est.forward_in_buffer(buf)
+            ops.flow_update(flow_up, res, out=buf[:, est._n_total:])          # flow_up + res -> context network input
+            fine = self.context_networks(buf)
+            flow = ops.flow_update(flow_up, res, fine)                        # flow_up + (res + fine)
+            flows.append([flow[:B], flow[B:]])
+        flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
+        if sgu:
+            H4, W4 = flow.shape[2:]
+            sbuf, sslot = sgi.dense_estimator_mask.alloc_buffer(nb, H4, W4, dt, dev)
+            G = sgi.output_conv(X, out=sslot[:, :32])
+            if tuple(G.shape[2:]) != (H4, W4):
+                raise RuntimeError('sgu output_conv / flow size mismatch %s vs %s' % (tuple(G.shape), tuple(flow.shape)))
+            flow_out = sgi.forward_in_buffer(flow, sbuf, sslot, output_level_flow=flow_out, batch_shift=B)[1]
         return flow_out[:B], flow_out[B:], flows[::-1]
 
     def _level_update(self, Fn, Fwn, A, flow_up):

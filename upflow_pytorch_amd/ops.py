@@ -165,6 +165,55 @@ def warp(x, flow, mask_mode='literal', batch_shift=0):
     return WarpFunction.apply(x, flow, _MASKS[mask_mode], batch_shift)
 
 
+def _is_channel_slice(t):
+    B, C, H, W = t.shape
+    return t.stride()[1:] == (H * W, W, 1) and t.stride(0) >= C * H * W
+
+
+def warp_into(x_view, flow, y_view, mask_mode='literal', batch_shift=0):
+    """Inference-only warp whose input / output are channel slices of wider contiguous NCHW buffers (the
+    concatenation buffers the convolutions read): no slot copies.  Returns y_view."""
+    if x_view.shape != y_view.shape or not _is_channel_slice(x_view) or not _is_channel_slice(y_view):
+        raise UpflowHipError('warp_into: x / y must be equal-shape channel slices of contiguous NCHW buffers')
+    flow = _f32(flow).contiguous()
+    B, C, H, W = x_view.shape
+    if flow.shape != (B, 2, H, W):
+        raise UpflowHipError('warp_into: flow [B,2,H,W] expected, got %s' % (tuple(flow.shape),))
+    dev = x_view.device
+    if not (x_view.is_cuda and y_view.is_cuda and flow.is_cuda) or x_view.dtype != y_view.dtype:
+        raise UpflowHipError('warp_into: GPU tensors of one dtype expected (there is no CPU fallback)')
+    with torch.cuda.device(dev):
+        _lib.call('upf_warp_forward_strided', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(flow), _lib.ptr(y_view), y_view.stride(0),
+                  B, C, H, W, _lib.dtype_code(x_view), _MASKS[mask_mode], int(batch_shift), _lib.stream_ptr(dev))
+    return y_view
+
+
+def flow_update(a, b=None, c=None, out=None):
+    """out = cast(a + (b + c)) in fp32 (b, c optional 16-bit conv outputs): the per-level flow bookkeeping
+    (model/upflow.py:566-572) in one launch.  a: fp32 [N,C,H,W]; out: None (new fp32 tensor), or an fp32 / 16-bit
+    tensor or channel slice [N,C,H,W]."""
+    a = _f32(a).contiguous()
+    N = a.shape[0]
+    per = a[0].numel()
+    if out is None:
+        out = torch.empty_like(a)
+    if tuple(out.shape) != tuple(a.shape) or not _is_channel_slice(out):
+        raise UpflowHipError('flow_update: out must be a [N,C,H,W] tensor or channel slice shaped like a')
+    for t in (b, c):
+        if t is not None and (tuple(t.shape) != tuple(a.shape) or not t.is_contiguous() or t.dtype not in (torch.bfloat16, torch.float16)):
+            raise UpflowHipError('flow_update: b / c must be contiguous bf16 / fp16 tensors shaped like a')
+    ref = b if b is not None else out
+    if out.dtype != torch.float32 and (out.dtype not in (torch.bfloat16, torch.float16) or (b is not None and b.dtype != out.dtype)):
+        raise UpflowHipError('flow_update: out must be fp32 or the 16-bit dtype of b / c')
+    if not a.is_cuda or not out.is_cuda:
+        raise UpflowHipError('flow_update: GPU tensors expected (there is no CPU fallback)')
+    code = _lib.dtype_code(ref) if ref.dtype != torch.float32 else _lib.UPF_BF16
+    with torch.cuda.device(a.device):
+        _lib.call('upf_flow_update', _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(out), out.stride(0),
+                  int(out.dtype == torch.float32), N, per, code, _lib.stream_ptr(a.device))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # flow up-sampling
 # ------------------------------------------------------------------------------------------------
