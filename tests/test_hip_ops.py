@@ -260,3 +260,40 @@ def test_forward_kernels_are_bit_deterministic(hip):
                lambda: hip.sgu_blend(flow, xo)[1], lambda: hip.flow_upsample(flow, 96, 320, True),
                lambda: hip.occ_check(flow, -flow)[0]):
         assert torch.equal(fn(), fn())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(4, 8, 12, 40), (2, 5, 7, 13), (2, 3, 9, 1)])
+def test_warp_into_channel_slices_equals_warp(dtype, shape):
+    """upf_warp_forward_strided: x / y as channel slices of wider buffers == the plain warp, bit for bit."""
+    from upflow_pytorch_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    xbuf = torch.randn(B, C + 3, H, W, generator=g).to(dtype).cuda()
+    flow = (torch.randn(B, 2, H, W, generator=g) * 3).cuda()
+    ybuf = torch.full((B, 2 * C + 1, H, W), 5.0, dtype=dtype, device='cuda')
+    for mode in ('literal', 'robust', 'none'):
+        for shift in (0, B // 2):
+            want = ops.warp(xbuf[:, 2:2 + C].contiguous(), flow, mode, shift)
+            got = ops.warp_into(xbuf[:, 2:2 + C], flow, ybuf[:, C:2 * C], mode, shift)
+            assert torch.equal(got, want)
+            assert bool((ybuf[:, :C] == 5).all()) and bool((ybuf[:, 2 * C:] == 5).all()), 'wrote outside its slice'
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_flow_update_matches_torch_chain(dtype):
+    """upf_flow_update == the convert / add / convert chain of torch ops it replaces (model/upflow.py:566-572)."""
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(6, 2, 12, 40, generator=g).cuda() * 4
+    b = torch.randn(6, 2, 12, 40, generator=g).to(dtype).cuda()
+    c = torch.randn(6, 2, 12, 40, generator=g).to(dtype).cuda()
+    assert torch.equal(ops.flow_update(a, b, c), a + (b.float() + c.float()))
+    assert torch.equal(ops.flow_update(a, b), a + b.float())
+    buf = torch.full((6, 7, 12, 40), 9.0, dtype=dtype, device='cuda')
+    ops.flow_update(a, b, out=buf[:, 3:5])
+    assert torch.equal(buf[:, 3:5], (a + b.float()).to(dtype))
+    ops.flow_update(a, out=buf[:, 5:7])
+    assert torch.equal(buf[:, 5:7], a.to(dtype)) and bool((buf[:, :3] == 9).all())
+    with pytest.raises(RuntimeError):
+        ops.flow_update(a.cpu(), b.cpu())
