@@ -138,13 +138,20 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   constexpr int XW = xw(S, marg);
   constexpr int XWP = XW + 1;                        // LDS row pitch in entries: +1 so that the staging writes of 16 lanes
                                                      // (one staged row each, 16 B at the same column) hit 16 different bank quads
+  // PH (compile-time dilation >= 2): ROW-PHASE decomposition.  A workgroup's TH output rows are D image rows apart
+  // (rows y0 + D*r of one phase y0 % D), so the three kernel rows read ADJACENT staged rows — the vertical halo is 2
+  // rows instead of 2*D (dilation 8: 10 staged rows per 8 output rows instead of 24), and only the horizontal taps
+  // keep the dilation, as a window shift inside the LDS row.
+  constexpr bool PH = (D >= 2 && S == 1);
+  constexpr int RS = PH ? D : 1;                     // image rows between consecutive tile rows
+  constexpr int DV = PH ? 1 : D;                     // staged rows between consecutive kernel rows (D >= 0)
   const int d = (D >= 0) ? D : d_rt;
-  const int rows = S * (TH - 1) + 2 * d + 1;         // staged input rows
+  const int rows = (D >= 0) ? S * (TH - 1) + 2 * DV + 1 : S * (TH - 1) + 2 * d + 1;         // staged input rows
   extern __shared__ __attribute__((aligned(16))) uint4 xs[];   // [octet][rows][XWP] entries of 8 channels x 1 pixel
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-  const int x0 = tx * TW, y0 = ty * TH;
+  const int x0 = tx * TW, y0 = PH ? (ty / RS) * (RS * TH) + ty % RS : ty * TH;     // PH: tiles_y counts (row block, phase) pairs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
   const int cb = wave % MTW, rg = wave / MTW;
@@ -176,7 +183,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   // entry it fills, and (GEN) the pixels by which the load window is shifted left to end at the row end
   auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), g = rem / rows, r = rem - g * rows;   // row fastest
-    const int gy = S * y0 - d + r, gx = S * x0 - marg + 8 * g;
+    const int gy = PH ? y0 + (r - 1) * RS : S * y0 - d + r, gx = S * x0 - marg + 8 * g;
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // !GEN: W % 8 == 0, a group is all in or all out
     sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
@@ -229,7 +236,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(0, tap, ks);
 
-  constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * D) * 3 < 9 * RPW);
+  constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * DV) * 3 < 9 * RPW);
 
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();                                 // previous chunk fully consumed
@@ -246,10 +253,10 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     if constexpr (PRE) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
 
     if constexpr (REUSE) {
-      // staged row sr of this wave's strip feeds output rows r = sr - ky*D.  The three windows (kx) of row sr+1 are
+      // staged row sr of this wave's strip feeds output rows r = sr - ky*DV.  The three windows (kx) of row sr+1 are
       // read from LDS while the (up to 9*KS) MFMAs of row sr run: left to itself hipcc issues each ds_read right
       // before its first use and the ~130-cycle LDS latency stalls the matrix pipe twice per row.
-      constexpr int NR = RPW + 2 * D;
+      constexpr int NR = RPW + 2 * DV;
       uint4 bq[2][3 * KS];
       auto bload = [&](int sr, uint4 (&b)[3 * KS]) {
 #pragma unroll
@@ -268,11 +275,11 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
-              if (sr - ky * D >= 0 && sr - ky * D < RPW)
-                acc[sr - ky * D] = Mma32<T>::mma(wa[ky * 3 + kx][ks], bq[sr & 1][kx * KS + ks], acc[sr - ky * D]);
+              if (sr - ky * DV >= 0 && sr - ky * DV < RPW)
+                acc[sr - ky * DV] = Mma32<T>::mma(wa[ky * 3 + kx][ks], bq[sr & 1][kx * KS + ks], acc[sr - ky * DV]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
-          if (sr == ky * D + RPW - 1) {              // kernel row ky is finished: fetch the next chunk's
+          if (sr == ky * DV + RPW - 1) {              // kernel row ky is finished: fetch the next chunk's
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -302,13 +309,13 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   // ---- epilogue (bias is already in the accumulators)
   Epilogue ep;
   epilogue_init<T, GEN>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0);
-  const int gy0 = __builtin_amdgcn_readfirstlane(y0 + RPW * rg);
+  const int gy0 = __builtin_amdgcn_readfirstlane(y0 + RPW * rg * RS);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
-    if (gy0 + r < Ho) {
+    if (gy0 + r * RS < Ho) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        epilogue_store<T, GEN>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r) * Wo) * 2u, slope);
+        epilogue_store<T, GEN>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * Wo) * 2u, slope);
     }
   }
 }
@@ -505,9 +512,10 @@ struct Args {
 template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN>
 int launch_one(const Args& a, int slabs) {
   constexpr int TH = (4 / MTW) * RPW;
+  constexpr bool PH = (D >= 2 && S == 1);            // row-phase decomposition (see the kernel)
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
-  const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
-  const int rows = S * (TH - 1) + 2 * a.d + 1;
+  const int tiles_x = cdiv(Wo, TW), tiles_y = PH ? cdiv(Ho, D * TH) * D : cdiv(Ho, TH);
+  const int rows = PH ? TH + 2 : S * (TH - 1) + 2 * a.d + 1;
   const size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + 1) * 16;
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
   static size_t attr_lds = 0;
@@ -524,7 +532,7 @@ int launch_one(const Args& a, int slabs) {
 // run-time (kernel size, dilation, Cin) -> compile-time (D, NOCTS).  16-channel chunks (NOCTS = 2) where 72 weight
 // registers + the accumulators would spill (four channel blocks per workgroup: 128 accumulator registers per wave),
 // where the halo of the dilation would not fit LDS, and for the RGB / 16-channel layers (half the staging).
-template <int MTW, int D> constexpr int wide_nocts() { return (MTW == 4 || D == 16 || D < 0 || (MTW == 2 && D == 2)) ? 2 : 4; }
+template <int MTW, int D> constexpr int wide_nocts() { return (MTW == 4 || D < 0 || (MTW == 2 && D == 16)) ? 2 : 4; }
 
 template <typename T, int MTW, int RPW, int S, bool GEN>
 int launch_shape(const Args& a, int slabs) {
@@ -538,10 +546,10 @@ int launch_shape(const Args& a, int slabs) {
       case 1: UPF_CONV_D(1)
       case 2: UPF_CONV_D(2)
       case 4: UPF_CONV_D(4)
+      case 8: UPF_CONV_D(8)
+      case 16: UPF_CONV_D(16)
     }
-    if constexpr (MTW < 4) {                         // (launch() never sends these to four-block workgroups)
-      if (a.d == 8) { UPF_CONV_D(8) }
-      if (a.d == 16) { UPF_CONV_D(16) }
+    if constexpr (MTW < 4) {                         // (launch() never sends a run-time dilation to four-block workgroups)
       UPF_CONV_D(-1)
     }
     set_error("conv_forward: internal routing error (dilation %d, MTW %d)", a.d, MTW);
@@ -595,7 +603,7 @@ int launch(const Args& a) {
     mtw = (tiles * cdiv(mt, 2) >= 384) ? 2 : 1;
   }
   // four-block workgroups keep 128 accumulator registers per wave: only the window-reuse loops fit beside them
-  const bool reuse_d = a.ntaps == 1 || a.d == 1 || a.d == 2 || a.d == 4;
+  const bool reuse_d = a.ntaps == 1 || a.d == 1 || a.d == 2 || a.d == 4 || a.d == 8 || a.d == 16;
   if (mtw == 4 && (a.stride == 2 || !reuse_d)) mtw = 2;
   const int slabs = cdiv(mt, mtw);
   if (a.stride == 2) {
