@@ -119,6 +119,52 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, float v0, flo
 }
 __device__ __forceinline__ uint32_t epilogue_choff(int j) { return (uint32_t)((2 * j & 3) + 8 * (2 * j >> 2)); }   // channel offset of register 2j
 
+// Wide epilogue (Wo % 8 == 0, 16-byte aligned rows): 4-byte stores issue at ~4 B/clk/CU, which bounds every layer with a
+// large output (the 3->16 full-resolution layer wrote 126 MB in 94 us).  So each wave transposes its tile through a
+// private LDS patch, two tile rows at a time — [row][channel][32 px] with an 80-byte channel pitch — and writes 16 bytes
+// (8 pixels) per lane: 4x fewer store instructions, each covering whole 64-byte row segments.
+constexpr int EPI_PITCH = 80;                                  // bytes per (row, channel) in the patch
+constexpr int EPI_WAVE_BYTES = 2 * 32 * EPI_PITCH;             // two tile rows of one wave
+template <typename T, int RPW>
+__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned char* patch, T* y_img, int Cout, int Ho, int Wo,
+                                              int slab, int lane, int x0, int gy0, int row_step, float slope) {
+  static_assert(RPW % 2 == 0, "two tile rows per pass");
+  const int px = lane & 31, kg = lane >> 5;
+  const bool odd = px & 1;
+  const uint32_t sel = odd ? 0x03020706u : 0x05040100u;
+  const uint32_t plane2 = (uint32_t)(Ho * Wo) * 2u;
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y_img, 0, (uint32_t)Cout * plane2, 0x00020000);
+  // write side: this lane's pixel pair of channel (its register pair's channel) -> patch[row][channel][pixel pair]
+  unsigned char* wbase = patch + (4 * kg + (odd ? 1 : 0)) * EPI_PITCH + (px & ~1) * 2;
+  // read side: lane -> (channel l/4 of a 16-channel half, 8-pixel segment l%4)
+  const int rc = lane >> 2, seg = lane & 3;
+  const unsigned char* rbase = patch + rc * EPI_PITCH + seg * 16;
+  const int gx = x0 + seg * 8;
+  const uint32_t goff = (gx < Wo) ? ((uint32_t)(slab * 32 + rc) * plane2 + (uint32_t)gx * 2u) : 0x80000000u;
+#pragma unroll
+  for (int rb = 0; rb < RPW; rb += 2) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v0 = acc[rb + rr][2 * j], v1 = acc[rb + rr][2 * j + 1];
+        v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
+        const uint32_t p = pack2<T>(v0, v1);
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);
+        *reinterpret_cast<uint32_t*>(wbase + (rr * 32 + (int)epilogue_choff(j)) * EPI_PITCH) = __builtin_amdgcn_perm(recv, p, sel);
+      }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int gy = gy0 + (rb + rr) * row_step;               // uniform
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(rbase + (rr * 32 + h * 16) * EPI_PITCH);
+        if (gy < Ho) __builtin_amdgcn_raw_buffer_store_b128(v, yr, goff + (uint32_t)(h * 16) * plane2 + (uint32_t)(gy * Wo) * 2u, 0, 0);
+      }
+    }
+  }
+}
+
 // MTW: 32-channel output blocks per workgroup (1, 2, 4) = waves along Cout;  RPW: tile rows per wave
 // (tile height TH = (4/MTW)*RPW);  S: stride;  NOCTS: channel octets per chunk (4 = 32 channels, 2 = 16);
 // D: compile-time dilation (see margin_of);  GEN: the staged rows need not be 16-byte aligned (W % 8 != 0, or x is an
@@ -307,9 +353,17 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   }
 
   // ---- epilogue (bias is already in the accumulators)
+  const int gy0 = __builtin_amdgcn_readfirstlane(y0 + RPW * rg * RS);
+  if constexpr (!GEN) {
+    if ((Wo & 7) == 0) {                             // uniform: 16-byte stores through a per-wave LDS patch
+      __syncthreads();                               // every wave is done with the x tile
+      epilogue_wide<T, RPW>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
+                            slab, lane, x0, gy0, RS, slope);
+      return;
+    }
+  }
   Epilogue ep;
   epilogue_init<T, GEN>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0);
-  const int gy0 = __builtin_amdgcn_readfirstlane(y0 + RPW * rg * RS);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     if (gy0 + r * RS < Ho) {
@@ -516,7 +570,8 @@ int launch_one(const Args& a, int slabs) {
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int tiles_x = cdiv(Wo, TW), tiles_y = PH ? cdiv(Ho, D * TH) * D : cdiv(Ho, TH);
   const int rows = PH ? TH + 2 : S * (TH - 1) + 2 * a.d + 1;
-  const size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + 1) * 16;
+  size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + 1) * 16;
+  if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;        // the wide epilogue's patches reuse the region
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
   static size_t attr_lds = 0;
   auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN>;
