@@ -172,8 +172,11 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
 // ends at the row end (gfx950 executes the 2-byte-aligned 16-byte load; tools/unaligned_b128_probe.hip), and the
 // shift is undone by the LDS entry index each transposed pixel is written to — no load ever leaves its row, so
 // nothing depends on what follows the buffer.
-template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN>
-__global__ __launch_bounds__(NTHREADS, 2)
+// ONE: Cin <= 16 = a single 16-channel chunk (the RGB and 16-channel layers at full / half resolution: pure
+// bandwidth, thousands of short-lived workgroups): no chunk loop, nothing loop-carried, so the register budget allows
+// four workgroups per CU to overlap their load / store latencies.
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false>
+__global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
 void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                  T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
                  int tiles_x, int tiles_y, float slope) {
@@ -203,7 +206,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   const int cb = wave % MTW, rg = wave / MTW;
   const int slab = blockIdx.y * MTW + cb;            // this wave's 32-channel output block
   const int cip = pad32(Cin);
-  const int nchunks = cip / KCH, nksteps = cip / 16;
+  const int nchunks = ONE ? 1 : cip / KCH, nksteps = cip / 16;
   const int HW = H * W;
 
   // buffer descriptor over this image's Cin input planes: rows/cols outside the image get offset
@@ -563,7 +566,7 @@ struct Args {
   int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
 };
 
-template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN>
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false>
 int launch_one(const Args& a, int slabs) {
   constexpr int TH = (4 / MTW) * RPW;
   constexpr bool PH = (D >= 2 && S == 1);            // row-phase decomposition (see the kernel)
@@ -574,7 +577,7 @@ int launch_one(const Args& a, int slabs) {
   if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;        // the wide epilogue's patches reuse the region
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
   static size_t attr_lds = 0;
-  auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN>;
+  auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN, ONE>;
   if (lds > attr_lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
@@ -592,7 +595,7 @@ template <int MTW, int D> constexpr int wide_nocts() { return (MTW == 4 || D < 0
 template <typename T, int MTW, int RPW, int S, bool GEN>
 int launch_shape(const Args& a, int slabs) {
   const bool narrow = a.Cin <= 16;
-#define UPF_CONV_D(DD) return narrow ? launch_one<T, MTW, RPW, S, 2, DD, GEN>(a, slabs) : launch_one<T, MTW, RPW, S, wide_nocts<MTW, DD>(), DD, GEN>(a, slabs);
+#define UPF_CONV_D(DD) return narrow ? launch_one<T, MTW, RPW, S, 2, DD, GEN, true>(a, slabs) : launch_one<T, MTW, RPW, S, wide_nocts<MTW, DD>(), DD, GEN>(a, slabs);
   if constexpr (S == 2) {
     UPF_CONV_D(1)
   } else {
