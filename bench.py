@@ -42,11 +42,11 @@ FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': Fal
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_net(dtype, device):
+def build_net(dtype, device, hip_pyramid_convs=True):
     import _weights
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     conf = UPFlow_net.config()
-    conf.update(FLAGS, verbose=False)
+    conf.update(dict(FLAGS, hip_pyramid_convs=hip_pyramid_convs), verbose=False)
     torch.manual_seed(0)
     net = conf()
     net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))      # random-init weights of the architecture
@@ -79,6 +79,38 @@ def roofline_probe(B, H, W, dtype, device):
     return {'bound': 'hbm', 'kernel': 'corr81_mfma_kernel' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w], 'achieved': round(achieved, 1),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
             'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2)}
+
+
+def conv_roofline_probe(B, H, W, dtype, device):
+    """The kernel a step spends most of its time in: the matrix-core convolution, measured on its largest launch —
+    the context network's first layer (565 -> 128 channels, 3x3) at the 1/4-resolution level, both flow directions
+    stacked (2B items).  MFMA-bound: algorithmic flop 2*9*Cin*Cout*N*H*W over the average of `nrep` back-to-back
+    launches between two HIP events on the launch stream, against the dense bf16/fp16 MFMA peak (2.5 PFLOP/s)."""
+    from upflow_pytorch_amd import ops
+    if dtype == torch.float32:
+        return None                                                          # fp32 convolutions are MIOpen's (parity mode)
+    N, Cin, Cout, h, w = 2 * B, 565, 128, (H + 3) // 4, (W + 3) // 4
+    g = torch.Generator(device='cpu').manual_seed(2005)
+    x = torch.randn(N, Cin, h, w, generator=g).to(device).to(dtype)
+    wgt = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(device).to(dtype)
+    bias = torch.zeros(Cout, device=device)
+    y = torch.empty(N, Cout, h, w, device=device, dtype=dtype)
+    packed = ops.conv3x3_pack(wgt)
+    for _ in range(5):
+        ops.conv3x3_forward_raw(x, packed, bias, y, 1, 0.1)
+    nrep = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nrep):
+        ops.conv3x3_forward_raw(x, packed, bias, y, 1, 0.1)
+    e1.record()
+    torch.cuda.synchronize(device)
+    avg_us = e0.elapsed_time(e1) * 1e3 / nrep
+    flop = 2.0 * 9 * Cin * Cout * N * h * w
+    achieved = flop / (avg_us * 1e-6) / 1e12
+    return {'bound': 'mfma', 'kernel': 'conv_kernel<MTW=4> (context network layer 1, 565->128, 3x3)', 'shape': [N, Cin, h, w],
+            'achieved': round(achieved, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(achieved / 2500.0, 4), 'traffic': None,
+            'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
 
 
 def cpu_baseline(H, W):
@@ -157,6 +189,8 @@ def main():
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--torch-pyramid', action='store_true',
+                    help="the north star's literal split: feature-pyramid convolutions through PyTorch-ROCm (MIOpen)")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help='train = BASELINE config 3: unsupervised step (fwd+loss+bwd+Adam), 256x832 crops, batch 4 per GPU, DDP')
     args = ap.parse_args()
@@ -174,7 +208,7 @@ def main():
     dname = args.dtype or dname
     dtype = DT[dname]
     import _weights
-    net = build_net(dtype, device)
+    net = build_net(dtype, device, hip_pyramid_convs=not args.torch_pyramid)
     im1, im2 = _weights.make_images(2, B, H, W)
     im1, im2 = im1.to(device), im2.to(device)                               # inputs resident in HBM
 
@@ -213,9 +247,13 @@ def main():
             'config': {'workload': '%s: UPFlow_net inference forward (flow fwd+bwd, occlusion masks, SGU on), '
                                    '%dx%d, batch %d per GPU, random-init weights' % (args.workload, H, W, B),
                        'global_batch': world * B, 'parallelism': 'replicas x%d (image pairs sharded, no collective)' % world,
-                       'hip_graph': not args.no_graph},
+                       'hip_graph': not args.no_graph,
+                       'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or dtype == torch.float32 else 'HIP (MFMA kernel)'},
             'roofline': roofline_probe(B, H, W, dtype, device),
         }
+        conv_rf = conv_roofline_probe(B, H, W, dtype, device)
+        if conv_rf is not None:
+            line['roofline_conv'] = conv_rf
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(384, 1280)
         print(json.dumps(line), flush=True)

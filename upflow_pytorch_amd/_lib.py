@@ -71,6 +71,11 @@ def lib():
         L.upf_version.restype = _c.c_char_p
         L.upf_last_error.restype = _c.c_char_p
         _lib = L
+        # tuning hook: UPF_CONV_OPTS="sk_grid=48,rpw4_min=512" -> upf_conv_set_option (include/upflow_hip.h)
+        for item in filter(None, os.environ.get('UPF_CONV_OPTS', '').split(',')):
+            k, v = item.split('=')
+            if L.upf_conv_set_option(k.strip().encode(), int(v)) < 0:
+                raise UpflowHipError('UPF_CONV_OPTS: unknown option %r' % k)
     return _lib
 
 

@@ -99,9 +99,10 @@ class FeatureExtractor(nn.Module):
         """outs (inference fast path): per stage, None or the [B, C, H, W] view the stage's output is written to."""
         pyramid = []
         cache = self.__dict__.setdefault('_fast_cache', {})
+        hip = getattr(self, 'hip_convs', True)         # False: PyTorch-ROCm (MIOpen) even where the MFMA kernel applies
         for i, stage in enumerate(self.convs):
-            x = fast_conv_seq(stage[0], x, cache)      # stride-2 conv
-            x = fast_conv_seq(stage[1], x, cache, out=None if outs is None else outs[i])   # stride-1 conv
+            x = fast_conv_seq(stage[0], x, cache, allow_hip=hip)      # stride-2 conv
+            x = fast_conv_seq(stage[1], x, cache, out=None if outs is None else outs[i], allow_hip=hip)   # stride-1 conv
             pyramid.append(x)
         return pyramid[::-1]
 
@@ -172,13 +173,13 @@ class _PackedConv3x3(object):
                                        self.conv.kernel_size[0])
 
 
-def fast_conv_seq(seq, x, cache, out=None):
+def fast_conv_seq(seq, x, cache, out=None, allow_hip=True):
     """Run one `conv(...)` Sequential (Conv2d [+ LeakyReLU]) — through the matrix-core kernel when it is a
     3x3 (stride 1/2, dilation <= 16) or 1x1 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
     that keeps the packed weights per Sequential.  `out`: optional destination (a channel slice of a wider NCHW buffer)."""
     c = seq[0]
     k = c.kernel_size[0]
-    if (_fast_conv_ok(x) and c.kernel_size in ((3, 3), (1, 1)) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
+    if (allow_hip and _fast_conv_ok(x) and c.kernel_size in ((3, 3), (1, 1)) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
             and c.padding == (((k - 1) * c.dilation[0]) // 2,) * 2
             and ops.conv3x3_supported(x, c.out_channels, c.dilation[0], c.stride[0], k)):
         pc = cache.get(id(seq))

@@ -8,12 +8,16 @@ What is native here (one hand-written HIP launch each, csrc/*.hip):
     cost volume (+LeakyReLU, written straight into the estimator's 115-channel input buffer),
     backward warp (+validity mask), flow up-sampling (+rescale), SGU interpolation-blend,
     feature normalisation, occlusion check.
-Convolutions stay PyTorch-ROCm.  Precision: with bf16/fp16 weights (net.bfloat16()) features and
-conv activations are 16-bit, while flows, sampling positions, masks, normalisation statistics and
-all accumulators stay fp32; fp32 weights give the parity mode.
+Convolutions: fp32 (the parity mode) and everything under autograd stay PyTorch-ROCm (MIOpen); in bf16/fp16
+inference the flow-estimator / context / SGU-estimator convolutions run on the hand-written MFMA kernel
+(csrc/conv3x3.hip), and so do the feature-pyramid and 1x1 convolutions unless
+`hip_pyramid_convs=False` restores the north star's literal split ("the feature-pyramid convolutions stay
+PyTorch-ROCm").  Precision: with bf16/fp16 weights (net.bfloat16()) features and conv activations are 16-bit,
+while flows, sampling positions, masks, normalisation statistics and all accumulators stay fp32.
 
 Extra (non-reference) config flags, all defaulting to the reference's behaviour:
     warp_mask_mode = 'literal' | 'robust'   validity-mask semantics of the feature warps (§7-H2)
+    hip_pyramid_convs = True | False        16-bit inference: feature pyramid on the MFMA kernel / on MIOpen
 """
 import torch
 import torch.nn as nn
@@ -208,6 +212,7 @@ class UPFlow_net(tools.abstract_model):
             self.if_use_cor_pytorch = False
             # --- not in the reference; defaults keep its behaviour
             self.warp_mask_mode = 'literal'
+            self.hip_pyramid_convs = True
 
         def __call__(self, ):
             return UPFlow_net(self)
@@ -228,6 +233,7 @@ class UPFlow_net(tools.abstract_model):
         self.num_levels = 7
         self.leakyRELU = nn.LeakyReLU(0.1, inplace=True)
         self.feature_pyramid_extractor = FeatureExtractor(self.num_chs)
+        self.feature_pyramid_extractor.hip_convs = bool(getattr(conf, 'hip_pyramid_convs', True))
         self.warping_layer = WarpingLayer_no_div(conf.warp_mask_mode)
         self.dim_corr = (self.search_range * 2 + 1) ** 2
         self.num_ch_in = self.dim_corr + 32 + 2
