@@ -297,3 +297,28 @@ def test_flow_update_matches_torch_chain(dtype):
     assert torch.equal(buf[:, 5:7], a.to(dtype)) and bool((buf[:, :3] == 9).all())
     with pytest.raises(RuntimeError):
         ops.flow_update(a.cpu(), b.cpu())
+
+
+@pytest.mark.parametrize('shape', [((6, 20), (12, 40)), ((4, 13), (256, 832)), ((64, 208), (256, 832)), ((1, 3), (7, 9)),
+                                   ((5, 1), (11, 6)), ((24, 40), (9, 15)), ((3, 5), (3, 5))])
+@pytest.mark.parametrize('if_rate', [True, False])
+def test_flow_upsample_backward_matches_autograd(shape, if_rate):
+    """upf_flow_upsample_backward (deterministic gather, both kernel variants) vs autograd through
+    F.interpolate(bilinear, align_corners=True) * size ratio (model/pwc_modules.py:77-90)."""
+    import torch.nn.functional as F
+    from upflow_pytorch_amd import ops
+    (h, w), (H, W) = shape
+    g = torch.Generator().manual_seed(h * 1000 + W)
+    x = torch.randn(3, 2, h, w, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(3, 2, H, W, generator=g).cuda()
+    y = ops.flow_upsample(x, H, W, if_rate)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(H, W), mode='bilinear', align_corners=True)
+    if if_rate:
+        yr = yr * torch.tensor([W / w, H / h], device='cuda').view(1, 2, 1, 1)
+    (gr,) = torch.autograd.grad(yr, xr, gy)
+    assert relerr(y.detach().cpu(), yr.detach().cpu()) <= 2e-6
+    assert relerr(gx.cpu(), gr.cpu()) <= 1e-5, float((gx - gr).abs().max())
+    (gx2,) = torch.autograd.grad(ops.flow_upsample(x, H, W, if_rate), x, gy)
+    assert torch.equal(gx, gx2), 'backward must be deterministic'

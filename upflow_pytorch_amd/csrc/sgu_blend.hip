@@ -161,21 +161,55 @@ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int
   y[(size_t)nc * HW + p] = v;
 }
 
+// Backward of the resize as a GATHER: every input pixel (a, b) sums the output pixels whose two-tap interpolation
+// reads it — no atomics, deterministic.  (The first version scattered with fp32 atomics from one thread per OUTPUT
+// pixel: the pyramid-distillation loss up-samples 4x13 flows to 256x832, i.e. 4096 threads per target address, and one
+// such launch took 1.9 ms — a third of a training step.)  The candidate output range of an input row/column is
+// bracketed generously and each candidate is re-tested with the forward's own make_lerp, so the weights are exactly
+// the forward's.  WG = false: one thread per input pixel (small footprints); WG = true: one workgroup per input pixel,
+// threads stride over the footprint, fixed-order LDS tree reduction.
+__device__ __forceinline__ void upsample_bwd_range(int a, int in_size, int out_size, int& lo, int& hi) {
+  if (in_size <= 1 || out_size <= 1) { lo = 0; hi = out_size - 1; return; }
+  const float inv = (float)(out_size - 1) / (float)(in_size - 1);
+  lo = max(0, (int)floorf((float)(a - 1) * inv) - 1);
+  hi = min(out_size - 1, (int)ceilf((float)(a + 1) * inv) + 1);
+}
+__device__ __forceinline__ float upsample_bwd_weight(const Lerp& l, int a) {
+  return (l.i0 == a ? l.l0 : 0.f) + (l.i1 == a ? l.l1 : 0.f);
+}
+template <bool WG>
 __global__ __launch_bounds__(THREADS)
-void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate) {
-  const int HW = H * W;
-  const int p = blockIdx.x * THREADS + threadIdx.x;
-  if (p >= HW) return;
-  const int nc = blockIdx.y, c = nc % C;
-  const int i = p / W, j = p - i * W;
-  const Lerp ly = make_lerp(i, h, H), lx = make_lerp(j, w, W);
-  float g = gy[(size_t)nc * HW + p];
-  if (if_rate) g *= (c == 0) ? (float)((double)W / (double)w) : (float)((double)H / (double)h);
-  float* d = gx + (size_t)nc * h * w;
-  atomicAdd(d + ly.i0 * w + lx.i0, g * ly.l0 * lx.l0);
-  atomicAdd(d + ly.i0 * w + lx.i1, g * ly.l0 * lx.l1);
-  atomicAdd(d + ly.i1 * w + lx.i0, g * ly.l1 * lx.l0);
-  atomicAdd(d + ly.i1 * w + lx.i1, g * ly.l1 * lx.l1);
+void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate, long long total) {
+  __shared__ float red[THREADS];
+  const long long idx = WG ? (long long)blockIdx.x : blockIdx.x * (long long)THREADS + threadIdx.x;
+  if (!WG && idx >= total) return;
+  const int b = (int)(idx % w), a = (int)((idx / w) % h);
+  const long long nc = idx / ((long long)w * h);
+  const int c = (int)(nc % C);
+  int ilo, ihi, jlo, jhi;
+  upsample_bwd_range(a, h, H, ilo, ihi);
+  upsample_bwd_range(b, w, W, jlo, jhi);
+  const float* g = gy + (size_t)nc * H * W;
+  const int nj = jhi - jlo + 1, cnt = (ihi - ilo + 1) * nj;
+  float acc = 0.f;
+  for (int t = WG ? (int)threadIdx.x : 0; t < cnt; t += WG ? THREADS : 1) {
+    const int i = ilo + t / nj, j = jlo + t % nj;
+    const float wy = upsample_bwd_weight(make_lerp(i, h, H), a);
+    const float wx = upsample_bwd_weight(make_lerp(j, w, W), b);
+    if (wy != 0.f && wx != 0.f) acc += g[(size_t)i * W + j] * wy * wx;
+  }
+  if (WG) {
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = THREADS / 2; sft > 0; sft >>= 1) {
+      if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+      __syncthreads();
+    }
+    acc = red[0];
+    if (threadIdx.x != 0) return;
+  }
+  if (if_rate) acc *= (c == 0) ? (float)((double)W / (double)w) : (float)((double)H / (double)h);
+  gx[idx] = acc;
 }
 
 // out[n, :] = cast(a + (b + c))  — the flow bookkeeping of one pyramid level (model/upflow.py:566-572:
@@ -249,10 +283,13 @@ extern "C" int upf_flow_upsample_backward(const float* grad_y, float* gx, int B,
   UPF_REQUIRE(grad_y && gx, UPF_EINVAL, "flow_upsample_backward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && (long long)B * C <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, UPF_EINVAL, "flow_upsample_backward: bad shape");
   UPF_REQUIRE(!if_rate || C == 2, UPF_EINVAL, "flow_upsample_backward: if_rate needs a 2-channel flow, got C=%d", C);
-  hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * C * h * w * sizeof(float), (hipStream_t)stream);
-  UPF_REQUIRE(e == hipSuccess, (int)e, "flow_upsample_backward: memset failed: %s", hipGetErrorString(e));
-  dim3 grid(cdiv(H * W, sgu::THREADS), B * C);
-  hipLaunchKernelGGL(sgu::upsample_bwd_kernel, grid, dim3(sgu::THREADS), 0, (hipStream_t)stream, grad_y, gx, C, h, w, H, W, if_rate);
+  const long long total = (long long)B * C * h * w;
+  // footprint of one input pixel ~ (2H/h) x (2W/w) outputs: a workgroup per input pixel once it exceeds a few hundred
+  const long long fp = (2LL * cdiv(H, h) + 2) * (2LL * cdiv(W, w) + 2);
+  if (fp > 512 && total < (1LL << 31))
+    hipLaunchKernelGGL(sgu::upsample_bwd_kernel<true>, dim3((unsigned)total), dim3(sgu::THREADS), 0, (hipStream_t)stream, grad_y, gx, C, h, w, H, W, if_rate, total);
+  else
+    hipLaunchKernelGGL(sgu::upsample_bwd_kernel<false>, dim3((unsigned)((total + sgu::THREADS - 1) / sgu::THREADS)), dim3(sgu::THREADS), 0, (hipStream_t)stream, grad_y, gx, C, h, w, H, W, if_rate, total);
   return check_launch("flow_upsample_backward");
 }
 
