@@ -10,7 +10,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libupflow_hip.so')
+LIB_PATH = os.environ.get('UPF_HIP_LIB') or os.path.join(_PKG, 'libupflow_hip.so')   # (override: A/B runs of two builds)
 
 UPF_F32, UPF_F16, UPF_BF16 = 0, 1, 2
 MASK_NONE, MASK_LITERAL, MASK_ROBUST = 0, 1, 2

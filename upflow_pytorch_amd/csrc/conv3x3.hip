@@ -64,6 +64,12 @@ template <> struct Mma32<f16_t> {
 
 __host__ __device__ constexpr int pad32(int v) { return (v + 31) / 32 * 32; }
 
+// LDS x tile: row pitch XW+1 entries, and inside every 8-pixel group the pixel slots are ROTATED by 2*(group/2):
+// a staging write phase (16 lanes = consecutive 8-pixel groups of a few rows, each lane writing pixel q of its group)
+// then spreads over the bank quads instead of piling onto two of them, while the global loads stay coalesced (lanes
+// adjacent along the row).  swz(col) = position of staged column `col` inside its row.
+__device__ __forceinline__ int swz(int col) { return (col & ~7) | ((col + 2 * (col >> 4)) & 7); }
+
 // w [Cout, Cin, k, k] (k*k = ntaps) -> packed [slab = co/32][k-step = ci/16][tap][kg = (ci/8)%2][px = co%32][ci%8],
 // zero padded to pad32(Cout) x pad32(Cin): the 1 KB block of one (slab, k-step, tap) is exactly the A operand of one
 // v_mfma_f32_32x32x16 in lane order (lane = kg*32 + px holds 8 consecutive input channels of output channel px),
@@ -185,8 +191,8 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
   constexpr int RG = 4 / MTW, TH = RG * RPW;
   constexpr int XW = xw(S, marg);
-  constexpr int XWP = XW + 1;                        // LDS row pitch in entries: +1 so that the staging writes of 16 lanes
-                                                     // (one staged row each, 16 B at the same column) hit 16 different bank quads
+  constexpr int XWP = XW + 1;                        // LDS row pitch in entries: +1 (and rotated pixel slots, see swz) so that
+                                                     // the staging writes of a 16-lane phase spread over the bank quads
   // PH (compile-time dilation >= 2): ROW-PHASE decomposition.  A workgroup's TH output rows are D image rows apart
   // (rows y0 + D*r of one phase y0 % D), so the three kernel rows read ADJACENT staged rows — the vertical halo is 2
   // rows instead of 2*D (dilation 8: 10 staged rows per 8 output rows instead of 24), and only the horizontal taps
@@ -231,12 +237,12 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   // task t -> buffer-load offset of channel 0 of its octet in chunk 0 (0x80000000 = outside the image), the LDS
   // entry it fills, and (GEN) the pixels by which the load window is shifted left to end at the row end
   auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
-    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), g = rem / rows, r = rem - g * rows;   // row fastest
+    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;   // group fastest: coalesced loads
     const int gy = PH ? y0 + (r - 1) * RS : S * y0 - d + r, gx = S * x0 - marg + 8 * g;
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // !GEN: W % 8 == 0, a group is all in or all out
     sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
-    dst = (oct * rows + r) * XWP + 8 * g;
+    dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((2 * (g >> 1)) & 7);   // entry index * 8 + slot rotation of the group
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
     const uint32_t o = off + (uint32_t)cc * KCH * plane;                           // stays >= 2^31 for outside tasks
@@ -244,7 +250,8 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
   };
   auto task_store = [&](int dsti, int sh, const u32x4 (&ch)[8]) {                 // 8 channel rows x 8 px -> 8 px x 8 channels
-    uint4* dst = xs + dsti;
+    uint4* dst = xs + (dsti >> 3);
+    const int rot = dsti & 7;
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
       uint4 e0, e1;
@@ -256,11 +263,11 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
         const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
         e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
         e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
-        dst[(2 * pp - sh) & 7] = e0;
-        dst[(2 * pp + 1 - sh) & 7] = e1;
+        dst[(2 * pp - sh + rot) & 7] = e0;
+        dst[(2 * pp + 1 - sh + rot) & 7] = e1;
       } else {
-        dst[2 * pp] = e0;
-        dst[2 * pp + 1] = e1;
+        dst[(2 * pp + rot) & 7] = e0;
+        dst[(2 * pp + 1 + rot) & 7] = e1;
       }
     }
   };
@@ -286,6 +293,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(0, tap, ks);
 
   constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * DV) * 3 < 9 * RPW);
+  const int colx[3] = {swz(marg + px - (D > 0 ? D : 0)), swz(marg + px), swz(marg + px + (D > 0 ? D : 0))};   // REUSE windows
 
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();                                 // previous chunk fully consumed
@@ -311,12 +319,14 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) b[kx * KS + ks] = xs[((2 * ks + kg) * rows + RPW * rg + sr) * XWP + marg + px + (kx - 1) * D];
+          for (int ks = 0; ks < KS; ++ks) b[kx * KS + ks] = xs[((2 * ks + kg) * rows + RPW * rg + sr) * XWP + colx[kx]];
       };
-      bload(0, bq[0]);
+      constexpr bool PIPEB = !ONE;                   // (the single-chunk variants run 4 workgroups per CU on 128 registers)
+      if constexpr (PIPEB) bload(0, bq[0]);
 #pragma unroll
       for (int sr = 0; sr < NR; ++sr) {
-        if (sr + 1 < NR) bload(sr + 1, bq[(sr + 1) & 1]);
+        if constexpr (PIPEB) { if (sr + 1 < NR) bload(sr + 1, bq[(sr + 1) & 1]); }
+        else bload(sr, bq[sr & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
@@ -341,7 +351,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
       for (int tap = 0; tap < ntaps; ++tap) {
         const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
         // shifted window: output pixel (row, px) reads staged entry (S*row + ky*d, marg + S*px + (kx-1)*d)
-        const int col = marg + S * px + (kx - 1) * d;
+        const int col = swz(marg + S * px + (kx - 1) * d);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -425,12 +435,12 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   }
 
   auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
-    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), g = rem / rows, r = rem - g * rows;   // row fastest
+    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;   // group fastest: coalesced loads
     const int gy = y0 - D + r, gx = x0 - marg + 8 * g;
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;
     sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
-    dst = (oct * rows + r) * XWP + 8 * g;
+    dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((2 * (g >> 1)) & 7);   // entry index * 8 + slot rotation of the group
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
     const uint32_t o = (cc < nchunks) ? off + (uint32_t)cc * KCH * plane : 0x80000000u;
@@ -438,7 +448,8 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
     for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
   };
   auto task_store = [&](int dsti, int sh, const u32x4 (&ch)[8]) {
-    uint4* dst = xs + dsti;
+    uint4* dst = xs + (dsti >> 3);
+    const int rot = dsti & 7;
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       uint4 e0, e1;
@@ -450,11 +461,11 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
         const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
         e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
         e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
-        dst[(2 * pp - sh) & 7] = e0;
-        dst[(2 * pp + 1 - sh) & 7] = e1;
+        dst[(2 * pp - sh + rot) & 7] = e0;
+        dst[(2 * pp + 1 - sh + rot) & 7] = e1;
       } else {
-        dst[2 * pp] = e0;
-        dst[2 * pp + 1] = e1;
+        dst[(2 * pp + rot) & 7] = e0;
+        dst[(2 * pp + 1 + rot) & 7] = e1;
       }
     }
   };
@@ -478,6 +489,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
     for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(wave, tap, ks);
 
   constexpr bool REUSE = (D >= 1 && (RPW + 2 * D) * 3 < 9 * RPW);
+  const int colx[3] = {swz(marg + px - D), swz(marg + px), swz(marg + px + D)};
 
   for (int cc = wave; cc < nchunks; cc += 4) {
     // ---- stage this wave's chunk (LDS operations of one wave execute in order: no barrier against its own reads)
@@ -502,7 +514,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const uint4 b = xs[((2 * ks + kg) * rows + sr) * XWP + marg + px + (kx - 1) * D];
+            const uint4 b = xs[((2 * ks + kg) * rows + sr) * XWP + colx[kx]];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
               if (sr - ky * D >= 0 && sr - ky * D < RPW) acc[sr - ky * D] = Mma32<T>::mma(wa[ky * 3 + kx][ks], b, acc[sr - ky * D]);
@@ -520,7 +532,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 #pragma unroll
       for (int tap = 0; tap < ntaps; ++tap) {
         const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
-        const int col = marg + px + (kx - 1) * D;
+        const int col = swz(marg + px + (kx - 1) * D);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
