@@ -64,11 +64,12 @@ template <> struct Mma32<f16_t> {
 
 __host__ __device__ constexpr int pad32(int v) { return (v + 31) / 32 * 32; }
 
-// LDS x tile: row pitch XW+1 entries, and inside every 8-pixel group the pixel slots are ROTATED by 2*(group/2):
+// LDS x tile: row pitch XW + XW/16 entries, and inside every 8-pixel group the pixel slots are ROTATED by group/2:
 // a staging write phase (16 lanes = consecutive 8-pixel groups of a few rows, each lane writing pixel q of its group)
-// then spreads over the bank quads instead of piling onto two of them, while the global loads stay coalesced (lanes
-// adjacent along the row).  swz(col) = position of staged column `col` inside its row.
-__device__ __forceinline__ int swz(int col) { return (col & ~7) | ((col + 2 * (col >> 4)) & 7); }
+// then hits 16 different bank quads (tools: brute-force search over rotations and pitches) instead of piling onto two
+// of them, while the global loads stay coalesced (lanes adjacent along the row).  A 16-column read window that starts
+// inside a group sees one 2-way conflict at most.  swz(col) = position of staged column `col` inside its row.
+__device__ __forceinline__ int swz(int col) { return (col & ~7) | ((col + (col >> 4)) & 7); }
 
 // w [Cout, Cin, k, k] (k*k = ntaps) -> packed [slab = co/32][k-step = ci/16][tap][kg = (ci/8)%2][px = co%32][ci%8],
 // zero padded to pad32(Cout) x pad32(Cin): the 1 KB block of one (slab, k-step, tap) is exactly the A operand of one
@@ -191,8 +192,8 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
   constexpr int RG = 4 / MTW, TH = RG * RPW;
   constexpr int XW = xw(S, marg);
-  constexpr int XWP = XW + 1;                        // LDS row pitch in entries: +1 (and rotated pixel slots, see swz) so that
-                                                     // the staging writes of a 16-lane phase spread over the bank quads
+  constexpr int XWP = XW + XW / 16;                  // LDS row pitch in entries (with the rotated pixel slots of swz: the
+                                                     // staging writes of a 16-lane phase hit 16 different bank quads)
   // PH (compile-time dilation >= 2): ROW-PHASE decomposition.  A workgroup's TH output rows are D image rows apart
   // (rows y0 + D*r of one phase y0 % D), so the three kernel rows read ADJACENT staged rows — the vertical halo is 2
   // rows instead of 2*D (dilation 8: 10 staged rows per 8 output rows instead of 24), and only the horizontal taps
@@ -242,7 +243,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;      // !GEN: W % 8 == 0, a group is all in or all out
     sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
-    dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((2 * (g >> 1)) & 7);   // entry index * 8 + slot rotation of the group
+    dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);   // entry index * 8 + slot rotation of the group
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
     const uint32_t o = off + (uint32_t)cc * KCH * plane;                           // stays >= 2^31 for outside tasks
@@ -401,7 +402,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   constexpr int marg = margin_of(D);
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;
   constexpr int RPW = 2, TH = 2;
-  constexpr int XW = xw(1, marg), XWP = XW + 1;
+  constexpr int XW = xw(1, marg), XWP = XW + XW / 16;
   constexpr int rows = TH + 2 * D;                   // staged input rows
   constexpr int ngroups = XW / 8;
   constexpr int ntasks = NOCTS * rows * ngroups;     // per wave and chunk
@@ -440,7 +441,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;
     sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
     off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
-    dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((2 * (g >> 1)) & 7);   // entry index * 8 + slot rotation of the group
+    dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);   // entry index * 8 + slot rotation of the group
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
     const uint32_t o = (cc < nchunks) ? off + (uint32_t)cc * KCH * plane : 0x80000000u;
@@ -585,7 +586,7 @@ int launch_one(const Args& a, int slabs) {
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int tiles_x = cdiv(Wo, TW), tiles_y = PH ? cdiv(Ho, D * TH) * D : cdiv(Ho, TH);
   const int rows = PH ? TH + 2 : S * (TH - 1) + 2 * a.d + 1;
-  size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + 1) * 16;
+  size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + xw(S, margin_of(D)) / 16) * 16;
   if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;        // the wide epilogue's patches reuse the region
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
   static size_t attr_lds = 0;
@@ -632,7 +633,7 @@ template <typename T, int NOCTS, int D, bool GEN>
 int launch_sk_one(const Args& a) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, 2);
   constexpr int rows = 2 + 2 * D;
-  size_t lds = (size_t)4 * NOCTS * rows * (xw(1, margin_of(D)) + 1) * 16;
+  size_t lds = (size_t)4 * NOCTS * rows * (xw(1, margin_of(D)) + xw(1, margin_of(D)) / 16) * 16;
   if (lds < 4 * 2 * 16 * 64 * 4) lds = 4 * 2 * 16 * 64 * 4;       // the partial-sum exchange reuses the region
   static bool attr_set = false;
   auto kern = &conv_sk_kernel<T, NOCTS, D, GEN>;
