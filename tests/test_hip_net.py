@@ -137,3 +137,29 @@ def test_16bit_all_hip_path_vs_fp32():
             e = oracle.epe(out.cpu(), ref.cpu())
             print('%s all-HIP path EPE vs fp32 %.3g px (mean |flow| %.3g px)' % (dtype, e, mag))
             assert e <= tol * max(mag, 1.0)
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 resolution (384x1280, bf16), size-independent properties of the whole forward:
+    (1) direction symmetry — swapping the two frames swaps flow_f / flow_b and the occlusion masks, bit for bit
+        (every operator is per-item; the stacked-batch schedule only changes which batch slot an item occupies);
+    (2) the hipGraph replay equals the eager forward bit for bit;
+    (3) the flow stays inside the bf16 rounding envelope of the fp32 (parity-mode) forward of the same network."""
+    from upflow_pytorch_amd.runtime import GraphedInference
+    im1, im2 = _weights.make_smooth_images(11, 1, 384, 1280)
+    im1, im2 = im1.cuda(), im2.cuda()
+    net = build('robust', torch.bfloat16)
+    with torch.no_grad():
+        a = net({'im1': im1, 'im2': im2, 'if_loss': False})
+        b = net({'im1': im2, 'im2': im1, 'if_loss': False})
+        ref = build('robust', torch.float32)({'im1': im1, 'im2': im2, 'if_loss': False})
+    assert torch.equal(a['flow_f_out'], b['flow_b_out']) and torch.equal(a['flow_b_out'], b['flow_f_out'])
+    assert torch.equal(a['occ_fw'], b['occ_bw']) and torch.equal(a['occ_bw'], b['occ_fw'])
+    runner = GraphedInference(net, 1, 384, 1280, device=im1.device)
+    runner.load(im1, im2)
+    g = runner.replay()
+    assert torch.equal(g['flow_f_out'], a['flow_f_out']) and torch.equal(g['flow_b_out'], a['flow_b_out'])
+    mag = float(ref['flow_f_out'].pow(2).sum(1).sqrt().mean())
+    e = oracle.epe(a['flow_f_out'].cpu(), ref['flow_f_out'].cpu())
+    print('384x1280 bf16 vs fp32 forward: EPE %.3g px (mean |flow| %.3g px)' % (e, mag))
+    assert e <= 0.25 * max(mag, 1.0)
