@@ -7,12 +7,15 @@
 //   g1[n,c,y,x] = (1/C) sum_d gO[n,d,y,x]       * f2[n,c,y+dy,x+dx]
 //   g2[n,c,y,x] = (1/C) sum_d gO[n,d,y-dy,x-dx] * f1[n,c,y-dy,x-dx]      (out-of-range terms dropped)
 //
-// Both are "81 per-pixel weights times a 9x9 neighbourhood of one feature channel".  A thread owns
+// Both are "81 per-pixel weights times a 9x9 neighbourhood of one feature channel".  Two kernels: the LDS-tiled one
+// further down (W % 4 == 0: every level the trainer's crops produce except the two coarsest) and this gather kernel
+// (any shape), in which a thread owns
 // one pixel: it loads its 81 weights ONCE into registers (gO is the big tensor: 81 channels), then
 // walks its slice of the C channels gathering the neighbourhood (L1/L2 hits: neighbouring lanes read
 // neighbouring addresses).  gO is therefore read exactly once per direction from HBM; fp32
 // accumulation.  One launch covers the whole batch and both gradients (blockIdx.z selects which).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace upf {
 namespace corr {
@@ -57,6 +60,112 @@ void corr81_bwd_kernel(const T* __restrict__ f1, const T* __restrict__ f2, const
   }
 }
 
+
+// ---- LDS-tiled version (W % 4 == 0) ----------------------------------------------------------------------------
+// The gather kernel above issues 81 four-byte loads per (pixel, channel): TA-bound at a few percent of the HBM
+// roofline.  Here a workgroup owns a 16 x 64 pixel tile and CC channels of ONE gradient (WHICH = 0: g1, 1: g2):
+//   * the feature tile (+ 4-pixel halo, zero padded through the buffer descriptor) of the CC channels is staged once
+//     into LDS as fp32;
+//   * a thread owns 4 consecutive pixels: per displacement row it fetches its 9 x 4 weights (gO at the pixel itself for
+//     g1, at the displaced source pixel for g2) and then, per channel, reads the 12-float window that holds every
+//     neighbour of its 4 pixels with three 16-byte LDS reads: 36 FMAs per 3 LDS reads instead of per 36 global loads.
+// gO is read once per channel chunk (L2-resident after the first), the features once, fp32 accumulation.
+constexpr int BTH = 16, BTW = 64, BCC = 4;
+constexpr int BROWS = BTH + 8, BPITCH = BTW + 8;                 // tile incl. halo, floats
+
+template <typename T, bool WHICH>
+__global__ __launch_bounds__(256, 4)
+void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ gO, T* __restrict__ gout,
+                             int C, int H, int W, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) float tile[BCC * BROWS * BPITCH];
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * BTW, y0 = ty * BTH;
+  const int c0 = blockIdx.y * BCC;
+  const int n = blockIdx.z;
+  const int HW = H * W;
+  const int tid = threadIdx.x;
+  constexpr int ES = sizeof(typename Elem<T>::store_t);
+  const uint32_t plane = (uint32_t)HW * ES;
+  __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(feat + (size_t)n * C * HW), 0, (uint32_t)C * plane, 0x00020000);
+  __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(gO + (size_t)n * 81 * HW), 0, 81u * plane, 0x00020000);
+  auto load4 = [&](__amdgpu_buffer_rsrc_t r, uint32_t off, float (&v)[4]) {       // 4 consecutive elements -> fp32
+    if constexpr (ES == 4) {
+      const auto t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+      v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
+    } else {
+      const auto t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+      T e[4];
+      e[0].v = (uint16_t)t[0]; e[1].v = (uint16_t)(t[0] >> 16); e[2].v = (uint16_t)t[1]; e[3].v = (uint16_t)(t[1] >> 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = Elem<T>::load(&e[i]);
+    }
+  };
+  // ---- stage the feature tile: groups of 4 columns (all in or all out of the row: x0 - 4 and W are multiples of 4)
+  constexpr int GPR = BPITCH / 4;                                // 18 groups per tile row
+  for (int g = tid; g < BCC * BROWS * GPR; g += 256) {
+    const int c = g / (BROWS * GPR), rem = g - c * (BROWS * GPR), r = rem / GPR, k = rem - r * GPR;
+    const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * k;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;      // (channels >= C fall off the descriptor)
+    float v[4];
+    load4(fr, in ? (uint32_t)((c0 + c) * HW + gy * W + gx) * ES : 0x80000000u, v);
+    *reinterpret_cast<float4*>(&tile[(c * BROWS + r) * BPITCH + 4 * k]) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __syncthreads();
+
+  const int r = tid >> 4, cg = tid & 15;                         // tile row, 4-pixel column group
+  const int y = y0 + r, x = x0 + 4 * cg;
+  float acc[BCC][4];
+#pragma unroll
+  for (int c = 0; c < BCC; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = 0.f;
+  const bool live = y < H && x < W;
+  // weights of displacement row dyi: g1: gO[d] at the pixels themselves; g2: gO[d] at the displaced SOURCE pixels
+  // (columns of a displaced vector that leave the row meet the zero halo of the feature tile)
+  auto load_w = [&](int dyi, float (&w)[9][4]) {
+    const int dy = dyi - 4;
+#pragma unroll
+    for (int dxi = 0; dxi < 9; ++dxi) {
+      const int yy = WHICH ? y - dy : y, xx = WHICH ? x - (dxi - 4) : x;
+      const bool in = live && yy >= 0 && yy < H;
+      load4(gr, in ? (uint32_t)(((dyi * 9 + dxi) * H + yy) * W + xx) * ES : 0x80000000u, w[dxi]);
+    }
+  };
+  auto compute = [&](int dyi, const float (&w)[9][4]) {
+    const int dy = dyi - 4;
+    const int srow = r + 4 + (WHICH ? -dy : dy);
+#pragma unroll
+    for (int c = 0; c < BCC; ++c) {
+      const float* row = &tile[(c * BROWS + srow) * BPITCH + 4 * cg];
+      const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4), d = *reinterpret_cast<const float4*>(row + 8);
+      const float win[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int dxi = 0; dxi < 9; ++dxi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[c][i] = __builtin_fmaf(w[dxi][i], win[WHICH ? i + 8 - dxi : i + dxi], acc[c][i]);
+    }
+  };
+  // (latency of the 9 weight loads per row is hidden by occupancy: 27 KB of LDS and ~100 registers per workgroup)
+  float w[9][4];
+#pragma unroll 1
+  for (int dyi = 0; dyi < 9; ++dyi) {
+    load_w(dyi, w);
+    compute(dyi, w);
+  }
+  if (!live) return;
+  const float invC = 1.0f / (float)C;
+#pragma unroll
+  for (int c = 0; c < BCC; ++c) {
+    if (c0 + c >= C) break;
+    T* dst = gout + ((size_t)n * C + c0 + c) * HW + (size_t)y * W + x;
+    if constexpr (ES == 4) {
+      *reinterpret_cast<float4*>(dst) = make_float4(acc[c][0] * invC, acc[c][1] * invC, acc[c][2] * invC, acc[c][3] * invC);
+    } else {
+      *reinterpret_cast<uint2*>(dst) = make_uint2(pack2<T>(acc[c][0] * invC, acc[c][1] * invC), pack2<T>(acc[c][2] * invC, acc[c][3] * invC));
+    }
+  }
+}
+
 }  // namespace corr
 }  // namespace upf
 
@@ -66,6 +175,16 @@ extern "C" int upf_corr81_backward(const void* f1, const void* f2, const void* g
   UPF_REQUIRE(f1 && f2 && grad_out && g1 && g2, UPF_EINVAL, "corr81_backward: null pointer");
   UPF_REQUIRE(B > 0 && 2 * B <= 65535 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_backward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   const int HW = H * W;
+  const size_t es = dtype == UPF_F32 ? 4 : 2;
+  if (W % 4 == 0 && (size_t)81 * HW * es < (1ull << 31) && (size_t)C * HW * es < (1ull << 31) && aligned_to(f1, 16) && aligned_to(f2, 16) &&
+      aligned_to(grad_out, 8) && aligned_to(g1, 16) && aligned_to(g2, 16) && getenv("UPF_CORR_BWD_GATHER") == nullptr) {
+    const int tiles_x = cdiv(W, corr::BTW), tiles_y = cdiv(H, corr::BTH);
+    dim3 grid(tiles_x * tiles_y, cdiv(C, corr::BCC), B);
+    UPF_DISPATCH(dtype, T,
+                 hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f2, (const T*)grad_out, (T*)g1, C, H, W, tiles_x);
+                 hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f1, (const T*)grad_out, (T*)g2, C, H, W, tiles_x));
+    return check_launch("corr81_backward");
+  }
   // split channels over blockIdx.y until there are a few thousand waves in flight
   int split = 1;
   while (split < C && (long long)2 * B * cdiv(HW, corr::BT) * split < 4096 && C / (split * 2) >= 2) split *= 2;
