@@ -142,6 +142,8 @@ def train_main(args, rank, world, device):
     from upflow_pytorch_amd import parallel
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     from upflow_pytorch_amd.train import Trainer, synthetic_train_batch
+    if os.environ.get('UPF_MIOPEN_BENCHMARK'):
+        torch.backends.cudnn.benchmark = True          # MIOpen exhaustive solver search for the fp32 convolutions
     conf = UPFlow_net.config()
     d = dict(FLAGS)
     d.update(TRAIN_FLAGS)
