@@ -77,7 +77,7 @@ class network_tools():
             c1 = slot.shape[1] // 2
             ops.warp_into(slot[:, :c1], flow_init, slot[:, c1:], self.warping_layer.mask_mode, batch_shift)
             _, x_out = self.dense_estimator_mask.forward_in_buffer(buf)
-            return ops.sgu_blend(flow_init, x_out, output_level_flow)
+            return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)   # (flow_init, flow_up, None, None)
 
         def output_conv(self, x, out=None):
             cache = self.__dict__.setdefault('_fast_cache', {})
