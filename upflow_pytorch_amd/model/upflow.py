@@ -340,7 +340,10 @@ class UPFlow_net(tools.abstract_model):
         cdt = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype      # compute dtype of the convs
         x1_raw = x1_raw.to(cdt)
         x2_raw = x2_raw.to(cdt)
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() or getattr(self, 'stacked_training', True):
+            # (training too: every operator on this path is per-item and differentiable — both directions as one
+            # batch halve the launch count and double every convolution's batch; `stacked_training = False` restores
+            # the reference's per-direction schedule below)
             return self._forward_stacked(x1_raw, x2_raw)
         x1_pyramid = self.feature_pyramid_extractor(x1_raw)
         x2_pyramid = self.feature_pyramid_extractor(x2_raw)
@@ -486,10 +489,7 @@ class UPFlow_net(tools.abstract_model):
             buf[:, est._n_total:] = flow_up + res
             fine = self.context_networks(buf).float()
             return res + fine
-        x = torch.empty((nb, self.num_ch_in, H, W), dtype=Fn.dtype, device=Fn.device)
-        ops.corr81_forward_raw(Fn.contiguous(), Fwn.contiguous(), out=x[:, :nc], leaky_slope=0.1)
-        x[:, nc:nc + 32] = A
-        x[:, nc + 32:] = flow_up
+        x = self._estimator_input(Fn, Fwn, A, flow_up)          # (autograd-aware: cat of differentiable pieces under grad)
         feat, res = est(x)
         res = res.float()
         fine = self.context_networks(torch.cat([feat, (flow_up + res).to(feat.dtype)], dim=1)).float()
