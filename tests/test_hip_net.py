@@ -20,14 +20,15 @@ FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': Fal
          'norm_moments_across_images': False, 'if_sgu_upsample': True}
 
 
-def build(mask_mode='literal', dtype=torch.float32):
+def build(mask_mode='literal', dtype=torch.float32, **extra):
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     conf = UPFlow_net.config()
     d = dict(FLAGS)
+    d.update(extra)
     d['warp_mask_mode'] = mask_mode
     conf.update(d, verbose=False)
     net = conf()
-    net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1), strict=not extra)   # (SGU off: its keys are unused)
     return net.cuda().to(dtype).eval()
 
 
@@ -163,3 +164,18 @@ def test_full_size_config2_properties():
     e = oracle.epe(a['flow_f_out'].cpu(), ref['flow_f_out'].cpu())
     print('384x1280 bf16 vs fp32 forward: EPE %.3g px (mean |flow| %.3g px)' % (e, mag))
     assert e <= 0.25 * max(mag, 1.0)
+
+
+def test_in_buffer_schedule_without_sgu_and_with_torch_pyramid():
+    """The same bit-equality for the other branches of the fast schedule: SGU off, and the feature pyramid kept in
+    PyTorch-ROCm (`hip_pyramid_convs=False`, the north star's literal split: its outputs are copied into the pair buffers)."""
+    im1, im2 = _weights.make_smooth_images(4, 1, 128, 512)
+    for extra in ({'if_sgu_upsample': False}, {'hip_pyramid_convs': False}):
+        net = build('robust', torch.bfloat16, **extra)
+        with torch.no_grad():
+            fast = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+            net._no_fast_stacked = True
+            slow = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        for k in ('flow_f_out', 'flow_b_out'):
+            assert torch.isfinite(fast[k]).all()
+            assert oracle.epe(fast[k].cpu(), slow[k].cpu()) <= (0.0 if extra.get('if_sgu_upsample') is False else 1e-2), (extra, k)
