@@ -47,15 +47,22 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     cc = hipcc()
+    jobs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [cc] + COMMON + extra + ['-c', s, '-o', o]
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append([cc] + COMMON + extra + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if jobs:                                           # independent translation units: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
