@@ -9,6 +9,8 @@ for f in sorted(glob.glob(sys.argv[1] + '/*_counter_collection.csv')):
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     kt = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(f.replace('counter_collection', 'kernel_trace'))) if 'conv_kernel' in r['Kernel_Name']]
     m = {k: sum(v[-3:]) / len(v[-3:]) for k, v in agg.items()}
+    if 'SQ_WAVE_CYCLES' not in m:
+        continue
     wc = m['SQ_WAVE_CYCLES']
     cyc = m['GRBM_GUI_ACTIVE'] / 8
     print(f.split('/')[-1], 'dur us', [round(v, 1) for v in kt[-3:]], 'clock %.2f GHz' % (cyc / kt[-1] / 1e3))
