@@ -322,3 +322,26 @@ def test_flow_upsample_backward_matches_autograd(shape, if_rate):
     assert relerr(gx.cpu(), gr.cpu()) <= 1e-5, float((gx - gr).abs().max())
     (gx2,) = torch.autograd.grad(ops.flow_upsample(x, H, W, if_rate), x, gy)
     assert torch.equal(gx, gx2), 'backward must be deterministic'
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """upf_warp_forward_strided / upf_flow_update / upf_conv_set_option fail loudly (RuntimeError) on misuse."""
+    from upflow_pytorch_amd import ops, _lib
+    x = torch.zeros(2, 4, 8, 16, dtype=torch.bfloat16, device='cuda')
+    flow = torch.zeros(2, 2, 8, 16, device='cuda')
+    with pytest.raises(RuntimeError):
+        ops.warp_into(x, flow, torch.zeros(2, 4, 8, 8, dtype=torch.bfloat16, device='cuda'))          # shape mismatch
+    with pytest.raises(RuntimeError):
+        ops.warp_into(x.permute(0, 1, 3, 2), flow, x.clone())                                          # not a channel slice
+    with pytest.raises(RuntimeError):
+        ops.warp_into(x, flow, x.float())                                                             # dtype mismatch
+    with pytest.raises(RuntimeError):                                                                 # y batch stride < C*H*W
+        _lib.call('upf_warp_forward_strided', _lib.ptr(x), 0, _lib.ptr(flow), _lib.ptr(x), 7, 2, 4, 8, 16, _lib.UPF_BF16, 1, 0,
+                  _lib.stream_ptr(x.device))
+    a = torch.zeros(2, 2, 8, 16, device='cuda')
+    with pytest.raises(RuntimeError):
+        ops.flow_update(a, None, a.bfloat16())                                                        # c without b
+    with pytest.raises(RuntimeError):
+        ops.flow_update(a, a.bfloat16(), out=torch.zeros(2, 2, 8, 16, dtype=torch.float16, device='cuda'))   # mixed 16-bit types
+    with pytest.raises(RuntimeError):
+        ops.conv_set_option('no_such_option', 1)

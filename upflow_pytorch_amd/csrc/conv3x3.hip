@@ -90,6 +90,34 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
   }
 }
 
+// ---- x staging helpers shared by both kernels -------------------------------------------------------------------------
+// 8 channel rows x 8 pixels (eight 16-byte loads of one 8-pixel group) -> 8 LDS entries of 8 channels x 1 pixel.
+// `enc` = (entry index of the group's first pixel) * 8 + slot rotation (see swz); GEN: `sh` = pixels the load window was
+// shifted left so that it ends at the row end — pixel q sits at column q - sh, columns >= 8 - sh are zero padding.
+template <bool GEN>
+__device__ __forceinline__ void stage_store(uint4* tile, int enc, int sh, const u32x4 (&ch)[8]) {
+  uint4* dst = tile + (enc >> 3);
+  const int rot = enc & 7;
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
+    uint4 e0, e1;
+    e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
+    e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
+    e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
+    e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
+    if constexpr (GEN) {
+      const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
+      e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
+      e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
+      dst[(2 * pp - sh + rot) & 7] = e0;
+      dst[(2 * pp + 1 - sh + rot) & 7] = e1;
+    } else {
+      dst[(2 * pp + rot) & 7] = e0;
+      dst[(2 * pp + 1 + rot) & 7] = e1;
+    }
+  }
+}
+
 // ---- epilogue: accumulators -> LeakyReLU -> 16-bit -> y.  D[co][pixel]: lane -> pixel column px, register e ->
 // output channel (e&3) + 8*(e>>2) + 4*kg of the 32-channel block.  Lane pairs (px, px^1) swap halves (one DPP move +
 // one v_perm): the even lane stores pixels (px, px+1) of the even registers' channels, the odd lane pixels (px-1, px) of
@@ -250,28 +278,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 #pragma unroll
     for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
   };
-  auto task_store = [&](int dsti, int sh, const u32x4 (&ch)[8]) {                 // 8 channel rows x 8 px -> 8 px x 8 channels
-    uint4* dst = xs + (dsti >> 3);
-    const int rot = dsti & 7;
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
-      uint4 e0, e1;
-      e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
-      e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
-      e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
-      e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
-      if constexpr (GEN) {                           // loaded pixel q is column q - sh of the group; columns >= 8 - sh are past the row end
-        const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
-        e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
-        e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
-        dst[(2 * pp - sh + rot) & 7] = e0;
-        dst[(2 * pp + 1 - sh + rot) & 7] = e1;
-      } else {
-        dst[(2 * pp + rot) & 7] = e0;
-        dst[(2 * pp + 1 + rot) & 7] = e1;
-      }
-    }
-  };
+  auto task_store = [&](int enc, int sh, const u32x4 (&ch)[8]) { stage_store<GEN>(xs, enc, sh, ch); };
   // this thread's first x task of chunk cc+1 is loaded into registers BEFORE the matrix phase of chunk cc and
   // lands in LDS after it
   constexpr bool PRE = !(MTW == 1 && RPW == 4 && NOCTS == 4);     // (that one would spill)
@@ -448,28 +455,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
   };
-  auto task_store = [&](int dsti, int sh, const u32x4 (&ch)[8]) {
-    uint4* dst = xs + (dsti >> 3);
-    const int rot = dsti & 7;
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
-      uint4 e0, e1;
-      e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
-      e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
-      e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
-      e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
-      if constexpr (GEN) {
-        const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
-        e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
-        e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
-        dst[(2 * pp - sh + rot) & 7] = e0;
-        dst[(2 * pp + 1 - sh + rot) & 7] = e1;
-      } else {
-        dst[(2 * pp + rot) & 7] = e0;
-        dst[(2 * pp + 1 + rot) & 7] = e1;
-      }
-    }
-  };
+  auto task_store = [&](int enc, int sh, const u32x4 (&ch)[8]) { stage_store<GEN>(xs, enc, sh, ch); };
 
   // geometry of this lane's staging tasks (the same for every chunk) and the prefetch registers of the first NPF
   uint32_t toff[NT]; int tdst[NT], tsh[NT];
