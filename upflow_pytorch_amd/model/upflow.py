@@ -338,13 +338,17 @@ class UPFlow_net(tools.abstract_model):
     def forward_2_frame_v3(self, x1_raw, x2_raw, if_loss=False):
         """Coarse-to-fine bidirectional decode, model/upflow.py:494-533."""
         cdt = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype      # compute dtype of the convs
-        x1_raw = x1_raw.to(cdt)
-        x2_raw = x2_raw.to(cdt)
         if not torch.is_grad_enabled() or getattr(self, 'stacked_training', True):
             # (training too: every operator on this path is per-item and differentiable — both directions as one
             # batch halve the launch count and double every convolution's batch; `stacked_training = False` restores
             # the reference's per-direction schedule below)
-            return self._forward_stacked(x1_raw, x2_raw)
+            B = x1_raw.shape[0]
+            X = torch.empty((2 * B,) + tuple(x1_raw.shape[1:]), dtype=cdt, device=x1_raw.device)
+            X[:B].copy_(x1_raw)                         # cast + stack in one pass per frame (was: two casts, then a cat)
+            X[B:].copy_(x2_raw)
+            return self._forward_stacked(X, B)
+        x1_raw = x1_raw.to(cdt)
+        x2_raw = x2_raw.to(cdt)
         x1_pyramid = self.feature_pyramid_extractor(x1_raw)
         x2_pyramid = self.feature_pyramid_extractor(x2_raw)
         B, _, h0, w0 = x1_pyramid[0].shape
@@ -368,15 +372,14 @@ class UPFlow_net(tools.abstract_model):
             flow_b_out = self.self_guided_upsample(flow_up_bilinear=flow_b, feature_1=g2, feature_2=g1, output_level_flow=flow_b_out)
         return flow_f_out, flow_b_out, flows[::-1]
 
-    def _forward_stacked(self, x1_raw, x2_raw):
+    def _forward_stacked(self, X, B):
         """Inference form of forward_2_frame_v3 (model/upflow.py:494-533), same arithmetic, different schedule:
         the two frames are stacked along the batch, X = [im1; im2], so item n < B carries the forward direction
         and item n >= B the backward one.  Every stage then runs ONCE on 2B items with shared weights — feature
         pyramid, 1x1 convs, SGU, warp (batch_shift = B samples "the other frame" without a gather copy),
         normalisation, cost volume, estimator, context network — halving the launch count and doubling every
         grid, which is what the coarse levels need on a 256-CU chip."""
-        B = x1_raw.shape[0]
-        X = torch.cat([x1_raw, x2_raw], dim=0)
+
         if (_fast_conv_ok(X) and self.conf.if_norm_before_cost_volume and not self.conf.norm_moments_across_channels
                 and not self.conf.norm_moments_across_images and not getattr(self, '_no_fast_stacked', False)
                 and self.feature_pyramid_extractor.out_shapes(X.shape[2], X.shape[3])[-1][2] >= 8):   # every level takes the conv kernel
