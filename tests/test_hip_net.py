@@ -179,3 +179,26 @@ def test_in_buffer_schedule_without_sgu_and_with_torch_pyramid():
         for k in ('flow_f_out', 'flow_b_out'):
             assert torch.isfinite(fast[k]).all()
             assert oracle.epe(fast[k].cpu(), slow[k].cpu()) <= (0.0 if extra.get('if_sgu_upsample') is False else 1e-2), (extra, k)
+
+
+def test_native_kitti_size_ragged_levels():
+    """375x1242 (KITTI's native frame, not a multiple of 64): every pyramid level is ragged (W = 311, 156, 78, 39, 20; odd
+    heights), so the convolutions take the unaligned-row variants, the cost volume the element-wise staging path, and the
+    warps the odd-width path.  The in-buffer schedule must agree with the generic one (not bit for bit here: normalising
+    the [features; warped] pair as ONE tensor changes how the row reductions are split over workgroups, i.e. the fp32
+    summation order of the statistics), and stay inside the bf16 envelope of the fp32 forward."""
+    im1, im2 = _weights.make_smooth_images(9, 2, 375, 1242)
+    im1, im2 = im1.cuda(), im2.cuda()
+    net = build('robust', torch.bfloat16)
+    with torch.no_grad():
+        fast = net({'im1': im1, 'im2': im2, 'if_loss': False})
+        net._no_fast_stacked = True
+        slow = net({'im1': im1, 'im2': im2, 'if_loss': False})
+        ref = build('robust', torch.float32)({'im1': im1, 'im2': im2, 'if_loss': False})
+    for k in ('flow_f_out', 'flow_b_out'):
+        assert fast[k].shape == (2, 2, 375, 1242) and torch.isfinite(fast[k]).all()
+        assert oracle.epe(fast[k].cpu(), slow[k].cpu()) <= 2e-3, (k, float((fast[k] - slow[k]).abs().max()))
+    mag = float(ref['flow_f_out'].pow(2).sum(1).sqrt().mean())
+    e = oracle.epe(fast['flow_f_out'].cpu(), ref['flow_f_out'].cpu())
+    print('375x1242 bf16 vs fp32 forward: EPE %.3g px (mean |flow| %.3g px)' % (e, mag))
+    assert e <= 0.25 * max(mag, 1.0)
