@@ -35,6 +35,7 @@ WORKLOADS = {
     'config2': (4, 384, 1280, 'bf16'),
     'config4': (8, 448, 1024, 'fp16'),
     'config5': (1, 960, 2880, 'bf16'),
+    'kitti_native': (4, 375, 1242, 'bf16'),      # not a BASELINE config: un-padded KITTI frames, every pyramid level ragged
 }
 DT = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
 FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
