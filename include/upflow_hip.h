@@ -22,7 +22,10 @@
  *   - return value: 0 (UPF_OK) on success, a negative UPF_E* code on a rejected argument, a
  *     positive hipError_t if the launch failed; upf_last_error() gives the message of the last
  *     failure on the calling thread (the reference printf()s and returns 0,
- *     correlation_cuda_kernel.cu:383-392, which its .cc turns into AT_ERROR, :81-83).
+ *     correlation_cuda_kernel.cu:383-392, which its .cc turns into AT_ERROR, :81-83);
+ *   - threading: like the reference's FFI (called with the GIL held, one process per GPU) the library expects
+ *     one calling thread per device at a time; its only process-wide state is launch bookkeeping (kernel
+ *     attributes set on first use, the heuristics of upf_conv_set_option) — no allocations, no caches of data.
  */
 #ifndef UPFLOW_HIP_H
 #define UPFLOW_HIP_H
