@@ -185,6 +185,16 @@ int upf_flow_update(const float* a, const void* b, const void* c, void* out, lon
 int upf_occ_check(const float* flow_f, const float* flow_b, float* occ_fw, float* occ_bw,
                   int B, int H, int W, float alpha1, float alpha2, void* stream);
 
+/* ---- soft census distance of the photometric loss  (utils/loss.py:50-91) ----
+ * gray1, gray2 : [B,1,H,W] fp32 grey images (0.2989 r + 0.5870 g + 0.1140 b);  dist : [B,1,H,W] fp32,
+ *   dist(p) = sum_k d_k/(0.1+d_k),  d_k = (t_k(gray1,p) - t_k(gray2,p))^2,  t_k(I,p) = u/sqrt(0.81+u^2),  u = I(p+k) - I(p),
+ * k over the (2*max_distance+1)^2 offsets, images zero padded — the reference's 49-channel identity conv2d + ~10
+ * element-wise passes in one launch.  Backward: gradients wrt either grey image (a NULL output is skipped), gather
+ * formulation, deterministic. */
+int upf_census_forward(const float* gray1, const float* gray2, float* dist, int B, int H, int W, int max_distance, void* stream);
+int upf_census_backward(const float* gray1, const float* gray2, const float* grad_dist, float* g_gray1, float* g_gray2,
+                        int B, int H, int W, int max_distance, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

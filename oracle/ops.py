@@ -287,3 +287,21 @@ def occ_check(flow_f, flow_b, alpha1=0.1, alpha2=0.5):
 def epe(a, b):
     """Mean end-point error, dataset/kitti_dataset.py:464-475 with mask == 1."""
     return float((a.double() - b.double()).pow(2).sum(1).sqrt().mean())
+
+
+def census_distance(img1, img2, max_distance=3):
+    """Soft census (ternary) distance of two RGB images, the reference's spelling
+    (/root/reference/utils/loss.py:52-67): 49-channel identity conv2d, t = d/sqrt(0.81+d^2), sum d2/(0.1+d2).
+    -> [B,1,H,W].  (Differentiable torch ops: tests also take its autograd gradient as the oracle.)"""
+    import torch.nn.functional as F
+    patch = 2 * max_distance + 1
+    n = patch * patch
+
+    def ternary(image):
+        r, g, b = torch.split(image, 1, 1)
+        gray = 0.2989 * r + 0.5870 * g + 0.1140 * b
+        weight = torch.eye(n, dtype=gray.dtype, device=gray.device).view(n, 1, patch, patch)
+        t = F.conv2d(gray, weight, bias=None, stride=[1, 1], padding=[max_distance, max_distance]) - gray
+        return t / torch.sqrt(0.81 + t ** 2)
+    d = (ternary(img1) - ternary(img2)) ** 2
+    return torch.sum(d / (0.1 + d), 1, keepdim=True)

@@ -404,10 +404,34 @@ def golden_train(upflow, pwc, tools):
         mu.upsample2d_flow_as = old_up
 
 
+def golden_census():
+    """utils/loss.py:50-91 (loss_functions.census_loss_torch): the soft census distance is only reachable through the
+    reduced loss, so the fixture holds the reference's scalar for several masks / reductions plus its gradient wrt
+    the warped image."""
+    from utils.loss import loss_functions
+    for i, (B, H, W) in enumerate([(2, 24, 40), (1, 13, 17)]):
+        g = gen(7000 + i)
+        im1 = torch.rand(B, 3, H, W, generator=g) - 0.45
+        im2 = im1 + 0.1 * torch.randn(B, 3, H, W, generator=g)
+        masks = (torch.rand(3, B, 1, H, W, generator=g) > 0.3).float()
+        d = {'img1': im1, 'img1_warp': im2, 'masks': masks}
+        for k in range(3):
+            w = im2.clone().requires_grad_(True)
+            v = loss_functions.census_loss_torch(img1=im1, img1_warp=w, mask=masks[k], q=0.4, charbonnier_or_abs_robust=False,
+                                                 if_use_occ=True, averge=True)
+            (gw,) = torch.autograd.grad(v, w)
+            d['loss_occ_%d' % k] = np.array([float(v)])
+            d['grad_occ_%d' % k] = gw
+        v = loss_functions.census_loss_torch(img1=im1, img1_warp=im2, mask=masks[0], q=0.4, charbonnier_or_abs_robust=False,
+                                             if_use_occ=False, averge=True)
+        d['loss_mean'] = np.array([float(v)])
+        save('census_%d' % i, **d)
+
+
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'net', 'train']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'net', 'train']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -420,6 +444,8 @@ def main():
         golden_sgu_blend(upflow, tools)
     if 'occ' in which:
         golden_occ(tools)
+    if 'census' in which:
+        golden_census()
     if 'net' in which:
         golden_net(upflow, pwc, tools)
     if 'train' in which:

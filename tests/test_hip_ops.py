@@ -345,3 +345,49 @@ def test_new_entry_points_reject_bad_arguments():
         ops.flow_update(a, a.bfloat16(), out=torch.zeros(2, 2, 8, 16, dtype=torch.float16, device='cuda'))   # mixed 16-bit types
     with pytest.raises(RuntimeError):
         ops.conv_set_option('no_such_option', 1)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 24, 40), (1, 3, 7, 9), (1, 3, 64, 208)])
+def test_census_distance_matches_reference_spelling(shape):
+    """upf_census_forward / _backward vs the reference's 49-channel conv2d formulation (oracle.census_distance,
+    utils/loss.py:52-67) and its autograd gradient."""
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    im1 = torch.rand(shape, generator=g) - 0.45
+    im2 = (im1 + 0.1 * torch.randn(shape, generator=g)).requires_grad_(True)
+    want = oracle.census_distance(im1, im2)
+    gout = torch.randn(want.shape, generator=g)
+    (gwant,) = torch.autograd.grad(want, im2, gout)
+
+    def grey(t):
+        r, gg, b = torch.split(t, 1, 1)
+        return 0.2989 * r + 0.5870 * gg + 0.1140 * b
+    a = im1.cuda()
+    b = im2.detach().cuda().requires_grad_(True)
+    got = ops.census_distance(grey(a), grey(b))
+    (ggot,) = torch.autograd.grad(got, b, gout.cuda())
+    assert relerr(got.detach().cpu(), want.detach()) <= 2e-6
+    assert relerr(ggot.cpu(), gwant) <= 2e-5, float((ggot.cpu() - gwant).abs().max())
+    (ggot2,) = torch.autograd.grad(ops.census_distance(grey(a), grey(b)), b, gout.cuda())
+    assert torch.equal(ggot, ggot2)
+    with pytest.raises(RuntimeError):
+        ops.census_distance(grey(im1), grey(im1))          # CPU tensors are rejected
+
+
+@pytest.mark.parametrize('i', [0, 1])
+def test_census_loss_golden(i):
+    """The package's census loss (fused HIP distance + the reference's reduction) against the reference's own scalars and
+    gradients wrt the warped image (tests/golden/census_*.npz, generated by importing utils/loss.py)."""
+    from upflow_pytorch_amd.utils.loss import loss_functions
+    g = load_golden('census_%d' % i)
+    im1 = dev(g['img1'])
+    for k in range(3):
+        w = dev(g['img1_warp']).requires_grad_(True)
+        v = loss_functions.census_loss_torch(img1=im1, img1_warp=w, mask=dev(g['masks'][k]), q=0.4, charbonnier_or_abs_robust=False,
+                                             if_use_occ=True, averge=True)
+        (gw,) = torch.autograd.grad(v, w)
+        assert abs(float(v) - float(g['loss_occ_%d' % k])) <= 2e-6 * max(1.0, abs(float(v)))
+        assert (gw.cpu() - g['grad_occ_%d' % k]).abs().max() <= 2e-6
+    v = loss_functions.census_loss_torch(img1=im1, img1_warp=dev(g['img1_warp']), mask=dev(g['masks'][0]), q=0.4,
+                                         charbonnier_or_abs_robust=False, if_use_occ=False, averge=True)
+    assert abs(float(v) - float(g['loss_mean'])) <= 2e-6

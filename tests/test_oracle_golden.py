@@ -103,3 +103,30 @@ def test_occ_check(i):
     # thresholded floats: allow a handful of borderline pixels
     assert (o1 != g['occ_fw']).float().mean() <= 1e-4
     assert (o2 != g['occ_bw']).float().mean() <= 1e-4
+
+
+def _census_loss(dist, mask, q=0.4, use_occ=True, max_distance=3):
+    """The reduction the reference applies to the census distance (utils/loss.py:36-48, :82-90), restated."""
+    B, _, H, W = mask.shape
+    valid = torch.zeros_like(mask)
+    valid[:, :, max_distance:H - max_distance, max_distance:W - max_distance] = 1.0
+    d = (dist.abs() + 0.01).pow(q)
+    if use_occ:
+        m = mask * valid
+        return (d * m).sum() / (m.sum() * 2 + 1e-6)
+    return d.mean()
+
+
+@pytest.mark.parametrize('i', [0, 1])
+def test_census_distance(i):
+    """oracle.census_distance against the reference's census_loss_torch scalars and gradients (utils/loss.py:50-91)."""
+    g = load_golden('census_%d' % i)
+    im1 = g['img1']
+    for k in range(3):
+        w = g['img1_warp'].clone().requires_grad_(True)
+        v = _census_loss(ops.census_distance(im1, w), g['masks'][k])
+        (gw,) = torch.autograd.grad(v, w)
+        assert abs(float(v) - float(g['loss_occ_%d' % k])) <= 1e-6 * max(1.0, abs(float(v)))
+        assert (gw - g['grad_occ_%d' % k]).abs().max() <= 1e-6
+    v = _census_loss(ops.census_distance(im1, g['img1_warp']), g['masks'][0], use_occ=False)
+    assert abs(float(v) - float(g['loss_mean'])) <= 1e-6

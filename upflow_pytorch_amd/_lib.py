@@ -38,6 +38,8 @@ SIGNATURES = {
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_conv_pack_weights': [_vp, _vp, _i, _i, _i, _i, _vp],
     'upf_conv_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    'upf_census_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'upf_census_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_occ_check': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
 }
 

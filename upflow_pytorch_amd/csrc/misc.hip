@@ -177,6 +177,95 @@ void occ_check_kernel(const float* __restrict__ ff, const float* __restrict__ fb
   occ_bw[(size_t)n * HW + p] = (cb || !inb_) ? 1.f : 0.f;
 }
 
+
+// ---- soft census (ternary) distance  (utils/loss.py:50-91) -------------------------------------
+// The reference builds the 7x7 neighbourhoods with a 49-channel identity conv2d, i.e. two [B,49,H,W] tensors per call
+// and ~10 element-wise passes over them (and their autograd twins).  Here the whole per-pixel distance is one launch:
+//     t_k(I, p) = u / sqrt(0.81 + u^2),  u = I(p+k) - I(p)   (I = grey image, zero padded, k over the (2R+1)^2 offsets)
+//     dist(p)   = sum_k d_k / (0.1 + d_k),  d_k = (t_k(I1,p) - t_k(I2,p))^2
+// and the backward is a GATHER (deterministic, no atomics): I(q) appears in dist(q) as the centre of all its terms and
+// in dist(q-k) as the neighbour of offset k, so  dI(q) = sum_k [ G(q-k) c_k(q-k) ] - G(q) sum_k c_k(q)  with
+// c_k(p) = d dist(p) / d u_k, every factor recomputed from the two grey images.
+__device__ __forceinline__ float census_t(float u) { return u / sqrtf(0.81f + u * u); }
+
+__global__ __launch_bounds__(256)
+void census_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ dist, int H, int W, int R) {
+  const int HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int n = blockIdx.y;
+  const int i = p / W, j = p - i * W;
+  const float* a = g1 + (size_t)n * HW;
+  const float* b = g2 + (size_t)n * HW;
+  const float ca = a[p], cb = b[p];
+  float acc = 0.f;
+  for (int dy = -R; dy <= R; ++dy) {
+    const int y = i + dy;
+    const bool iny = y >= 0 && y < H;
+    for (int dx = -R; dx <= R; ++dx) {
+      const int x = j + dx;
+      const bool in = iny && x >= 0 && x < W;
+      const float va = in ? a[y * W + x] : 0.f, vb = in ? b[y * W + x] : 0.f;
+      const float t = census_t(va - ca) - census_t(vb - cb);
+      const float d = t * t;
+      acc += d / (0.1f + d);
+    }
+  }
+  dist[(size_t)n * HW + p] = acc;
+}
+
+// c(p, u1, u2, sign): d dist / d u of image `which` for one term; dt/du = 0.81 / (0.81 + u^2)^(3/2)
+__device__ __forceinline__ float census_c(float u1, float u2, bool wrt2) {
+  const float t1 = census_t(u1), t2 = census_t(u2);
+  const float df = t1 - t2, d = df * df;
+  const float dh = 0.1f / ((0.1f + d) * (0.1f + d));            // d/dd of d/(0.1+d)
+  const float u = wrt2 ? u2 : u1;
+  const float s = 0.81f + u * u;
+  const float dt = 0.81f / (s * sqrtf(s));
+  return dh * 2.f * df * (wrt2 ? -dt : dt);
+}
+
+// grad wrt g1 (gg1, may be null) and g2 (gg2, may be null); G = grad of dist [B,1,H,W]
+__global__ __launch_bounds__(256)
+void census_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ G,
+                       float* __restrict__ gg1, float* __restrict__ gg2, int H, int W, int R) {
+  const int HW = H * W;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= HW) return;
+  const int n = blockIdx.y;
+  const int i = q / W, j = q - i * W;
+  const float* a = g1 + (size_t)n * HW;
+  const float* b = g2 + (size_t)n * HW;
+  const float* Gn = G + (size_t)n * HW;
+  const float aq = a[q], bq = b[q], Gq = Gn[q];
+  float s1 = 0.f, s2 = 0.f;
+  for (int dy = -R; dy <= R; ++dy)
+    for (int dx = -R; dx <= R; ++dx) {
+      // (1) q as the CENTRE of its own term k = (dy,dx): neighbour value at q+k (zero outside), du/dI(q) = -1
+      {
+        const int y = i + dy, x = j + dx;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const float va = in ? a[y * W + x] : 0.f, vb = in ? b[y * W + x] : 0.f;
+        const float u1 = va - aq, u2 = vb - bq;
+        s1 -= Gq * census_c(u1, u2, false);
+        s2 -= Gq * census_c(u1, u2, true);
+      }
+      // (2) q as the NEIGHBOUR of offset k of the centre p = q - k (if p is inside the image), du/dI(q) = +1
+      {
+        const int y = i - dy, x = j - dx;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+          const int pp = y * W + x;
+          const float u1 = aq - a[pp], u2 = bq - b[pp];
+          const float Gp = Gn[pp];
+          s1 += Gp * census_c(u1, u2, false);
+          s2 += Gp * census_c(u1, u2, true);
+        }
+      }
+    }
+  if (gg1) gg1[(size_t)n * HW + q] = s1;
+  if (gg2) gg2[(size_t)n * HW + q] = s2;
+}
+
 }  // namespace misc
 }  // namespace upf
 
@@ -231,4 +320,23 @@ extern "C" int upf_occ_check(const float* flow_f, const float* flow_b, float* oc
   dim3 grid(cdiv(H * W, 256), B);
   hipLaunchKernelGGL(misc::occ_check_kernel, grid, dim3(256), 0, (hipStream_t)stream, flow_f, flow_b, occ_fw, occ_bw, H, W, alpha1, alpha2);
   return check_launch("occ_check");
+}
+
+extern "C" int upf_census_forward(const float* gray1, const float* gray2, float* dist, int B, int H, int W, int max_distance, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(gray1 && gray2 && dist, UPF_EINVAL, "census_forward: null pointer");
+  UPF_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && max_distance >= 1 && max_distance <= 8, UPF_EINVAL, "census_forward: bad shape / max_distance");
+  dim3 grid(cdiv(H * W, 256), B);
+  hipLaunchKernelGGL(misc::census_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gray1, gray2, dist, H, W, max_distance);
+  return check_launch("census_forward");
+}
+
+extern "C" int upf_census_backward(const float* gray1, const float* gray2, const float* grad_dist, float* g_gray1, float* g_gray2,
+                                   int B, int H, int W, int max_distance, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(gray1 && gray2 && grad_dist && (g_gray1 || g_gray2), UPF_EINVAL, "census_backward: null pointer");
+  UPF_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && max_distance >= 1 && max_distance <= 8, UPF_EINVAL, "census_backward: bad shape / max_distance");
+  dim3 grid(cdiv(H * W, 256), B);
+  hipLaunchKernelGGL(misc::census_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gray1, gray2, grad_dist, g_gray1, g_gray2, H, W, max_distance);
+  return check_launch("census_backward");
 }

@@ -407,3 +407,43 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
                   _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
                   float(leaky_slope), _lib.dtype_code(x_view), _lib.stream_ptr(dev))
     return y_view
+
+
+# ------------------------------------------------------------------------------------------------
+# soft census distance (photometric loss, utils/loss.py:50-91)
+# ------------------------------------------------------------------------------------------------
+class CensusFunction(Function):
+    @staticmethod
+    def forward(ctx, gray1, gray2, max_distance):
+        gray1 = _f32(gray1).contiguous()
+        gray2 = _f32(gray2).contiguous()
+        if gray1.dim() != 4 or gray1.shape[1] != 1 or gray1.shape != gray2.shape:
+            raise UpflowHipError('census: two [B,1,H,W] grey images expected, got %s / %s' % (tuple(gray1.shape), tuple(gray2.shape)))
+        B, _, H, W = gray1.shape
+        dev = _lib.check_gpu(gray1, gray2)
+        dist = torch.empty_like(gray1)
+        with torch.cuda.device(dev):
+            _lib.call('upf_census_forward', _lib.ptr(gray1), _lib.ptr(gray2), _lib.ptr(dist), B, H, W, int(max_distance), _lib.stream_ptr(dev))
+        ctx.save_for_backward(gray1, gray2)
+        ctx.max_distance = int(max_distance)
+        return dist
+
+    @staticmethod
+    def backward(ctx, g):
+        gray1, gray2 = ctx.saved_tensors
+        B, _, H, W = gray1.shape
+        g = _f32(g).contiguous()
+        dev = _lib.check_gpu(gray1, gray2, g)
+        g1 = torch.empty_like(gray1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(gray2) if ctx.needs_input_grad[1] else None
+        if g1 is None and g2 is None:
+            return None, None, None
+        with torch.cuda.device(dev):
+            _lib.call('upf_census_backward', _lib.ptr(gray1), _lib.ptr(gray2), _lib.ptr(g), _lib.ptr(g1), _lib.ptr(g2), B, H, W,
+                      ctx.max_distance, _lib.stream_ptr(dev))
+        return g1, g2, None
+
+
+def census_distance(gray1, gray2, max_distance=3):
+    """Soft census (ternary) distance [B,1,H,W] of two grey images, one launch (csrc/misc.hip)."""
+    return CensusFunction.apply(gray1, gray2, max_distance)

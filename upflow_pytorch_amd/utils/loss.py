@@ -23,21 +23,16 @@ class loss_functions():
     @classmethod
     def census_loss_torch(cls, img1, img1_warp, mask, q, charbonnier_or_abs_robust, if_use_occ, averge=True, max_distance=3):
         """Soft census (ternary) transform distance, utils/loss.py:50-91."""
-        patch = 2 * max_distance + 1
-        n = patch * patch
+        # ONE fused HIP launch (csrc/misc.hip: upf_census_forward / _backward) instead of the reference's two 49-channel
+        # identity convolutions and ~10 element-wise passes over [B,49,H,W] tensors (utils/loss.py:52-67); same fp32
+        # arithmetic, deterministic gather backward.  GPU only, like every operator of this package (oracle/ops.py keeps
+        # the reference's spelling as the test oracle).
+        from .. import ops
 
-        def ternary(image):
-            r, g, b = torch.split(image, 1, 1)
-            gray = 0.2989 * r + 0.5870 * g + 0.1140 * b
-            weight = torch.eye(n, dtype=gray.dtype, device=gray.device).view(n, 1, patch, patch)
-            t = torch.conv2d(gray, weight, bias=None, stride=[1, 1], padding=[max_distance, max_distance]) - gray
-            return t / torch.sqrt(0.81 + t ** 2)
-
-        def hamming(t1, t2):
-            d = (t1 - t2) ** 2
-            return torch.sum(d / (0.1 + d), 1, keepdim=True)
-
-        dist = hamming(ternary(img1), ternary(img1_warp))
+        def grey(image):
+            r, g, b = torch.split(image.float(), 1, 1)
+            return 0.2989 * r + 0.5870 * g + 0.1140 * b
+        dist = ops.census_distance(grey(img1), grey(img1_warp), max_distance).to(img1.dtype)
         inner = torch.ones(mask.shape[0], mask.shape[1], mask.shape[2] - 2 * max_distance, mask.shape[3] - 2 * max_distance,
                            dtype=mask.dtype, device=mask.device)
         valid = F.pad(inner, [max_distance] * 4)
