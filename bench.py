@@ -2,8 +2,9 @@
 """bench.py — frame-pairs/sec of the UPFlow inference hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W)
+      N>1 without a launcher: bench.py re-executes itself under torch.distributed.run (one rank per GPU, RCCL);
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          (the driver's form: RANK/LOCAL_RANK/WORLD_SIZE from the env)
 
 A "step" is one UPFlow_net inference forward (both flow directions + occlusion masks, SGU on, flags
 of the reference's test.py:22-30) over one batch of synthetic frame pairs, inputs already resident in
@@ -26,7 +27,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import torch  # noqa: E402
 
@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def build_net(dtype, device, hip_pyramid_convs=True):
-    import _weights
+    from upflow_pytorch_amd import synthetic as _weights
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     conf = UPFlow_net.config()
     conf.update(dict(FLAGS, hip_pyramid_convs=hip_pyramid_convs), verbose=False)
@@ -55,7 +55,14 @@ def build_net(dtype, device, hip_pyramid_convs=True):
 
 
 def roofline_probe(B, H, W, dtype, device):
-    """Dominant kernel: corr81 forward at the 1/4-resolution level (C=32) of this workload."""
+    """Dominant hand-written kernel: corr81 forward at the 1/4-resolution level (C=32) of this workload.
+
+    `achieved` / `frac` = algorithmic bytes s*B*H*W*(2C+81) / the average duration of 200 BACK-TO-BACK launches, each
+    bracketed by its own pair of HIP events recorded on the launch stream (hipExtLaunchKernel start/stop events) — the
+    inputs of a back-to-back launch are resident in the 256 MB infinity cache, as they are in the pipeline where the
+    normalisation kernel has just written them.  `frac_cold` is the same launch after a 512 MB fill has evicted L2 and the
+    infinity cache (every byte from HBM).  rocprofv3 --kernel-trace of this very command reports the same launches
+    (profiles/r02_*: its per-kernel average sits ~1 us above the event figure, both are committed)."""
     from upflow_pytorch_amd import ops
     C, h, w = 32, (H + 3) // 4, (W + 3) // 4
     g = torch.Generator(device='cpu').manual_seed(2004)
@@ -64,22 +71,36 @@ def roofline_probe(B, H, W, dtype, device):
     out = torch.empty(B, 81, h, w, device=device, dtype=dtype)
     ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=20)                      # warm
     avg_us, min_us = ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=200)
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
+    cold = []
+    for _ in range(30):
+        flush.fill_(1)
+        cold.append(ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=1)[0])
+    del flush
+    cold_us = sum(cold) / len(cold)
     s = f1.element_size()
     alg_bytes = s * B * h * w * (2 * C + 81)
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
     # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) cannot be
     # collected from inside this process; it is the committed rocprofv3 measurement of the same launch
-    # (profiles/r01_corr81_l4_cfg2_bf16_pmc.json, separate --pmc passes) when shape and dtype match.
+    # (profiles/*_pmc.json, separate --pmc passes) when shape and dtype match.
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_corr81_l4_cfg2_bf16_pmc.json')))['summary']
-        if pmc['shape'] == [B, C, h, w] and pmc['dtype'] == {torch.bfloat16: 'bf16', torch.float16: 'fp16'}.get(dtype, 'fp32'):
-            traffic = int(pmc['traffic_bytes'])
-    except Exception:
-        pass
-    return {'bound': 'hbm', 'kernel': 'corr81_mfma_kernel' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w], 'achieved': round(achieved, 1),
-            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-            'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2)}
+    dn = {torch.bfloat16: 'bf16', torch.float16: 'fp16'}.get(dtype, 'fp32')
+    for name in sorted(os.listdir(os.path.join(ROOT, 'profiles')), reverse=True):
+        if not (name.endswith('_pmc.json') and 'corr81' in name):
+            continue
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))['summary']
+            if pmc['shape'] == [B, C, h, w] and pmc['dtype'] == dn:
+                traffic = int(pmc['traffic_bytes'])
+                break
+        except Exception:
+            pass
+    return {'bound': 'hbm', 'kernel': 'corr81_mfma_kernel' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w],
+            'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2),
+            'timing': 'HIP events around each of 200 back-to-back launches (inputs resident in the infinity cache)',
+            'cold_kernel_us': round(cold_us, 2), 'frac_cold': round(alg_bytes / (cold_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def conv_roofline_probe(B, H, W, dtype, device):
@@ -114,23 +135,65 @@ def conv_roofline_probe(B, H, W, dtype, device):
             'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
 
 
-def cpu_baseline(H, W):
-    """The reference's CPU fallback (pure-PyTorch unfold correlation inside the full forward), as
-    restated in oracle/, on this box's host cores.  Bounded sample: ONE 384x1280 frame pair."""
-    import _weights
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_baseline():
+    """The reference's CPU fallback (pure-PyTorch unfold correlation inside the full fp32 forward), as restated in
+    oracle/ (kind "port"), on this box's host cores — BASELINE.md §3: full UPFlow_net forward at 384x1280 B=1 (the
+    metric's shape; `value`) and 256x256 B=1 (config 1), median of 5 timed runs after 2 warm-ups, the share of the time
+    spent inside the 10 fallback-correlation calls, and the correlation alone at the five pyramid-level shapes."""
+    from upflow_pytorch_amd import synthetic as _weights
     from oracle import net as onet
+    from oracle import ops as oops
     sd = _weights.make_state_dict(0, head_scale=0.1)
-    im1, im2 = _weights.make_images(2, 1, H, W)
-    with torch.no_grad():
-        a, b = _weights.make_images(2, 1, 64, 128)
-        onet.forward(sd, a, b, corr='unfold')                                # warm the thread pool
-        t0 = time.time()
-        onet.forward(sd, im1, im2, mask_mode='literal', corr='unfold')
-        dt = time.time() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'frame-pairs/s', 'cores': torch.get_num_threads(),
+    spent = [0.0]
+    inner = onet._corr
+
+    def timed_corr(a, b, corr):
+        t = time.perf_counter()
+        r = inner(a, b, corr)
+        spent[0] += time.perf_counter() - t
+        return r
+    res = {}
+    onet._corr = timed_corr
+    try:
+        with torch.no_grad():
+            for name, (H, W, cid) in (('256x256', (256, 256, 1)), ('384x1280', (384, 1280, 2))):
+                im1, im2 = _weights.make_images(cid, 1, H, W)
+                times, shares = [], []
+                for it in range(7):
+                    spent[0] = 0.0
+                    t0 = time.perf_counter()
+                    onet.forward(sd, im1, im2, mask_mode='literal', corr='unfold')
+                    dt = time.perf_counter() - t0
+                    if it >= 2:
+                        times.append(dt)
+                        shares.append(spent[0] / dt)
+                res[name] = {'s_per_pair': round(_median(times), 4), 'frame_pairs_per_s': round(1.0 / _median(times), 5),
+                             'correlation_share': round(_median(shares), 3)}
+            levels = {}
+            for C, h, w in ((196, 6, 20), (128, 12, 40), (96, 24, 80), (64, 48, 160), (32, 96, 320)):
+                g = torch.Generator().manual_seed(2000 + C)
+                a, b = torch.randn(1, C, h, w, generator=g), torch.randn(1, C, h, w, generator=g)
+                ts = []
+                for it in range(7):
+                    t0 = time.perf_counter()
+                    oops.corr81_unfold(a, b)
+                    if it >= 2:
+                        ts.append(time.perf_counter() - t0)
+                levels['%dx%dx%d' % (C, h, w)] = round(_median(ts) * 1e3, 3)
+    finally:
+        onet._corr = inner
+    main_ = res['384x1280']
+    return {'value': main_['frame_pairs_per_s'], 'unit': 'frame-pairs/s', 'cores': torch.get_num_threads(),
             'host_cpus': os.cpu_count(), 'kind': 'port',
-            'sample': '1 frame pair %dx%d fp32, full UPFlow_net forward with the unfold-based fallback correlation '
-                      '(utils/pytorch_correlation.py:27-50 restated in oracle/), %.1f s' % (H, W, dt)}
+            'sample': 'full UPFlow_net fp32 forward of ONE 384x1280 frame pair with the unfold-based fallback correlation '
+                      '(utils/pytorch_correlation.py:27-50 restated in oracle/): median of 5 timed runs after 2 warm-ups, '
+                      '%.2f s per pair, %.0f %% of it inside the 10 correlation calls' % (main_['s_per_pair'], 100 * main_['correlation_share']),
+            'shapes': res, 'correlation_alone_ms': levels}
 
 
 TRAIN_FLAGS = {'photo_loss_census_weight': 1, 'multi_scale_distillation_weight': 1, 'multi_scale_distillation_style': 'upup',
@@ -139,7 +202,7 @@ TRAIN_FLAGS = {'photo_loss_census_weight': 1, 'multi_scale_distillation_weight':
 
 def train_main(args, rank, world, device):
     """BASELINE config 3: unsupervised training step, global batch 4*N, DDP gradient all-reduce over RCCL."""
-    import _weights
+    from upflow_pytorch_amd import synthetic as _weights
     from upflow_pytorch_amd import parallel
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     from upflow_pytorch_amd.train import Trainer, synthetic_train_batch
@@ -176,8 +239,41 @@ def train_main(args, rank, world, device):
             'dtype': dname, 'data': 'synthetic',
             'config': {'workload': 'config3: photometric + smooth + census + pyramid-distillation loss, fwd+bwd+Adam(amsgrad), '
                                    '256x832 crops of 288x864 frames, batch 4 per GPU', 'global_batch': world * B,
-                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world},
+                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world,
+                       'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None},
             'final_loss': stats}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: re-execute this command under torch.distributed.run with
+    one rank per GPU of this node (RCCL over xGMI; rendezvous on 127.0.0.1, a free port), pass the ranks' output
+    through and return their exit code.  Replaces the reference's single-process nn.DataParallel (utils/tools.py:130-148)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: the only mode the host driver supports
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args, rank, world):
+    """--mode launch-check: only the multi-rank plumbing of this file (rendezvous, barrier, max-over-ranks, one JSON
+    line from rank 0) with no GPU work — what tests/test_distributed_cpu.py runs with --backend gloo."""
+    from upflow_pytorch_amd import parallel
+    if world > 1:
+        torch.distributed.barrier()
+    t = parallel.max_over_ranks(float(rank + 1))
+    if rank == 0:
+        print(json.dumps({'metric': 'launch-check', 'n_gpus': world, 'ranks': world, 'max_over_ranks': t,
+                          'backend': torch.distributed.get_backend() if world > 1 else None}), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -194,13 +290,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--torch-pyramid', action='store_true',
                     help="the north star's literal split: feature-pyramid convolutions through PyTorch-ROCm (MIOpen)")
-    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train', 'launch-check'],
                     help='train = BASELINE config 3: unsupervised step (fwd+loss+bwd+Adam), 256x832 crops, batch 4 per GPU, DDP')
+    ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'],
+                    help='process-group backend (default nccl = RCCL; gloo only for --mode launch-check on a CPU box)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus)                   # no external launcher: spawn one rank per GPU ourselves
     from upflow_pytorch_amd import parallel
-    rank, world, local = parallel.init_from_env()
-    assert world == max(args.gpus, 1), 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    rank, world, local = parallel.init_from_env(backend=args.backend)
+    assert world == max(args.gpus, 1), 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
+    if args.mode == 'launch-check':
+        return launch_check(args, rank, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU path in the product)'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -210,7 +312,7 @@ def main():
     B, H, W, dname = WORKLOADS[args.workload]
     dname = args.dtype or dname
     dtype = DT[dname]
-    import _weights
+    from upflow_pytorch_amd import synthetic as _weights
     net = build_net(dtype, device, hip_pyramid_convs=not args.torch_pyramid)
     im1, im2 = _weights.make_images(2, B, H, W)
     im1, im2 = im1.to(device), im2.to(device)                               # inputs resident in HBM
@@ -250,6 +352,7 @@ def main():
             'config': {'workload': '%s: UPFlow_net inference forward (flow fwd+bwd, occlusion masks, SGU on), '
                                    '%dx%d, batch %d per GPU, random-init weights' % (args.workload, H, W, B),
                        'global_batch': world * B, 'parallelism': 'replicas x%d (image pairs sharded, no collective)' % world,
+                       'ranks': world, 'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
                        'hip_graph': not args.no_graph,
                        'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or dtype == torch.float32 else 'HIP (MFMA kernel)'},
             'roofline': roofline_probe(B, H, W, dtype, device),
@@ -258,7 +361,7 @@ def main():
         if conv_rf is not None:
             line['roofline_conv'] = conv_rf
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(384, 1280)
+            line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

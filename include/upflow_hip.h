@@ -106,8 +106,9 @@ int upf_warp_forward(const void* x, const float* flow, void* y,
  * inference path warps straight out of / into the concatenation buffers the convolutions read (no slot copies). */
 int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
                              int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
-/* grad wrt x (scatter-add, fp32 buffer gx32 [B,C,H,W] that the CALLER has zero-filled) and wrt
- * flow (gflow [B,2,H,W] fp32, fully written).  grad_y : [B,C,H,W] of `dtype`. */
+/* grad wrt x (fp32 buffer gx32 [B,C,H,W]) and wrt flow (gflow [B,2,H,W] fp32); both are fully produced by the call
+ * (it zero-fills its scatter targets itself on `stream`; the caller passes uninitialised memory).
+ * grad_y : [B,C,H,W] of `dtype`. */
 int upf_warp_backward(const void* x, const float* flow, const void* grad_y,
                       float* gx32, float* gflow,
                       int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);

@@ -1,8 +1,10 @@
 """N>1 path on CPU: two `gloo` processes (world_size 2) exercise the multi-GPU plumbing that the driver
 runs with RCCL — rank/env initialisation, image-pair sharding, DDP gradient all-reduce equivalence
 (1 process x B=4 == 2 processes x B=2), the loss all-reduce and bench.py's max-over-ranks timing.
-The HIP operators need a GPU, so a small pure-torch module with the UPFlow_net dict contract stands
-in for the network here; the Trainer / parallel code under test is the product code."""
+Two layers: (1) a small pure-torch module with the UPFlow_net dict contract (pure DDP arithmetic); (2) the REAL
+UPFlow_net training forward + Trainer + DDP bucket, with the HIP operator entry points replaced by the oracle's
+differentiable restatements (tests/_ops_cpu_stub.py — the product itself has no CPU path); (3) bench.py's own
+rank launcher (`python bench.py --gpus 2` with no torchrun around it)."""
 import os
 import socket
 import sys
@@ -112,3 +114,94 @@ def test_single_process_helpers():
     total, parts = Loss_manager().compute_loss({'photo_loss': torch.tensor([1.0, 3.0]), 'smooth_loss': torch.tensor(0.5),
                                                 'census_loss': None, 'msd_loss': None})
     assert float(total) == 2.5 and set(parts) == {'photo_loss', 'smooth_loss'}
+
+
+# ------------------------------------------------------------------------------------------------ the real network
+NET_FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False, 'norm_moments_across_images': False,
+             'if_sgu_upsample': True, 'warp_mask_mode': 'robust'}
+
+
+def _real_net():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _ops_cpu_stub
+    _ops_cpu_stub.install()
+    from upflow_pytorch_amd import synthetic
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    conf = UPFlow_net.config()
+    d = dict(NET_FLAGS)
+    d.update(synthetic.TRAIN_FLAGS)
+    conf.update(d, verbose=False)
+    net = conf()
+    net.load_state_dict(synthetic.make_state_dict(0, head_scale=0.1))
+    return net, synthetic.make_train_batch(B=2, crop_hw=(64, 128), raw_hw=(80, 160))
+
+
+def _flat_grads(net):
+    return torch.cat([p.grad.flatten() for _, p in sorted(net.named_parameters())])
+
+
+def _real_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    net, batch = _real_net()
+    from upflow_pytorch_amd import parallel
+    from upflow_pytorch_amd.train import Trainer
+    parallel.init_from_env(backend='gloo')
+    tr = Trainer(net, lr=1e-4)
+    assert tr.distributed and tr.world == world and type(tr.net).__name__ == 'DistributedDataParallel'
+    stats = tr.step(tr.shard(batch))
+    q.put((rank, stats, _flat_grads(tr.raw_net).numpy(), sum(int(p.grad is not None) for p in tr.raw_net.parameters())))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_real_upflow_net_trainer_under_ddp_two_ranks():
+    """UPFlow_net (80 parameters, stacked training schedule, all four loss terms) + Trainer + DDP: both ranks end with the
+    same all-reduced gradient, equal to the mean of the two shards' single-process gradients (the loss terms that are
+    ratios of sums — occlusion-weighted distillation — are per-replica quantities, exactly as under the reference's
+    nn.DataParallel, utils/tools.py:130-148 + `loss.mean()`, scripts/simple_train.py:23-54)."""
+    torch.set_num_threads(4)
+    net, batch = _real_net()
+    from upflow_pytorch_amd.train import Trainer
+    ref = []
+    for r in range(2):
+        net.zero_grad(set_to_none=True)
+        tr = Trainer(net, lr=0.0, weight_decay=0.0, distributed=False)        # lr 0: the weights stay put between shards
+        shard = {k: (v[r:r + 1] if torch.is_tensor(v) else v) for k, v in batch.items()}
+        ref.append((tr.step(shard), _flat_grads(net).clone()))
+    want = (ref[0][1] + ref[1][1]) / 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    g0, g1 = torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])
+    assert res[0][3] == res[1][3] == 80, 'every parameter takes part in the bucket'
+    assert torch.equal(g0, g1)
+    scale = float(want.abs().max())
+    assert float((g0 - want).abs().max()) <= 1e-5 * scale, float((g0 - want).abs().max()) / scale
+    assert res[0][1] == res[1][1]
+    assert abs(res[0][1]['loss'] - (ref[0][0]['loss'] + ref[1][0]['loss']) / 2) <= 1e-5 * abs(res[0][1]['loss'])
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it re-executes under torch.distributed.run (here: gloo,
+    --mode launch-check, since this box has no GPU) and rank 0 prints ONE JSON line naming the rank count."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--mode', 'launch-check', '--backend', 'gloo'],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['ranks'] == 2 and d['n_gpus'] == 2 and d['max_over_ranks'] == 2.0 and d['backend'] == 'gloo'

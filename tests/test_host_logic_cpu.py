@@ -1,0 +1,84 @@
+"""Host-side logic of the package (model/upflow.py orchestration, loss assembly, Trainer) pinned on the REFERENCE's golden
+vectors without a GPU: the HIP operator entry points are replaced by the oracle's restatements (tests/_ops_cpu_stub.py,
+test infrastructure only), everything else — UPFlow_net.forward / forward_2_frame_v3 / _forward_stacked /
+decode_level_res / _losses, the state_dict contract, Loss_manager — is the product code."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import _weights
+from conftest import load_golden
+
+FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
+         'norm_moments_across_images': False, 'if_sgu_upsample': True, 'warp_mask_mode': 'robust'}
+
+
+@pytest.fixture(scope='module')
+def stub():
+    import _ops_cpu_stub
+    import importlib
+    from upflow_pytorch_amd import ops
+    saved = dict(ops.__dict__)
+    _ops_cpu_stub.install()
+    yield ops
+    ops.__dict__.clear()
+    ops.__dict__.update(saved)
+    importlib.invalidate_caches()
+
+
+def _net(extra=None):
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    conf = UPFlow_net.config()
+    d = dict(FLAGS)
+    d.update(extra or {})
+    conf.update(d, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
+    return net
+
+
+@pytest.mark.parametrize('stacked', [True, False])
+def test_inference_orchestration_vs_reference_golden(stub, stacked):
+    """Both schedules of forward_2_frame_v3 (stacked batch / the reference's per-direction calls, model/upflow.py:494-573)
+    reproduce the reference's output at 64x128 (robust mask both sides): EPE <= 1e-4."""
+    net = _net().eval()
+    net.stacked_training = stacked
+    im1, im2 = _weights.make_smooth_images(1, 1, 64, 128)
+    g = load_golden('net_64x128_robust')
+    ctx = torch.no_grad() if stacked else torch.enable_grad()       # grad mode + stacked_training=False -> per-direction path
+    with ctx:
+        out = net({'im1': im1, 'im2': im2, 'if_loss': False})
+    assert oracle.epe(out['flow_f_out'].detach(), g['flow_f_out']) <= 1e-4
+    assert oracle.epe(out['flow_b_out'].detach(), g['flow_b_out']) <= 1e-4
+    assert (out['occ_fw'] != g['occ_fw'].float()).float().mean() <= 2e-3
+
+
+def test_training_losses_and_gradient_norms_vs_reference_golden(stub):
+    """_losses (photometric on the boundary-dilated warp, edge-aware smoothness, census, pyramid distillation:
+    model/upflow.py:394-491) and the gradient of every parameter, against tests/golden/train_128x192.npz."""
+    g = load_golden('train_128x192')
+    net = _net(_weights.TRAIN_FLAGS).train()
+    batch = dict(_weights.make_train_batch())
+    batch['if_loss'] = True
+    out = net(batch)
+    terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')}
+    for k, v in terms.items():
+        assert abs(float(v) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(v), float(g[k]))
+    sum(terms.values()).backward()
+    names = sorted(n for n, _ in net.named_parameters())
+    params = dict(net.named_parameters())
+    got = np.array([float(params[n].grad.norm()) for n in names])
+    want = g['grad_norms'].numpy()
+    assert len(names) == 80 and (np.abs(got - want) / np.maximum(want, 1e-3)).max() <= 2e-3
+
+
+def test_loss_manager_handles_python_zero_terms(stub):
+    """smooth_order_*_weight <= 0 makes the net return the python int 0 for smooth_loss (model/upflow.py:404-419);
+    the trainer must still stack its statistics (device mismatch)."""
+    from upflow_pytorch_amd.train import Trainer
+    flags = dict(_weights.TRAIN_FLAGS, smooth_order_1_weight=0, smooth_order_2_weight=0)
+    net = _net(flags)
+    tr = Trainer(net, distributed=False)
+    stats = tr.step(_weights.make_train_batch(B=1, crop_hw=(64, 128), raw_hw=(80, 160)))
+    assert stats['smooth_loss'] == 0.0 and np.isfinite(stats['loss'])

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/upflow_hip.h"
 
@@ -21,6 +22,24 @@ int  check_launch(const char* what);          // hipGetLastError() -> 0 / positi
       return (code);                                 \
     }                                                \
   } while (0)
+
+// > 48 KiB of dynamic LDS must be opted into per (kernel, DEVICE): hipFuncAttributeMaxDynamicSharedMemorySize.  One
+// `LdsOptIn` per kernel instantiation (a function-local static at the launch site) remembers the size already granted
+// on each device, so a process that drives several GPUs (or several host threads) sets it wherever it is missing.
+struct LdsOptIn {
+  static constexpr int MAXDEV = 64;
+  std::atomic<size_t> granted[MAXDEV] = {};
+  void ensure(const void* kernel, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < MAXDEV && granted[dev].load(std::memory_order_acquire) >= bytes) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (dev >= 0 && dev < MAXDEV) {
+      size_t cur = granted[dev].load(std::memory_order_relaxed);
+      while (cur < bytes && !granted[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    }
+  }
+};
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

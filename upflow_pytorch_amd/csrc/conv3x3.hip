@@ -575,12 +575,9 @@ int launch_one(const Args& a, int slabs) {
   size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + xw(S, margin_of(D)) / 16) * 16;
   if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;        // the wide epilogue's patches reuse the region
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
-  static size_t attr_lds = 0;
+  static LdsOptIn opt;
   auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN, ONE>;
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_lds = lds;
-  }
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
                      (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, a.d, tiles_x, tiles_y, a.slope);
   return check_launch("conv_forward");
@@ -621,12 +618,9 @@ int launch_sk_one(const Args& a) {
   constexpr int rows = 2 + 2 * D;
   size_t lds = (size_t)4 * NOCTS * rows * (xw(1, margin_of(D)) + xw(1, margin_of(D)) / 16) * 16;
   if (lds < 4 * 2 * 16 * 64 * 4) lds = 4 * 2 * 16 * 64 * 4;       // the partial-sum exchange reuses the region
-  static bool attr_set = false;
+  static LdsOptIn opt;
   auto kern = &conv_sk_kernel<T, NOCTS, D, GEN>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), cdiv(a.Cout, 32)), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
                      (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope);
   return check_launch("conv_forward");

@@ -38,12 +38,9 @@ namespace corr {
 template <typename T, int KC>
 void launch_kc(bool aligned, unsigned nblocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const T* f1, const T* f2,
                T* out, int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope) {
-  static bool attr_set = false;
-  if (!attr_set) {   // > 48 KiB of dynamic LDS must be opted into once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr81_fwd_kernel<T, true, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(KC));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr81_fwd_kernel<T, false, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(KC));
-    attr_set = true;
-  }
+  static LdsOptIn opt_a, opt_u;   // > 48 KiB of dynamic LDS: opted into per kernel and per device
+  opt_a.ensure(reinterpret_cast<const void*>(&corr81_fwd_kernel<T, true, KC>), lds_bytes(KC));
+  opt_u.ensure(reinterpret_cast<const void*>(&corr81_fwd_kernel<T, false, KC>), lds_bytes(KC));
   // hipExtLaunchKernelGGL == hipLaunchKernelGGL plus optional start/stop events recorded right around
   // THIS kernel on its stream (used by upf_corr81_forward_timed; null events = plain launch)
   if (aligned)
@@ -58,11 +55,8 @@ void launch_kc(bool aligned, unsigned nblocks, hipStream_t stream, hipEvent_t ev
 template <typename T, bool SINGLE>
 void launch_mfma(unsigned nblocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const T* f1, const T* f2, T* out,
                  int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corrm::corr81_mfma_kernel<T, SINGLE>), hipFuncAttributeMaxDynamicSharedMemorySize, corrm::LDS_BYTES);
-    attr_set = true;
-  }
+  static LdsOptIn opt;
+  opt.ensure(reinterpret_cast<const void*>(&corrm::corr81_mfma_kernel<T, SINGLE>), corrm::LDS_BYTES);
   hipExtLaunchKernelGGL((corrm::corr81_mfma_kernel<T, SINGLE>), dim3(nblocks), dim3(corrm::NTHREADS), corrm::LDS_BYTES, stream, ev0, ev1, 0,
                         f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope);
 }

@@ -149,7 +149,9 @@ class WarpingLayer(nn.Module):
 
 class _PackedConv3x3(object):
     """Lazily packed weights of one `conv(...)` Sequential for the matrix-core kernel (csrc/conv3x3.hip):
-    re-packed when the parameter changes (version counter), dtype or device."""
+    re-packed when weight OR bias changes (autograd version counters), dtype, device or storage.  In-place edits through
+    `.data` (EMA, manual surgery) do not bump the version counter: call `net.invalidate_packed()` after those
+    (`load_state_dict` / `load_model` do it themselves)."""
 
     def __init__(self, seq):
         self.conv = seq[0]
@@ -159,13 +161,16 @@ class _PackedConv3x3(object):
         self.bias = None
 
     def get(self):
-        w = self.conv.weight
-        key = (w._version, w.dtype, w.device, w.data_ptr())
+        w, b = self.conv.weight, self.conv.bias
+        key = (w._version, w.dtype, w.device, w.data_ptr(), b._version, b.data_ptr())
         if key != self.key:
             self.packed = ops.conv3x3_pack(w)
             self.bias = self.conv.bias.detach().float().contiguous()
             self.key = key
         return self.packed, self.bias
+
+    def invalidate(self):
+        self.key = None
 
     def __call__(self, x_view, y_view):
         packed, bias = self.get()

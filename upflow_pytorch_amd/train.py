@@ -26,11 +26,14 @@ class Loss_manager():
     def compute_loss(self, output_dict):
         total = None
         parts = {}
+        like = next((v for v in (output_dict.get(k) for k in self.keys) if torch.is_tensor(v)), None)
         for k in self.keys:
             v = output_dict.get(k)
             if v is None:
                 continue
-            v = v.mean() if torch.is_tensor(v) else torch.as_tensor(float(v))
+            if not torch.is_tensor(v):          # e.g. smooth_loss == 0 (python int) when both smooth weights are <= 0
+                v = like.new_tensor(float(v)) if like is not None else torch.as_tensor(float(v))
+            v = v.mean()
             parts[k] = v.detach()
             total = v if total is None else total + v
         return total, parts

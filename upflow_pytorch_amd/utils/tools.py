@@ -71,6 +71,18 @@ class tools():
                 loaded = own
             self.load_state_dict(loaded)
 
+        def invalidate_packed(self):
+            """Drop every packed-weight copy the 16-bit convolution path keeps (model/pwc_modules.py:_PackedConv3x3).
+            Needed only after in-place parameter edits that bypass autograd's version counter (`p.data.copy_()`, EMA)."""
+            for m in self.modules():
+                for pc in list(m.__dict__.get('_fast_cache', {}).values()) + list(m.__dict__.get('_packed', None) or []):
+                    pc.invalidate()
+
+        def load_state_dict(self, *args, **kwargs):
+            r = super().load_state_dict(*args, **kwargs)
+            self.invalidate_packed()
+            return r
+
         @classmethod
         def choose_gpu(cls, model, gpu_opt=None):
             """The reference wraps in nn.DataParallel over all GPUs (utils/tools.py:130-148).  Here the
