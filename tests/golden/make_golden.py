@@ -376,6 +376,26 @@ def golden_net(upflow, pwc, tools):
     print(json.dumps(meta, indent=1))
 
 
+def golden_net_headline(upflow, pwc, tools):
+    """BASELINE config 2's resolution (384x1280, B=1, fp32, robust mask on both sides so that the comparison is
+    well-posed): the reference's forward flow + occlusion mask, and its self-sensitivity."""
+    old = robust_mask_patch(pwc)
+    try:
+        net = build_net(upflow, head_scale=0.1)
+        im1, im2 = _weights.make_smooth_images(2, 1, 384, 1280)
+        with torch.no_grad():
+            out = net({'im1': im1, 'im2': im2, 'if_loss': False})
+            g = gen(77)
+            out_n = net({'im1': im1 + 1e-7 * torch.randn(im1.shape, generator=g), 'im2': im2, 'if_loss': False})
+        sens = float((out['flow_f_out'] - out_n['flow_f_out']).pow(2).sum(1).sqrt().mean())
+        save('net_384x1280_robust', flow_f_out=out['flow_f_out'], occ_fw=np.packbits(out['occ_fw'].to(torch.uint8).numpy()),
+             flow_b_checksum=np.array([float(out['flow_b_out'].double().sum()), float(out['flow_b_out'].double().abs().sum())]),
+             self_sensitivity_epe=np.array([sens]))
+        print('384x1280 robust: self-sensitivity %.3g, mean |flow| %.3g' % (sens, float(out['flow_f_out'].abs().mean())))
+    finally:
+        pwc.WarpingLayer_no_div.forward = old
+
+
 def golden_train(upflow, pwc, tools):
     """Train-mode forward + backward of the reference (BASELINE config 3 at a small crop): loss terms and
     the gradient norm of every parameter.  Robust mask on (so the comparison is well-posed, §7-H2) and the
@@ -431,7 +451,7 @@ def golden_census():
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'net', 'train']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'net', 'net384', 'train']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -448,6 +468,8 @@ def main():
         golden_census()
     if 'net' in which:
         golden_net(upflow, pwc, tools)
+    if 'net384' in which:
+        golden_net_headline(upflow, pwc, tools)
     if 'train' in which:
         golden_train(upflow, pwc, tools)
 

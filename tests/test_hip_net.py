@@ -72,7 +72,7 @@ def test_free_running_literal_vs_noise_floor():
         out = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
     e = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
     floor = META['net_64x128_literal_self_sensitivity_epe']
-    print('P3a literal free-running EPE %.3g; reference self-sensitivity under 1e-7 input noise %.3g' % (e, floor))
+    print('P3a literal free-running EPE %.3g px; reference self-sensitivity under 1e-7 input noise %.3g px (ratio %.2f)' % (e, floor, e / floor))
     assert e <= 3 * floor
 
 
@@ -89,7 +89,7 @@ def test_reduced_precision_delta(dtype):
     e = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
     mag = float(g['flow_f_out'].pow(2).sum(1).sqrt().mean())
     print('%s EPE vs fp32 reference %.3g px (mean |flow| %.3g px)' % (dtype, e, mag))
-    assert e <= (0.25 if dtype == torch.bfloat16 else 0.05) * max(mag, 1.0)
+    assert e <= ENVELOPE_PX[dtype]
 
 
 def test_batch_independence_and_repeatability():
@@ -133,11 +133,11 @@ def test_16bit_all_hip_path_vs_fp32():
     with torch.no_grad():
         ref = build('robust', torch.float32)({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})['flow_f_out']
         mag = float(ref.pow(2).sum(1).sqrt().mean())
-        for dtype, tol in ((torch.float16, 0.05), (torch.bfloat16, 0.25)):
+        for dtype, tol in ((torch.float16, ENVELOPE_PX[torch.float16]), (torch.bfloat16, ENVELOPE_PX[torch.bfloat16])):
             out = build('robust', dtype)({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})['flow_f_out']
             e = oracle.epe(out.cpu(), ref.cpu())
             print('%s all-HIP path EPE vs fp32 %.3g px (mean |flow| %.3g px)' % (dtype, e, mag))
-            assert e <= tol * max(mag, 1.0)
+            assert e <= tol
 
 
 def test_full_size_config2_properties():
@@ -163,7 +163,7 @@ def test_full_size_config2_properties():
     mag = float(ref['flow_f_out'].pow(2).sum(1).sqrt().mean())
     e = oracle.epe(a['flow_f_out'].cpu(), ref['flow_f_out'].cpu())
     print('384x1280 bf16 vs fp32 forward: EPE %.3g px (mean |flow| %.3g px)' % (e, mag))
-    assert e <= 0.25 * max(mag, 1.0)
+    assert e <= ENVELOPE_PX[torch.bfloat16]
 
 
 def test_in_buffer_schedule_without_sgu_and_with_torch_pyramid():
@@ -201,4 +201,71 @@ def test_native_kitti_size_ragged_levels():
     mag = float(ref['flow_f_out'].pow(2).sum(1).sqrt().mean())
     e = oracle.epe(fast['flow_f_out'].cpu(), ref['flow_f_out'].cpu())
     print('375x1242 bf16 vs fp32 forward: EPE %.3g px (mean |flow| %.3g px)' % (e, mag))
-    assert e <= 0.25 * max(mag, 1.0)
+    assert e <= ENVELOPE_PX[torch.bfloat16]
+
+
+# ------------------------------------------------------------------------------- BASELINE configs at full size
+def test_headline_resolution_vs_reference_golden():
+    """BASELINE config 2's resolution, fp32 (the parity mode), robust mask on both sides: the HIP path against the
+    REFERENCE's own output at 384x1280 (tests/golden/net_384x1280_robust.npz) — EPE <= 1e-4 (north_star's bar)."""
+    import numpy as np
+    net = build('robust')
+    im1, im2 = _weights.make_smooth_images(2, 1, 384, 1280)
+    g = load_golden('net_384x1280_robust')
+    with torch.no_grad():
+        out = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    e = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
+    fb = out['flow_b_out'].cpu().double()
+    print('384x1280 fp32 HIP path vs reference: EPE %.3g px (reference self-sensitivity %.3g, mean |flow| %.3g)'
+          % (e, float(g['self_sensitivity_epe'][0]), float(g['flow_f_out'].abs().mean())))
+    assert e <= 1e-4
+    occ = torch.from_numpy(np.unpackbits(g['occ_fw'].numpy())[:384 * 1280].reshape(1, 1, 384, 1280)).float()
+    assert (out['occ_fw'].cpu() != occ).float().mean() <= 2e-3
+    assert abs(float(fb.abs().sum()) - float(g['flow_b_checksum'][1])) <= 1e-4 * fb.numel()
+    assert abs(float(fb.sum()) - float(g['flow_b_checksum'][0])) <= 1e-4 * fb.numel()
+
+
+# measured on MI355X (printed by the tests): 16-bit all-HIP path vs the fp32 forward of the same network, robust mask,
+# flows of ~1 px: bf16 0.0115 px, fp16 0.0018 px.  The bounds are ~3x those figures, not a fraction of the flow.
+ENVELOPE_PX = {torch.bfloat16: 0.035, torch.float16: 0.006}
+
+
+@pytest.mark.parametrize('cfg', ['config2', 'config4', 'config5'])
+def test_full_size_baseline_configs(cfg):
+    """BASELINE configs 2 / 4 / 5 at their FULL sizes and dtypes (384x1280 bf16 B=4, 448x1024 fp16 B=8, 960x2880 bf16 B=1),
+    size-independent properties of the whole forward:
+      (1) direction symmetry: swapping the frames swaps flow_f / flow_b and the occlusion masks bit for bit;
+      (2) the hipGraph replay (what bench.py times) equals the eager forward bit for bit;
+      (3) batch items are independent: item 0 of the batch vs the same pair run alone (a batch of one may select other
+          convolution launch variants — split-K at the coarse levels — so: inside the rounding envelope, not bit for bit);
+      (4) the flow stays inside the 16-bit rounding envelope (ENVELOPE_PX) of the fp32 parity-mode forward."""
+    from upflow_pytorch_amd.runtime import GraphedInference
+    B, H, W, dtype = {'config2': (4, 384, 1280, torch.bfloat16), 'config4': (8, 448, 1024, torch.float16),
+                      'config5': (1, 960, 2880, torch.bfloat16)}[cfg]
+    im1, im2 = _weights.make_smooth_images(20 + B, B, H, W)
+    im1, im2 = im1.cuda(), im2.cuda()
+    net = build('robust', dtype)
+    with torch.no_grad():
+        a = net({'im1': im1, 'im2': im2, 'if_loss': False})
+        b = net({'im1': im2, 'im2': im1, 'if_loss': False})
+        one = net({'im1': im1[:1], 'im2': im2[:1], 'if_loss': False})
+    assert a['flow_f_out'].shape == (B, 2, H, W) and a['flow_f_out'].dtype == torch.float32
+    assert torch.equal(a['flow_f_out'], b['flow_b_out']) and torch.equal(a['flow_b_out'], b['flow_f_out'])
+    assert torch.equal(a['occ_fw'], b['occ_bw']) and torch.equal(a['occ_bw'], b['occ_fw'])
+    assert oracle.epe(a['flow_f_out'][:1].cpu(), one['flow_f_out'].cpu()) <= ENVELOPE_PX[dtype]
+    assert oracle.epe(a['flow_b_out'][:1].cpu(), one['flow_b_out'].cpu()) <= ENVELOPE_PX[dtype]
+    runner = GraphedInference(net, B, H, W, device=im1.device)
+    runner.load(im1, im2)
+    g = runner.replay()
+    assert torch.equal(g['flow_f_out'], a['flow_f_out']) and torch.equal(g['flow_b_out'], a['flow_b_out'])
+    del runner
+    ref = build('robust', torch.float32)
+    with torch.no_grad():
+        errs = []
+        for i in range(0, B, 2):                         # fp32 (MIOpen) two items at a time: bounded workspace
+            r = ref({'im1': im1[i:i + 2], 'im2': im2[i:i + 2], 'if_loss': False})
+            errs.append(oracle.epe(a['flow_f_out'][i:i + 2].cpu(), r['flow_f_out'].cpu()))
+            mag = float(r['flow_f_out'].pow(2).sum(1).sqrt().mean())
+    e = max(errs)
+    print('%s %dx%d %s B=%d vs fp32 forward: EPE %.3g px (mean |flow| %.3g px)' % (cfg, H, W, dtype, B, e, mag))
+    assert e <= ENVELOPE_PX[dtype]

@@ -44,7 +44,10 @@ def test_corr_golden(hip, i):
 
 
 CORR_SHAPES = [(1, 1, 1, 1), (1, 3, 2, 5), (2, 32, 8, 32), (1, 32, 9, 33), (1, 33, 17, 44), (2, 64, 48, 160),
-               (1, 196, 6, 20), (1, 128, 12, 40), (1, 96, 24, 80), (4, 32, 96, 320), (1, 16, 7, 13), (1, 5, 40, 36)]
+               (1, 196, 6, 20), (1, 128, 12, 40), (1, 96, 24, 80), (4, 32, 96, 320), (1, 16, 7, 13), (1, 5, 40, 36),
+               # the 1/4-resolution and coarse levels of BASELINE configs 3, 4 and 5 (SURVEY.md §8 level table)
+               (8, 32, 112, 256), (1, 32, 240, 720), (1, 196, 15, 45), (1, 128, 30, 90), (2, 196, 4, 13), (2, 128, 8, 26),
+               (8, 196, 7, 16), (8, 128, 14, 32), (2, 96, 28, 64), (1, 64, 120, 360), (8, 196, 6, 20), (8, 64, 48, 160)]
 
 
 @pytest.mark.parametrize('shape', CORR_SHAPES)
@@ -81,8 +84,9 @@ def test_corr_into_wider_buffer(hip):
     assert bool((buf[:, 81:] == 7.0).all())
 
 
-@pytest.mark.parametrize('shape', [(1, 3, 2, 5), (2, 32, 24, 40), (1, 33, 17, 44), (1, 196, 6, 20), (2, 32, 64, 208)])
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(1, 3, 2, 5), (2, 32, 24, 40), (1, 33, 17, 44), (1, 196, 6, 20), (2, 32, 64, 208),
+                                   (2, 32, 112, 256), (1, 32, 240, 720), (1, 196, 15, 45), (1, 128, 30, 90), (2, 196, 4, 13)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_corr_backward_vs_oracle(hip, shape, dtype):
     g = torch.Generator().manual_seed(11 + sum(shape))
     f1 = torch.randn(shape, generator=g).to(dtype)
@@ -93,7 +97,7 @@ def test_corr_backward_vs_oracle(hip, shape, dtype):
     b = dev(f2).requires_grad_(True)
     out = hip.corr81(a, b)
     g1, g2 = torch.autograd.grad(out, (a, b), dev(go))
-    tol = 5e-6 if dtype == torch.float32 else 2.0 ** -8 * max(1.0, float(w1.abs().max()))
+    tol = 5e-6 if dtype == torch.float32 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * max(1.0, float(w1.abs().max()))
     assert (g1.cpu().float() - w1).abs().max() <= tol
     assert (g2.cpu().float() - w2).abs().max() <= tol
 
@@ -140,7 +144,8 @@ def test_warp_golden(hip, name):
     assert relerr(gf2.cpu(), g['gflow_nomask']) <= 1e-4
 
 
-@pytest.mark.parametrize('shape', [(1, 1, 1, 1), (2, 3, 5, 7), (1, 32, 96, 320), (2, 128, 12, 40), (1, 7, 33, 65)])
+@pytest.mark.parametrize('shape', [(1, 1, 1, 1), (2, 3, 5, 7), (1, 32, 96, 320), (2, 128, 12, 40), (1, 7, 33, 65),
+                                   (2, 32, 112, 256), (1, 32, 240, 720), (1, 128, 30, 90), (1, 96, 60, 180), (2, 128, 8, 26)])
 @pytest.mark.parametrize('mode', ['literal', 'robust', None])
 def test_warp_vs_oracle(hip, shape, mode):
     B, C, H, W = shape
@@ -217,6 +222,25 @@ def test_normalize_golden(hip, i):
     ga, gb = torch.autograd.grad([na, nb], [a, b], [dev(g['goa']), dev(g['gob'])])
     assert relerr(ga.cpu(), g['ga']) <= 1e-4
     assert relerr(gb.cpu(), g['gb']) <= 1e-4
+
+
+@pytest.mark.parametrize('shape', [(8, 32, 112, 256), (1, 32, 240, 720), (1, 196, 15, 45), (1, 128, 30, 90), (2, 196, 4, 13), (1, 3, 1, 2)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_normalize_vs_oracle_config_shapes(hip, shape, dtype):
+    """The level shapes of BASELINE configs 3-5 (ragged 15x45 / 30x90 / 4x13 rows included), values and gradients."""
+    g = torch.Generator().manual_seed(41 + sum(shape))
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(dtype)
+    go = torch.randn(shape, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    want = oracle.normalize_pair(xr, xr)[0]
+    (gwant,) = torch.autograd.grad(want, xr, go.float())
+    xd = dev(x).requires_grad_(True)
+    got = hip.normalize(xd)
+    (ggot,) = torch.autograd.grad(got, xd, dev(go))
+    eps = {torch.float32: 3e-6, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    assert (got.detach().cpu().float() - want.detach()).abs().max() <= eps * max(1.0, float(want.abs().max()))
+    geps = {torch.float32: 1e-4, torch.bfloat16: 2.0 ** -6, torch.float16: 2.0 ** -9}[dtype]
+    assert (ggot.cpu().float() - gwant).abs().max() <= geps * max(1.0, float(gwant.abs().max()))
 
 
 def test_normalize_bf16(hip):
@@ -391,3 +415,49 @@ def test_census_loss_golden(i):
     v = loss_functions.census_loss_torch(img1=im1, img1_warp=dev(g['img1_warp']), mask=dev(g['masks'][0]), q=0.4,
                                          charbonnier_or_abs_robust=False, if_use_occ=False, averge=True)
     assert abs(float(v) - float(g['loss_mean'])) <= 2e-6
+
+
+# ------------------------------------------------------------------- the reference's literal FFI (legacy shim)
+@pytest.mark.parametrize('i', [0, 1, 2, 3])
+def test_legacy_correlation_cuda_ffi_golden(i):
+    """`correlation_cuda.forward / backward` with the pybind signatures of correlation_cuda.cc:10-17, :89-97 and the
+    reference's ownership rules (the caller passes EMPTY tensors, `input1.new()`, correlation.py:22-24,35-39; the callee
+    resize_s them and writes in place, returns 1) against the reference's vectors."""
+    from upflow_pytorch_amd import correlation_cuda
+    g = load_golden('corr_%d' % i)
+    a, b = dev(g['f1']), dev(g['f2'])
+    r1, r2, out = a.new(), a.new(), a.new()
+    assert out.numel() == 0
+    assert correlation_cuda.forward(a, b, r1, r2, out, 4, 1, 4, 1, 1, 1) == 1
+    assert out.shape == g['out'].shape and out.device == a.device
+    assert (out.cpu() - g['out']).abs().max() <= 2e-6
+    g1, g2 = a.new(), a.new()
+    assert correlation_cuda.backward(a, b, r1, r2, dev(g['grad_out']), g1, g2, 4, 1, 4, 1, 1, 1) == 1
+    assert g1.shape == a.shape and g2.shape == b.shape
+    assert (g1.cpu() - g['g1']).abs().max() <= 2e-6 and (g2.cpu() - g['g2']).abs().max() <= 2e-6
+    # a pre-sized, stale output tensor is resized and fully overwritten too (correlation_cuda.cc:36-42 resize_ + fill_)
+    stale = torch.full((3, 5), 9.0, device=a.device)
+    assert correlation_cuda.forward(a, b, r1, r2, stale, 4, 1, 4, 1, 1, 1) == 1
+    assert torch.equal(stale, out)
+    # other parameter sets: forward through the general kernel, backward raises (INTEGRATION.md)
+    other = a.new()
+    assert correlation_cuda.forward(a, b, r1, r2, other, 2, 1, 2, 1, 1, 1) == 1
+    assert (other.cpu() - oops.correlation_general(g['f1'], g['f2'], 2, 1, 2, 1, 1)).abs().max() <= 5e-6
+    with pytest.raises(RuntimeError):
+        correlation_cuda.backward(a, b, r1, r2, dev(g['grad_out']), g1, g2, 2, 1, 2, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        correlation_cuda.forward(g['f1'], g['f2'], r1, r2, out, 4, 1, 4, 1, 1, 1)          # CPU tensors: no fallback
+
+
+def test_operator_on_second_device_after_first():
+    """LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is per device: an operator used on cuda:1 after cuda:0
+    must work.  Skipped on 1-GPU boxes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(1)
+    f1 = torch.randn(1, 32, 16, 32, generator=g).bfloat16()
+    f2 = torch.randn(1, 32, 16, 32, generator=g).bfloat16()
+    a = ops.corr81(f1.cuda(0), f2.cuda(0)).cpu()
+    b = ops.corr81(f1.cuda(1), f2.cuda(1)).cpu()
+    assert torch.equal(a, b)

@@ -33,6 +33,22 @@ def test_free_running_robust_mask(name, H, W, cid):
     assert (out['occ_bw'] != g['occ_bw'].float()).float().mean() <= 2e-3
 
 
+def test_free_running_robust_mask_headline_resolution():
+    """The oracle at BASELINE config 2's resolution (384x1280) against the reference's output: EPE <= 1e-4."""
+    import numpy as np
+    sd = _weights.make_state_dict(0, head_scale=0.1)
+    im1, im2 = _weights.make_smooth_images(2, 1, 384, 1280)
+    g = load_golden('net_384x1280_robust')
+    with torch.no_grad():
+        out = onet.forward(sd, im1, im2, mask_mode='robust')
+    assert oracle.epe(out['flow_f_out'], g['flow_f_out']) <= 1e-4
+    occ = torch.from_numpy(np.unpackbits(g['occ_fw'].numpy())[:384 * 1280].reshape(1, 1, 384, 1280)).float()
+    assert (out['occ_fw'] != occ).float().mean() <= 2e-3
+    s, a = float(out['flow_b_out'].double().sum()), float(out['flow_b_out'].double().abs().sum())
+    assert abs(a - float(g['flow_b_checksum'][1])) <= 1e-4 * 384 * 1280 * 2          # mean |d| <= 1e-4 on the backward flow too
+    assert abs(s - float(g['flow_b_checksum'][0])) <= 1e-4 * 384 * 1280 * 2
+
+
 def test_free_running_literal_mask_vs_noise_floor():
     """P3a: literal `mask >= 1.0` semantics.  The reference is chaotic against itself here (its own
     output moves by META[...self_sensitivity] px under 1e-7 input noise), so the bar is that floor."""

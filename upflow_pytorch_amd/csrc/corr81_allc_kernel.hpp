@@ -1,0 +1,262 @@
+// 81-neighbour cost volume, forward, bf16 / fp16 — matrix-core kernel with the WHOLE channel depth resident in LDS.
+//
+// Same matrix mapping as corr81_mfma_kernel.hpp (v_mfma_f32_4x4x4_16b: block b multiplies 4 candidate pixels of f2 by
+// 4 pixels of f1 over a channel quad; each lane ends up owning one pixel and 12 candidates; a two-stage barrel shift
+// aligns them to the 9 dx), but the structure around it is different:
+//
+//   * NO channel loop.  A workgroup stages ALL ceil(C/4) channel quads of its f1 tile and f2 tile + halo at once: every
+//     global load of the workgroup is in flight together, ONE barrier, then units (64 pixels x one dy per wave) are
+//     computed and stored one after the other, stores of unit u overlapping the matrix work of unit u+1.  The chunked
+//     kernel walked C/32 chunks serially (load latency + 2 barriers each): at the coarse pyramid levels (C = 196 / 128 /
+//     96 on 6x20 ... 24x80 pixels, 8-16 workgroups on 256 CUs) that serial chain WAS the kernel time (33 / 18 / 15 us).
+//   * Tile geometry is a template parameter so that the tile shrinks as C grows (LDS is 160 KB) and as the image
+//     shrinks (more workgroups): unit = UR x UW pixels (2x32 or 4x16), tile = NU units stacked vertically.
+//         <UW=32,NU=4>  8x32 tile   C <=  40   (1/4-resolution level)      <UW=32,NU=1>  2x32 tile   C <= 156
+//         <UW=32,NU=2>  4x32 tile   C <= 120                               <UW=16,NU=1>  4x16 tile   C <= 208
+//   * RAGGED: any W (rows not 8-byte aligned: 2-byte-aligned b64 buffer loads are legal on gfx950, the quad that
+//     straddles the row end is masked; results leave as per-pixel 2-byte stores) — so every level of every
+//     configuration (W = 20, 45, 90, 13, 26, 311 ...) takes the matrix-core path, none falls back to the VALU kernel.
+//   * NORM: network_tools.normalize_features (model/upflow.py:94-137, inference flags) fused into the loader — the
+//     statistics kernel leaves per-row (count, mean, M2) partials, the workgroup merges the rows it needs (Chan), and
+//     every element is normalised and re-rounded to 16 bits on its way into LDS: bit-identical to
+//     normalize_apply + corr81, without the write + read of both normalised feature maps and without that launch.
+#pragma once
+#include "common.hpp"
+#include "norm_merge.hpp"
+
+namespace upf {
+namespace corrx {
+
+constexpr int R = 4, D = 9;
+constexpr int NWAVES = D, NTHREADS = NWAVES * 64;
+constexpr int PATCH_BYTES = D * 64 * 2;      // per-wave output transposition patch (1152 B)
+
+template <int UW, int NU> struct Geo {
+  static constexpr int UR = 64 / UW, TH = NU * UR, TW = UW;
+  static constexpr int F2W = UW + 2 * R, F2H = TH + 2 * R;
+  static constexpr int F1_E = TH * TW, F2_E = F2H * F2W, E = F1_E + F2_E;     // 8-byte entries per channel quad
+  static constexpr int Q1 = F1_E / 4, Q2 = F2_E / 4;                           // 4-pixel staging tasks per channel quad
+};
+
+template <int UW, int NU>
+__host__ __device__ constexpr size_t lds_bytes(int KQ, bool ragged, bool norm) {
+  return (size_t)KQ * Geo<UW, NU>::E * 8 + (ragged ? 0 : NWAVES * PATCH_BYTES) + (norm ? (size_t)2 * KQ * 4 * 8 : 0);
+}
+template <int UW, int NU>
+__host__ __device__ constexpr int ntasks(int KQ) {       // f1 tasks padded to a whole number of waves, then the f2 tasks
+  return ((KQ * Geo<UW, NU>::Q1 + 63) & ~63) + KQ * Geo<UW, NU>::Q2;
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ f32x4 mma(uint2 a, uint2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float lo(uint32_t v) { return __uint_as_float(v << 16); }
+  static __device__ __forceinline__ float hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+};
+template <> struct Mma<f16_t> {
+  static __device__ __forceinline__ f32x4 mma(uint2 a, uint2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float lo(uint32_t v) { return f16_bits_to_f32(v & 0xffffu); }
+  static __device__ __forceinline__ float hi(uint32_t v) { return f16_bits_to_f32(v >> 16); }
+};
+
+struct Task {
+  int lds;         // 8-byte entry index of the first of 4 pixels; -1 = no task
+  uint32_t voff;   // byte offset of (channel quad, row, column) inside the batch item; 0x80000000 = outside the image
+  int kq;          // channel quad (NORM) | pixels of the quad inside the row, 1..4, << 16 (RAGGED)
+};
+
+// out: [B,81,H,W] (batch stride out_bs).  !RAGGED requires W % 8 == 0 and 16-byte aligned pointers / strides.
+// ws1 / ws2 (NORM): (count, mean, M2) partials of normalize_stats, [B*C][nseg][3] for f1 / f2.
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM>
+__global__ __launch_bounds__(NTHREADS, (NT > 4 ? 3 : 5))
+void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* __restrict__ out,
+                        int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope,
+                        const float* __restrict__ ws1, const float* __restrict__ ws2, int nseg) {
+  using G = Geo<UW, NU>;
+  extern __shared__ __attribute__((aligned(16))) uint2 lds[];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_x;
+  const int ty = (bid / tiles_x) % tiles_y;
+  const int n = bid / (tiles_x * tiles_y);
+  const int x0 = tx * G::TW, y0 = ty * G::TH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int dyi = __builtin_amdgcn_readfirstlane(tid >> 6);            // 0..8 <-> dy = dyi-4
+  const int KQ = (C + 3) >> 2;
+  uint2* const lds_f1 = lds;
+  uint2* const lds_f2 = lds + KQ * G::F1_E;
+
+  const size_t item = (size_t)n * C * H * W;
+  const uint32_t plane = (uint32_t)H * (uint32_t)W * 2u;               // bytes per channel plane
+  const uint32_t item_bytes = (uint32_t)C * plane;
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1 + item), 0, item_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f2 + item), 0, item_bytes, 0x00020000);
+
+  // ---- staging tasks: every load of the workgroup is issued before anything is consumed
+  const int n1 = KQ * G::Q1, N1 = (n1 + 63) & ~63, n2 = KQ * G::Q2;
+  Task task[NT];
+  u32x2 raw[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = tid + j * NTHREADS;
+    const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;     // wave-uniform
+    Task s;
+    s.lds = -1; s.voff = 0x80000000u; s.kq = 0;
+    int kq = 0, gy = -1, gx = -1;
+    if (!from_f2) {
+      if (t < n1) {
+        kq = t / G::Q1;
+        const int rem = t - kq * G::Q1, r = rem / (G::TW / 4), g = rem - r * (G::TW / 4);
+        gy = y0 + r; gx = x0 + 4 * g;
+        s.lds = kq * G::F1_E + r * G::TW + 4 * g;
+      }
+    } else {
+      const int u = t - N1;
+      if (u < n2) {
+        kq = u / G::Q2;
+        const int rem = u - kq * G::Q2, r = rem / (G::F2W / 4), g = rem - r * (G::F2W / 4);
+        gy = y0 - R + r; gx = x0 - R + 4 * g;
+        s.lds = KQ * G::F1_E + kq * G::F2_E + r * G::F2W + 4 * g;
+      }
+    }
+    if (s.lds >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      s.voff = (uint32_t)((kq * 4 * H + gy) * W + gx) * 2u;
+      s.kq = kq | (min(W - gx, 4) << 16);
+    }
+    task[j] = s;
+    const __amdgpu_buffer_rsrc_t rs = from_f2 ? r2 : r1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[j][k] = __builtin_amdgcn_raw_buffer_load_b64(rs, s.voff + k * plane, 0, 0);
+  }
+
+  // ---- NORM: merge the (count, mean, M2) partials of the 2 x C rows this workgroup needs -> (mean, rstd) in LDS
+  float2* const st = reinterpret_cast<float2*>(lds + KQ * G::E + (RAGGED ? 0 : NWAVES * PATCH_BYTES / 8));
+  if constexpr (NORM) {
+    const int c4 = KQ * 4;
+    if (tid < 2 * c4) {
+      const int sel = tid >= c4, c = tid - sel * c4;
+      float2 ms = make_float2(0.f, 0.f);               // channels >= C: (x - 0) * 0 keeps the zero padding of the quad
+      if (c < C) ms = norm_merge((sel ? ws2 : ws1) + ((size_t)n * C + c) * nseg * 3, nseg, H * W);
+      st[tid] = ms;
+    }
+    __syncthreads();
+  }
+
+  // ---- 4 channel rows x 4 pixels -> 4 pixel entries of 4 channels (v_perm), 2 ds_write_b128 per task
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (task[j].lds < 0) continue;
+    u32x2 v[4] = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
+    if constexpr (NORM) {
+      if (task[j].voff != 0x80000000u) {
+        const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;
+        const float2* sp = st + (from_f2 ? KQ * 4 : 0) + (task[j].kq & 0xffff) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 ms = sp[k];
+          v[k].x = pack2<T>((Mma<T>::lo(v[k].x) - ms.x) * ms.y, (Mma<T>::hi(v[k].x) - ms.x) * ms.y);
+          v[k].y = pack2<T>((Mma<T>::lo(v[k].y) - ms.x) * ms.y, (Mma<T>::hi(v[k].y) - ms.x) * ms.y);
+        }
+      }
+    }
+    if constexpr (RAGGED) {                             // the quad that straddles the row end: drop pixels >= W
+      const int nv = task[j].kq >> 16;                  // 0 (outside: loads returned zeros) or 1..4
+      const uint32_t mx = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
+      const uint32_t my = nv >= 4 ? 0xffffffffu : (nv == 3 ? 0x0000ffffu : 0u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k].x &= mx; v[k].y &= my; }
+    }
+    uint4 lo, hi;                                       // pixels 0,1 | pixels 2,3
+    lo.x = __builtin_amdgcn_perm(v[1].x, v[0].x, 0x05040100u);  lo.y = __builtin_amdgcn_perm(v[3].x, v[2].x, 0x05040100u);
+    lo.z = __builtin_amdgcn_perm(v[1].x, v[0].x, 0x07060302u);  lo.w = __builtin_amdgcn_perm(v[3].x, v[2].x, 0x07060302u);
+    hi.x = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x05040100u);  hi.y = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x05040100u);
+    hi.z = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x07060302u);  hi.w = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x07060302u);
+    *reinterpret_cast<uint4*>(lds + task[j].lds) = lo;
+    *reinterpret_cast<uint4*>(lds + task[j].lds + 2) = hi;
+  }
+  __syncthreads();
+
+  // ---- matrix work: NU units x KQ channel quads x 3 candidate quads; a finished unit is stored while the next computes
+  const int rsel = lane / UW, pix = lane % UW;                          // pix = 4*quad + j
+  const int p = lane & 3;
+  const uint32_t m1 = (p & 1) ? 0xffffffffu : 0u, m2 = (p & 2) ? 0xffffffffu : 0u;   // per-lane select masks
+  const float invC = 1.0f / (float)C;
+  using st16 = uint16_t;
+  st16* obase = reinterpret_cast<st16*>(out) + (size_t)n * out_bs + (size_t)(dyi * D) * H * W;
+  uint16_t* patch = reinterpret_cast<uint16_t*>(lds + KQ * G::E) + (tid >> 6) * (PATCH_BYTES / 2);
+  auto sel = [](uint32_t mask, float a, float b) {
+    return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
+  };
+
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+    const uint2* pb = lds_f1 + (u * G::UR + rsel) * G::TW + pix;                           // f1 (B operand)
+    const uint2* pa = lds_f2 + (u * G::UR + rsel + dyi) * G::F2W + pix;                    // f2 (A operand), q = 0
+#pragma unroll 4
+    for (int kq = 0; kq < KQ; ++kq) {
+      const uint2 bv = pb[kq * G::F1_E];
+      const uint2 c0 = pa[kq * G::F2_E], c1 = pa[kq * G::F2_E + 4], c2 = pa[kq * G::F2_E + 8];
+      a0 = Mma<T>::mma(c0, bv, a0);
+      a1 = Mma<T>::mma(c1, bv, a1);
+      a2 = Mma<T>::mma(c2, bv, a2);
+    }
+    // candidates 0..11 of this lane's pixel; displacement t = dx+4 is candidate t + p: two-stage barrel shift by the
+    // lane's 2-bit position, as bit-selects on scalars (arrays indexed by a lane-dependent value go to scratch)
+    const float t0 = sel(m1, a0[1], a0[0]), t1 = sel(m1, a0[2], a0[1]), t2 = sel(m1, a0[3], a0[2]), t3 = sel(m1, a1[0], a0[3]);
+    const float t4 = sel(m1, a1[1], a1[0]), t5 = sel(m1, a1[2], a1[1]), t6 = sel(m1, a1[3], a1[2]), t7 = sel(m1, a2[0], a1[3]);
+    const float t8 = sel(m1, a2[1], a2[0]), t9 = sel(m1, a2[2], a2[1]), t10 = sel(m1, a2[3], a2[2]);
+    const float f[9] = {sel(m2, t2, t0), sel(m2, t3, t1), sel(m2, t4, t2), sel(m2, t5, t3), sel(m2, t6, t4),
+                        sel(m2, t7, t5), sel(m2, t8, t6), sel(m2, t9, t7), sel(m2, t10, t8)};
+    if constexpr (RAGGED) {
+      const int y = y0 + u * G::UR + rsel, x = x0 + pix;
+      if (y < H && x < W) {
+        st16* o = obase + (size_t)y * W + x;
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+          float v = f[t] * invC;
+          v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
+          T tmp;
+          Elem<T>::store(&tmp, v);
+          o[(size_t)t * H * W] = tmp.v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < D; ++t) {
+        float v = f[t] * invC;
+        v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
+        T tmp;
+        Elem<T>::store(&tmp, v);
+        patch[t * 64 + lane] = tmp.v;                                  // [t][row-in-unit][UW px]
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // 72 chunks of 8 pixels (16 B): chunk L = (t, row-in-unit, 8-px segment)
+      const int yb = y0 + u * G::UR;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int L = lane + 64 * pass;
+        if (L < D * 8) {
+          constexpr int SPR = UW / 8;
+          const int t = L >> 3, rr = (L / SPR) % G::UR, seg = L % SPR;
+          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(patch) + L * 16);
+          const int y = yb + rr, x = x0 + 8 * seg;
+          if (y < H && x < W) *reinterpret_cast<uint4*>(obase + ((size_t)t * H + y) * W + x) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+}  // namespace corrx
+}  // namespace upf

@@ -25,6 +25,8 @@
 // run of tiles.
 #include "corr81_fwd_kernel.hpp"
 #include "corr81_mfma_kernel.hpp"
+#include "corr81_allc_kernel.hpp"
+#include "internal.hpp"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 
@@ -61,6 +63,88 @@ void launch_mfma(unsigned nblocks, hipStream_t stream, hipEvent_t ev0, hipEvent_
                         f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope);
 }
 
+// ---- bf16 / fp16, C <= 208: the whole channel depth resident in LDS (corr81_allc_kernel.hpp) ----------------------
+struct AllcVariant { int uw, nu, nt; };
+constexpr AllcVariant ALLC[] = {{32, 4, 4}, {32, 2, 8}, {32, 1, 8}, {16, 1, 8}};
+constexpr int NALLC = 4;
+constexpr size_t LDS_MAX = 160 * 1024;
+
+template <int UW, int NU, int NT>
+static bool allc_fits(int KQ, bool ragged, bool norm) {
+  return corrx::ntasks<UW, NU>(KQ) <= NT * corrx::NTHREADS && corrx::lds_bytes<UW, NU>(KQ, ragged, norm) <= LDS_MAX;
+}
+static bool allc_fits(int v, int KQ, bool ragged, bool norm) {
+  switch (v) {
+    case 0: return allc_fits<32, 4, 4>(KQ, ragged, norm);
+    case 1: return allc_fits<32, 2, 8>(KQ, ragged, norm);
+    case 2: return allc_fits<32, 1, 8>(KQ, ragged, norm);
+    case 3: return allc_fits<16, 1, 8>(KQ, ragged, norm);
+  }
+  return false;
+}
+static long long allc_nwg(int v, int B, int H, int W) {
+  const int th = ALLC[v].nu * (64 / ALLC[v].uw);
+  return (long long)B * cdiv(H, th) * cdiv(W, ALLC[v].uw);
+}
+// the largest tile (least halo traffic) that still gives every CU a workgroup; otherwise the variant with most workgroups
+static int allc_pick(int B, int C, int H, int W, bool ragged, bool norm) {
+  static const int forced = getenv("UPF_CORR_VARIANT") ? atoi(getenv("UPF_CORR_VARIANT")) : -1;
+  const int KQ = (C + 3) / 4;
+  if (forced >= 0 && forced < NALLC && allc_fits(forced, KQ, ragged, norm)) return forced;
+  int best = -1;
+  long long best_n = -1;
+  for (int v = 0; v < NALLC; ++v) {
+    if (!allc_fits(v, KQ, ragged, norm)) continue;
+    const long long nwg = allc_nwg(v, B, H, W);
+    if (nwg >= 256) return v;
+    if (nwg > best_n) { best = v; best_n = nwg; }
+  }
+  return best;
+}
+
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM>
+int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
+                    const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+  using G = corrx::Geo<UW, NU>;
+  const int tiles_x = cdiv(W, G::TW), tiles_y = cdiv(H, G::TH);
+  const long long nblocks = (long long)B * tiles_x * tiles_y;
+  UPF_REQUIRE(nblocks < (1ll << 31), UPF_EINVAL, "corr81_forward: grid too large");
+  const size_t lds = corrx::lds_bytes<UW, NU>((C + 3) / 4, RAGGED, NORM);
+  static LdsOptIn opt;
+  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipExtLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(corrx::NTHREADS), lds, stream, ev0, ev1, 0,
+                        f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg);
+  return check_launch("corr81_forward");
+}
+
+template <typename T, bool RAGGED, bool NORM>
+int launch_allc(int v, const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
+                const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, RAGGED, NORM>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1)
+  switch (v) {
+    case 0: UPF_ALLC(32, 4, 4);
+    case 1: UPF_ALLC(32, 2, 8);
+    case 2: UPF_ALLC(32, 1, 8);
+    case 3: UPF_ALLC(16, 1, 8);
+  }
+#undef UPF_ALLC
+  set_error("corr81_forward: internal routing error (variant %d)", v);
+  return UPF_EUNSUPPORTED;
+}
+
+// -> UPF_OK / error, or 1 = "not applicable" (C too deep, item too large): the caller takes the chunked kernels
+template <typename T, bool NORM>
+int try_allc(const void* f1, const void* f2, void* out, int B, int C, int H, int W, long long out_bs, float slope,
+             const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+  if ((size_t)C * H * W * 2 >= (1ull << 31)) return 1;                       // buffer-descriptor range
+  const bool ragged = !((W % 8 == 0) && (out_bs % 8 == 0) && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out, 16));
+  const int v = allc_pick(B, C, H, W, ragged, NORM);
+  if (v < 0) return 1;
+  if (ragged) return launch_allc<T, true, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1);
+  return launch_allc<T, false, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1);
+}
+
 template <typename T>
 int launch_fwd(const void* f1, const void* f2, void* out, int B, int C, int H, int W,
                long long out_bs, float slope, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
@@ -71,6 +155,11 @@ int launch_fwd(const void* f1, const void* f2, void* out, int B, int C, int H, i
   const bool aligned = (W % 4 == 0) && (out_bs % 4 == 0) && aligned_to(f1, va) && aligned_to(f2, va) && aligned_to(out, va) &&
                        (size_t)C * H * W * sizeof(typename Elem<T>::store_t) < (1ull << 31);   // buffer-descriptor range
   if constexpr (sizeof(typename Elem<T>::store_t) == 2) {
+    static const bool old_path = getenv("UPF_CORR_OLD") != nullptr;           // (A/B runs against the round-1 kernels)
+    if (!old_path && getenv("UPF_CORR_NO_MFMA") == nullptr) {
+      const int rc = try_allc<T, false>(f1, f2, out, B, C, H, W, out_bs, slope, nullptr, nullptr, 0, stream, ev0, ev1);
+      if (rc != 1) return rc;
+    }
     const bool mfma_ok = aligned && (W % 8 == 0) && (out_bs % 8 == 0) && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out, 16) &&
                          getenv("UPF_CORR_NO_MFMA") == nullptr;
     if (mfma_ok) {
@@ -196,4 +285,37 @@ extern "C" int upf_correlation_forward(const void* in1, const void* in2, void* o
                                   (const T*)in1, (const T*)in2, (T*)out, B, C, H, W, pad_size, kr, max_displacement,
                                   stride1, stride2, dr, oh, ow, kernel_size));
   return check_launch("correlation_forward");
+}
+
+// ---- normalisation fused into the cost volume's loader ----------------------------------------------------------
+extern "C" int upf_corr81_norm_supported(int C, int dtype) {
+  return (dtype == UPF_F16 || dtype == UPF_BF16) && C > 0 && upf::corr::allc_fits(upf::corr::NALLC - 1, (C + 3) / 4, true, true);
+}
+
+extern "C" long long upf_corr81_norm_workspace_bytes(int B, int C, int H, int W) {
+  return (long long)2 * B * C * upf::misc::stats2_nseg((long long)B * C, H * W) * 3 * sizeof(float);
+}
+
+extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
+                                       long long out_batch_stride, float leaky_slope, void* workspace, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(f1 && f2 && out && workspace, UPF_EINVAL, "corr81_norm_forward: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_norm_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+  UPF_REQUIRE(upf_corr81_norm_supported(C, dtype), UPF_EUNSUPPORTED,
+              "corr81_norm_forward: bf16 / fp16 with C <= 208 only (dtype %d, C %d): use upf_normalize_forward + upf_corr81_forward", dtype, C);
+  UPF_REQUIRE((size_t)C * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward: batch item >= 2 GiB");
+  if (out_batch_stride == 0) out_batch_stride = (long long)corr::ND * H * W;
+  UPF_REQUIRE(out_batch_stride >= (long long)corr::ND * H * W, UPF_EINVAL, "corr81_norm_forward: out_batch_stride %lld < 81*H*W", out_batch_stride);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const long long N = (long long)B * C;
+  const int nseg = misc::launch_stats2(f1, f2, ws, N, H * W, dtype, s);
+  int rc = check_launch("corr81_norm_forward (statistics)");
+  if (rc != UPF_OK) return rc;
+  const float* ws1 = ws;
+  const float* ws2 = ws + (size_t)N * nseg * 3;
+  if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
+  else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
+  UPF_REQUIRE(rc != 1, UPF_EUNSUPPORTED, "corr81_norm_forward: no kernel variant fits C=%d", C);
+  return rc;
 }

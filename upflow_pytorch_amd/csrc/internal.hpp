@@ -1,0 +1,11 @@
+// Cross-translation-unit helpers of libupflow_hip.so (C++ linkage, not part of the C-ABI).
+#pragma once
+#include "common.hpp"
+
+namespace upf {
+namespace misc {
+// (count, mean, M2) partials of the rows of two [N,HW] tensors in ONE launch: ws[2N][nseg][3]; returns nseg.
+int launch_stats2(const void* x1, const void* x2, float* ws, long long N, int HW, int dtype, hipStream_t stream);
+int stats2_nseg(long long N, int HW);
+}  // namespace misc
+}  // namespace upf

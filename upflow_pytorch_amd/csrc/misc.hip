@@ -10,6 +10,8 @@
 // opposite flow, |.|_1 magnitudes, threshold, outgoing-flow mask — one launch.
 // Compiled with -ffp-contract=off.
 #include "sampling.hpp"
+#include "norm_merge.hpp"
+#include "internal.hpp"
 
 namespace upf {
 namespace misc {
@@ -39,13 +41,14 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // pointers allow it; otherwise element accesses.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(NT)
-void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, int nseg, int seglen) {
+void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, int nseg, int seglen,
+                            const T* __restrict__ x2 = nullptr, size_t rows1 = ~(size_t)0) {
   __shared__ float sh[NT / 64];
   constexpr int V = VEC ? VecIO<T>::N : 1;
   const size_t row = blockIdx.x / nseg;
   const int seg = blockIdx.x - (int)row * nseg;
   const int i0 = seg * seglen, i1 = min(HW, i0 + seglen);
-  const T* xr = x + row * HW;
+  const T* xr = (row < rows1) ? x + row * HW : x2 + (row - rows1) * HW;      // (two tensors in one launch: rows >= rows1 -> x2)
   const float cnt = (float)(i1 - i0);
   float mean, m2;
   if constexpr (sizeof(typename Elem<T>::store_t) == 2) {
@@ -87,6 +90,16 @@ void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int
   }
 }
 
+// fp32 (the parity mode): (x - mean) / std with an IEEE division, the reference's arithmetic (model/upflow.py:130-134).
+// 16-bit: (x - mean) * (1/std) — the fused loader of the cost volume (corr81_allc_kernel.hpp, NORM) computes exactly
+// this, so the fused and the two-kernel paths agree bit for bit; the difference to the division (<= 1 ulp of fp32)
+// is far below the 16-bit output rounding.
+template <typename T>
+__device__ __forceinline__ float apply1(float v, float mean, float std, float rstd) {
+  if constexpr (sizeof(typename Elem<T>::store_t) == 4) return (v - mean) / std;
+  else return (v - mean) * rstd;
+}
+
 template <typename T, bool VEC>
 __global__ __launch_bounds__(NT)
 void normalize_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ ws,
@@ -95,30 +108,21 @@ void normalize_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const fl
   const size_t row = blockIdx.x / nseg;
   const int seg = blockIdx.x - (int)row * nseg;
   // merge the partials (every thread redundantly: nseg is small and the values are L2-resident)
-  const float* w = ws + (size_t)row * nseg * 3;
-  float n = w[0], mean = w[1], m2 = w[2];
-  for (int k = 1; k < nseg; ++k) {
-    const float nb = w[3 * k], mb = w[3 * k + 1], m2b = w[3 * k + 2];
-    const float tot = n + nb, delta = mb - mean;
-    mean = mean + delta * (nb / tot);
-    m2 = m2 + m2b + delta * delta * (n * nb / tot);
-    n = tot;
-  }
-  const float var = m2 / (float)(HW - 1);                           // unbiased, torch.var default (upflow.py:114)
-  const float std = sqrtf(var + 1e-16f);                            // upflow.py:126
+  const RowStats rs = norm_merge_full(ws + (size_t)row * nseg * 3, nseg, HW);
+  const float mean = rs.mean, std = rs.std, rstd = rs.rstd;
   const int i0 = seg * seglen, i1 = min(HW, i0 + seglen);
   const T* xr = x + row * HW;
   T* yr = y + row * HW;
   for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
     if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
 #pragma unroll
-      for (int k = 0; k < V; ++k) v[k] = (v[k] - mean) / std;
+      for (int k = 0; k < V; ++k) v[k] = apply1<T>(v[k], mean, std, rstd);
       VecIO<T>::store(yr + i, v);
-    } else Elem<T>::store(yr + i, (Elem<T>::load(xr + i) - mean) / std);
+    } else Elem<T>::store(yr + i, apply1<T>(Elem<T>::load(xr + i), mean, std, rstd));
   }
   if (threadIdx.x == 0 && seg == 0) {
     if (mean_out) mean_out[row] = mean;
-    if (rstd_out) rstd_out[row] = 1.0f / std;
+    if (rstd_out) rstd_out[row] = rstd;
   }
 }
 
@@ -275,6 +279,20 @@ static int normalize_nseg(long long N, int HW) {
   while (N * nseg < 1024 && HW / (nseg * 2) >= 2048) nseg *= 2;
   return nseg;
 }
+
+// statistics of TWO [N,HW] tensors in one launch -> ws[(2N rows)][nseg][3]; returns nseg (internal.hpp)
+int upf::misc::launch_stats2(const void* x1, const void* x2, float* ws, long long N, int HW, int dtype, hipStream_t stream) {
+  const int nseg = normalize_nseg(2 * N, HW);
+  const int seglen = cdiv(HW, nseg);
+  const unsigned grid = (unsigned)(2 * N * nseg);
+  const int vn = (dtype == UPF_F32) ? 4 : 8;
+  const bool vec = (HW % vn == 0) && (seglen % vn == 0) && aligned_to(x1, 16) && aligned_to(x2, 16);
+  UPF_DISPATCH(dtype, T,
+               if (vec) hipLaunchKernelGGL((misc::normalize_stats_kernel<T, true>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N);
+               else hipLaunchKernelGGL((misc::normalize_stats_kernel<T, false>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N));
+  return nseg;
+}
+int upf::misc::stats2_nseg(long long N, int HW) { return normalize_nseg(2 * N, HW); }
 
 extern "C" long long upf_normalize_workspace_bytes(long long N, int HW) {
   return (long long)N * normalize_nseg(N, HW) * 3 * sizeof(float);

@@ -1,0 +1,35 @@
+// Merge of the per-segment (count, mean, M2) partials of normalize_stats_kernel into a row's mean and 1/std — shared by
+// normalize_apply_kernel (csrc/misc.hip) and the fused loader of corr81_allc_kernel.hpp, which must agree BIT FOR BIT
+// (the fused path is tested for bit-equality against normalize + corr81).  Every step is an explicitly rounded fp32
+// operation, so the result does not depend on the translation unit's -ffp-contract setting.
+#pragma once
+#include "common.hpp"
+
+namespace upf {
+
+struct RowStats { float mean, std, rstd; };
+
+// w: [nseg][3] partials of one row, merged in fixed order with Chan's parallel-variance formula;
+// unbiased variance over HW elements (torch.var default, model/upflow.py:114), std = sqrt(var + 1e-16) (:126).
+__device__ __forceinline__ RowStats norm_merge_full(const float* __restrict__ w, int nseg, int HW) {
+  float n = w[0], mean = w[1], m2 = w[2];
+  for (int k = 1; k < nseg; ++k) {
+    const float nb = w[3 * k], mb = w[3 * k + 1], m2b = w[3 * k + 2];
+    const float tot = __fadd_rn(n, nb), delta = __fsub_rn(mb, mean);
+    mean = __fadd_rn(mean, __fmul_rn(delta, __fdiv_rn(nb, tot)));
+    m2 = __fadd_rn(__fadd_rn(m2, m2b), __fmul_rn(__fmul_rn(delta, delta), __fdiv_rn(__fmul_rn(n, nb), tot)));
+    n = tot;
+  }
+  RowStats r;
+  r.mean = mean;
+  r.std = __fsqrt_rn(__fadd_rn(__fdiv_rn(m2, (float)(HW - 1)), 1e-16f));
+  r.rstd = __fdiv_rn(1.0f, r.std);
+  return r;
+}
+
+__device__ __forceinline__ float2 norm_merge(const float* __restrict__ w, int nseg, int HW) {
+  const RowStats r = norm_merge_full(w, nseg, HW);
+  return make_float2(r.mean, r.rstd);
+}
+
+}  // namespace upf
