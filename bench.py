@@ -55,7 +55,8 @@ def build_net(dtype, device, hip_pyramid_convs=True):
 
 
 def roofline_probe(B, H, W, dtype, device):
-    """Dominant hand-written kernel: corr81 forward at the 1/4-resolution level (C=32) of this workload.
+    """Dominant hand-written kernel: corr81 forward at the 1/4-resolution level (C=32) of this workload, with the shape
+    of the launch the model makes there ([2B,32,H/4,W/4]: both flow directions of the B frame pairs in one launch).
 
     `achieved` / `frac` = algorithmic bytes s*B*H*W*(2C+81) / the average duration of 200 BACK-TO-BACK launches, each
     bracketed by its own pair of HIP events recorded on the launch stream (hipExtLaunchKernel start/stop events) — the
@@ -65,6 +66,7 @@ def roofline_probe(B, H, W, dtype, device):
     (profiles/r02_*: its per-kernel average sits ~1 us above the event figure, both are committed)."""
     from upflow_pytorch_amd import ops
     C, h, w = 32, (H + 3) // 4, (W + 3) // 4
+    B = 2 * B            # the launch the model makes: both flow directions stacked along the batch (UPFlow_net._forward_stacked)
     g = torch.Generator(device='cpu').manual_seed(2004)
     f1 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
     f2 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
@@ -96,7 +98,7 @@ def roofline_probe(B, H, W, dtype, device):
                 break
         except Exception:
             pass
-    return {'bound': 'hbm', 'kernel': 'corr81_mfma_kernel' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w],
+    return {'bound': 'hbm', 'kernel': 'corr81_allc_kernel<8x32 tile>' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w],
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2),
             'timing': 'HIP events around each of 200 back-to-back launches (inputs resident in the infinity cache)',

@@ -67,6 +67,25 @@ int upf_corr81_forward_timed(const void* f1, const void* f2, void* out,
                              long long out_batch_stride, float leaky_slope, void* stream,
                              int nrep, float* avg_us, float* min_us);
 
+/* Feature normalisation fused into the cost volume (model/upflow.py:549-562):
+ *     out = corr81(normalize(f1), normalize(f2))        normalize = upf_normalize_forward's arithmetic, per tensor
+ * in TWO launches — one statistics pass over both tensors, then the cost volume whose loader normalises every element
+ * (and re-rounds it to `dtype`) on its way into LDS — instead of four, and without writing / re-reading the two
+ * normalised feature maps.  Bit-identical to upf_normalize_forward x2 + upf_corr81_forward.  bf16 / fp16, C <= 208
+ * (upf_corr81_norm_supported), W >= 4; `workspace`: upf_corr81_norm_workspace_bytes(B,C,H,W) bytes of device memory. */
+int upf_corr81_norm_supported(int C, int dtype);
+long long upf_corr81_norm_workspace_bytes(int B, int C, int H, int W);
+int upf_corr81_norm_forward(const void* f1, const void* f2, void* out,
+                            int B, int C, int H, int W, int dtype,
+                            long long out_batch_stride, float leaky_slope, void* workspace, void* stream);
+
+/* Launch heuristics of the 16-bit cost volume, for tuning and for the tests to reach every kernel variant:
+ *   "variant"  (-1)  -1 = choose by shape; 0..3 = force tile geometry 8x32 / 4x32 / 2x32 / 4x16 where C fits
+ *   "old_path" (0)   1 = the channel-chunked kernels (corr81_mfma_kernel / corr81_fwd_kernel) instead of the
+ *                    all-channels-in-LDS kernel
+ * returns the previous value, or -1000 for an unknown name. */
+int upf_corr_set_option(const char* name, int value);
+
 /* Gradients of the above (correlation_cuda.backward, correlation_cuda.cc:89-167 ->
  * correlation_cuda_kernel.cu:116-300, 396-530):
  *   g1[n,c,y,x] = (1/C) sum_d gO[n,d,y,x]       * f2[n,c,y+dy,x+dx]

@@ -73,6 +73,81 @@ def test_corr_vs_oracle(hip, shape, dtype):
     assert (got_l - want_l).abs().max() <= tol
 
 
+ALLC_SHAPES = [(1, 1, 1, 1), (2, 5, 3, 3), (1, 3, 5, 4), (1, 9, 3, 5), (2, 32, 24, 40), (1, 32, 9, 33), (2, 64, 48, 160), (1, 96, 24, 80), (1, 128, 12, 40), (2, 196, 6, 20),
+               (1, 196, 15, 45), (2, 128, 8, 26), (1, 7, 5, 9), (1, 208, 9, 17), (1, 40, 19, 70), (2, 120, 10, 64)]
+
+
+@pytest.mark.parametrize('shape', ALLC_SHAPES)
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+def test_corr_every_tile_geometry(hip, shape, variant):
+    """Every tile geometry of the all-channels-in-LDS kernel (8x32 / 4x32 / 2x32 / 4x16), forced where C fits, aligned and
+    ragged widths, against the oracle; and against the channel-chunked round-1 kernels bit for bit (same products, same
+    fp32 accumulation order per pixel: the channel quads are walked in the same order)."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(100 + sum(shape))
+    f1 = torch.randn(shape, generator=g).bfloat16()
+    f2 = torch.randn(shape, generator=g).bfloat16()
+    want = oracle.corr81(f1.float(), f2.float())
+    prev = hip.corr_set_option('variant', variant)
+    try:
+        got = hip.corr81(dev(f1), dev(f2), 0.1).cpu().float()
+        got16 = hip.corr81(dev(f1.half()), dev(f2.half())).cpu().float()
+    finally:
+        hip.corr_set_option('variant', prev)
+    want_l = torch.nn.functional.leaky_relu(want, 0.1)
+    assert (got - want_l).abs().max() <= 2.0 ** -8 * max(1.0, float(want.abs().max())) + 1e-6
+    want16 = oracle.corr81(f1.half().float(), f2.half().float())
+    assert (got16 - want16).abs().max() <= 2.0 ** -11 * max(1.0, float(want16.abs().max())) + 1e-6
+    hip.corr_set_option('old_path', 1)
+    try:
+        old = hip.corr81(dev(f1), dev(f2), 0.1).cpu().float()
+    finally:
+        hip.corr_set_option('old_path', 0)
+    assert (got - old).abs().max() <= 2.0 ** -8 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize('shape', ALLC_SHAPES + [(8, 32, 96, 320), (2, 32, 240, 720), (16, 32, 112, 256)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_corr_with_fused_normalisation_is_bit_identical(hip, shape, dtype):
+    """upf_corr81_norm_forward (statistics launch + cost volume whose loader normalises) ==
+    upf_normalize_forward on the [f1; f2] pair + upf_corr81_forward, BIT FOR BIT — plain and into a wider buffer with the
+    fused LeakyReLU, incl. ragged widths, C not a multiple of 4 and rows split into several statistics segments."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(200 + sum(shape))
+    pair = (torch.randn((2,) + shape, generator=g) * 1.7 + 0.3).to(dtype).cuda()
+    if W < 4:                                            # rows shorter than a staging quad: not fused, and said so loudly
+        assert not hip.corr81_norm_supported(pair[0])
+        with pytest.raises(RuntimeError):
+            hip.corr81_norm_forward_raw(pair[0], pair[1])
+        return
+    assert hip.corr81_norm_supported(pair[0])
+    normed = hip.normalize(pair.view(2 * B, C, H, W))
+    want = hip.corr81_forward_raw(normed[:B], normed[B:])
+    got = hip.corr81_norm_forward_raw(pair[0], pair[1])
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    buf = torch.full((B, 115, H, W), 3.0, dtype=dtype, device='cuda')
+    hip.corr81_norm_forward_raw(pair[0], pair[1], out=buf[:, :81], leaky_slope=0.1)
+    assert torch.equal(buf[:, :81], hip.corr81_forward_raw(normed[:B], normed[B:], leaky_slope=0.1))
+    assert bool((buf[:, 81:] == 3.0).all())
+    # and against the oracle's normalisation + correlation (fp32 reference arithmetic): within 16-bit rounding
+    ref = oracle.corr81(*[t.float() for t in oracle.normalize_pair(pair[0].cpu().float(), pair[1].cpu().float())])
+    eps = 2.0 ** -6 if dtype == torch.bfloat16 else 2.0 ** -9
+    assert (got.cpu().float() - ref).abs().max() <= eps * max(1.0, float(ref.abs().max()))
+
+
+def test_corr_norm_rejects_unsupported(hip):
+    a = torch.zeros(1, 8, 8, 8, device='cuda')
+    assert not hip.corr81_norm_supported(a)
+    with pytest.raises(RuntimeError):
+        hip.corr81_norm_forward_raw(a, a)                                    # fp32: not fused (parity mode)
+    b = torch.zeros(1, 212, 8, 8, device='cuda', dtype=torch.bfloat16)
+    assert not hip.corr81_norm_supported(b)
+    with pytest.raises(RuntimeError):
+        hip.corr81_norm_forward_raw(b, b)
+    with pytest.raises(RuntimeError):
+        hip.corr_set_option('nope', 1)
+
+
 def test_corr_into_wider_buffer(hip):
     """out_batch_stride: write straight into the first 81 of 115 channels (model/upflow.py:565)."""
     g = torch.Generator().manual_seed(3)

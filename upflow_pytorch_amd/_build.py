@@ -15,7 +15,7 @@ LIB = os.path.join(PKG, 'libupflow_hip.so')
 # mask `grid_sample(ones) >= 1.0` of the reference is bit-sensitive (csrc/sampling.hpp).
 SOURCES = [
     ('api.hip', []),
-    ('corr81_fwd.hip', []),
+    ('corr81_fwd.hip', ['-ffp-contract=off']),      # (the fused normalisation must round like misc.hip's)
     ('corr81_bwd.hip', []),
     ('conv3x3.hip', []),
     ('warp.hip', ['-ffp-contract=off']),

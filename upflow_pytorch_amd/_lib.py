@@ -23,6 +23,7 @@ _vp, _i, _f, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_longlong
 SIGNATURES = {
     'upf_corr81_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp],
     'upf_corr81_forward_timed': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
+    'upf_corr81_norm_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp],
     'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_out_shape': [_i, _i, _i, _i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],
@@ -66,6 +67,12 @@ def lib():
             fn.restype = _i
         L.upf_normalize_workspace_bytes.argtypes = [_ll, _i]
         L.upf_normalize_workspace_bytes.restype = _ll
+        L.upf_corr81_norm_supported.argtypes = [_i, _i]
+        L.upf_corr81_norm_supported.restype = _i
+        L.upf_corr81_norm_workspace_bytes.argtypes = [_i, _i, _i, _i]
+        L.upf_corr81_norm_workspace_bytes.restype = _ll
+        L.upf_corr_set_option.argtypes = [_c.c_char_p, _i]
+        L.upf_corr_set_option.restype = _i
         L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]
         L.upf_conv_packed_bytes.restype = _ll
         L.upf_conv_set_option.argtypes = [_c.c_char_p, _i]

@@ -56,6 +56,11 @@ __device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
   return (float)__builtin_bit_cast(_Float16, (uint16_t)b);
 }
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+  // The empty asm makes the fp32 value opaque: otherwise hipcc selects v_fma_mixlo_f16 for cvt_f16(a * b) — even with
+  // -ffp-contract=off — which rounds the exact product ONCE to fp16.  Every operator here is defined as "fp32 arithmetic,
+  // then round to the storage type" (what torch's .half() of an fp32 result gives), and the fused / unfused paths of
+  // the normalisation are compared bit for bit; the single rounding differs in about one element in 2^13.
+  asm("" : "+v"(f));
   return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
 
@@ -87,6 +92,7 @@ template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) 
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float a, float b) {
+  asm("" : "+v"(a), "+v"(b));                 // (see f32_to_f16_bits: no single-rounding v_fma_mix* fusion)
   f32x2_t v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }

@@ -68,16 +68,19 @@ template <> struct Mma<f16_t> {
   static __device__ __forceinline__ float hi(uint32_t v) { return f16_bits_to_f32(v >> 16); }
 };
 
-struct Task {
-  int lds;         // 8-byte entry index of the first of 4 pixels; -1 = no task
+struct Task {      // two registers per task: NT = 8 tasks + their 64 raw-data registers must stay under 96 VGPRs
+  int meta;        // 8-byte LDS entry index of the first of 4 pixels (bits 0-15) | channel quad << 16 | pixels of the quad
+                   // inside the row (0 = outside the image, 1..4) << 24;  < 0 = no task
   uint32_t voff;   // byte offset of (channel quad, row, column) inside the batch item; 0x80000000 = outside the image
-  int kq;          // channel quad (NORM) | pixels of the quad inside the row, 1..4, << 16 (RAGGED)
+  __device__ __forceinline__ int lds() const { return meta & 0xffff; }
+  __device__ __forceinline__ int kq() const { return (meta >> 16) & 0xff; }
+  __device__ __forceinline__ int nv() const { return (meta >> 24) & 0x7; }
 };
 
 // out: [B,81,H,W] (batch stride out_bs).  !RAGGED requires W % 8 == 0 and 16-byte aligned pointers / strides.
 // ws1 / ws2 (NORM): (count, mean, M2) partials of normalize_stats, [B*C][nseg][3] for f1 / f2.
 template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM>
-__global__ __launch_bounds__(NTHREADS, (NT > 4 ? 3 : 5))
+__global__ __launch_bounds__(NTHREADS, 5)       // <= 102 VGPRs: two 9-wave workgroups per CU
 void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* __restrict__ out,
                         int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope,
                         const float* __restrict__ ws1, const float* __restrict__ ws2, int nseg) {
@@ -109,14 +112,14 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
     const int t = tid + j * NTHREADS;
     const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;     // wave-uniform
     Task s;
-    s.lds = -1; s.voff = 0x80000000u; s.kq = 0;
-    int kq = 0, gy = -1, gx = -1;
+    s.meta = -1; s.voff = 0x80000000u;
+    int kq = 0, gy = -1, gx = -1, lds_at = -1;
     if (!from_f2) {
       if (t < n1) {
         kq = t / G::Q1;
         const int rem = t - kq * G::Q1, r = rem / (G::TW / 4), g = rem - r * (G::TW / 4);
         gy = y0 + r; gx = x0 + 4 * g;
-        s.lds = kq * G::F1_E + r * G::TW + 4 * g;
+        lds_at = kq * G::F1_E + r * G::TW + 4 * g;
       }
     } else {
       const int u = t - N1;
@@ -124,12 +127,18 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
         kq = u / G::Q2;
         const int rem = u - kq * G::Q2, r = rem / (G::F2W / 4), g = rem - r * (G::F2W / 4);
         gy = y0 - R + r; gx = x0 - R + 4 * g;
-        s.lds = KQ * G::F1_E + kq * G::F2_E + r * G::F2W + 4 * g;
+        lds_at = KQ * G::F1_E + kq * G::F2_E + r * G::F2W + 4 * g;
       }
     }
-    if (s.lds >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      s.voff = (uint32_t)((kq * 4 * H + gy) * W + gx) * 2u;
-      s.kq = kq | (min(W - gx, 4) << 16);
+    if (lds_at >= 0) s.meta = lds_at | (kq << 16);
+    if (lds_at >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const int nv = min(W - gx, 4);                   // pixels of the quad inside the row
+      // RAGGED (W >= 4): the quad that straddles the row end is loaded shifted left so that it ENDS at the row end
+      // (every byte of every load then lies inside the row: nothing is read past the tensor, and the bounds check of
+      // the descriptor, which works in whole dwords, never cuts off an odd-sized tensor's last element); the shift is
+      // undone in registers below
+      s.voff = (uint32_t)((kq * 4 * H + gy) * W + gx - (RAGGED ? 4 - nv : 0)) * 2u;
+      s.meta |= nv << 24;
     }
     task[j] = s;
     const __amdgpu_buffer_rsrc_t rs = from_f2 ? r2 : r1;
@@ -153,22 +162,35 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
   // ---- 4 channel rows x 4 pixels -> 4 pixel entries of 4 channels (v_perm), 2 ds_write_b128 per task
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    if (task[j].lds < 0) continue;
-    u32x2 v[4] = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
-    if constexpr (NORM) {
-      if (task[j].voff != 0x80000000u) {
-        const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;
-        const float2* sp = st + (from_f2 ? KQ * 4 : 0) + (task[j].kq & 0xffff) * 4;
+    if (task[j].meta < 0) continue;
+    if constexpr (RAGGED) {                             // the quad that straddles the row end
+      const int nv = task[j].nv();                      // 0 (outside: loads returned zeros) or 1..4
+      if (nv > 0 && nv < 4) {                           // undo the left shift of the load: pixel i = loaded pixel i + (4 - nv)
+        const int sh = 16 * (4 - nv);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float2 ms = sp[k];
-          v[k].x = pack2<T>((Mma<T>::lo(v[k].x) - ms.x) * ms.y, (Mma<T>::hi(v[k].x) - ms.x) * ms.y);
-          v[k].y = pack2<T>((Mma<T>::lo(v[k].y) - ms.x) * ms.y, (Mma<T>::hi(v[k].y) - ms.x) * ms.y);
+          const unsigned long long q = (((unsigned long long)raw[j][k].y << 32) | raw[j][k].x) >> sh;
+          raw[j][k].x = (uint32_t)q; raw[j][k].y = (uint32_t)(q >> 32);
         }
       }
     }
-    if constexpr (RAGGED) {                             // the quad that straddles the row end: drop pixels >= W
-      const int nv = task[j].kq >> 16;                  // 0 (outside: loads returned zeros) or 1..4
+    u32x2 v[4] = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
+    if constexpr (NORM) {
+      if (task[j].nv() != 0) {
+        const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;
+        const float2* sp = st + (from_f2 ? KQ * 4 : 0) + task[j].kq() * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 ms = sp[k];
+          // (x - mean) * rstd in separately rounded fp32 steps, then ONE rounding to the storage type (pack2), exactly
+          // like normalize_apply_kernel
+          v[k].x = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].x), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].x), ms.x), ms.y));
+          v[k].y = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].y), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].y), ms.x), ms.y));
+        }
+      }
+    }
+    if constexpr (RAGGED && NORM) {                     // pixels >= W were normalised zeros: drop them again
+      const int nv = task[j].nv();
       const uint32_t mx = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
       const uint32_t my = nv >= 4 ? 0xffffffffu : (nv == 3 ? 0x0000ffffu : 0u);
 #pragma unroll
@@ -179,8 +201,8 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
     lo.z = __builtin_amdgcn_perm(v[1].x, v[0].x, 0x07060302u);  lo.w = __builtin_amdgcn_perm(v[3].x, v[2].x, 0x07060302u);
     hi.x = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x05040100u);  hi.y = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x05040100u);
     hi.z = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x07060302u);  hi.w = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x07060302u);
-    *reinterpret_cast<uint4*>(lds + task[j].lds) = lo;
-    *reinterpret_cast<uint4*>(lds + task[j].lds + 2) = hi;
+    *reinterpret_cast<uint4*>(lds + task[j].lds()) = lo;
+    *reinterpret_cast<uint4*>(lds + task[j].lds() + 2) = hi;
   }
   __syncthreads();
 
@@ -201,8 +223,26 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
     const uint2* pb = lds_f1 + (u * G::UR + rsel) * G::TW + pix;                           // f1 (B operand)
     const uint2* pa = lds_f2 + (u * G::UR + rsel + dyi) * G::F2W + pix;                    // f2 (A operand), q = 0
-#pragma unroll 4
-    for (int kq = 0; kq < KQ; ++kq) {
+    // channel quads four at a time (16 ds_read_b64 in flight for 12 MFMAs), written out because hipcc does not partially
+    // unroll the run-time-bounded loop around the MFMA builtins.  (A hand-pipelined version that loads group g+1 during
+    // the MFMAs of group g was measured SLOWER at every level — 13.9 -> 17.6 us at the 1/4-resolution level: twice the
+    // operand registers and a block of moves per group; the 2-3 waves per SIMD already hide the LDS latency.)
+    int kq = 0;
+    for (; kq + 4 <= KQ; kq += 4) {
+      uint2 bv[4], c0[4], c1[4], c2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bv[i] = pb[(kq + i) * G::F1_E];
+        c0[i] = pa[(kq + i) * G::F2_E]; c1[i] = pa[(kq + i) * G::F2_E + 4]; c2[i] = pa[(kq + i) * G::F2_E + 8];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a0 = Mma<T>::mma(c0[i], bv[i], a0);
+        a1 = Mma<T>::mma(c1[i], bv[i], a1);
+        a2 = Mma<T>::mma(c2[i], bv[i], a2);
+      }
+    }
+    for (; kq < KQ; ++kq) {
       const uint2 bv = pb[kq * G::F1_E];
       const uint2 c0 = pa[kq * G::F2_E], c1 = pa[kq * G::F2_E + 4], c2 = pa[kq * G::F2_E + 8];
       a0 = Mma<T>::mma(c0, bv, a0);

@@ -29,6 +29,7 @@
 #include "internal.hpp"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace upf {
 namespace corr {
@@ -64,6 +65,8 @@ void launch_mfma(unsigned nblocks, hipStream_t stream, hipEvent_t ev0, hipEvent_
 }
 
 // ---- bf16 / fp16, C <= 208: the whole channel depth resident in LDS (corr81_allc_kernel.hpp) ----------------------
+static int g_variant = -1;     // upf_corr_set_option("variant"): -1 = choose, 0..3 = force where it fits
+static int g_old_path = 0;     // upf_corr_set_option("old_path"): 1 = the chunked round-1 kernels (A/B runs)
 struct AllcVariant { int uw, nu, nt; };
 constexpr AllcVariant ALLC[] = {{32, 4, 4}, {32, 2, 8}, {32, 1, 8}, {16, 1, 8}};
 constexpr int NALLC = 4;
@@ -86,20 +89,42 @@ static long long allc_nwg(int v, int B, int H, int W) {
   const int th = ALLC[v].nu * (64 / ALLC[v].uw);
   return (long long)B * cdiv(H, th) * cdiv(W, ALLC[v].uw);
 }
-// the largest tile (least halo traffic) that still gives every CU a workgroup; otherwise the variant with most workgroups
-static int allc_pick(int B, int C, int H, int W, bool ragged, bool norm) {
-  static const int forced = getenv("UPF_CORR_VARIANT") ? atoi(getenv("UPF_CORR_VARIANT")) : -1;
+static size_t allc_lds(int v, int KQ, bool ragged, bool norm) {
+  switch (v) {
+    case 0: return corrx::lds_bytes<32, 4>(KQ, ragged, norm);
+    case 1: return corrx::lds_bytes<32, 2>(KQ, ragged, norm);
+    case 2: return corrx::lds_bytes<32, 1>(KQ, ragged, norm);
+    default: return corrx::lds_bytes<16, 1>(KQ, ragged, norm);
+  }
+}
+// Tile geometry by shape (measured on MI355X, tools/corr_levels.py -> profiles/r02_corr81_levels.txt):
+//   * never a geometry whose grid needs a second round of workgroups when a smaller tile fits in one round
+//     (workgroups per CU = min(2, 160 KB / LDS per workgroup));
+//   * with >= 200 workgroups in one round: the LARGEST such tile (least halo staging per output pixel);
+//   * fewer than that (the coarse levels): the geometry with the MOST workgroups — the kernel is a latency chain there
+//     and a smaller tile shortens it;
+//   * everything needs several rounds (the large levels): the largest tile.
+// -1: nothing fits (C > 208).  -2: C > 40 on a grid of >= 160 8x32 tiles — the channel-chunked kernel with its larger
+// tile stages 36 % fewer bytes per pixel and wins there (1/8-resolution level of the large configurations).
+static int allc_pick(int B, int C, int H, int W, bool ragged, bool norm, bool chunked_ok) {
+  const int forced = g_variant;
   const int KQ = (C + 3) / 4;
   if (forced >= 0 && forced < NALLC && allc_fits(forced, KQ, ragged, norm)) return forced;
-  int best = -1;
-  long long best_n = -1;
+  if (chunked_ok && !norm && C > 40 && (long long)B * cdiv(H, 8) * cdiv(W, 32) >= 160) return -2;
+  int first = -1, big = -1, most = -1;
+  long long most_n = -1;
   for (int v = 0; v < NALLC; ++v) {
     if (!allc_fits(v, KQ, ragged, norm)) continue;
+    if (first < 0) first = v;
     const long long nwg = allc_nwg(v, B, H, W);
-    if (nwg >= 256) return v;
-    if (nwg > best_n) { best = v; best_n = nwg; }
+    const long long per_cu = LDS_MAX / allc_lds(v, KQ, ragged, norm) >= 2 ? 2 : 1;
+    if (nwg > 256 * per_cu) continue;                              // more than one round
+    if (nwg >= 200 && big < 0) big = v;
+    if (nwg > most_n) { most = v; most_n = nwg; }
   }
-  return best;
+  if (big >= 0) return big;
+  if (most >= 0) return most;
+  return first;
 }
 
 template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM>
@@ -139,7 +164,8 @@ int try_allc(const void* f1, const void* f2, void* out, int B, int C, int H, int
              const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if ((size_t)C * H * W * 2 >= (1ull << 31)) return 1;                       // buffer-descriptor range
   const bool ragged = !((W % 8 == 0) && (out_bs % 8 == 0) && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out, 16));
-  const int v = allc_pick(B, C, H, W, ragged, NORM);
+  if (ragged && W < 4) return 1;                                             // (rows shorter than a staging quad)
+  const int v = allc_pick(B, C, H, W, ragged, NORM, !ragged);
   if (v < 0) return 1;
   if (ragged) return launch_allc<T, true, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1);
   return launch_allc<T, false, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1);
@@ -155,8 +181,7 @@ int launch_fwd(const void* f1, const void* f2, void* out, int B, int C, int H, i
   const bool aligned = (W % 4 == 0) && (out_bs % 4 == 0) && aligned_to(f1, va) && aligned_to(f2, va) && aligned_to(out, va) &&
                        (size_t)C * H * W * sizeof(typename Elem<T>::store_t) < (1ull << 31);   // buffer-descriptor range
   if constexpr (sizeof(typename Elem<T>::store_t) == 2) {
-    static const bool old_path = getenv("UPF_CORR_OLD") != nullptr;           // (A/B runs against the round-1 kernels)
-    if (!old_path && getenv("UPF_CORR_NO_MFMA") == nullptr) {
+    if (!g_old_path && getenv("UPF_CORR_NO_MFMA") == nullptr) {
       const int rc = try_allc<T, false>(f1, f2, out, B, C, H, W, out_bs, slope, nullptr, nullptr, 0, stream, ev0, ev1);
       if (rc != 1) return rc;
     }
@@ -316,6 +341,17 @@ extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out
   const float* ws2 = ws + (size_t)N * nseg * 3;
   if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
   else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
-  UPF_REQUIRE(rc != 1, UPF_EUNSUPPORTED, "corr81_norm_forward: no kernel variant fits C=%d", C);
+  UPF_REQUIRE(rc != 1, UPF_EUNSUPPORTED, "corr81_norm_forward: no kernel variant fits C=%d W=%d (W >= 4 required)", C, W);
   return rc;
+}
+
+extern "C" int upf_corr_set_option(const char* name, int value) {
+  using namespace upf::corr;
+  int* slot = nullptr;
+  if (name && !strcmp(name, "variant")) slot = &g_variant;
+  else if (name && !strcmp(name, "old_path")) slot = &g_old_path;
+  if (!slot) return -1000;
+  const int prev = *slot;
+  *slot = value;
+  return prev;
 }

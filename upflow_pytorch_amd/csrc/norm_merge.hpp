@@ -1,7 +1,9 @@
 // Merge of the per-segment (count, mean, M2) partials of normalize_stats_kernel into a row's mean and 1/std — shared by
 // normalize_apply_kernel (csrc/misc.hip) and the fused loader of corr81_allc_kernel.hpp, which must agree BIT FOR BIT
-// (the fused path is tested for bit-equality against normalize + corr81).  Every step is an explicitly rounded fp32
-// operation, so the result does not depend on the translation unit's -ffp-contract setting.
+// (the fused path is tested for bit-equality against normalize + corr81).  Contraction is switched off inside the
+// function: HIP's __fmul_rn / __fadd_rn are plain `*` / `+` (clang's __clang_hip_math.h:271) and WOULD be fused into
+// FMAs under the default -ffp-contract=fast — the statistics of one row in a few thousand then differ by one ulp between
+// translation units.  (Both users are also compiled with -ffp-contract=off, upflow_pytorch_amd/_build.py.)
 #pragma once
 #include "common.hpp"
 
@@ -12,6 +14,7 @@ struct RowStats { float mean, std, rstd; };
 // w: [nseg][3] partials of one row, merged in fixed order with Chan's parallel-variance formula;
 // unbiased variance over HW elements (torch.var default, model/upflow.py:114), std = sqrt(var + 1e-16) (:126).
 __device__ __forceinline__ RowStats norm_merge_full(const float* __restrict__ w, int nseg, int HW) {
+#pragma clang fp contract(off)
   float n = w[0], mean = w[1], m2 = w[2];
   for (int k = 1; k < nseg; ++k) {
     const float nb = w[3 * k], mb = w[3 * k + 1], m2b = w[3 * k + 2];

@@ -457,8 +457,12 @@ class UPFlow_net(tools.abstract_model):
                 if use_sgu:
                     flow_up = sgi.forward_in_buffer(flow_up, sbuf, sslot, batch_shift=B)[1]
                 ops.warp_into(Fm, flow_up, pair[1], self.warping_layer.mask_mode, B)
-            normed = ops.normalize(pair.view(2 * nb, C, H, W))                # rows are (item, channel): one launch pair
-            ops.corr81_forward_raw(normed[:nb], normed[nb:], out=slot[:, :nc], leaky_slope=0.1)
+            if ops.corr81_norm_supported(pair) and not getattr(self, '_no_fused_norm', False):
+                # statistics pass + cost volume whose loader normalises: the normalised maps are never materialised
+                ops.corr81_norm_forward_raw(pair[0], pair[1], out=slot[:, :nc], leaky_slope=0.1)
+            else:
+                normed = ops.normalize(pair.view(2 * nb, C, H, W))            # rows are (item, channel): one launch pair
+                ops.corr81_forward_raw(normed[:nb], normed[nb:], out=slot[:, :nc], leaky_slope=0.1)
             ops.flow_update(flow_up, out=slot[:, nc + 32:])
             _, res = est.forward_in_buffer(buf)
             ops.flow_update(flow_up, res, out=buf[:, est._n_total:])          # flow_up + res -> context network input

@@ -43,6 +43,46 @@ def corr81_forward_raw(f1, f2, out=None, leaky_slope=0.0):
     return out
 
 
+def corr_set_option(name, value):
+    """Launch heuristics of the 16-bit cost volume (include/upflow_hip.h: "variant", "old_path"); returns the previous value."""
+    prev = _lib.lib().upf_corr_set_option(name.encode(), int(value))
+    if prev == -1000:
+        raise UpflowHipError('unknown cost-volume option %r' % name)
+    return prev
+
+
+def corr81_norm_supported(f):
+    """The fused normalise + cost-volume launch pair applies (bf16 / fp16 features with C <= 208, rows of >= 4 pixels, or
+    aligned rows of any length)."""
+    return (f.dtype in (torch.bfloat16, torch.float16) and f.shape[3] >= 4
+            and bool(_lib.lib().upf_corr81_norm_supported(f.shape[1], _lib.dtype_code(f))))
+
+
+def corr81_norm_forward_raw(f1, f2, out=None, leaky_slope=0.0):
+    """corr81(normalize(f1), normalize(f2)) with the normalisation applied inside the cost volume's loader
+    (upf_corr81_norm_forward: one statistics launch + one cost-volume launch; bit-identical to normalize x2 + corr81).
+    Inference only.  `out` as in corr81_forward_raw."""
+    if f1.shape != f2.shape or f1.dim() != 4 or f1.dtype != f2.dtype:
+        raise UpflowHipError('corr81_norm: inputs must be two [B,C,H,W] tensors of one dtype, got %s %s / %s %s'
+                             % (tuple(f1.shape), f1.dtype, tuple(f2.shape), f2.dtype))
+    B, C, H, W = f1.shape
+    dev = _lib.check_gpu(f1, f2)
+    if out is None:
+        out = torch.empty((B, 81, H, W), dtype=f1.dtype, device=f1.device)
+        bstride = 0
+    else:
+        if out.shape != (B, 81, H, W) or out.dtype != f1.dtype or out.device != f1.device:
+            raise UpflowHipError('corr81_norm: bad `out` %s %s' % (tuple(out.shape), out.dtype))
+        if out.stride()[1:] != (H * W, W, 1):
+            raise UpflowHipError('corr81_norm: `out` must be a channel slice of a contiguous NCHW buffer')
+        bstride = out.stride(0)
+    ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
+    with torch.cuda.device(dev):
+        _lib.call('upf_corr81_norm_forward', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(out), B, C, H, W,
+                  _lib.dtype_code(f1), bstride, float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
+    return out
+
+
 def corr81_forward_timed(f1, f2, out, leaky_slope=0.0, nrep=50):
     """-> (avg_us, min_us) of `nrep` launches, each timed by HIP events recorded around the kernel on
     the current stream (upf_corr81_forward_timed).  Measurement helper for bench.py."""
