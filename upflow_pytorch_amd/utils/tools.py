@@ -4,7 +4,8 @@ Same names and call signatures as `/root/reference/utils/tools.py` (class `tools
 namespace), so code written against the reference (`tools.torch_warp(x, flo)`,
 `tools.occ_check_model(...)(flow_f=..., flow_b=...)`, `tools.abstract_config`, `net.load_model(...)`)
 keeps working; the arithmetic runs in the HIP kernels of libupflow_hip.so.
-Out of scope: data prefetcher, meters, file I/O, visualisation, SP_transform.
+File formats (.flo, KITTI flow PNG) live in utils/flow_io.py, the KITTI readers and the evaluation bench in
+dataset/kitti_dataset.py.  Out of scope: data prefetcher, visualisation, SP_transform.
 """
 import torch
 import torch.nn as nn
@@ -104,6 +105,67 @@ class tools():
         def save_model_gpu(cls, model, path):
             inner = getattr(model, 'module', model)      # unwrap DDP / DataParallel (utils/tools.py:150-155)
             inner.save_model(path)
+
+    class AverageMeter():
+        """utils/tools.py:282-297."""
+
+        def __init__(self):
+            self.reset()
+
+        def reset(self):
+            self.val = 0
+            self.avg = 0
+            self.sum = 0
+            self.count = 0
+
+        def update(self, val, num):
+            self.val = val
+            self.sum += val * num
+            self.count += num
+            self.avg = self.sum / self.count
+
+    class time_clock():
+        """Wall-clock stopwatch (utils/tools.py time_clock)."""
+
+        def __init__(self):
+            self.st = 0.0
+            self.en = 0.0
+
+        def start(self):
+            import time
+            self.st = time.time()
+
+        def end(self):
+            import time
+            self.en = time.time()
+
+        def get_during(self):
+            return self.en - self.st
+
+    # ---- file formats of the data / evaluation edge (utils/tools.py:1482-1632), see utils/flow_io.py ---------------
+    @classmethod
+    def write_flo(cls, flow, filename):
+        from . import flow_io
+        flow_io.write_flo(flow, filename)
+
+    write_flow = write_flo
+
+    @classmethod
+    def read_flo(cls, filename):
+        from . import flow_io
+        return flow_io.read_flo(filename)
+
+    read_flow = read_flo
+
+    @classmethod
+    def write_kitti_png_file(cls, flow_fn, flow_data, mask_data=None):
+        from . import flow_io
+        flow_io.write_kitti_png_file(flow_fn, flow_data, mask_data)
+
+    @classmethod
+    def write_flow_png(cls, filename, uv, v=None, mask=None):
+        from . import flow_io
+        flow_io.write_flow_png(filename, uv, v, mask)
 
     class abs_test_model():
         """Evaluation protocol of utils/tools.py:157-164."""
