@@ -125,11 +125,13 @@ int upf_warp_forward(const void* x, const float* flow, void* y,
  * inference path warps straight out of / into the concatenation buffers the convolutions read (no slot copies). */
 int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
                              int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
-/* grad wrt x (fp32 buffer gx32 [B,C,H,W]) and wrt flow (gflow [B,2,H,W] fp32); both are fully produced by the call
- * (it zero-fills its scatter targets itself on `stream`; the caller passes uninitialised memory).
- * grad_y : [B,C,H,W] of `dtype`. */
+/* Gradients of the warp: gx [B,C,H,W] of `dtype` (wrt x; with batch_shift it lands on the item that was sampled) and
+ * gflow [B,2,H,W] fp32.  The scatter into gx is accumulated in 64-bit fixed point (value * 2^44, integer atomics), so the
+ * result is bit-reproducible run to run; `workspace`: upf_warp_backward_workspace_bytes(B,C,H,W) bytes of device memory
+ * (zero-filled by the call itself).  grad_y : [B,C,H,W] of `dtype`. */
+long long upf_warp_backward_workspace_bytes(int B, int C, int H, int W);
 int upf_warp_backward(const void* x, const float* flow, const void* grad_y,
-                      float* gx32, float* gflow,
+                      void* gx, float* gflow, void* workspace,
                       int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
 
 /* ---- flow up-sampling -------------------------------------------------------------------------
@@ -152,10 +154,12 @@ int upf_flow_upsample_backward(const float* grad_y, float* gx, int B, int C, int
 int upf_sgu_blend_forward(const float* flow_init, const void* x_out, float* flow_up,
                           float* inter_flow, float* inter_mask,
                           int B, int h, int w, int Hf, int Wf, int dtype, void* stream);
-/* g_flow_init32 [B,2,Hf,Wf] and g_x_out32 [B,3,h,w] are fp32 scatter-add targets, zero-filled by the
- * call itself (hipMemsetAsync on `stream`). */
+/* g_flow_init32 [B,2,Hf,Wf] and g_x_out32 [B,3,h,w] fp32, fully produced by the call.  The scatters accumulate in 64-bit
+ * fixed point (bit-reproducible); `workspace`: upf_sgu_blend_backward_workspace_bytes(B,h,w,Hf,Wf) bytes, zero-filled
+ * by the call itself on `stream`. */
+long long upf_sgu_blend_backward_workspace_bytes(int B, int h, int w, int Hf, int Wf);
 int upf_sgu_blend_backward(const float* flow_init, const void* x_out, const float* grad_flow_up,
-                           float* g_flow_init32, float* g_x_out32,
+                           float* g_flow_init32, float* g_x_out32, void* workspace,
                            int B, int h, int w, int Hf, int Wf, int dtype, void* stream);
 
 /* ---- feature normalisation  (network_tools.normalize_features, model/upflow.py:94-137) ---------
@@ -214,6 +218,38 @@ int upf_occ_check(const float* flow_f, const float* flow_b, float* occ_fw, float
 int upf_census_forward(const float* gray1, const float* gray2, float* dist, int B, int H, int W, int max_distance, void* stream);
 int upf_census_backward(const float* gray1, const float* gray2, const float* grad_dist, float* g_gray1, float* g_gray2,
                         int B, int H, int W, int max_distance, void* stream);
+
+/* ---- loss-side operators of the unsupervised training step  (SURVEY.md §8f rank 3), fp32 ---------------------------
+ * boundary-dilated warp, tools.boundary_dilated_warp.warp_im (utils/tools.py:351-499): out[n,c,i,j] = clamp-to-edge
+ * bilinear sample of the UN-cropped frame image[n,c] ([B,C,Hi,Wi]) at (j + start[n,0] + flow[n,0,i,j],
+ * i + start[n,1] + flow[n,1,i,j]), weights from the clamped corner coordinates.  flow [B,2,h,w], start [B,2] (x, y),
+ * out [B,C,h,w].  Backward: gradient wrt the flow (the image is data). */
+int upf_boundary_warp_forward(const float* image, const float* flow, const float* start, float* out,
+                              int B, int C, int Hi, int Wi, int h, int w, void* stream);
+int upf_boundary_warp_backward(const float* image, const float* flow, const float* start, const float* grad_out,
+                               float* grad_flow, int B, int C, int Hi, int Wi, int h, int w, void* stream);
+
+/* Deterministic reductions: a forward call writes upf_loss_partials(n_pixels) pairs of floats (one per workgroup) that
+ * the caller sums in order; n_pixels = B*H*W. */
+int upf_loss_partials(long long n_pixels);
+
+/* 'abs_robust' photometric / distillation term, network_tools.photo_loss_multi_type (model/upflow.py:265-288):
+ *   partials[k] = { sum (|x - y| + eps)^q * occ,  sum occ }   over workgroup k's pixels, all C channels;
+ * x, y [B,C,HW]; occ [B,HW] or NULL (= 1).  Backward: grad_x = coef[0] * occ * q * (|d|+eps)^(q-1) * sign(d),
+ * grad_y = -grad_x (either may be NULL); coef is a DEVICE scalar (upstream gradient / the loss's denominator). */
+int upf_robust_loss_forward(const float* x, const float* y, const float* occ, float* partials,
+                            int B, int C, int HW, float eps, float q, void* stream);
+int upf_robust_loss_backward(const float* x, const float* y, const float* occ, const float* coef,
+                             float* grad_x, float* grad_y, int B, int C, int HW, float eps, float q, void* stream);
+
+/* first-order edge-aware smoothness, network_tools.edge_aware_smoothness_order1 (model/upflow.py:197-216):
+ *   partials[k] = { sum |pred(i,j)-pred(i+1,j)| * exp(-mean_c |img(i,j)-img(i+1,j)|),  the same along j };
+ * loss = sum_x / (B*Cp*(H-1)*W) + sum_y / (B*Cp*H*(W-1)).  img [B,Ci,H,W], pred [B,Cp,H,W].
+ * Backward: gradient wrt pred of that loss times the device scalar grad_up[0] (gather, deterministic). */
+int upf_smooth_edge1_forward(const float* img, const float* pred, float* partials,
+                             int B, int Ci, int Cp, int H, int W, void* stream);
+int upf_smooth_edge1_backward(const float* img, const float* pred, const float* grad_up, float* grad_pred,
+                              int B, int Ci, int Cp, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

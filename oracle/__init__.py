@@ -19,4 +19,5 @@ interpolate), anchored on the reference's call sites `model/pwc_modules.py:74,79
 `utils/tools.py:1257,1261,1304`, `utils/pytorch_correlation.py:30-31,38`.
 """
 from .ops import (corr81, corr81_unfold, corr81_backward, correlation_general, warp, warp_backward,
-                  flow_upsample, sgu_blend, normalize_pair, occ_check, census_distance, epe)  # noqa: F401
+                  flow_upsample, sgu_blend, normalize_pair, occ_check, census_distance, epe,
+                  boundary_warp, robust_loss_sums, smooth_edge1)  # noqa: F401

@@ -305,3 +305,60 @@ def census_distance(img1, img2, max_distance=3):
         return t / torch.sqrt(0.81 + t ** 2)
     d = (ternary(img1) - ternary(img2)) ** 2
     return torch.sum(d / (0.1 + d), 1, keepdim=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss-side operators (training): boundary-dilated warp, abs_robust term, edge-aware smoothness
+# ------------------------------------------------------------------------------------------------
+def boundary_warp(I_nchw, flow_nchw, start_n211):
+    """tools.boundary_dilated_warp.warp_im restated (/root/reference/utils/tools.py:351-499): grid + crop offset
+    (:353-367), + flow (:497), floor / clamp of the corner indices (:404-412), four gathers, weights from the CLAMPED
+    corner coordinates (:458-466), output = wa*Ia + wb*Ib + wc*Ic + wd*Id (:467).  Differentiable torch ops (autograd
+    through this function is the oracle of the backward kernel)."""
+    B, C, Hi, Wi = I_nchw.shape
+    _, _, h, w = flow_nchw.shape
+    xx = torch.arange(w, dtype=torch.float32).view(1, 1, w)
+    yy = torch.arange(h, dtype=torch.float32).view(1, h, 1)
+    start = start_n211.float().reshape(-1, 2)
+    if start.shape[0] == 1:
+        start = start.expand(B, 2)
+    x = (xx + start[:, 0].view(B, 1, 1)) + flow_nchw[:, 0].float()
+    y = (yy + start[:, 1].view(B, 1, 1)) + flow_nchw[:, 1].float()
+    x0 = torch.floor(x).int()
+    y0 = torch.floor(y).int()
+    x1 = torch.clamp(x0 + 1, 0, Wi - 1)
+    y1 = torch.clamp(y0 + 1, 0, Hi - 1)
+    x0 = torch.clamp(x0, 0, Wi - 1)
+    y0 = torch.clamp(y0, 0, Hi - 1)
+    flat = I_nchw.float().reshape(B, C, Hi * Wi)
+
+    def tap(yi, xi):
+        idx = (yi.long() * Wi + xi.long()).view(B, 1, h * w).expand(B, C, h * w)
+        return torch.gather(flat, 2, idx).view(B, C, h, w)
+    x0f, x1f, y0f, y1f = x0.float(), x1.float(), y0.float(), y1.float()
+    wa = ((x1f - x) * (y1f - y)).unsqueeze(1)
+    wb = ((x1f - x) * (y - y0f)).unsqueeze(1)
+    wc = ((x - x0f) * (y1f - y)).unsqueeze(1)
+    wd = ((x - x0f) * (y - y0f)).unsqueeze(1)
+    return wa * tap(y0, x0) + wb * tap(y1, x0) + wc * tap(y0, x1) + wd * tap(y1, x1)
+
+
+def robust_loss_sums(x, y, occ=None, q=0.4, eps=0.01):
+    """The two sums of network_tools.photo_loss_multi_type('abs_robust') (model/upflow.py:270-272, :284-287):
+    sum((|x - y| + eps)^q * occ) and sum(occ) (occ = 1 without a mask)."""
+    d = (torch.abs(x - y) + eps).pow(q)
+    if occ is None:
+        return d.sum(), torch.tensor(float(x.shape[0] * x.shape[2] * x.shape[3]))
+    return (d * occ).sum(), occ.sum()
+
+
+def smooth_edge1(img, pred):
+    """network_tools.edge_aware_smoothness_order1 (model/upflow.py:197-216)."""
+    def gx(t):
+        return t[:, :, :-1, :] - t[:, :, 1:, :]
+
+    def gy(t):
+        return t[:, :, :, :-1] - t[:, :, :, 1:]
+    wx = torch.exp(-torch.mean(torch.abs(gx(img)), 1, keepdim=True))
+    wy = torch.exp(-torch.mean(torch.abs(gy(img)), 1, keepdim=True))
+    return torch.mean(torch.abs(gx(pred)) * wx) + torch.mean(torch.abs(gy(pred)) * wy)

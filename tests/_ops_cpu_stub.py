@@ -48,6 +48,9 @@ def install():
     ops.corr81_forward_raw = corr81_forward_raw
     ops.occ_check = lambda ff, fb, a1=0.1, a2=0.5: oops.occ_check(ff.detach().float(), fb.detach().float(), a1, a2)
     ops.census_distance = _census_distance
+    ops.boundary_warp = oops.boundary_warp
+    ops.robust_loss_sums = oops.robust_loss_sums
+    ops.smooth_edge1 = oops.smooth_edge1
     # Correlation's autograd Function calls corr81_forward_raw / corr81_backward_raw explicitly
     ops.corr81_backward_raw = lambda a, b, go: oops.corr81_backward(a, b, go)
     return ops

@@ -448,10 +448,47 @@ def golden_census():
         save('census_%d' % i, **d)
 
 
+def golden_losses(upflow, tools):
+    """Loss-side operators: tools.boundary_dilated_warp.warp_im (utils/tools.py:351-499) with its
+    gradient wrt the flow; network_tools.photo_loss_multi_type('abs_robust') with and without the occlusion weighting
+    (model/upflow.py:265-288) and its gradients; network_tools.edge_aware_smoothness_order1 (:197-216) and its gradient."""
+    nt = upflow.network_tools
+    for i, (B, C, Hi, Wi, h, w, sx, sy) in enumerate([(2, 3, 40, 56, 24, 40, 8, 8), (1, 3, 20, 30, 20, 30, 0, 0), (1, 2, 9, 7, 5, 4, 2, 3)]):
+        g = gen(7100 + i)
+        I = torch.rand(B, C, Hi, Wi, generator=g) - 0.45
+        flow = (torch.randn(B, 2, h, w, generator=g) * 4).requires_grad_(True)        # some samples leave the frame: clamping
+        start = torch.tensor([sx, sy], dtype=torch.float32).view(1, 2, 1, 1).repeat(B, 1, 1, 1)
+        out = tools.boundary_dilated_warp.warp_im(I, flow, start)
+        go = torch.randn(out.shape, generator=g)
+        (gf,) = torch.autograd.grad(out, flow, go)
+        save('bwarp_%d' % i, image=I, flow=flow, start=start, out=out, grad_out=go, gflow=gf)
+    for i, (B, C, H, W) in enumerate([(2, 3, 24, 40), (1, 2, 13, 17)]):
+        g = gen(7200 + i)
+        x = (torch.rand(B, C, H, W, generator=g) - 0.45).requires_grad_(True)
+        y = (x.detach() + 0.2 * torch.randn(B, C, H, W, generator=g)).requires_grad_(True)
+        y.data[0, 0, 0, :3] = x.data[0, 0, 0, :3]                                       # exact zeros: sign(0) = 0 in the gradient
+        occ = (torch.rand(B, 1, H, W, generator=g) > 0.3).float()
+        d = {'x': x, 'y': y, 'occ': occ}
+        for use_occ in (False, True):
+            v = nt.photo_loss_multi_type(x, y, occ, photo_loss_type='abs_robust', photo_loss_delta=0.4, photo_loss_use_occ=use_occ)
+            gx, gy = torch.autograd.grad(v, (x, y))
+            tag = 'occ' if use_occ else 'mean'
+            d.update({'loss_' + tag: np.array([float(v)]), 'gx_' + tag: gx, 'gy_' + tag: gy})
+        save('robust_%d' % i, **d)
+    for i, (B, H, W) in enumerate([(2, 24, 40), (1, 7, 5)]):
+        g = gen(7300 + i)
+        img = torch.rand(B, 3, H, W, generator=g) - 0.45
+        pred = (torch.randn(B, 2, H, W, generator=g) * 2).requires_grad_(True)
+        pred.data[0, 0, 1, :2] = pred.data[0, 0, 0, :2]                                 # exact zero differences
+        v = nt.edge_aware_smoothness_order1(img=img, pred=pred)
+        (gp,) = torch.autograd.grad(v, pred)
+        save('smooth1_%d' % i, img=img, pred=pred, loss=np.array([float(v)]), gpred=gp)
+
+
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'net', 'net384', 'train']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'net', 'net384', 'train']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -466,6 +503,8 @@ def main():
         golden_occ(tools)
     if 'census' in which:
         golden_census()
+    if 'losses' in which:
+        golden_losses(upflow, tools)
     if 'net' in which:
         golden_net(upflow, pwc, tools)
     if 'net384' in which:

@@ -536,3 +536,142 @@ def test_operator_on_second_device_after_first():
     a = ops.corr81(f1.cuda(0), f2.cuda(0)).cpu()
     b = ops.corr81(f1.cuda(1), f2.cuda(1)).cpu()
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------- loss-side operators (csrc/loss.hip)
+@pytest.mark.parametrize('i', range(3))
+def test_boundary_warp_hip_golden(hip, i):
+    """upf_boundary_warp_forward / _backward against the reference's tools.boundary_dilated_warp.warp_im and its autograd
+    gradient wrt the flow (tests/golden/bwarp_*.npz)."""
+    g = load_golden('bwarp_%d' % i)
+    flow = dev(g['flow']).requires_grad_(True)
+    out = hip.boundary_warp(dev(g['image']), flow, dev(g['start']))
+    assert (out.detach().cpu() - g['out']).abs().max() <= 1e-6
+    (gf,) = torch.autograd.grad(out, flow, dev(g['grad_out']))
+    assert (gf.cpu() - g['gflow']).abs().max() <= 1e-5
+    (gf2,) = torch.autograd.grad(hip.boundary_warp(dev(g['image']), flow, dev(g['start'])), flow, dev(g['grad_out']))
+    assert torch.equal(gf, gf2)
+    with pytest.raises(RuntimeError):
+        hip.boundary_warp(g['image'], g['flow'], g['start'])                  # CPU tensors: no fallback
+
+
+def test_boundary_warp_out_of_frame_and_nan(hip):
+    """Clamp-to-edge: samples far outside the frame read edge pixels with the reference's clamped-corner weights
+    (utils/tools.py:409-412, :458-466); NaN / huge flows must not fault."""
+    g = torch.Generator().manual_seed(1)
+    I = torch.rand(1, 3, 12, 16, generator=g)
+    flow = torch.zeros(1, 2, 6, 8)
+    flow[0, 0, 0, 0], flow[0, 1, 1, 1], flow[0, 0, 2, 2] = 1e30, -1e30, float('nan')
+    flow[0, :, 3, 3] = torch.tensor([100.5, -40.25])
+    start = torch.tensor([3.0, 2.0]).view(1, 2, 1, 1)
+    got = hip.boundary_warp(I.cuda(), flow.cuda(), start.cuda()).cpu()
+    want = oops.boundary_warp(I, flow, start)
+    ok = torch.ones(6, 8, dtype=torch.bool)
+    ok[0, 0] = ok[1, 1] = ok[2, 2] = False                                    # (int conversion of 1e30 / NaN is undefined in torch)
+    assert (got - want)[0, :, ok].abs().max() <= 1e-6 and torch.isfinite(got[0, :, ok]).all()
+
+
+@pytest.mark.parametrize('i', range(2))
+def test_robust_loss_hip_golden(hip, i):
+    g = load_golden('robust_%d' % i)
+    for tag, occ in (('mean', None), ('occ', g['occ'])):
+        x, y = dev(g['x']).requires_grad_(True), dev(g['y']).requires_grad_(True)
+        s, so = hip.robust_loss_sums(x, y, None if occ is None else dev(occ))
+        v = s / (so + 1e-6) if occ is not None else s / x.numel()
+        assert abs(float(v) - float(g['loss_' + tag])) <= 2e-6 * max(1.0, abs(float(v)))
+        gx, gy = torch.autograd.grad(v, (x, y))
+        assert (gx.cpu() - g['gx_' + tag]).abs().max() <= 1e-7 and (gy.cpu() - g['gy_' + tag]).abs().max() <= 1e-7
+        s2, _ = hip.robust_loss_sums(x, y, None if occ is None else dev(occ))
+        assert torch.equal(s, s2)                                             # deterministic reduction
+
+
+@pytest.mark.parametrize('shape', [(4, 3, 256, 832), (2, 2, 64, 208), (1, 3, 5, 7)])
+def test_robust_loss_hip_vs_oracle(hip, shape):
+    """Full training sizes (config 3: 256x832 crops): value and gradients against the oracle's torch spelling."""
+    gg = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(shape, generator=gg) - 0.45
+    y = x + 0.1 * torch.randn(shape, generator=gg)
+    occ = (torch.rand(shape[0], 1, shape[2], shape[3], generator=gg) > 0.2).float()
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    sw, sow = oops.robust_loss_sums(xr, yr, occ)
+    vw = sw / (sow + 1e-6)
+    gxw, gyw = torch.autograd.grad(vw, (xr, yr))
+    xd, yd = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+    s, so = hip.robust_loss_sums(xd, yd, dev(occ))
+    v = s / (so + 1e-6)
+    gx, gy = torch.autograd.grad(v, (xd, yd))
+    assert abs(float(v) - float(vw)) <= 5e-6 * abs(float(vw)) and float(so) == float(sow)
+    assert relerr(gx.cpu(), gxw) <= 1e-5 and relerr(gy.cpu(), gyw) <= 1e-5
+
+
+@pytest.mark.parametrize('i', range(2))
+def test_smooth_edge1_hip_golden(hip, i):
+    g = load_golden('smooth1_%d' % i)
+    pred = dev(g['pred']).requires_grad_(True)
+    v = hip.smooth_edge1(dev(g['img']), pred)
+    assert abs(float(v) - float(g['loss'])) <= 2e-6
+    (gp,) = torch.autograd.grad(v, pred)
+    assert (gp.cpu() - g['gpred']).abs().max() <= 1e-8
+    (gp2,) = torch.autograd.grad(hip.smooth_edge1(dev(g['img']), pred), pred)
+    assert torch.equal(gp, gp2)
+
+
+def test_smooth_edge1_hip_vs_oracle_full_size(hip):
+    gg = torch.Generator().manual_seed(3)
+    img = torch.rand(4, 3, 256, 832, generator=gg) - 0.45
+    pred = torch.randn(4, 2, 256, 832, generator=gg) * 2
+    pr = pred.clone().requires_grad_(True)
+    vw = oops.smooth_edge1(img, pr)
+    (gw,) = torch.autograd.grad(vw, pr)
+    pd = dev(pred).requires_grad_(True)
+    v = hip.smooth_edge1(dev(img), pd)
+    (gp,) = torch.autograd.grad(v, pd)
+    assert abs(float(v) - float(vw)) <= 5e-6 * abs(float(vw))
+    assert (gp.cpu() - gw).abs().max() <= 1e-9 + 1e-5 * float(gw.abs().max())
+
+
+def test_backward_kernels_are_bit_deterministic(hip):
+    """warp / SGU-blend backward scatter through 64-bit fixed-point integer atomics (csrc/common.hpp: fix_add): two runs on
+    the same bits give the same bits, also where many output pixels hit the same source pixel (constant converging flow)
+    and where the channel range is split over workgroups."""
+    g = torch.Generator().manual_seed(17)
+    for (B, C, H, W) in [(2, 128, 12, 40), (4, 32, 64, 208), (1, 3, 33, 65)]:
+        x = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_(True)
+        flow = (torch.randn(B, 2, H, W, generator=g) * 3).cuda()
+        flow[:, :, : H // 2] = -torch.stack(torch.meshgrid(torch.arange(H // 2), torch.arange(W), indexing='ij')[::-1]).float().cuda() + 2.25   # all -> one pixel
+        flow = flow.requires_grad_(True)
+        gy = torch.randn(B, C, H, W, generator=g).cuda()
+        outs = []
+        for _ in range(2):
+            y = hip.warp(x, flow, 'literal', B // 2)
+            outs.append(torch.autograd.grad(y, (x, flow), gy))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for (B, h, w, Hf, Wf) in [(2, 24, 80, 24, 80), (2, 16, 52, 64, 208)]:
+        xo = torch.randn(B, 3, h, w, generator=g).cuda().requires_grad_(True)
+        fi = (torch.randn(B, 2, Hf, Wf, generator=g) * 3).cuda().requires_grad_(True)
+        gu = torch.randn(B, 2, Hf, Wf, generator=g).cuda()
+        outs = []
+        for _ in range(2):
+            up = hip.sgu_blend(fi, xo, None if (Hf, Wf) == (h, w) else fi)[1]
+            outs.append(torch.autograd.grad(up, (xo, fi), gu))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12, 20), (1, 32, 24, 40)])
+def test_warp_backward_vs_oracle_with_batch_shift_and_collisions(hip, shape):
+    """Gradient of the warp wrt x and flow against autograd through the oracle, incl. the stacked-batch form
+    (batch_shift: item n samples item (n + shift) % B, so gx lands on the shifted item) and many-to-one sampling."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(5 + sum(shape))
+    x = torch.randn(shape, generator=g)
+    flow = torch.randn(B, 2, H, W, generator=g) * 2
+    flow[:, :, :3] = 0.5 - torch.stack(torch.meshgrid(torch.arange(3), torch.arange(W), indexing='ij')[::-1]).float()   # converge on (0.5, 0.5)
+    gy = torch.randn(shape, generator=g)
+    for shift in (0, B // 2):
+        xr = x.clone().requires_grad_(True)
+        fr = flow.clone().requires_grad_(True)
+        yw = oracle.warp(torch.roll(xr, -shift, 0), fr, 'robust')
+        gxw, gfw = torch.autograd.grad(yw, (xr, fr), gy)
+        xd, fd = dev(x).requires_grad_(True), dev(flow).requires_grad_(True)
+        gx, gf = torch.autograd.grad(hip.warp(xd, fd, 'robust', shift), (xd, fd), dev(gy))
+        assert relerr(gx.cpu(), gxw) <= 1e-5 and relerr(gf.cpu(), gfw) <= 1e-4

@@ -130,3 +130,36 @@ def test_census_distance(i):
         assert (gw - g['grad_occ_%d' % k]).abs().max() <= 1e-6
     v = _census_loss(ops.census_distance(im1, g['img1_warp']), g['masks'][0], use_occ=False)
     assert abs(float(v) - float(g['loss_mean'])) <= 1e-6
+
+
+# ------------------------------------------------------------------------------- loss-side operators
+@pytest.mark.parametrize('i', range(3))
+def test_boundary_warp_golden(i):
+    g = load_golden('bwarp_%d' % i)
+    flow = g['flow'].clone().requires_grad_(True)
+    out = ops.boundary_warp(g['image'], flow, g['start'])
+    assert (out - g['out']).abs().max() <= 1e-6
+    (gf,) = torch.autograd.grad(out, flow, g['grad_out'])
+    assert (gf - g['gflow']).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize('i', range(2))
+def test_robust_loss_golden(i):
+    g = load_golden('robust_%d' % i)
+    for tag, occ in (('mean', None), ('occ', g['occ'])):
+        x, y = g['x'].clone().requires_grad_(True), g['y'].clone().requires_grad_(True)
+        s, so = ops.robust_loss_sums(x, y, occ)
+        v = s / (so + 1e-6) if occ is not None else s / x.numel()
+        assert abs(float(v) - float(g['loss_' + tag])) <= 1e-6 * max(1.0, abs(float(v)))
+        gx, gy = torch.autograd.grad(v, (x, y))
+        assert (gx - g['gx_' + tag]).abs().max() <= 1e-7 and (gy - g['gy_' + tag]).abs().max() <= 1e-7
+
+
+@pytest.mark.parametrize('i', range(2))
+def test_smooth_edge1_golden(i):
+    g = load_golden('smooth1_%d' % i)
+    pred = g['pred'].clone().requires_grad_(True)
+    v = ops.smooth_edge1(g['img'], pred)
+    assert abs(float(v) - float(g['loss'])) <= 1e-6
+    (gp,) = torch.autograd.grad(v, pred)
+    assert (gp - g['gpred']).abs().max() <= 1e-8

@@ -21,6 +21,7 @@ SOURCES = [
     ('warp.hip', ['-ffp-contract=off']),
     ('sgu_blend.hip', ['-ffp-contract=off']),
     ('misc.hip', ['-ffp-contract=off']),
+    ('loss.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 

@@ -30,17 +30,23 @@ SIGNATURES = {
     'upf_warp_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_warp_forward_strided': [_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_update': [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp],
-    'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_forward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_backward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_sgu_blend_forward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    'upf_sgu_blend_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_sgu_blend_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_normalize_forward': [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_conv_pack_weights': [_vp, _vp, _i, _i, _i, _i, _vp],
     'upf_conv_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_census_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_census_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'upf_boundary_warp_forward': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_boundary_warp_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_robust_loss_forward': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
+    'upf_robust_loss_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
+    'upf_smooth_edge1_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_smooth_edge1_backward': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_occ_check': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
 }
 
@@ -73,6 +79,12 @@ def lib():
         L.upf_corr81_norm_workspace_bytes.restype = _ll
         L.upf_corr_set_option.argtypes = [_c.c_char_p, _i]
         L.upf_corr_set_option.restype = _i
+        L.upf_warp_backward_workspace_bytes.argtypes = [_i, _i, _i, _i]
+        L.upf_warp_backward_workspace_bytes.restype = _ll
+        L.upf_sgu_blend_backward_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
+        L.upf_sgu_blend_backward_workspace_bytes.restype = _ll
+        L.upf_loss_partials.argtypes = [_ll]
+        L.upf_loss_partials.restype = _i
         L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]
         L.upf_conv_packed_bytes.restype = _ll
         L.upf_conv_set_option.argtypes = [_c.c_char_p, _i]

@@ -134,6 +134,20 @@ template <> struct VecIO<f16_t> {
   }
 };
 
+// ---- deterministic scatter-add: 64-bit fixed point (value * 2^44) through native integer atomics ---------------------
+// Integer addition is associative, so the accumulated value does not depend on the arrival order of the workgroups
+// (fp32 atomicAdd does).  Quantum 2^-44 = 5.7e-14, range +-2^19.  Used by the backward kernels whose inverse map is
+// unbounded (warp, SGU blend).
+constexpr float FIX_SCALE = 17592186044416.0f;        // 2^44
+constexpr float FIX_INV = 1.0f / 17592186044416.0f;
+__device__ __forceinline__ void fix_add(unsigned long long* p, float v) {
+  // saturate far below the int64 range (NaN -> 0: a non-finite gradient is already visible in the loss)
+  const float s = fminf(fmaxf(v * FIX_SCALE, -4.0e18f), 4.0e18f);
+  const long long q = (s == s) ? __float2ll_rn(s) : 0ll;
+  atomicAdd(p, (unsigned long long)q);
+}
+__device__ __forceinline__ float fix_get(unsigned long long v) { return (float)((double)(long long)v * (double)FIX_INV); }
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md), each
 // XCD has a private 4 MiB L2.  Give every XCD a contiguous run of tiles so that neighbouring tiles
 // (which share their 4-pixel halos) hit the same L2.  Bijective for any grid size.

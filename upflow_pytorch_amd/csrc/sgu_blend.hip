@@ -77,14 +77,16 @@ void blend_fwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
 }
 
 // Backward of the blend.  g = grad of flow_up (2 channels).
-//   d/d flow_init : m*g at p, plus (1-m)*g*w_tap scattered to the 4 taps        (atomics)
+//   d/d flow_init : m*g at p, plus (1-m)*g*w_tap scattered to the 4 taps
 //   d/d inter_flow: (1-m) * sum_c g_c * d(warp_c)/d(pos)
 //   d/d m         : sum_c g_c * (flow_init_c(p) - warped_c);  d/d logit through sigmoid' (and through
-//                   the bilinear up-sampling weights at the final level)         (atomics at final level)
+//                   the bilinear up-sampling weights at the final level: a scatter into the low-resolution map)
+// Both scatters accumulate in 64-bit fixed point (common.hpp: fix_add) => bit-reproducible; a second launch converts.
 template <typename T>
 __global__ __launch_bounds__(THREADS)
 void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__ x_out, const float* __restrict__ g_up,
-                      float* __restrict__ g_init, float* __restrict__ g_xo, int h, int w, int Hf, int Wf) {
+                      unsigned long long* __restrict__ g_init, unsigned long long* __restrict__ g_xo64, float* __restrict__ g_xo,
+                      int h, int w, int Hf, int Wf) {
   const int HW = Hf * Wf, hw = h * w;
   const int p = blockIdx.x * THREADS + threadIdx.x;
   if (p >= HW) return;
@@ -104,7 +106,7 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
   const float dwx[4] = {-ay, ay, -by, by}, dwy[4] = {-ax, -bx, ax, bx};
   const float om = 1.0f - m;
   float gix = 0.f, giy = 0.f, gm = 0.f;
-  float* gi = g_init + (size_t)n * 2 * HW;
+  unsigned long long* gi = g_init + (size_t)n * 2 * HW;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const float* f = f0 + c * HW;
@@ -115,11 +117,11 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
       if (!t.in[k]) continue;
       const float v = f[o[k]];
       warped += v * t.w[k];
-      atomicAdd(gi + c * HW + o[k], om * g * t.w[k]);
+      fix_add(gi + c * HW + o[k], om * g * t.w[k]);
       gix += v * dwx[k] * g;
       giy += v * dwy[k] * g;
     }
-    atomicAdd(gi + c * HW + p, m * g);
+    fix_add(gi + c * HW + p, m * g);
     gm += g * (f[p] - warped);
   }
   const float mx = ((float)(Wf - 1) * 0.5f) * (2.0f / (float)max(Wf - 1, 1));
@@ -127,6 +129,7 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
   gix *= om * mx;
   giy *= om * my;
   float* gx = g_xo + (size_t)n * 3 * hw;
+  unsigned long long* gx64 = g_xo64 + (size_t)n * 3 * hw;
   if (Hf == h && Wf == w) {
     gx[p] = gix;
     gx[hw + p] = giy;
@@ -138,11 +141,18 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
   const float bw[4] = {ly.l0 * lx.l0, ly.l0 * lx.l1, ly.l1 * lx.l0, ly.l1 * lx.l1};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    atomicAdd(gx + q[k], gix * su * bw[k]);
-    atomicAdd(gx + hw + q[k], giy * sv * bw[k]);
+    fix_add(gx64 + q[k], gix * su * bw[k]);
+    fix_add(gx64 + hw + q[k], giy * sv * bw[k]);
     const float s = sigmoidf(Elem<T>::load(xo + 2 * hw + q[k]));
-    atomicAdd(gx + 2 * hw + q[k], gm * bw[k] * s * (1.0f - s));
+    fix_add(gx64 + 2 * hw + q[k], gm * bw[k] * s * (1.0f - s));
   }
+}
+
+__global__ void blend_bwd_finish_kernel(const unsigned long long* __restrict__ gi64, float* __restrict__ g_init, long long n_init,
+                                        const unsigned long long* __restrict__ gx64, float* __restrict__ g_xo, long long n_xo) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n_init) g_init[i] = fix_get(gi64[i]);
+  if (gx64 && i < n_xo) g_xo[i] = fix_get(gx64[i]);
 }
 
 // ---- flow up-sampling -------------------------------------------------------------------------
@@ -249,20 +259,30 @@ extern "C" int upf_sgu_blend_forward(const float* flow_init, const void* x_out, 
   return check_launch("sgu_blend_forward");
 }
 
+extern "C" long long upf_sgu_blend_backward_workspace_bytes(int B, int h, int w, int Hf, int Wf) {
+  return ((long long)B * 2 * Hf * Wf + (long long)B * 3 * h * w) * (long long)sizeof(unsigned long long);
+}
+
 extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out, const float* grad_flow_up,
-                                      float* g_flow_init32, float* g_x_out32, int B, int h, int w, int Hf, int Wf,
+                                      float* g_flow_init32, float* g_x_out32, void* workspace, int B, int h, int w, int Hf, int Wf,
                                       int dtype, void* stream) {
   using namespace upf;
-  UPF_REQUIRE(flow_init && x_out && grad_flow_up && g_flow_init32 && g_x_out32, UPF_EINVAL, "sgu_blend_backward: null pointer");
+  UPF_REQUIRE(flow_init && x_out && grad_flow_up && g_flow_init32 && g_x_out32 && workspace, UPF_EINVAL, "sgu_blend_backward: null pointer");
   UPF_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && Hf >= h && Wf >= w, UPF_EINVAL, "sgu_blend_backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(g_flow_init32, 0, (size_t)B * 2 * Hf * Wf * sizeof(float), s);
-  if (e == hipSuccess) e = hipMemsetAsync(g_x_out32, 0, (size_t)B * 3 * h * w * sizeof(float), s);
+  const long long n_init = (long long)B * 2 * Hf * Wf, n_xo = (long long)B * 3 * h * w;
+  const bool final_level = !(Hf == h && Wf == w);           // the low-resolution map is a scatter target only then
+  unsigned long long* gi64 = (unsigned long long*)workspace;
+  unsigned long long* gx64 = gi64 + n_init;
+  hipError_t e = hipMemsetAsync(gi64, 0, (size_t)(n_init + (final_level ? n_xo : 0)) * sizeof(unsigned long long), s);
   UPF_REQUIRE(e == hipSuccess, (int)e, "sgu_blend_backward: memset failed: %s", hipGetErrorString(e));
   dim3 grid(cdiv(Hf * Wf, sgu::THREADS), B);
   UPF_DISPATCH(dtype, T,
                hipLaunchKernelGGL((sgu::blend_bwd_kernel<T>), grid, dim3(sgu::THREADS), 0, s,
-                                  flow_init, (const T*)x_out, grad_flow_up, g_flow_init32, g_x_out32, h, w, Hf, Wf));
+                                  flow_init, (const T*)x_out, grad_flow_up, gi64, gx64, g_x_out32, h, w, Hf, Wf));
+  const long long n_fin = n_init > n_xo ? n_init : n_xo;
+  hipLaunchKernelGGL(sgu::blend_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, s,
+                     gi64, g_flow_init32, n_init, final_level ? gx64 : nullptr, g_x_out32, n_xo);
   return check_launch("sgu_blend_backward");
 }
 

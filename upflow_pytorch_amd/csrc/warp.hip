@@ -137,14 +137,17 @@ void warp_fwd_narrow_kernel(const T* __restrict__ x, long long xbs, const float*
   }
 }
 
-// Backward: one thread per pixel, loops over its channel slice.
-//   gx[tap] += w_tap * gy            (fp32 atomics into gx32)
-//   gflow   += gy * d(sample)/d(pos) (summed over the slice, one atomic per thread per component
-//                                     when the channel range is split over blockIdx.y)
+// Backward: one thread per OUTPUT pixel, loops over its channel slice and scatters into the source image:
+//   gx[tap] += w_tap * gy            gflow += gy * d(sample)/d(pos)
+// A scatter because the inverse map (which output pixels sample a given source pixel) is unbounded for arbitrary flows.
+// DETERMINISTIC all the same: contributions are accumulated as 64-bit FIXED-POINT integers (value * 2^44, native 64-bit
+// integer atomics) — integer addition is associative, so the sum does not depend on the order in which the workgroups
+// arrive, unlike the fp32 atomicAdd of the first version.  Quantum 2^-44 = 5.7e-14 (below fp32 resolution for every
+// gradient >= 1e-6, absolute error 5.7e-14 below that), range +-2^19; a second launch converts to the output type.
 template <typename T>
 __global__ __launch_bounds__(THREADS)
 void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, const T* __restrict__ gy,
-                     float* __restrict__ gx32, float* __restrict__ gflow,
+                     unsigned long long* __restrict__ gx64, unsigned long long* __restrict__ gf64, float* __restrict__ gflow,
                      int C, int H, int W, int cpt, int mask_mode, int shift) {
   const int HW = H * W;
   const int p = blockIdx.x * THREADS + threadIdx.x;
@@ -156,8 +159,11 @@ void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, co
   const float fx = flow[((size_t)n * 2 + 0) * HW + p];
   const float fy = flow[((size_t)n * 2 + 1) * HW + p];
   const Taps t = make_taps(j, i, fx, fy, H, W);
-  if (!taps_valid(t, mask_mode, j, i, fx, fy, H, W)) return;   // mask is a constant factor: zero grads
-
+  float* gf = gflow + (size_t)n * 2 * HW + p;
+  if (!taps_valid(t, mask_mode, j, i, fx, fy, H, W)) {   // mask is a constant factor: zero grads
+    if (gridDim.y == 1) { gf[0] = 0.f; gf[HW] = 0.f; }
+    return;
+  }
   const int xa = min(max(t.x0, 0), W - 1), xb1 = min(max(t.x0 + 1, 0), W - 1);
   const int ya = min(max(t.y0, 0), H - 1), yb1 = min(max(t.y0 + 1, 0), H - 1);
   const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
@@ -166,21 +172,32 @@ void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, co
   const float ay = (float)(t.y0 + 1) - t.iy, by = t.iy - (float)t.y0;
   const T* xb = x + ((size_t)ns * C + c_begin) * HW;
   const T* gb = gy + ((size_t)n * C + c_begin) * HW + p;
-  float* gxb = gx32 + ((size_t)ns * C + c_begin) * HW;
+  unsigned long long* gxb = gx64 + ((size_t)ns * C + c_begin) * HW;
   float gix = 0.f, giy = 0.f;
   for (int c = c_begin; c < c_end; ++c, xb += HW, gb += HW, gxb += HW) {
     const float g = Elem<T>::load(gb);
-    if (t.in[0]) { const float v = Elem<T>::load(xb + o0); atomicAdd(gxb + o0, t.w[0] * g); gix -= v * ay * g; giy -= v * ax * g; }
-    if (t.in[1]) { const float v = Elem<T>::load(xb + o1); atomicAdd(gxb + o1, t.w[1] * g); gix += v * ay * g; giy -= v * bx * g; }
-    if (t.in[2]) { const float v = Elem<T>::load(xb + o2); atomicAdd(gxb + o2, t.w[2] * g); gix -= v * by * g; giy += v * ax * g; }
-    if (t.in[3]) { const float v = Elem<T>::load(xb + o3); atomicAdd(gxb + o3, t.w[3] * g); gix += v * by * g; giy += v * bx * g; }
+    if (t.in[0]) { const float v = Elem<T>::load(xb + o0); fix_add(gxb + o0, t.w[0] * g); gix -= v * ay * g; giy -= v * ax * g; }
+    if (t.in[1]) { const float v = Elem<T>::load(xb + o1); fix_add(gxb + o1, t.w[1] * g); gix += v * ay * g; giy -= v * bx * g; }
+    if (t.in[2]) { const float v = Elem<T>::load(xb + o2); fix_add(gxb + o2, t.w[2] * g); gix -= v * by * g; giy += v * ax * g; }
+    if (t.in[3]) { const float v = Elem<T>::load(xb + o3); fix_add(gxb + o3, t.w[3] * g); gix += v * by * g; giy += v * bx * g; }
   }
   // chain rule through un-normalise ((W-1)/2) and the python-side normalise (2/max(W-1,1))
   const float mx = ((float)(W - 1) * 0.5f) * (2.0f / (float)max(W - 1, 1));
   const float my = ((float)(H - 1) * 0.5f) * (2.0f / (float)max(H - 1, 1));
-  float* gf = gflow + (size_t)n * 2 * HW + p;
   if (gridDim.y == 1) { gf[0] = gix * mx; gf[HW] = giy * my; }
-  else { atomicAdd(gf, gix * mx); atomicAdd(gf + HW, giy * my); }
+  else {                                                 // channel range split over blockIdx.y: fixed-point partial sums
+    unsigned long long* q = gf64 + (size_t)n * 2 * HW + p;
+    fix_add(q, gix * mx); fix_add(q + HW, giy * my);
+  }
+}
+
+// fixed point -> output type (gx in the feature dtype; gflow fp32 when the channel range was split)
+template <typename T>
+__global__ void warp_bwd_finish_kernel(const unsigned long long* __restrict__ gx64, T* __restrict__ gx, long long n_gx,
+                                       const unsigned long long* __restrict__ gf64, float* __restrict__ gflow, long long n_gf) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n_gx) Elem<T>::store(gx + i, fix_get(gx64[i]));
+  if (gf64 && i < n_gf) gflow[i] = fix_get(gf64[i]);
 }
 
 static int pick_cpt(int B, int C, int HW) {
@@ -227,22 +244,33 @@ extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B
   return upf_warp_forward_strided(x, 0, flow, y, 0, B, C, H, W, dtype, mask_mode, batch_shift, stream);
 }
 
-extern "C" int upf_warp_backward(const void* x, const float* flow, const void* grad_y, float* gx32, float* gflow,
+extern "C" long long upf_warp_backward_workspace_bytes(int B, int C, int H, int W) {
+  return ((long long)B * C * H * W + (long long)B * 2 * H * W) * (long long)sizeof(unsigned long long);
+}
+
+extern "C" int upf_warp_backward(const void* x, const float* flow, const void* grad_y, void* gx, float* gflow, void* workspace,
                                  int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream) {
   using namespace upf;
-  UPF_REQUIRE(x && flow && grad_y && gx32 && gflow, UPF_EINVAL, "warp_backward: null pointer");
+  UPF_REQUIRE(x && flow && grad_y && gx && gflow && workspace, UPF_EINVAL, "warp_backward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_backward: bad shape");
   UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_backward: bad mask_mode %d", mask_mode);
   UPF_REQUIRE(batch_shift >= 0 && batch_shift < B, UPF_EINVAL, "warp_backward: batch_shift %d not in [0,%d)", batch_shift, B);
   const int HW = H * W;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(gx32, 0, (size_t)B * C * HW * sizeof(float), s);
-  if (e == hipSuccess) e = hipMemsetAsync(gflow, 0, (size_t)B * 2 * HW * sizeof(float), s);
-  UPF_REQUIRE(e == hipSuccess, (int)e, "warp_backward: memset failed: %s", hipGetErrorString(e));
+  const long long n_gx = (long long)B * C * HW, n_gf = (long long)B * 2 * HW;
+  unsigned long long* gx64 = (unsigned long long*)workspace;
+  unsigned long long* gf64 = gx64 + n_gx;
   const int cpt = warp::pick_cpt(B, C, HW);
+  const bool split = cdiv(C, cpt) > 1;
+  hipError_t e = hipMemsetAsync(gx64, 0, (size_t)(n_gx + (split ? n_gf : 0)) * sizeof(unsigned long long), s);
+  UPF_REQUIRE(e == hipSuccess, (int)e, "warp_backward: memset failed: %s", hipGetErrorString(e));
   dim3 grid(cdiv(HW, warp::THREADS), cdiv(C, cpt), B);
+  const long long n_fin = n_gx > n_gf ? n_gx : n_gf;
+  UPF_REQUIRE((n_fin + 255) / 256 < (1ll << 31), UPF_EINVAL, "warp_backward: tensor too large");
   UPF_DISPATCH(dtype, T,
                hipLaunchKernelGGL((warp::warp_bwd_kernel<T>), grid, dim3(warp::THREADS), 0, s,
-                                  (const T*)x, flow, (const T*)grad_y, gx32, gflow, C, H, W, cpt, mask_mode, batch_shift));
+                                  (const T*)x, flow, (const T*)grad_y, gx64, gf64, gflow, C, H, W, cpt, mask_mode, batch_shift);
+               hipLaunchKernelGGL((warp::warp_bwd_finish_kernel<T>), dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, s,
+                                  gx64, (T*)gx, n_gx, split ? gf64 : nullptr, gflow, n_gf));
   return check_launch("warp_backward");
 }

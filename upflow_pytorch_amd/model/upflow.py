@@ -110,15 +110,8 @@ class network_tools():
     # ---- loss terms (training only; plain torch ops) --------------------------------------------
     @classmethod
     def edge_aware_smoothness_order1(cls, img, pred):
-        """model/upflow.py:197-216."""
-        def dx(t):
-            return t[:, :, :-1, :] - t[:, :, 1:, :]
-
-        def dy(t):
-            return t[:, :, :, :-1] - t[:, :, :, 1:]
-        wx = torch.exp(-dx(img).abs().mean(1, keepdim=True))
-        wy = torch.exp(-dy(img).abs().mean(1, keepdim=True))
-        return (dx(pred).abs() * wx).mean() + (dy(pred).abs() * wy).mean()
+        """model/upflow.py:197-216 — one fused reduction launch (csrc/loss.hip: upf_smooth_edge1_*)."""
+        return ops.smooth_edge1(img, pred)
 
     @classmethod
     def edge_aware_smoothness_order2(cls, img, pred):
@@ -168,7 +161,9 @@ class network_tools():
         """model/upflow.py:265-288."""
         occ_weight = occ_mask
         if photo_loss_type == 'abs_robust':
-            loss_diff = ((x - y).abs() + 0.01).pow(photo_loss_delta)
+            # sub / abs / add / pow / mul / sum of the reference as ONE deterministic reduction (csrc/loss.hip)
+            s, s_occ = ops.robust_loss_sums(x, y, occ_mask if photo_loss_use_occ else None, q=photo_loss_delta, eps=0.01)
+            return s / (s_occ + 1e-6) if photo_loss_use_occ else s / float(x.numel())
         elif photo_loss_type == 'charbonnier':
             loss_diff = ((x - y) ** 2 + 1e-6).pow(photo_loss_delta)
         elif photo_loss_type == 'L1':

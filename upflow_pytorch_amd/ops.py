@@ -190,12 +190,13 @@ class WarpFunction(Function):
         B, C, H, W = x.shape
         gy = gy.to(x.dtype).contiguous()
         dev = _lib.check_gpu(x, flow, gy)
-        gx32 = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x)
         gflow = torch.empty_like(flow)
+        ws = torch.empty((_lib.lib().upf_warp_backward_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(dev):
-            _lib.call('upf_warp_backward', _lib.ptr(x), _lib.ptr(flow), _lib.ptr(gy), _lib.ptr(gx32), _lib.ptr(gflow),
+            _lib.call('upf_warp_backward', _lib.ptr(x), _lib.ptr(flow), _lib.ptr(gy), _lib.ptr(gx), _lib.ptr(gflow), _lib.ptr(ws),
                       B, C, H, W, _lib.dtype_code(x), ctx.mask_mode, ctx.batch_shift, _lib.stream_ptr(dev))
-        return gx32.to(x.dtype), gflow, None, None
+        return gx, gflow, None, None
 
 
 def warp(x, flow, mask_mode='literal', batch_shift=0):
@@ -321,9 +322,10 @@ class SguBlendFunction(Function):
         dev = _lib.check_gpu(flow_init, x_out, g_up)
         g_init = torch.empty_like(flow_init)
         g_xo = torch.empty((B, 3, h, w), dtype=torch.float32, device=x_out.device)
+        ws = torch.empty((_lib.lib().upf_sgu_blend_backward_workspace_bytes(B, h, w, Hf, Wf),), dtype=torch.uint8, device=x_out.device)
         with torch.cuda.device(dev):
             _lib.call('upf_sgu_blend_backward', _lib.ptr(flow_init), _lib.ptr(x_out), _lib.ptr(g_up), _lib.ptr(g_init),
-                      _lib.ptr(g_xo), B, h, w, Hf, Wf, _lib.dtype_code(x_out), _lib.stream_ptr(dev))
+                      _lib.ptr(g_xo), _lib.ptr(ws), B, h, w, Hf, Wf, _lib.dtype_code(x_out), _lib.stream_ptr(dev))
         return g_init, g_xo.to(x_out.dtype), None
 
 
@@ -487,3 +489,135 @@ class CensusFunction(Function):
 def census_distance(gray1, gray2, max_distance=3):
     """Soft census (ternary) distance [B,1,H,W] of two grey images, one launch (csrc/misc.hip)."""
     return CensusFunction.apply(gray1, gray2, max_distance)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss-side operators of the unsupervised training step (csrc/loss.hip, fp32)
+# ------------------------------------------------------------------------------------------------
+class BoundaryWarpFunction(Function):
+    @staticmethod
+    def forward(ctx, image, flow, start):
+        image = _f32(image).contiguous()
+        flow = _f32(flow).contiguous()
+        B, C, Hi, Wi = image.shape
+        if flow.dim() != 4 or flow.shape[0] != B or flow.shape[1] != 2:
+            raise UpflowHipError('boundary_warp: image [B,C,Hi,Wi] and flow [B,2,h,w] expected, got %s / %s' % (tuple(image.shape), tuple(flow.shape)))
+        start = _f32(start).to(flow.device).reshape(-1)
+        if start.numel() == 2:
+            start = start.repeat(B)
+        if start.numel() != 2 * B:
+            raise UpflowHipError('boundary_warp: start must hold (x, y) per batch item, got %d values for B=%d' % (start.numel(), B))
+        start = start.contiguous()
+        h, w = flow.shape[2:]
+        dev = _lib.check_gpu(image, flow, start)
+        out = torch.empty((B, C, h, w), dtype=torch.float32, device=flow.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_boundary_warp_forward', _lib.ptr(image), _lib.ptr(flow), _lib.ptr(start), _lib.ptr(out), B, C, Hi, Wi, h, w,
+                      _lib.stream_ptr(dev))
+        ctx.save_for_backward(image, flow, start)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        image, flow, start = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise UpflowHipError('boundary_warp: the gradient wrt the image is not implemented (frames are data)')
+        B, C, Hi, Wi = image.shape
+        h, w = flow.shape[2:]
+        g = _f32(g).contiguous()
+        dev = _lib.check_gpu(image, flow, g)
+        gflow = torch.empty_like(flow)
+        with torch.cuda.device(dev):
+            _lib.call('upf_boundary_warp_backward', _lib.ptr(image), _lib.ptr(flow), _lib.ptr(start), _lib.ptr(g), _lib.ptr(gflow),
+                      B, C, Hi, Wi, h, w, _lib.stream_ptr(dev))
+        return None, gflow, None
+
+
+def boundary_warp(image, flow, start):
+    """tools.boundary_dilated_warp.warp_im (utils/tools.py:351-499) — one gather launch; differentiable wrt the flow."""
+    return BoundaryWarpFunction.apply(image, flow, start)
+
+
+class RobustLossFunction(Function):
+    @staticmethod
+    def forward(ctx, x, y, occ, q, eps):
+        x = _f32(x).contiguous()
+        y = _f32(y).contiguous()
+        if x.shape != y.shape or x.dim() != 4:
+            raise UpflowHipError('robust_loss: two [B,C,H,W] tensors expected, got %s / %s' % (tuple(x.shape), tuple(y.shape)))
+        B, C, H, W = x.shape
+        if occ is not None:
+            occ = _f32(occ).contiguous()
+            if tuple(occ.shape) != (B, 1, H, W):
+                raise UpflowHipError('robust_loss: occlusion mask must be [B,1,H,W], got %s' % (tuple(occ.shape),))
+        dev = _lib.check_gpu(x, y, occ)
+        nb = _lib.lib().upf_loss_partials(B * H * W)
+        partials = torch.empty((nb, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_robust_loss_forward', _lib.ptr(x), _lib.ptr(y), _lib.ptr(occ), _lib.ptr(partials), B, C, H * W, float(eps), float(q),
+                      _lib.stream_ptr(dev))
+        sums = partials.sum(0)                               # fixed order: deterministic
+        ctx.save_for_backward(x, y, occ)
+        ctx.qe = (float(q), float(eps))
+        ctx.mark_non_differentiable(sums[1])
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g, _g_occ):
+        x, y, occ = ctx.saved_tensors
+        q, eps = ctx.qe
+        B, C, H, W = x.shape
+        coef = _f32(g).reshape(1).contiguous()
+        dev = _lib.check_gpu(x, y, coef)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None, None, None, None
+        with torch.cuda.device(dev):
+            _lib.call('upf_robust_loss_backward', _lib.ptr(x), _lib.ptr(y), _lib.ptr(occ), _lib.ptr(coef), _lib.ptr(gx), _lib.ptr(gy),
+                      B, C, H * W, eps, q, _lib.stream_ptr(dev))
+        return gx, gy, None, None, None
+
+
+def robust_loss_sums(x, y, occ=None, q=0.4, eps=0.01):
+    """-> (sum over [B,C,H,W] of (|x - y| + eps)^q * occ, sum of occ): the 'abs_robust' term of
+    network_tools.photo_loss_multi_type (model/upflow.py:265-288) as ONE deterministic reduction (differentiable wrt x, y)."""
+    return RobustLossFunction.apply(x, y, occ, q, eps)
+
+
+class SmoothEdge1Function(Function):
+    @staticmethod
+    def forward(ctx, img, pred):
+        img = _f32(img).contiguous()
+        pred = _f32(pred).contiguous()
+        if img.dim() != 4 or pred.dim() != 4 or img.shape[0] != pred.shape[0] or img.shape[2:] != pred.shape[2:]:
+            raise UpflowHipError('smooth_edge1: img [B,Ci,H,W] and pred [B,Cp,H,W] expected, got %s / %s' % (tuple(img.shape), tuple(pred.shape)))
+        B, Ci, H, W = img.shape
+        Cp = pred.shape[1]
+        if H < 2 or W < 2:
+            raise UpflowHipError('smooth_edge1: at least 2x2 pixels')
+        dev = _lib.check_gpu(img, pred)
+        nb = _lib.lib().upf_loss_partials(B * H * W)
+        partials = torch.empty((nb, 2), dtype=torch.float32, device=img.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_smooth_edge1_forward', _lib.ptr(img), _lib.ptr(pred), _lib.ptr(partials), B, Ci, Cp, H, W, _lib.stream_ptr(dev))
+        s = partials.sum(0)
+        ctx.save_for_backward(img, pred)
+        return s[0] / float(B * Cp * (H - 1) * W) + s[1] / float(B * Cp * H * (W - 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        img, pred = ctx.saved_tensors
+        B, Ci, H, W = img.shape
+        Cp = pred.shape[1]
+        gup = _f32(g).reshape(1).contiguous()
+        dev = _lib.check_gpu(img, pred, gup)
+        gp = torch.empty_like(pred)
+        with torch.cuda.device(dev):
+            _lib.call('upf_smooth_edge1_backward', _lib.ptr(img), _lib.ptr(pred), _lib.ptr(gup), _lib.ptr(gp), B, Ci, Cp, H, W, _lib.stream_ptr(dev))
+        return None, gp
+
+
+def smooth_edge1(img, pred):
+    """network_tools.edge_aware_smoothness_order1 (model/upflow.py:197-216) as one reduction launch + one gather backward."""
+    return SmoothEdge1Function.apply(img, pred)

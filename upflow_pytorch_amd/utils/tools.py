@@ -182,35 +182,11 @@ class tools():
         """Photometric-loss warp that samples the UN-cropped image, so flow leaving the crop still finds
         pixels (utils/tools.py:351-499).  Clamp-to-edge bilinear gather: indices are clamped to the
         image and the weights are computed from the CLAMPED corner coordinates (:409-412, :458-466).
-        Loss side only (training); torch ops."""
+        One HIP gather launch (csrc/loss.hip: upf_boundary_warp_*), differentiable wrt the flow."""
 
         @classmethod
         def warp_im(cls, I_nchw, flow_nchw, start_n211):
-            B, C, Hi, Wi = I_nchw.shape
-            _, _, h, w = flow_nchw.shape
-            dev = flow_nchw.device
-            xx = torch.arange(w, device=dev, dtype=torch.float32).view(1, 1, w)
-            yy = torch.arange(h, device=dev, dtype=torch.float32).view(1, h, 1)
-            start = start_n211.to(dev).float()
-            x = xx + start[:, 0] + flow_nchw[:, 0].float()           # [B,h,w]
-            y = yy + start[:, 1] + flow_nchw[:, 1].float()
-            x0 = torch.floor(x).int()
-            y0 = torch.floor(y).int()
-            x1 = torch.clamp(x0 + 1, 0, Wi - 1)
-            y1 = torch.clamp(y0 + 1, 0, Hi - 1)
-            x0 = torch.clamp(x0, 0, Wi - 1)
-            y0 = torch.clamp(y0, 0, Hi - 1)
-            flat = I_nchw.float().reshape(B, C, Hi * Wi)
-
-            def tap(yi, xi):
-                idx = (yi.long() * Wi + xi.long()).view(B, 1, h * w).expand(B, C, h * w)
-                return torch.gather(flat, 2, idx).view(B, C, h, w)
-            x0f, x1f, y0f, y1f = x0.float(), x1.float(), y0.float(), y1.float()
-            wa = ((x1f - x) * (y1f - y)).unsqueeze(1)
-            wb = ((x1f - x) * (y - y0f)).unsqueeze(1)
-            wc = ((x - x0f) * (y1f - y)).unsqueeze(1)
-            wd = ((x - x0f) * (y - y0f)).unsqueeze(1)
-            return wa * tap(y0, x0) + wb * tap(y1, x0) + wc * tap(y0, x1) + wd * tap(y1, x1)
+            return ops.boundary_warp(I_nchw, flow_nchw, start_n211)
 
     # ------------------------------------------------------------------------------------------
     @classmethod
