@@ -150,9 +150,12 @@ int upf_flow_upsample_backward(const float* grad_y, float* gx, int B, int C, int
  *                                        flow channels * Wf/w, Hf/h), flow_init = output_level_flow
  *   flow_up = torch_warp(flow_init, inter_flow) * (1 - inter_mask) + flow_init * inter_mask
  * flow_init, flow_up : [B,2,Hf,Wf] fp32; inter_flow [B,2,Hf,Wf], inter_mask [B,1,Hf,Wf] fp32 are
- * optional outputs (NULL = do not materialise).  One launch instead of ~8 ATen launches. */
+ * optional outputs (NULL = do not materialise).  One launch instead of ~8 ATen launches.
+ * At the final level the sigmoid of the mask logits is evaluated once per LOW-resolution pixel into `workspace`
+ * (upf_sgu_blend_forward_workspace_bytes(B,h,w,Hf,Wf) bytes; 0 / NULL at a decoder level) and interpolated from there. */
+long long upf_sgu_blend_forward_workspace_bytes(int B, int h, int w, int Hf, int Wf);
 int upf_sgu_blend_forward(const float* flow_init, const void* x_out, float* flow_up,
-                          float* inter_flow, float* inter_mask,
+                          float* inter_flow, float* inter_mask, void* workspace,
                           int B, int h, int w, int Hf, int Wf, int dtype, void* stream);
 /* g_flow_init32 [B,2,Hf,Wf] and g_x_out32 [B,3,h,w] fp32, fully produced by the call.  The scatters accumulate in 64-bit
  * fixed point (bit-reproducible); `workspace`: upf_sgu_blend_backward_workspace_bytes(B,h,w,Hf,Wf) bytes, zero-filled

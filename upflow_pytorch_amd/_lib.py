@@ -33,7 +33,7 @@ SIGNATURES = {
     'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_forward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_backward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    'upf_sgu_blend_forward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_sgu_blend_forward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_sgu_blend_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_normalize_forward': [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
@@ -83,6 +83,8 @@ def lib():
         L.upf_warp_backward_workspace_bytes.restype = _ll
         L.upf_sgu_blend_backward_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
         L.upf_sgu_blend_backward_workspace_bytes.restype = _ll
+        L.upf_sgu_blend_forward_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
+        L.upf_sgu_blend_forward_workspace_bytes.restype = _ll
         L.upf_loss_partials.argtypes = [_ll]
         L.upf_loss_partials.restype = _i
         L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]

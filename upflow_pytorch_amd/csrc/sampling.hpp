@@ -78,4 +78,18 @@ __device__ __forceinline__ Lerp make_lerp(int dst, int in_size, int out_size) {
   return r;
 }
 
+// the same with the scale (in_size-1)/(out_size-1) precomputed (host: lerp_scale — the identical IEEE fp32 division)
+static inline float lerp_scale(int in_size, int out_size) {
+  return (out_size > 1) ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+__device__ __forceinline__ Lerp make_lerp_scaled(int dst, int in_size, float scale) {
+  Lerp r;
+  const float src = __fmul_rn(scale, (float)dst);
+  r.i0 = min((int)src, in_size - 1);
+  r.i1 = min(r.i0 + 1, in_size - 1);
+  r.l1 = __fsub_rn(src, (float)r.i0);
+  r.l0 = __fsub_rn(1.0f, r.l1);
+  return r;
+}
+
 }  // namespace upf

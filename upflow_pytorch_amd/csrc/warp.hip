@@ -81,7 +81,8 @@ __device__ __forceinline__ float sample(const T* __restrict__ plane, const Pixel
   return ((a * s.wlT + b * s.whT) + c * s.wlB) + d * s.whB;
 }
 
-// PXT pixels per thread (2 for 16-bit types when W is even: 4-byte stores), W >= 2.
+// PXT consecutive pixels of a row per thread, W >= 2: 4 when rows keep pixel quads aligned (8-byte stores for 16-bit
+// features, 16-byte for fp32; 4x the gathers in flight per wave), 2 for 16-bit types with even W, else 1.
 template <typename T, int PXT>
 __global__ __launch_bounds__(THREADS)
 void warp_fwd_kernel(const T* __restrict__ x, long long xbs, const float* __restrict__ flow, T* __restrict__ y, long long ybs,
@@ -103,7 +104,11 @@ void warp_fwd_kernel(const T* __restrict__ x, long long xbs, const float* __rest
     float r[PXT];
 #pragma unroll
     for (int k = 0; k < PXT; ++k) r[k] = s[k].valid ? sample<T>(xb, s[k]) : 0.f;
-    if constexpr (PXT == 2 && sizeof(typename Elem<T>::store_t) == 2) {
+    if constexpr (PXT == 4 && sizeof(typename Elem<T>::store_t) == 2) {
+      *reinterpret_cast<uint2*>(yb) = make_uint2(pack2<T>(r[0], r[1]), pack2<T>(r[2], r[3]));
+    } else if constexpr (PXT == 4) {
+      *reinterpret_cast<float4*>(yb) = make_float4(r[0], r[1], r[2], r[3]);
+    } else if constexpr (PXT == 2 && sizeof(typename Elem<T>::store_t) == 2) {
       *reinterpret_cast<uint32_t*>(yb) = pack2<T>(r[0], r[1]);
     } else {
 #pragma unroll
@@ -228,13 +233,16 @@ extern "C" int upf_warp_forward_strided(const void* x, long long x_batch_stride,
                                               (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, mask_mode, batch_shift));
     return check_launch("warp_forward");
   }
-  // two pixels per thread (4-byte stores) for 16-bit features when rows keep pixel pairs aligned
-  const bool two = (dtype != UPF_F32) && (W % 2 == 0) && aligned_to(y, 4) && ybs % 2 == 0;
-  const int pxt = two ? 2 : 1;
+  // (4 consecutive pixels per thread with 8 / 16-byte stores were measured SLOWER for 16-bit features, 12.6 -> 16.2 us at
+  //  [4,32,96,320]: every gather instruction then spans 4x the cache lines; fp32 gained 12 %: kept for fp32 only)
+  const bool four = (dtype == UPF_F32) && (W % 4 == 0) && aligned_to(y, 16) && ybs % 4 == 0 && (long long)B * HW >= 4 * 64 * 256;
+  const bool two = !four && (dtype != UPF_F32) && (W % 2 == 0) && aligned_to(y, 4) && ybs % 2 == 0;
+  const int pxt = four ? 4 : (two ? 2 : 1);
   const int cpt = warp::pick_cpt(B, C, HW / pxt);
   dim3 grid(cdiv(cdiv(HW, pxt), warp::THREADS), cdiv(C, cpt), B);
   UPF_DISPATCH(dtype, T,
-               if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift);
+               if (four) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 4>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift);
+               else if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift);
                else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift));
   return check_launch("warp_forward");
 }

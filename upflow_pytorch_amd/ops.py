@@ -303,9 +303,11 @@ class SguBlendFunction(Function):
         flow_up = torch.empty_like(flow_init)
         inter_flow = torch.empty_like(flow_init) if want_inter else None
         inter_mask = torch.empty((B, 1, Hf, Wf), dtype=torch.float32, device=x_out.device) if want_inter else None
+        nws = _lib.lib().upf_sgu_blend_forward_workspace_bytes(B, h, w, Hf, Wf)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=x_out.device) if nws else None
         with torch.cuda.device(dev):
             _lib.call('upf_sgu_blend_forward', _lib.ptr(flow_init), _lib.ptr(x_out), _lib.ptr(flow_up),
-                      _lib.ptr(inter_flow), _lib.ptr(inter_mask), B, h, w, Hf, Wf, _lib.dtype_code(x_out),
+                      _lib.ptr(inter_flow), _lib.ptr(inter_mask), _lib.ptr(ws), B, h, w, Hf, Wf, _lib.dtype_code(x_out),
                       _lib.stream_ptr(dev))
         ctx.save_for_backward(flow_init, x_out)
         if want_inter:
