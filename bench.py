@@ -213,25 +213,27 @@ def train_main(args, rank, world, device):
     conf = UPFlow_net.config()
     d = dict(FLAGS)
     d.update(TRAIN_FLAGS)
-    conf.update(d, verbose=False)
+    dname = args.dtype or 'fp32'
+    d['train_conv_dtype'] = dname           # fp32: every convolution PyTorch-ROCm (the parity mode); bf16 / fp16: decoder
+    conf.update(d, verbose=False)           # convolutions (fwd, dgrad, wgrad) on the MFMA kernels, fp32 master weights
     net = conf()
     net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
-    dname = args.dtype or 'fp32'
-    tr = Trainer(net.to(DT[dname]), device=device)
+    tr = Trainer(net, device=device, graph=not args.no_graph)
     B = 4
-    batch = synthetic_train_batch(B, seed=rank, device=device, dtype=DT[dname])   # a different shard per rank
+    batch = synthetic_train_batch(B, seed=rank, device=device)                    # a different shard per rank
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, tr.graph_warmup + 1 if tr.use_graph else 0)):
         tr.step(batch)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stats = tr.step(batch)
+        stats = tr.step(batch, sync_stats=False)     # (no host round trip inside the timed region; the barrier below synchronises)
     barrier()
+    stats = {k: float(v) for k, v in zip(tr._names, stats.cpu())}
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
     if rank == 0:
         print(json.dumps({
@@ -241,7 +243,7 @@ def train_main(args, rank, world, device):
             'dtype': dname, 'data': 'synthetic',
             'config': {'workload': 'config3: photometric + smooth + census + pyramid-distillation loss, fwd+bwd+Adam(amsgrad), '
                                    '256x832 crops of 288x864 frames, batch 4 per GPU', 'global_batch': world * B,
-                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world,
+                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world, 'hip_graph': tr.use_graph,
                        'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None},
             'final_loss': stats}), flush=True)
     if world > 1:

@@ -199,6 +199,29 @@ int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_pack
                      int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
 
+/* ---- the same convolutions under autograd: training on the matrix cores  (model/pwc_modules.py:250-286, :396-412) ----
+ * forward      upf_conv_forward on weights packed straight from the fp32 master copy: upf_conv_pack_weights_f32(dgrad=0)
+ * data grad    of a stride-1 convolution = the same convolution of grad_y with the flipped, transposed kernel:
+ *              upf_conv_pack_weights_f32(dgrad=1) (packs [Cin x Cout], upf_conv_packed_bytes(Cout, Cin, k) bytes), then
+ *              upf_conv_forward(grad_pre, ..., Cin := Cout, Cout := Cin, leaky_slope 0, zero bias)
+ * activation   upf_leaky_backward: grad_pre = grad_y * (y > 0 ? 1 : slope), y = the forward OUTPUT (n % 8 == 0 elements)
+ * weight grad  upf_conv_wgrad: grad_w[co][ci][ky][kx] = sum_{n,y,x} grad_pre[n,co,y,x] * x[n,ci,y+(ky-1)d,x+(kx-1)d], fp32
+ *              [Cout,Cin,k,k], an MFMA GEMM with K = pixels, deterministic split-K (workspace:
+ *              upf_conv_wgrad_workspace_bytes).  bf16 / fp16, stride 1, W % 8 == 0, 3x3 with d in {1,2,4,8,16} or 1x1
+ *              (upf_conv_wgrad_supported); x / grad_pre may be channel slices of wider buffers (batch strides in elements).
+ * bias grad    upf_conv_bias_grad: grad_b[co] = sum_{n,y,x} grad_pre[n,co,y,x], fp32, fixed summation order (workspace:
+ *              upf_conv_bias_grad_workspace_bytes). */
+int upf_conv_pack_weights_f32(const float* w /* [Cout,Cin,k,k] fp32 */, void* w_packed, int Cin, int Cout, int kernel_size,
+                              int dtype, int dgrad, void* stream);
+int upf_leaky_backward(const void* grad_y, const void* y, void* grad_pre, long long n, float slope, int dtype, void* stream);
+int upf_conv_wgrad_supported(int Cin, int Cout, int H, int W, int kernel_size, int dilation, int stride, int dtype);
+long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation);
+int upf_conv_wgrad(const void* x, long long x_batch_stride, const void* grad_pre, long long g_batch_stride, float* grad_w,
+                   void* workspace, int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation, int dtype, void* stream);
+long long upf_conv_bias_grad_workspace_bytes(int Cout);
+int upf_conv_bias_grad(const void* grad_pre, long long g_batch_stride, float* grad_bias, void* workspace, int B, int Cout, int HW,
+                       int dtype, void* stream);
+
 /* ---- flow bookkeeping of a pyramid level  (model/upflow.py:566-572) -------------------------------
  * out[n,:] = cast(a + (b + c)) in fp32, b and c optional: `flow_up + res` into the context network's input,
  * `flow_up + (res + fine)` for the next level, or a plain fp32 -> 16-bit copy of a flow into an estimator slot.

@@ -39,6 +39,10 @@ SIGNATURES = {
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_conv_pack_weights': [_vp, _vp, _i, _i, _i, _i, _vp],
     'upf_conv_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    'upf_conv_pack_weights_f32': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_leaky_backward': [_vp, _vp, _vp, _ll, _f, _i, _vp],
+    'upf_conv_wgrad': [_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_conv_bias_grad': [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_census_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_census_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_boundary_warp_forward': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -85,6 +89,12 @@ def lib():
         L.upf_sgu_blend_backward_workspace_bytes.restype = _ll
         L.upf_sgu_blend_forward_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
         L.upf_sgu_blend_forward_workspace_bytes.restype = _ll
+        L.upf_conv_wgrad_supported.argtypes = [_i] * 8
+        L.upf_conv_wgrad_supported.restype = _i
+        L.upf_conv_wgrad_workspace_bytes.argtypes = [_i] * 7
+        L.upf_conv_wgrad_workspace_bytes.restype = _ll
+        L.upf_conv_bias_grad_workspace_bytes.argtypes = [_i]
+        L.upf_conv_bias_grad_workspace_bytes.restype = _ll
         L.upf_loss_partials.argtypes = [_ll]
         L.upf_loss_partials.restype = _i
         L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]

@@ -90,6 +90,27 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
   }
 }
 
+// The same packing straight from the fp32 MASTER weights of a training step (one launch instead of cast + pack), for the
+// forward convolution (dgrad = 0) or for its DATA GRADIENT (dgrad = 1): gx = conv(g, w') with w'[ci][co][tap] =
+// w[co][ci][ntaps-1-tap] — the spatially flipped, channel-transposed kernel — so the packed operand has Cout' = Cin rows
+// and Cin' = Cout k-columns.
+template <typename T>
+__global__ void pack_weights_f32_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps, int dgrad) {
+  const int cinp = dgrad ? Cout : Cin, coutp = dgrad ? Cin : Cout;          // channel counts of the convolution being packed
+  const int cip = pad32(cinp), cop = pad32(coutp), nk = cip / 16;
+  const long long total = (long long)ntaps * cop * cip;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), px = (int)((i >> 3) & 31), kg = (int)((i >> 8) & 1);
+    const long long b = i >> 9;
+    const int tap = (int)(b % ntaps), kstep = (int)((b / ntaps) % nk), slab = (int)(b / ((long long)ntaps * nk));
+    const int co = slab * 32 + px, ci = kstep * 16 + kg * 8 + j;
+    float v = 0.f;
+    if (ci < cinp && co < coutp)
+      v = dgrad ? w[((size_t)ci * Cin + co) * ntaps + (ntaps - 1 - tap)] : w[((size_t)co * Cin + ci) * ntaps + tap];
+    Elem<T>::store(wp + i, v);
+  }
+}
+
 // ---- x staging helpers shared by both kernels -------------------------------------------------------------------------
 // 8 channel rows x 8 pixels (eight 16-byte loads of one 8-pixel group) -> 8 LDS entries of 8 channels x 1 pixel.
 // `enc` = (entry index of the group's first pixel) * 8 + slot rotation (see swz); GEN: `sh` = pixels the load window was
@@ -702,6 +723,21 @@ extern "C" int upf_conv_pack_weights(const void* w, void* w_packed, int Cin, int
   else
     hipLaunchKernelGGL((conv::pack_weights_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)w, (f16_t*)w_packed, Cin, Cout, ntaps);
   return check_launch("conv_pack_weights");
+}
+
+extern "C" int upf_conv_pack_weights_f32(const float* w, void* w_packed, int Cin, int Cout, int kernel_size, int dtype, int dgrad, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(w && w_packed && Cin > 0 && Cout > 0, UPF_EINVAL, "conv_pack_weights_f32: bad arguments");
+  UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_pack_weights_f32: kernel_size %d (1 or 3)", kernel_size);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_pack_weights_f32: packs to bf16 / fp16");
+  const int ntaps = kernel_size * kernel_size;
+  const long long total = (long long)ntaps * conv::pad32(Cout) * conv::pad32(Cin);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == UPF_BF16)
+    hipLaunchKernelGGL((conv::pack_weights_f32_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_packed, Cin, Cout, ntaps, dgrad);
+  else
+    hipLaunchKernelGGL((conv::pack_weights_f32_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (f16_t*)w_packed, Cin, Cout, ntaps, dgrad);
+  return check_launch("conv_pack_weights_f32");
 }
 
 extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,

@@ -1,0 +1,326 @@
+// Weight gradient of the 3x3 (dilated) / 1x1 stride-1 convolutions on the bf16 / fp16 matrix cores — gfx950.
+//
+// Training (BASELINE config 3) spends 60 % of its step in MIOpen's fp32 convolution kernels, a third of that in the
+// weight-gradient kernels and their NCHW<->NHWC transposes (profiles/r02_train_fp32_step_kernels.txt).  The data gradient
+// of a stride-1 convolution IS a convolution (flipped, transposed weights), so it runs on the forward kernel of
+// conv3x3.hip; the weight gradient is the one new contraction:
+//
+//     dW[co][ci][ky][kx] = sum_{n,y,x} g[n,co,y,x] * X[n,ci, y+(ky-1)d, x+(kx-1)d]          (X zero padded)
+//
+// a GEMM per tap with M = co, N = ci and K = PIXELS.  v_mfma_f32_32x32x16: A = 32 co x 16 pixels, B = 16 pixels x 32 ci;
+// both operands want 8 consecutive K-elements per lane — 8 consecutive pixels of one channel row, which is exactly how
+// NCHW stores them: tiles are staged into LDS with plain 16-byte copies (no register transposition, unlike the forward
+// kernel whose K is the channel dimension).
+//
+//   * workgroup = 4 waves = a 64 co x 64 ci block of dW (wave w: co block w&1, ci block w>>1), all taps: 9 x 16
+//     accumulator registers per lane; grid = (K-split, block pairs).  A workgroup walks its share of the pixel tiles and
+//     writes ONE partial block at the end; partials are summed in fixed order by a second kernel (deterministic).
+//   * pixel tile = TR rows x 32 pixels.  Dilation by ROW PHASE: the TR rows of a tile are d image rows apart, so the
+//     three kernel rows read TR + 2 staged rows of X whatever d is; horizontally the taps are windows shifted by -d, 0,
+//     +d pixels inside the staged rows: whole 8-pixel blocks for d = 8, 16, dword selects for d = 2, 4, and a 2-byte
+//     funnel shift (v_alignbyte) for d = 1 — computed once per staged row and k-step, shared by the three kernel rows.
+//   * per staged row and 16-pixel k-step: 3-5 ds_read_b128 of X + 1 of g feed up to 9 MFMAs (each g row operand is kept
+//     in registers for the three kernel rows that use it).
+// Requirements: stride 1, W % 8 == 0, 16-byte aligned tensors (every level of the 256x832 training crops except the
+// three coarsest, which are a few hundred pixels and take the library path).
+#include "common.hpp"
+
+namespace upf {
+namespace wgrad {
+
+constexpr int NTHREADS = 256, TR = 4, TWP = 32;       // tile: 4 rows x 32 pixels
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <typename T> struct Mma32;
+template <> struct Mma32<bf16_t> {
+  static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma32<f16_t> {
+  static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// halo (pixels) on each side of the staged X rows: whole 8-pixel blocks
+__host__ __device__ constexpr int halo_of(int D) { return D == 16 ? 16 : (D == 0 ? 0 : 8); }
+// LDS geometry (16-byte blocks of 8 pixels).  Channel pitches are ODD numbers of blocks so that the 16 lanes of a
+// ds_read_b128 phase (consecutive channels, same row / column) fall on 16 different 16-byte bank groups.
+template <int D> struct Geo {
+  static constexpr int NT = (D == 0) ? 1 : 9;
+  static constexpr int XR = (D == 0) ? TR : TR + 2;                     // staged X rows
+  static constexpr int XB = (TWP + 2 * halo_of(D)) / 8;                  // blocks per staged X row
+  static constexpr int XCH = (XR * XB) | 1;                              // blocks per X channel (odd)
+  static constexpr int GB = TWP / 8;                                     // blocks per g row (4)
+  static constexpr int GCH = (TR * GB) | 1;                              // blocks per g channel (17)
+  static constexpr int X_BLOCKS = 64 * XCH, G_BLOCKS = 64 * GCH;
+  static constexpr int LDS_BYTES = (X_BLOCKS + G_BLOCKS) * 16;
+};
+
+// window of 8 pixels starting SH pixels before (SH > 0) / after (SH < 0) the start of block `c`, from the neighbouring
+// aligned blocks: p2, p1 = the two blocks before c, n1, n2 = the two after
+template <int SH>
+__device__ __forceinline__ uint4 window(const uint4& p2, const uint4& p1, const uint4& c, const uint4& n1, const uint4& n2) {
+  if constexpr (SH == 0) return c;
+  else if constexpr (SH == 16) return p2;
+  else if constexpr (SH == -16) return n2;
+  else if constexpr (SH == 8) return p1;
+  else if constexpr (SH == -8) return n1;
+  else if constexpr (SH == 4) return make_uint4(p1.z, p1.w, c.x, c.y);
+  else if constexpr (SH == -4) return make_uint4(c.z, c.w, n1.x, n1.y);
+  else if constexpr (SH == 2) return make_uint4(p1.w, c.x, c.y, c.z);
+  else if constexpr (SH == -2) return make_uint4(c.y, c.z, c.w, n1.x);
+  else if constexpr (SH == 1)
+    return make_uint4(__builtin_amdgcn_alignbyte(c.x, p1.w, 2), __builtin_amdgcn_alignbyte(c.y, c.x, 2),
+                      __builtin_amdgcn_alignbyte(c.z, c.y, 2), __builtin_amdgcn_alignbyte(c.w, c.z, 2));
+  else  // SH == -1
+    return make_uint4(__builtin_amdgcn_alignbyte(c.y, c.x, 2), __builtin_amdgcn_alignbyte(c.z, c.y, 2),
+                      __builtin_amdgcn_alignbyte(c.w, c.z, 2), __builtin_amdgcn_alignbyte(n1.x, c.w, 2));
+}
+
+// partial: [ksplit][tap][pad64(Cout)][pad64(Cin)] fp32
+template <typename T, int D>
+__global__ __launch_bounds__(NTHREADS, 2)
+void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ g, long long gbs, float* __restrict__ partial,
+                  int B, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, int ntiles, int nci2) {
+  using G = Geo<D>;
+  constexpr int DD = (D == 0) ? 1 : D;
+  constexpr int HALO = halo_of(D);
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  uint4* xs = smem;
+  uint4* gs = smem + G::X_BLOCKS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ksplit = gridDim.x, ks_id = blockIdx.x;
+  const int co2 = blockIdx.y / nci2, ci2 = blockIdx.y - co2 * nci2;      // 64-channel block pair of this workgroup
+  const int cob = wave & 1, cib = wave >> 1;
+  const int ch = lane & 31, kg = lane >> 5;
+  const uint32_t plane = (uint32_t)H * (uint32_t)W * 2u;
+  const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
+
+  f32x16 acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  for (int tile = ks_id; tile < ntiles; tile += ksplit) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int phase = ty % DD, q = ty / DD;
+    const int y0 = phase + DD * q * TR, x0 = tx * TWP;                    // output rows y0 + k*DD, k < TR
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs + (size_t)ci2 * 64 * H * W), 0,
+                                                                        (uint32_t)max(min(Cin - ci2 * 64, 64), 0) * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g + (size_t)n * gbs + (size_t)co2 * 64 * H * W), 0,
+                                                                        (uint32_t)max(min(Cout - co2 * 64, 64), 0) * plane, 0x00020000);
+    __syncthreads();                                                      // previous tile's LDS reads are done
+    // ---- stage X: 64 channels x XR rows x XB blocks; rows y0 + (s-1)*DD (3x3) / y0 + s (1x1), columns x0 - HALO + 8b
+#pragma unroll
+    for (int t = tid; t < 64 * G::XR * G::XB; t += NTHREADS) {
+      const int c = t / (G::XR * G::XB), rem = t - c * (G::XR * G::XB), s = rem / G::XB, b = rem - s * G::XB;
+      const int gy = (D == 0) ? y0 + s : y0 + (s - 1) * DD, gx = x0 - HALO + 8 * b;
+      const uint32_t off = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (uint32_t)c * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
+      xs[c * G::XCH + s * G::XB + b] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+    }
+    // ---- stage g: 64 channels x TR rows x 4 blocks
+#pragma unroll
+    for (int t = tid; t < 64 * TR * G::GB; t += NTHREADS) {
+      const int c = t / (TR * G::GB), rem = t - c * (TR * G::GB), k = rem / G::GB, b = rem - k * G::GB;
+      const int gy = y0 + k * DD, gx = x0 + 8 * b;
+      const uint32_t off = (gy < H && gx < W) ? (uint32_t)c * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
+      gs[c * G::GCH + k * G::GB + b] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0));
+    }
+    __syncthreads();
+    // ---- matrix work
+    const uint4* xw = xs + (cib * 32 + ch) * G::XCH;
+    const uint4* gw = gs + (cob * 32 + ch) * G::GCH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                                     // two 16-pixel k-steps per tile row
+      const int blk = 2 * ks + kg;                                       // this lane's 8-pixel block inside the 32-pixel row
+      if constexpr (D == 0) {
+#pragma unroll
+        for (int k = 0; k < TR; ++k) acc[0] = Mma32<T>::mma(gw[k * G::GB + blk], xw[k * G::XB + blk], acc[0]);
+      } else {
+        uint4 a[TR];
+#pragma unroll
+        for (int k = 0; k < TR; ++k) a[k] = gw[k * G::GB + blk];
+#pragma unroll
+        for (int s = 0; s < G::XR; ++s) {
+          const uint4* row = xw + s * G::XB + HALO / 8 + blk;
+          uint4 p2 = make_uint4(0, 0, 0, 0), n2 = p2;
+          const uint4 p1 = row[-1], c = row[0], n1 = row[1];
+          if constexpr (D == 16) { p2 = row[-2]; n2 = row[2]; }
+          const uint4 w0 = window<DD>(p2, p1, c, n1, n2), w2 = window<-DD>(p2, p1, c, n1, n2);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int k = s - ky;                                        // staged row s = output row k + kernel row ky
+            if (k >= 0 && k < TR) {
+              acc[ky * 3 + 0] = Mma32<T>::mma(a[k], w0, acc[ky * 3 + 0]);
+              acc[ky * 3 + 1] = Mma32<T>::mma(a[k], c, acc[ky * 3 + 1]);
+              acc[ky * 3 + 2] = Mma32<T>::mma(a[k], w2, acc[ky * 3 + 2]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- partial block: D layout col = lane & 31 (ci), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (co)
+  float* pb = partial + (size_t)ks_id * G::NT * cop * cip;
+  const int ci = ci2 * 64 + cib * 32 + ch;
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co2 * 64 + cob * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+      pb[((size_t)t * cop + co) * cip + ci] = acc[t][e];
+    }
+}
+
+// dw[co][ci][tap] = sum over the K-splits, in order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ksplit, int ntaps, int Cout, int Cin) {
+  const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
+  const long long total = (long long)Cout * Cin * ntaps;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int tap = (int)(i % ntaps);
+  const int ci = (int)((i / ntaps) % Cin);
+  const int co = (int)(i / ((long long)ntaps * Cin));
+  float s = 0.f;
+  for (int k = 0; k < ksplit; ++k) s += partial[(((size_t)k * ntaps + tap) * cop + co) * cip + ci];
+  dw[i] = s;
+}
+
+// g = gy * (y > 0 ? 1 : slope): gradient through the fused LeakyReLU of the forward kernel (y = its OUTPUT; for
+// slope > 0 the sign of the output is the sign of the pre-activation); 8 elements per thread.
+template <typename T>
+__global__ void leaky_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ g, long long n8, float slope) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float a[8], b[8];
+  VecIO<T>::load(gy + 8 * i, a);
+  VecIO<T>::load(y + 8 * i, b);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (b[k] > 0.f) ? a[k] : a[k] * slope;
+  VecIO<T>::store(g + 8 * i, a);
+}
+
+// db[co] = sum over n, pixels of g[n, co, :].  Two launches, fixed summation order: (channel, chunk) workgroups reduce
+// 1/NCH of a channel's pixels each (one workgroup per channel left 2..128 workgroups on 256 CUs: 69 us per layer),
+// then one thread per channel adds the NCH partial sums in order.
+constexpr int BIAS_NCH = 32;
+template <typename T>
+__global__ __launch_bounds__(256)
+void bias_grad_partial_kernel(const T* __restrict__ g, long long gbs, float* __restrict__ part, int B, int HW) {
+  __shared__ float sh[4];
+  const int co = blockIdx.x, chunk = blockIdx.y;
+  const long long total = (long long)B * HW, per = (total + BIAS_NCH - 1) / BIAS_NCH;
+  const long long e0 = chunk * per, e1 = min(total, e0 + per);
+  float s = 0.f;
+  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const long long n = e / HW;
+    s += Elem<T>::load(g + (size_t)n * gbs + (size_t)co * HW + (e - n * HW));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[co * BIAS_NCH + chunk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int Cout) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Cout) return;
+  float s = 0.f;
+  for (int k = 0; k < BIAS_NCH; ++k) s += part[co * BIAS_NCH + k];
+  db[co] = s;
+}
+
+static int pick_ksplit(int ntiles, int nblocks) {
+  int ks = (4 * 256 + nblocks - 1) / nblocks;          // ~4 workgroups per CU in total
+  if (ks > ntiles) ks = ntiles;
+  if (ks > 64) ks = 64;
+  return ks < 1 ? 1 : ks;
+}
+
+template <typename T, int D>
+int launch(const void* x, long long xbs, const void* g, long long gbs, float* dw, float* ws, int B, int Cin, int Cout, int H, int W,
+           hipStream_t stream) {
+  using G = Geo<D>;
+  constexpr int DD = (D == 0) ? 1 : D;
+  const int tiles_x = cdiv(W, TWP), tiles_y = DD * cdiv(cdiv(H, DD), TR);
+  const int ntiles = B * tiles_x * tiles_y;
+  const int nco2 = cdiv(Cout, 64), nci2 = cdiv(Cin, 64);
+  const int ksplit = pick_ksplit(ntiles, nco2 * nci2);
+  static LdsOptIn opt;
+  auto kern = &wgrad_kernel<T, D>;
+  opt.ensure(reinterpret_cast<const void*>(kern), G::LDS_BYTES);
+  hipLaunchKernelGGL(kern, dim3(ksplit, nco2 * nci2), dim3(NTHREADS), G::LDS_BYTES, stream, (const T*)x, xbs, (const T*)g, gbs, ws,
+                     B, Cin, Cout, H, W, tiles_x, tiles_y, ntiles, nci2);
+  const long long total = (long long)Cout * Cin * G::NT;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws, dw, ksplit, G::NT, Cout, Cin);
+  return check_launch("conv_wgrad");
+}
+
+}  // namespace wgrad
+}  // namespace upf
+
+extern "C" int upf_conv_wgrad_supported(int Cin, int Cout, int H, int W, int kernel_size, int dilation, int stride, int dtype) {
+  return (dtype == UPF_F16 || dtype == UPF_BF16) && stride == 1 && W % 8 == 0 && Cin > 0 && Cout > 0 && H > 0 &&
+         ((kernel_size == 1 && dilation == 1) || (kernel_size == 3 && (dilation == 1 || dilation == 2 || dilation == 4 || dilation == 8 || dilation == 16)));
+}
+
+extern "C" long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation) {
+  using namespace upf;
+  const int dd = kernel_size == 1 ? 1 : dilation, nt = kernel_size == 1 ? 1 : 9;
+  const int ntiles = B * cdiv(W, wgrad::TWP) * dd * cdiv(cdiv(H, dd), wgrad::TR);
+  const int ks = wgrad::pick_ksplit(ntiles, cdiv(Cout, 64) * cdiv(Cin, 64));
+  return (long long)ks * nt * (cdiv(Cout, 64) * 64) * (cdiv(Cin, 64) * 64) * (long long)sizeof(float);
+}
+
+extern "C" int upf_conv_wgrad(const void* x, long long x_batch_stride, const void* grad_y, long long g_batch_stride, float* grad_w,
+                              void* workspace, int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && grad_y && grad_w && workspace, UPF_EINVAL, "conv_wgrad: null pointer");
+  UPF_REQUIRE(upf_conv_wgrad_supported(Cin, Cout, H, W, kernel_size, dilation, 1, dtype), UPF_EUNSUPPORTED,
+              "conv_wgrad: bf16 / fp16, stride 1, W %% 8 == 0, 1x1 or 3x3 with dilation 1/2/4/8/16 only (k %d, d %d, W %d)", kernel_size, dilation, W);
+  const long long xbs = x_batch_stride ? x_batch_stride : (long long)Cin * H * W, gbs = g_batch_stride ? g_batch_stride : (long long)Cout * H * W;
+  UPF_REQUIRE(xbs >= (long long)Cin * H * W && gbs >= (long long)Cout * H * W && xbs % 8 == 0 && gbs % 8 == 0, UPF_EINVAL, "conv_wgrad: bad batch stride");
+  UPF_REQUIRE(aligned_to(x, 16) && aligned_to(grad_y, 16), UPF_EALIGN, "conv_wgrad: tensors must be 16-byte aligned");
+  UPF_REQUIRE((size_t)64 * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "conv_wgrad: image too large");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = kernel_size == 1 ? 0 : dilation;
+#define UPF_WG(DV) case DV: return dtype == UPF_BF16 ? wgrad::launch<bf16_t, DV>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s) : wgrad::launch<f16_t, DV>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s);
+  switch (D) {
+    UPF_WG(0) UPF_WG(1) UPF_WG(2) UPF_WG(4) UPF_WG(8) UPF_WG(16)
+  }
+#undef UPF_WG
+  set_error("conv_wgrad: internal routing error");
+  return UPF_EUNSUPPORTED;
+}
+
+extern "C" int upf_leaky_backward(const void* grad_y, const void* y, void* grad_pre, long long n, float slope, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(grad_y && y && grad_pre && n > 0 && n % 8 == 0, UPF_EINVAL, "leaky_backward: null pointer or element count not a multiple of 8");
+  UPF_REQUIRE(dtype == UPF_F16 || dtype == UPF_BF16, UPF_EDTYPE, "leaky_backward: bf16 / fp16 only");
+  UPF_REQUIRE(aligned_to(grad_y, 16) && aligned_to(y, 16) && aligned_to(grad_pre, 16), UPF_EALIGN, "leaky_backward: 16-byte alignment");
+  const long long n8 = n / 8;
+  UPF_REQUIRE((n8 + 255) / 256 < (1ll << 31), UPF_EINVAL, "leaky_backward: tensor too large");
+  const dim3 grid((unsigned)((n8 + 255) / 256));
+  if (dtype == UPF_BF16) hipLaunchKernelGGL((wgrad::leaky_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad_y, (const bf16_t*)y, (bf16_t*)grad_pre, n8, slope);
+  else hipLaunchKernelGGL((wgrad::leaky_bwd_kernel<f16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const f16_t*)grad_y, (const f16_t*)y, (f16_t*)grad_pre, n8, slope);
+  return check_launch("leaky_backward");
+}
+
+extern "C" long long upf_conv_bias_grad_workspace_bytes(int Cout) { return (long long)Cout * upf::wgrad::BIAS_NCH * (long long)sizeof(float); }
+
+extern "C" int upf_conv_bias_grad(const void* grad_y, long long g_batch_stride, float* grad_bias, void* workspace, int B, int Cout, int HW,
+                                  int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(grad_y && grad_bias && workspace && B > 0 && Cout > 0 && HW > 0, UPF_EINVAL, "conv_bias_grad: bad arguments");
+  const long long gbs = g_batch_stride ? g_batch_stride : (long long)Cout * HW;
+  hipStream_t s = (hipStream_t)stream;
+  UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((wgrad::bias_grad_partial_kernel<T>), dim3(Cout, wgrad::BIAS_NCH), dim3(256), 0, s, (const T*)grad_y, gbs, (float*)workspace, B, HW));
+  hipLaunchKernelGGL(wgrad::bias_grad_final_kernel, dim3(cdiv(Cout, 128)), dim3(128), 0, s, (const float*)workspace, grad_bias, Cout);
+  return check_launch("conv_bias_grad");
+}

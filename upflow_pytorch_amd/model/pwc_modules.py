@@ -193,11 +193,34 @@ def fast_conv_seq(seq, x, cache, out=None, allow_hip=True):
         ho, wo = ops.conv3x3_out_hw(x.shape[2], x.shape[3], c.stride[0])
         y = out if out is not None else torch.empty((x.shape[0], c.out_channels, ho, wo), dtype=x.dtype, device=x.device)
         return pc(x, y)
-    y = seq(x if x.is_contiguous() else x.contiguous())
+    if torch.is_grad_enabled() and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and c.weight.dtype == torch.float32:
+        y = train_conv_seq(seq, x)                       # training on the matrix cores: 16-bit activations, fp32 master weights
+    else:
+        y = seq(x if x.is_contiguous() else x.contiguous())
     if out is not None:
         out.copy_(y)
         return out
     return y
+
+
+def train_conv_seq(seq, x):
+    """One `conv(...)` Sequential under autograd with 16-bit activations and fp32 master weights (config
+    `train_conv_dtype`): forward, data gradient and weight gradient on the matrix cores (ops.ConvTrainFunction) where the
+    geometry allows (rows of >= 8 pixels; inside ConvTrainFunction the weight gradient of ragged-width levels and the
+    gradients of the stride-2 layers take PyTorch-ROCm's kernels), and the same arithmetic through PyTorch-ROCm in fp32
+    otherwise (rows shorter than 8 pixels)."""
+    c = seq[0]
+    k = c.kernel_size[0]
+    slope = 0.0
+    for m in list(seq)[1:]:
+        if isinstance(m, nn.LeakyReLU):
+            slope = float(m.negative_slope)
+        else:
+            return seq(x.float()).to(x.dtype)
+    if (c.kernel_size in ((3, 3), (1, 1)) and c.stride[0] == c.stride[1] and c.groups == 1 and c.padding == (((k - 1) * c.dilation[0]) // 2,) * 2
+            and ops.conv_train_supported(x, c.weight, c.stride[0], c.dilation[0])):
+        return ops.conv_train(x, c.weight, c.bias, c.dilation[0], slope, c.stride[0])
+    return seq(x.float()).to(x.dtype)
 
 
 def _fast_conv_ok(t):
@@ -252,9 +275,10 @@ class _DenseStack(tools.abstract_model):
             buf, slot = self.alloc_buffer(x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device)
             slot.copy_(x)
             return self.forward_in_buffer(buf)
+        cache = self.__dict__.setdefault('_fast_cache', {})
         for name in self._NAMES:
-            x = torch.cat([getattr(self, name)(x), x], dim=1)
-        return x, self.conv_last(x)
+            x = torch.cat([fast_conv_seq(getattr(self, name), x, cache), x], dim=1)
+        return x, fast_conv_seq(self.conv_last, x, cache)
 
 
 class FlowEstimatorDense_v2(_DenseStack):
@@ -293,8 +317,6 @@ class ContextNetwork_v2_(nn.Module):
         self.convs = nn.Sequential(*[conv(chans[i], chans[i + 1], 3, 1, dil[i], isReLU=(i < 6)) for i in range(7)])
 
     def forward(self, x):
-        if not _fast_conv_ok(x):
-            return self.convs(x)
         cache = self.__dict__.setdefault('_fast_cache', {})
         for seq in self.convs:                      # the dilation-16 layer falls back to MIOpen inside
             x = fast_conv_seq(seq, x, cache)

@@ -18,6 +18,9 @@ while flows, sampling positions, masks, normalisation statistics and all accumul
 Extra (non-reference) config flags, all defaulting to the reference's behaviour:
     warp_mask_mode = 'literal' | 'robust'   validity-mask semantics of the feature warps (§7-H2)
     hip_pyramid_convs = True | False        16-bit inference: feature pyramid on the MFMA kernel / on MIOpen
+    train_conv_dtype = 'fp32' | 'bf16' | 'fp16'   training: 'fp32' = the parity mode (every convolution PyTorch-ROCm);
+                                            16-bit = decoder activations in that type, fp32 master weights, forward /
+                                            data-gradient / weight-gradient of the decoder convolutions on the MFMA kernels
 """
 import torch
 import torch.nn as nn
@@ -208,6 +211,7 @@ class UPFlow_net(tools.abstract_model):
             # --- not in the reference; defaults keep its behaviour
             self.warp_mask_mode = 'literal'
             self.hip_pyramid_convs = True
+            self.train_conv_dtype = 'fp32'          # 'bf16' / 'fp16': decoder convolutions under autograd on the matrix cores
 
         def __call__(self, ):
             return UPFlow_net(self)
@@ -341,6 +345,11 @@ class UPFlow_net(tools.abstract_model):
             X = torch.empty((2 * B,) + tuple(x1_raw.shape[1:]), dtype=cdt, device=x1_raw.device)
             X[:B].copy_(x1_raw)                         # cast + stack in one pass per frame (was: two casts, then a cat)
             X[B:].copy_(x2_raw)
+            tdt = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(getattr(self.conf, 'train_conv_dtype', 'fp32'))
+            if tdt is not None and torch.is_grad_enabled() and cdt == torch.float32:
+                # training on the matrix cores: 16-bit activations from the first layer on, fp32 master weights
+                # (flows, sampling positions, masks, statistics and the losses stay fp32)
+                return self._forward_stacked(X.to(tdt), B, tdt)
             return self._forward_stacked(X, B)
         x1_raw = x1_raw.to(cdt)
         x2_raw = x2_raw.to(cdt)
@@ -367,7 +376,7 @@ class UPFlow_net(tools.abstract_model):
             flow_b_out = self.self_guided_upsample(flow_up_bilinear=flow_b, feature_1=g2, feature_2=g1, output_level_flow=flow_b_out)
         return flow_f_out, flow_b_out, flows[::-1]
 
-    def _forward_stacked(self, X, B):
+    def _forward_stacked(self, X, B, train_dtype=None):
         """Inference form of forward_2_frame_v3 (model/upflow.py:494-533), same arithmetic, different schedule:
         the two frames are stacked along the batch, X = [im1; im2], so item n < B carries the forward direction
         and item n >= B the backward one.  Every stage then runs ONCE on 2B items with shared weights — feature

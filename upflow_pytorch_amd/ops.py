@@ -623,3 +623,104 @@ class SmoothEdge1Function(Function):
 def smooth_edge1(img, pred):
     """network_tools.edge_aware_smoothness_order1 (model/upflow.py:197-216) as one reduction launch + one gather backward."""
     return SmoothEdge1Function.apply(img, pred)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution under autograd on the matrix cores (training; csrc/conv3x3.hip + csrc/conv_wgrad.hip)
+# ------------------------------------------------------------------------------------------------
+def conv_pack_from_master(weight32, dtype, dgrad=False):
+    """fp32 master weights [Cout,Cin,k,k] -> the MFMA kernel's packed 16-bit operand, for the forward convolution or
+    (dgrad) for its data gradient (flipped, transposed kernel)."""
+    w = weight32.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    Cout, Cin, k, _ = w.shape
+    dev = _lib.check_gpu(w)
+    nbytes = _lib.lib().upf_conv_packed_bytes(Cout if dgrad else Cin, Cin if dgrad else Cout, k)
+    packed = torch.empty((nbytes // 2,), dtype=dtype, device=w.device)
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_pack_weights_f32', _lib.ptr(w), _lib.ptr(packed), Cin, Cout, k, _lib.dtype_code(packed), int(bool(dgrad)), _lib.stream_ptr(dev))
+    return packed
+
+
+def conv_train_supported(x, weight, stride, dilation):
+    """The autograd convolution on the matrix cores applies (forward at least): 16-bit NCHW input, fp32 master weights,
+    1x1 or 3x3, stride 1 (dilation <= 16) or stride 2 (dilation 1), rows of >= 8 pixels."""
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4):
+        return False
+    Cout, Cin, k, k2 = weight.shape
+    return bool(k == k2 and k in (1, 3) and x.shape[1] == Cin and conv3x3_supported(x, Cout, dilation, stride, k))
+
+
+def conv_wgrad_supported(x, weight, stride, dilation):
+    Cout, Cin, k, _ = weight.shape
+    return bool(_lib.lib().upf_conv_wgrad_supported(Cin, Cout, x.shape[2], x.shape[3], k, dilation if k == 3 else 1, stride, _lib.dtype_code(x)))
+
+
+class ConvTrainFunction(Function):
+    """y = LeakyReLU_slope(conv2d(x, weight, bias, padding = dilation * (k-1)/2, dilation, stride)) with 16-bit activations,
+    fp32 master weights / bias and fp32 parameter gradients.  Forward on the MFMA kernel of csrc/conv3x3.hip; backward:
+    the data gradient of a stride-1 layer is the same kernel on the flipped, transposed weights, the weight gradient is
+    csrc/conv_wgrad.hip (stride 1, W % 8 == 0), the LeakyReLU and bias gradients one launch each; the remaining cases
+    (stride-2 layers, ragged coarse levels) take PyTorch-ROCm's gradient kernels on fp32 copies.
+    Replaces nn.Conv2d + nn.LeakyReLU (model/pwc_modules.py:10-49) in training."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dilation, slope, stride):
+        x = x.contiguous()
+        Cout, Cin, k, _ = weight.shape
+        B, _, H, W = x.shape
+        _lib.check_gpu(x, weight)
+        Ho, Wo = conv3x3_out_hw(H, W, stride)
+        y = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device)
+        b32 = bias.detach().float().contiguous() if bias is not None else torch.zeros(Cout, device=x.device)
+        conv3x3_forward_raw(x, conv_pack_from_master(weight, x.dtype), b32, y, dilation, slope, stride, k)
+        ctx.save_for_backward(x, weight, y if slope != 0.0 else None)
+        ctx.cfg = (int(dilation), float(slope), bias is not None, int(stride))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        dilation, slope, has_bias, stride = ctx.cfg
+        Cout, Cin, k, _ = weight.shape
+        B, _, H, W = x.shape
+        Ho, Wo = gy.shape[2:]
+        gy = gy.to(x.dtype).contiguous()
+        dev = _lib.check_gpu(x, gy)
+        code = _lib.dtype_code(x)
+        pad = dilation * (k - 1) // 2
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            if y is None:
+                g = gy
+            elif gy.numel() % 8 == 0:
+                g = torch.empty_like(gy)
+                _lib.call('upf_leaky_backward', _lib.ptr(gy), _lib.ptr(y), _lib.ptr(g), gy.numel(), slope, code, st)
+            else:
+                g = torch.where(y > 0, gy, gy * slope)
+            gx = gw = gb = None
+            if ctx.needs_input_grad[0]:
+                if stride == 1:
+                    gx = torch.empty_like(x)
+                    zero = torch.zeros(Cin, dtype=torch.float32, device=x.device)
+                    conv3x3_forward_raw(g, conv_pack_from_master(weight, x.dtype, dgrad=True), zero, gx, dilation, 0.0, 1, k)
+                else:
+                    gx = torch.nn.grad.conv2d_input(x.shape, weight.detach(), g.float(), stride=stride, padding=pad, dilation=dilation).to(x.dtype)
+            if ctx.needs_input_grad[1]:
+                if conv_wgrad_supported(x, weight, stride, dilation):
+                    gw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
+                    d = dilation if k == 3 else 1
+                    ws = torch.empty((_lib.lib().upf_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, k, d),), dtype=torch.uint8, device=x.device)
+                    _lib.call('upf_conv_wgrad', _lib.ptr(x), 0, _lib.ptr(g), 0, _lib.ptr(gw), _lib.ptr(ws), B, Cin, Cout, H, W, k, d, code, st)
+                else:
+                    gw = torch.nn.grad.conv2d_weight(x.float(), weight.shape, g.float(), stride=stride, padding=pad, dilation=dilation)
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+                ws = torch.empty((_lib.lib().upf_conv_bias_grad_workspace_bytes(Cout),), dtype=torch.uint8, device=x.device)
+                _lib.call('upf_conv_bias_grad', _lib.ptr(g), 0, _lib.ptr(gb), _lib.ptr(ws), B, Cout, Ho * Wo, code, st)
+        return gx, gw, gb, None, None, None
+
+
+def conv_train(x, weight, bias, dilation=1, slope=0.0, stride=1):
+    return ConvTrainFunction.apply(x, weight, bias, dilation, slope, stride)

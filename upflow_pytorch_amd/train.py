@@ -42,15 +42,25 @@ class Loss_manager():
 class Trainer():
     """net: a module with the UPFlow_net dict contract (input_dict -> output_dict with loss terms)."""
 
-    def __init__(self, net, lr=1e-4, weight_decay=1e-4, scheduler_gamma=1.0, device=None, distributed=None):
+    def __init__(self, net, lr=1e-4, weight_decay=1e-4, scheduler_gamma=1.0, device=None, distributed=None, graph=False):
         self.device = device
         self.distributed = dist.is_initialized() if distributed is None else distributed
         self.world = dist.get_world_size() if self.distributed else 1
         self.rank = dist.get_rank() if self.distributed else 0
         self.raw_net = net if device is None else net.to(device)
         self.net = parallel.ddp_wrap(self.raw_net, device) if self.distributed else self.raw_net
+        # graph=True: after `graph_warmup` eager steps the whole step (forward, losses, backward, Adam) is captured into ONE
+        # hipGraph and replayed — a training step is ~2300 launches, i.e. 35-40 ms of python / ctypes / dispatcher time
+        # that the GPU (22-30 ms of kernels once the convolutions run on the matrix cores) would otherwise wait for.
+        # Needs fixed batch shapes; every libupflow_hip.so entry point only enqueues work, so the step is capturable.
+        self.use_graph = bool(graph) and (device is not None) and torch.device(device).type == 'cuda' and not self.distributed
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr, amsgrad=True,
-                                          weight_decay=weight_decay)
+                                          weight_decay=weight_decay, capturable=self.use_graph)
+        self.graph_warmup = 3
+        self._graph = None
+        self._static = None
+        self._static_stats = None
+        self._eager_steps = 0
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=scheduler_gamma)
         self.loss_manager = Loss_manager()
 
@@ -62,22 +72,48 @@ class Trainer():
         idx = parallel.shard_indices(n, self.rank, self.world)
         return {k: (v[idx] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v) for k, v in batch.items()}
 
-    def step(self, batch):
-        """One optimisation step on this rank's shard; returns the loss terms averaged over ranks."""
-        self.net.train()
-        self.optimizer.zero_grad(set_to_none=True)
+    def _step_body(self, batch):
         batch = dict(batch)
         batch['if_loss'] = True
         out = self.net(batch)
         loss, parts = self.loss_manager.compute_loss(out)
         loss.backward()                      # DDP overlaps the gradient all-reduce with the rest of backward
         self.optimizer.step()
-        stats = torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
-        if self.distributed:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-            stats = stats / self.world
-        names = ['loss'] + sorted(parts)
-        return {k: float(v) for k, v in zip(names, stats.cpu())}
+        self._names = ['loss'] + sorted(parts)
+        return torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
+
+    def _capture(self, batch):
+        dev = torch.device(self.device)
+        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        self.optimizer.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_stats = self._step_body(self._static)
+        self._graph = g
+        torch.cuda.synchronize(dev)
+
+    def step(self, batch, sync_stats=True):
+        """One optimisation step on this rank's shard; returns the loss terms averaged over ranks
+        (sync_stats=False: the device tensor of the terms, no host synchronisation)."""
+        self.net.train()
+        if self.use_graph and self._graph is not None:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self._static[k].copy_(v, non_blocking=True)
+            self._graph.replay()
+            stats = self._static_stats
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+            stats = self._step_body(batch)
+            if self.distributed:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+                stats = stats / self.world
+            self._eager_steps += 1
+            if self.use_graph and self._eager_steps >= self.graph_warmup:
+                self._capture(batch)             # (the capture itself does not execute: this step already ran eagerly)
+        if not sync_stats:
+            return stats
+        return {k: float(v) for k, v in zip(self._names, stats.cpu())}
 
     def end_epoch(self):
         self.scheduler.step()
