@@ -83,13 +83,18 @@ __device__ __forceinline__ uint4 window(const uint4& p2, const uint4& p1, const 
 }
 
 // partial: [ksplit][tap][pad64(Cout)][pad64(Cin)] fp32
+// One workgroup per CU (512 registers per wave): 144 accumulators + the NEXT tile's staging data in registers — the global
+// loads of tile t+1 are issued before the 72 MFMAs of tile t and written to LDS after them, so the matrix pipe only waits
+// for two barriers and 13 ds_write_b128 per tile (the first version loaded, waited, computed: ~25 % MFMA utilisation).
 template <typename T, int D>
-__global__ __launch_bounds__(NTHREADS, 2)
+__global__ __launch_bounds__(NTHREADS, 1)
 void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ g, long long gbs, float* __restrict__ partial,
                   int B, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, int ntiles, int nci2) {
   using G = Geo<D>;
   constexpr int DD = (D == 0) ? 1 : D;
   constexpr int HALO = halo_of(D);
+  constexpr int NXT = (64 * G::XR * G::XB + NTHREADS - 1) / NTHREADS;      // X staging tasks per thread (9; 12 for D = 16)
+  constexpr int NGT = (64 * TR * G::GB + NTHREADS - 1) / NTHREADS;         // g staging tasks per thread (4)
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   uint4* xs = smem;
   uint4* gs = smem + G::X_BLOCKS;
@@ -100,6 +105,52 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
   const int ch = lane & 31, kg = lane >> 5;
   const uint32_t plane = (uint32_t)H * (uint32_t)W * 2u;
   const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
+  const uint32_t xrec = (uint32_t)max(min(Cin - ci2 * 64, 64), 0) * plane, grec = (uint32_t)max(min(Cout - co2 * 64, 64), 0) * plane;
+
+  // per-thread staging geometry (the same for every tile): channel, staged row, 8-pixel block -> LDS slot
+  int xc[NXT], xsr[NXT], xb8[NXT], xl[NXT];
+#pragma unroll
+  for (int i = 0; i < NXT; ++i) {
+    const int t = tid + i * NTHREADS;
+    const int c = t / (G::XR * G::XB), rem = t - c * (G::XR * G::XB), sr = rem / G::XB, bb = rem - sr * G::XB;
+    xc[i] = c; xsr[i] = sr; xb8[i] = bb; xl[i] = (t < 64 * G::XR * G::XB) ? c * G::XCH + sr * G::XB + bb : -1;
+  }
+  int gc[NGT], gk[NGT], gb8[NGT], gl[NGT];
+#pragma unroll
+  for (int i = 0; i < NGT; ++i) {
+    const int t = tid + i * NTHREADS;
+    const int c = t / (TR * G::GB), rem = t - c * (TR * G::GB), k = rem / G::GB, bb = rem - k * G::GB;
+    gc[i] = c; gk[i] = k; gb8[i] = bb; gl[i] = (t < 64 * TR * G::GB) ? c * G::GCH + k * G::GB + bb : -1;
+  }
+  u32x4 px[NXT], pg[NGT];
+  auto issue = [&](int tile) {                                           // global loads of one tile -> registers
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int phase = ty % DD, q = ty / DD;
+    const int y0 = phase + DD * q * TR, x0 = tx * TWP;                  // output rows y0 + k*DD, k < TR
+    const bool live = tile < ntiles;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs + (size_t)ci2 * 64 * H * W), 0, live ? xrec : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g + (size_t)n * gbs + (size_t)co2 * 64 * H * W), 0, live ? grec : 0u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NXT; ++i) {
+      const int gy = (D == 0) ? y0 + xsr[i] : y0 + (xsr[i] - 1) * DD, gx = x0 - HALO + 8 * xb8[i];
+      const uint32_t off = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (uint32_t)xc[i] * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
+      px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NGT; ++i) {
+      const int gy = y0 + gk[i] * DD, gx = x0 + 8 * gb8[i];
+      const uint32_t off = (gy < H && gx < W) ? (uint32_t)gc[i] * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
+      pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
+    }
+  };
+  auto land = [&]() {                                                    // registers -> LDS
+#pragma unroll
+    for (int i = 0; i < NXT; ++i)
+      if (xl[i] >= 0) xs[xl[i]] = __builtin_bit_cast(uint4, px[i]);
+#pragma unroll
+    for (int i = 0; i < NGT; ++i)
+      if (gl[i] >= 0) gs[gl[i]] = __builtin_bit_cast(uint4, pg[i]);
+  };
 
   f32x16 acc[G::NT];
 #pragma unroll
@@ -107,35 +158,14 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+  issue(ks_id);
+  land();
+  __syncthreads();
+  const uint4* xw = xs + (cib * 32 + ch) * G::XCH;
+  const uint4* gw = gs + (cob * 32 + ch) * G::GCH;
   for (int tile = ks_id; tile < ntiles; tile += ksplit) {
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int phase = ty % DD, q = ty / DD;
-    const int y0 = phase + DD * q * TR, x0 = tx * TWP;                    // output rows y0 + k*DD, k < TR
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs + (size_t)ci2 * 64 * H * W), 0,
-                                                                        (uint32_t)max(min(Cin - ci2 * 64, 64), 0) * plane, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g + (size_t)n * gbs + (size_t)co2 * 64 * H * W), 0,
-                                                                        (uint32_t)max(min(Cout - co2 * 64, 64), 0) * plane, 0x00020000);
-    __syncthreads();                                                      // previous tile's LDS reads are done
-    // ---- stage X: 64 channels x XR rows x XB blocks; rows y0 + (s-1)*DD (3x3) / y0 + s (1x1), columns x0 - HALO + 8b
-#pragma unroll
-    for (int t = tid; t < 64 * G::XR * G::XB; t += NTHREADS) {
-      const int c = t / (G::XR * G::XB), rem = t - c * (G::XR * G::XB), s = rem / G::XB, b = rem - s * G::XB;
-      const int gy = (D == 0) ? y0 + s : y0 + (s - 1) * DD, gx = x0 - HALO + 8 * b;
-      const uint32_t off = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (uint32_t)c * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
-      xs[c * G::XCH + s * G::XB + b] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-    }
-    // ---- stage g: 64 channels x TR rows x 4 blocks
-#pragma unroll
-    for (int t = tid; t < 64 * TR * G::GB; t += NTHREADS) {
-      const int c = t / (TR * G::GB), rem = t - c * (TR * G::GB), k = rem / G::GB, b = rem - k * G::GB;
-      const int gy = y0 + k * DD, gx = x0 + 8 * b;
-      const uint32_t off = (gy < H && gx < W) ? (uint32_t)c * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
-      gs[c * G::GCH + k * G::GB + b] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0));
-    }
-    __syncthreads();
-    // ---- matrix work
-    const uint4* xw = xs + (cib * 32 + ch) * G::XCH;
-    const uint4* gw = gs + (cob * 32 + ch) * G::GCH;
+    issue(tile + ksplit);                                                // (beyond the last tile: a null descriptor, zeros)
+    // ---- matrix work on the tile in LDS
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                                     // two 16-pixel k-steps per tile row
       const int blk = 2 * ks + kg;                                       // this lane's 8-pixel block inside the 32-pixel row
@@ -165,6 +195,9 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
         }
       }
     }
+    __syncthreads();                                                     // every wave is done reading this tile
+    land();
+    __syncthreads();
   }
   // ---- partial block: D layout col = lane & 31 (ci), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (co)
   float* pb = partial + (size_t)ks_id * G::NT * cop * cip;
@@ -178,18 +211,22 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
     }
 }
 
-// dw[co][ci][tap] = sum over the K-splits, in order
+// dw[co][ci][tap] = sum over the K-splits, in order.  Threads walk the PARTIAL layout ([tap][co][ci], ci fastest) so that
+// the ksplit reads per element are coalesced; the 36-byte-strided write of the [co][ci][tap] result is the cheap side.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ksplit, int ntaps, int Cout, int Cin) {
   const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
-  const long long total = (long long)Cout * Cin * ntaps;
+  const long long total = (long long)ntaps * Cout * cip;
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int tap = (int)(i % ntaps);
-  const int ci = (int)((i / ntaps) % Cin);
-  const int co = (int)(i / ((long long)ntaps * Cin));
+  const int ci = (int)(i % cip);
+  const int co = (int)((i / cip) % Cout);
+  const int tap = (int)(i / ((long long)cip * Cout));
+  if (ci >= Cin) return;
+  const float* p = partial + ((size_t)tap * cop + co) * cip + ci;
+  const size_t stride = (size_t)ntaps * cop * cip;
   float s = 0.f;
-  for (int k = 0; k < ksplit; ++k) s += partial[(((size_t)k * ntaps + tap) * cop + co) * cip + ci];
-  dw[i] = s;
+  for (int k = 0; k < ksplit; ++k) s += p[k * stride];
+  dw[((size_t)co * Cin + ci) * ntaps + tap] = s;
 }
 
 // g = gy * (y > 0 ? 1 : slope): gradient through the fused LeakyReLU of the forward kernel (y = its OUTPUT; for
@@ -236,10 +273,15 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __
   db[co] = s;
 }
 
-static int pick_ksplit(int ntiles, int nblocks) {
-  int ks = (4 * 256 + nblocks - 1) / nblocks;          // ~4 workgroups per CU in total
+// K-splits: one workgroup per CU in total (the kernel keeps a whole tile in registers: 1 workgroup per CU is resident), as
+// long as the fp32 partial blocks (ksplit x taps x pad64(Cout) x pad64(Cin)) stay under 32 MB — small layers (a single
+// 64x64 block) then use all 256 CUs instead of 64, large ones are bounded by their own block count anyway.
+static int pick_ksplit(int ntiles, int nblocks, int ntaps) {
+  int ks = (256 + nblocks / 2) / nblocks;
+  const long long per_split = (long long)nblocks * ntaps * 64 * 64 * 4;
+  const int cap = (int)((32ll << 20) / per_split);
+  if (ks > cap) ks = cap;
   if (ks > ntiles) ks = ntiles;
-  if (ks > 64) ks = 64;
   return ks < 1 ? 1 : ks;
 }
 
@@ -251,13 +293,13 @@ int launch(const void* x, long long xbs, const void* g, long long gbs, float* dw
   const int tiles_x = cdiv(W, TWP), tiles_y = DD * cdiv(cdiv(H, DD), TR);
   const int ntiles = B * tiles_x * tiles_y;
   const int nco2 = cdiv(Cout, 64), nci2 = cdiv(Cin, 64);
-  const int ksplit = pick_ksplit(ntiles, nco2 * nci2);
+  const int ksplit = pick_ksplit(ntiles, nco2 * nci2, G::NT);
   static LdsOptIn opt;
   auto kern = &wgrad_kernel<T, D>;
   opt.ensure(reinterpret_cast<const void*>(kern), G::LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3(ksplit, nco2 * nci2), dim3(NTHREADS), G::LDS_BYTES, stream, (const T*)x, xbs, (const T*)g, gbs, ws,
                      B, Cin, Cout, H, W, tiles_x, tiles_y, ntiles, nci2);
-  const long long total = (long long)Cout * Cin * G::NT;
+  const long long total = (long long)G::NT * Cout * (cdiv(Cin, 64) * 64);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws, dw, ksplit, G::NT, Cout, Cin);
   return check_launch("conv_wgrad");
 }
@@ -274,7 +316,7 @@ extern "C" long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, in
   using namespace upf;
   const int dd = kernel_size == 1 ? 1 : dilation, nt = kernel_size == 1 ? 1 : 9;
   const int ntiles = B * cdiv(W, wgrad::TWP) * dd * cdiv(cdiv(H, dd), wgrad::TR);
-  const int ks = wgrad::pick_ksplit(ntiles, cdiv(Cout, 64) * cdiv(Cin, 64));
+  const int ks = wgrad::pick_ksplit(ntiles, cdiv(Cout, 64) * cdiv(Cin, 64), nt);
   return (long long)ks * nt * (cdiv(Cout, 64) * 64) * (cdiv(Cin, 64) * 64) * (long long)sizeof(float);
 }
 

@@ -628,9 +628,33 @@ def smooth_edge1(img, pred):
 # ------------------------------------------------------------------------------------------------
 # convolution under autograd on the matrix cores (training; csrc/conv3x3.hip + csrc/conv_wgrad.hip)
 # ------------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+
+
 def conv_pack_from_master(weight32, dtype, dgrad=False):
     """fp32 master weights [Cout,Cin,k,k] -> the MFMA kernel's packed 16-bit operand, for the forward convolution or
-    (dgrad) for its data gradient (flipped, transposed kernel)."""
+    (dgrad) for its data gradient (flipped, transposed kernel).  Cached per parameter VERSION: the decoder's layers are
+    shared by the five pyramid levels, so a training step packs every layer once per direction instead of ten times
+    (the optimiser's in-place update bumps the version; `.data` surgery needs conv_pack_cache_clear())."""
+    key = (id(weight32), weight32.data_ptr(), weight32._version, dtype, bool(dgrad))
+    hit = _PACK_CACHE.get(id(weight32), {}).get(key)
+    if hit is not None:
+        return hit
+    packed = _conv_pack_from_master(weight32, dtype, dgrad)
+    slot = _PACK_CACHE.setdefault(id(weight32), {})
+    for k in [k for k in slot if k[2] != weight32._version or k[1] != weight32.data_ptr()]:
+        del slot[k]
+    slot[key] = packed
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    return packed
+
+
+def conv_pack_cache_clear():
+    _PACK_CACHE.clear()
+
+
+def _conv_pack_from_master(weight32, dtype, dgrad=False):
     w = weight32.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
