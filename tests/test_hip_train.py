@@ -89,6 +89,11 @@ def test_trainer_under_rccl_ddp_real_net():
         tr = Trainer(build(), lr=1e-4, device=torch.device('cuda', 0))
         assert tr.distributed and type(tr.net).__name__ == 'DistributedDataParallel' and dist.get_backend() == 'nccl'
         got = tr.step(tr.shard(batch))
+        # DDP + hipGraph: 11 eager warm-up steps, then the captured step (bucket all-reduce included) replays
+        trg = Trainer(build(), lr=1e-4, device=torch.device('cuda', 0), graph=True)
+        for _ in range(trg.graph_warmup + 2):
+            sg = trg.step(batch)
+        assert trg._graph is not None and all(np.isfinite(v) for v in sg.values())
         assert parallel.max_over_ranks(1.25, torch.device('cuda', 0)) == 1.25
         for k in want:
             assert abs(got[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k])), (k, got[k], want[k])

@@ -48,15 +48,28 @@ class Trainer():
         self.world = dist.get_world_size() if self.distributed else 1
         self.rank = dist.get_rank() if self.distributed else 0
         self.raw_net = net if device is None else net.to(device)
-        self.net = parallel.ddp_wrap(self.raw_net, device) if self.distributed else self.raw_net
+        if self.distributed and graph and device is not None and torch.device(device).type == 'cuda':
+            side = torch.cuda.Stream(device=device)              # (DDP + graph capture: construct on a side stream)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                self.net = parallel.ddp_wrap(self.raw_net, device)
+            torch.cuda.current_stream(device).wait_stream(side)
+        else:
+            self.net = parallel.ddp_wrap(self.raw_net, device) if self.distributed else self.raw_net
         # graph=True: after `graph_warmup` eager steps the whole step (forward, losses, backward, Adam) is captured into ONE
         # hipGraph and replayed — a training step is ~2300 launches, i.e. 35-40 ms of python / ctypes / dispatcher time
         # that the GPU (22-30 ms of kernels once the convolutions run on the matrix cores) would otherwise wait for.
         # Needs fixed batch shapes; every libupflow_hip.so entry point only enqueues work, so the step is capturable.
-        self.use_graph = bool(graph) and (device is not None) and torch.device(device).type == 'cuda' and not self.distributed
+        # Under DDP the capture follows PyTorch's whole-network recipe: DDP built on a side stream, 11 eager warm-up steps
+        # (the reducer finalises its buckets), then fwd + bwd (incl. the bucket's RCCL all-reduce) + Adam captured.
+        self.use_graph = bool(graph) and (device is not None) and torch.device(device).type == 'cuda'
+        if self.use_graph and self.distributed:
+            import os
+            os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
+            os.environ.setdefault('NCCL_ASYNC_ERROR_HANDLING', '0')
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr, amsgrad=True,
                                           weight_decay=weight_decay, capturable=self.use_graph)
-        self.graph_warmup = 3
+        self.graph_warmup = 11 if self.distributed else 3
         self._graph = None
         self._static = None
         self._static_stats = None
@@ -80,7 +93,11 @@ class Trainer():
         loss.backward()                      # DDP overlaps the gradient all-reduce with the rest of backward
         self.optimizer.step()
         self._names = ['loss'] + sorted(parts)
-        return torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
+        stats = torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
+        if self.distributed:                 # loss terms averaged over ranks (one 5-float all-reduce, for logging)
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            stats = stats / self.world
+        return stats
 
     def _capture(self, batch):
         dev = torch.device(self.device)
@@ -105,12 +122,16 @@ class Trainer():
         else:
             self.optimizer.zero_grad(set_to_none=True)
             stats = self._step_body(batch)
-            if self.distributed:
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-                stats = stats / self.world
             self._eager_steps += 1
             if self.use_graph and self._eager_steps >= self.graph_warmup:
-                self._capture(batch)             # (the capture itself does not execute: this step already ran eagerly)
+                try:
+                    self._capture(batch)         # (the capture itself does not execute: this step already ran eagerly)
+                except Exception as e:           # e.g. a collective library that cannot be captured: stay eager, say so
+                    import warnings
+                    warnings.warn('hipGraph capture of the training step failed (%s: %s); continuing with eager steps' % (type(e).__name__, e))
+                    self.use_graph = False
+                    self._graph = None
+                    torch.cuda.synchronize(torch.device(self.device))
         if not sync_stats:
             return stats
         return {k: float(v) for k, v in zip(self._names, stats.cpu())}
