@@ -207,7 +207,7 @@ int upf_conv_set_option(const char* name, int value);
  * activation   upf_leaky_backward: grad_pre = grad_y * (y > 0 ? 1 : slope), y = the forward OUTPUT (n % 8 == 0 elements)
  * weight grad  upf_conv_wgrad: grad_w[co][ci][ky][kx] = sum_{n,y,x} grad_pre[n,co,y,x] * x[n,ci,y+(ky-1)d,x+(kx-1)d], fp32
  *              [Cout,Cin,k,k], an MFMA GEMM with K = pixels, deterministic split-K (workspace:
- *              upf_conv_wgrad_workspace_bytes).  bf16 / fp16, stride 1, W % 8 == 0, 3x3 with d in {1,2,4,8,16} or 1x1
+ *              upf_conv_wgrad_workspace_bytes).  bf16 / fp16, stride 1, W >= 8, 3x3 with d in {1,2,4,8,16} or 1x1
  *              (upf_conv_wgrad_supported); x / grad_pre may be channel slices of wider buffers (batch strides in elements).
  * bias grad    upf_conv_bias_grad: grad_b[co] = sum_{n,y,x} grad_pre[n,co,y,x], fp32, fixed summation order (workspace:
  *              upf_conv_bias_grad_workspace_bytes). */

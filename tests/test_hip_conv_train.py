@@ -13,6 +13,10 @@ CASES = [  # (B, Cin, Cout, H, W, k, dilation, slope)
     (1, 128, 128, 24, 40, 3, 2, 0.1), (1, 128, 128, 20, 48, 3, 4, 0.1), (1, 128, 96, 26, 40, 3, 8, 0.1), (1, 96, 64, 40, 64, 3, 16, 0.1),
     (2, 64, 32, 9, 16, 3, 1, 0.1), (2, 32, 2, 7, 8, 3, 1, 0.0), (2, 196, 32, 6, 24, 1, 1, 0.1), (4, 32, 32, 64, 208, 1, 1, 0.1),
     (4, 64, 32, 32, 104, 3, 1, 0.1), (1, 184, 3, 10, 32, 3, 1, 0.0), (3, 5, 7, 5, 8, 3, 1, 0.1),
+    # ragged widths (the coarse levels of the 256x832 training crops: 52, 26, 13 pixels), odd sizes, every dilation
+    (2, 115, 128, 16, 52, 3, 1, 0.1), (2, 243, 128, 8, 26, 3, 1, 0.1), (2, 196, 32, 4, 13, 1, 1, 0.1), (1, 565, 128, 4, 13, 3, 1, 0.1),
+    (1, 128, 128, 16, 52, 3, 2, 0.1), (1, 128, 128, 9, 26, 3, 4, 0.1), (1, 128, 96, 17, 52, 3, 8, 0.1), (1, 96, 64, 33, 52, 3, 16, 0.1),
+    (3, 7, 5, 5, 9, 3, 1, 0.1), (1, 33, 31, 7, 37, 3, 1, 0.0),
 ]
 
 
@@ -89,4 +93,4 @@ def test_conv_train_unsupported_shapes_are_reported():
     assert not ops.conv_train_supported(x.float(), w, 1, 1)
     assert ops.conv_train_supported(x, w, 1, 1) and ops.conv_train_supported(x, w, 2, 1) and not ops.conv_train_supported(x, w, 2, 2)
     assert ops.conv_wgrad_supported(x, w, 1, 1) and not ops.conv_wgrad_supported(x, w, 2, 1) and not ops.conv_wgrad_supported(x, w, 1, 3)
-    assert not ops.conv_wgrad_supported(torch.zeros(1, 8, 8, 12, dtype=torch.bfloat16, device='cuda'), w, 1, 1)
+    assert ops.conv_wgrad_supported(torch.zeros(1, 8, 8, 12, dtype=torch.bfloat16, device='cuda'), w, 1, 1)

@@ -21,8 +21,8 @@
 //     funnel shift (v_alignbyte) for d = 1 — computed once per staged row and k-step, shared by the three kernel rows.
 //   * per staged row and 16-pixel k-step: 3-5 ds_read_b128 of X + 1 of g feed up to 9 MFMAs (each g row operand is kept
 //     in registers for the three kernel rows that use it).
-// Requirements: stride 1, W % 8 == 0, 16-byte aligned tensors (every level of the 256x832 training crops except the
-// three coarsest, which are a few hundred pixels and take the library path).
+// Requirements: stride 1, W >= 8 (rows that are not 16-byte aligned — the coarse levels of the 256x832 training crops are
+// 52, 26 and 13 pixels wide — take the RAGGED staging variant).
 #include "common.hpp"
 
 namespace upf {
@@ -86,7 +86,21 @@ __device__ __forceinline__ uint4 window(const uint4& p2, const uint4& p1, const 
 // One workgroup per CU (512 registers per wave): 144 accumulators + the NEXT tile's staging data in registers — the global
 // loads of tile t+1 are issued before the 72 MFMAs of tile t and written to LDS after them, so the matrix pipe only waits
 // for two barriers and 13 ds_write_b128 per tile (the first version loaded, waited, computed: ~25 % MFMA utilisation).
-template <typename T, int D>
+// RAGGED (any W >= 8, any alignment): the 8-pixel block that straddles the row end is loaded shifted left so that it
+// ENDS at the row end (2-byte-aligned 16-byte buffer loads are legal on gfx950) and shifted back in registers, zeros
+// filling the pixels beyond the row.
+__device__ __forceinline__ u32x4 shr_pixels(u32x4 v, int sh) {            // 128-bit logical shift right by sh pixels (16 bits each)
+  const unsigned long long lo = ((unsigned long long)v[1] << 32) | v[0], hi = ((unsigned long long)v[3] << 32) | v[2];
+  unsigned long long rl, rh;
+  if (sh >= 4) { rl = (sh >= 8) ? 0ull : (hi >> (16 * (sh - 4))); rh = 0ull; }
+  else if (sh == 0) { rl = lo; rh = hi; }
+  else { rl = (lo >> (16 * sh)) | (hi << (64 - 16 * sh)); rh = hi >> (16 * sh); }
+  u32x4 r;
+  r[0] = (uint32_t)rl; r[1] = (uint32_t)(rl >> 32); r[2] = (uint32_t)rh; r[3] = (uint32_t)(rh >> 32);
+  return r;
+}
+
+template <typename T, int D, bool RAGGED>
 __global__ __launch_bounds__(NTHREADS, 1)
 void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ g, long long gbs, float* __restrict__ partial,
                   int B, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, int ntiles, int nci2) {
@@ -123,6 +137,7 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
     gc[i] = c; gk[i] = k; gb8[i] = bb; gl[i] = (t < 64 * TR * G::GB) ? c * G::GCH + k * G::GB + bb : -1;
   }
   u32x4 px[NXT], pg[NGT];
+  int sx[RAGGED ? NXT : 1], sg[RAGGED ? NGT : 1];                         // RAGGED: left shift of each staged block
   auto issue = [&](int tile) {                                           // global loads of one tile -> registers
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int phase = ty % DD, q = ty / DD;
@@ -133,23 +148,29 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NXT; ++i) {
       const int gy = (D == 0) ? y0 + xsr[i] : y0 + (xsr[i] - 1) * DD, gx = x0 - HALO + 8 * xb8[i];
-      const uint32_t off = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (uint32_t)xc[i] * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      int sh = 0;
+      if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; sx[i] = sh; }
+      const uint32_t off = in ? (uint32_t)xc[i] * plane + (uint32_t)(gy * W + gx - sh) * 2u : 0x80000000u;
       px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NGT; ++i) {
       const int gy = y0 + gk[i] * DD, gx = x0 + 8 * gb8[i];
-      const uint32_t off = (gy < H && gx < W) ? (uint32_t)gc[i] * plane + (uint32_t)(gy * W + gx) * 2u : 0x80000000u;
+      const bool in = gy < H && gx < W;
+      int sh = 0;
+      if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; sg[i] = sh; }
+      const uint32_t off = in ? (uint32_t)gc[i] * plane + (uint32_t)(gy * W + gx - sh) * 2u : 0x80000000u;
       pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
     }
   };
   auto land = [&]() {                                                    // registers -> LDS
 #pragma unroll
     for (int i = 0; i < NXT; ++i)
-      if (xl[i] >= 0) xs[xl[i]] = __builtin_bit_cast(uint4, px[i]);
+      if (xl[i] >= 0) xs[xl[i]] = __builtin_bit_cast(uint4, RAGGED ? shr_pixels(px[i], sx[RAGGED ? i : 0]) : px[i]);
 #pragma unroll
     for (int i = 0; i < NGT; ++i)
-      if (gl[i] >= 0) gs[gl[i]] = __builtin_bit_cast(uint4, pg[i]);
+      if (gl[i] >= 0) gs[gl[i]] = __builtin_bit_cast(uint4, RAGGED ? shr_pixels(pg[i], sg[RAGGED ? i : 0]) : pg[i]);
   };
 
   f32x16 acc[G::NT];
@@ -285,7 +306,7 @@ static int pick_ksplit(int ntiles, int nblocks, int ntaps) {
   return ks < 1 ? 1 : ks;
 }
 
-template <typename T, int D>
+template <typename T, int D, bool RAGGED>
 int launch(const void* x, long long xbs, const void* g, long long gbs, float* dw, float* ws, int B, int Cin, int Cout, int H, int W,
            hipStream_t stream) {
   using G = Geo<D>;
@@ -295,7 +316,7 @@ int launch(const void* x, long long xbs, const void* g, long long gbs, float* dw
   const int nco2 = cdiv(Cout, 64), nci2 = cdiv(Cin, 64);
   const int ksplit = pick_ksplit(ntiles, nco2 * nci2, G::NT);
   static LdsOptIn opt;
-  auto kern = &wgrad_kernel<T, D>;
+  auto kern = &wgrad_kernel<T, D, RAGGED>;
   opt.ensure(reinterpret_cast<const void*>(kern), G::LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3(ksplit, nco2 * nci2), dim3(NTHREADS), G::LDS_BYTES, stream, (const T*)x, xbs, (const T*)g, gbs, ws,
                      B, Cin, Cout, H, W, tiles_x, tiles_y, ntiles, nci2);
@@ -308,7 +329,7 @@ int launch(const void* x, long long xbs, const void* g, long long gbs, float* dw
 }  // namespace upf
 
 extern "C" int upf_conv_wgrad_supported(int Cin, int Cout, int H, int W, int kernel_size, int dilation, int stride, int dtype) {
-  return (dtype == UPF_F16 || dtype == UPF_BF16) && stride == 1 && W % 8 == 0 && Cin > 0 && Cout > 0 && H > 0 &&
+  return (dtype == UPF_F16 || dtype == UPF_BF16) && stride == 1 && W >= 8 && Cin > 0 && Cout > 0 && H > 0 &&
          ((kernel_size == 1 && dilation == 1) || (kernel_size == 3 && (dilation == 1 || dilation == 2 || dilation == 4 || dilation == 8 || dilation == 16)));
 }
 
@@ -325,17 +346,19 @@ extern "C" int upf_conv_wgrad(const void* x, long long x_batch_stride, const voi
   using namespace upf;
   UPF_REQUIRE(x && grad_y && grad_w && workspace, UPF_EINVAL, "conv_wgrad: null pointer");
   UPF_REQUIRE(upf_conv_wgrad_supported(Cin, Cout, H, W, kernel_size, dilation, 1, dtype), UPF_EUNSUPPORTED,
-              "conv_wgrad: bf16 / fp16, stride 1, W %% 8 == 0, 1x1 or 3x3 with dilation 1/2/4/8/16 only (k %d, d %d, W %d)", kernel_size, dilation, W);
+              "conv_wgrad: bf16 / fp16, stride 1, W >= 8, 1x1 or 3x3 with dilation 1/2/4/8/16 only (k %d, d %d, W %d)", kernel_size, dilation, W);
   const long long xbs = x_batch_stride ? x_batch_stride : (long long)Cin * H * W, gbs = g_batch_stride ? g_batch_stride : (long long)Cout * H * W;
-  UPF_REQUIRE(xbs >= (long long)Cin * H * W && gbs >= (long long)Cout * H * W && xbs % 8 == 0 && gbs % 8 == 0, UPF_EINVAL, "conv_wgrad: bad batch stride");
-  UPF_REQUIRE(aligned_to(x, 16) && aligned_to(grad_y, 16), UPF_EALIGN, "conv_wgrad: tensors must be 16-byte aligned");
+  UPF_REQUIRE(xbs >= (long long)Cin * H * W && gbs >= (long long)Cout * H * W, UPF_EINVAL, "conv_wgrad: bad batch stride");
+  const bool ragged = !(W % 8 == 0 && xbs % 8 == 0 && gbs % 8 == 0 && aligned_to(x, 16) && aligned_to(grad_y, 16));
   UPF_REQUIRE((size_t)64 * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "conv_wgrad: image too large");
   hipStream_t s = (hipStream_t)stream;
   const int D = kernel_size == 1 ? 0 : dilation;
-#define UPF_WG(DV) case DV: return dtype == UPF_BF16 ? wgrad::launch<bf16_t, DV>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s) : wgrad::launch<f16_t, DV>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s);
+#define UPF_WG2(DV, TT) (ragged ? wgrad::launch<TT, DV, true>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s) : wgrad::launch<TT, DV, false>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s))
+#define UPF_WG(DV) case DV: return dtype == UPF_BF16 ? UPF_WG2(DV, bf16_t) : UPF_WG2(DV, f16_t);
   switch (D) {
     UPF_WG(0) UPF_WG(1) UPF_WG(2) UPF_WG(4) UPF_WG(8) UPF_WG(16)
   }
+#undef UPF_WG2
 #undef UPF_WG
   set_error("conv_wgrad: internal routing error");
   return UPF_EUNSUPPORTED;
