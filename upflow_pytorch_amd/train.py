@@ -63,10 +63,6 @@ class Trainer():
         # Under DDP the capture follows PyTorch's whole-network recipe: DDP built on a side stream, 11 eager warm-up steps
         # (the reducer finalises its buckets), then fwd + bwd (incl. the bucket's RCCL all-reduce) + Adam captured.
         self.use_graph = bool(graph) and (device is not None) and torch.device(device).type == 'cuda'
-        if self.use_graph and self.distributed:
-            import os
-            os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
-            os.environ.setdefault('NCCL_ASYNC_ERROR_HANDLING', '0')
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr, amsgrad=True,
                                           weight_decay=weight_decay, capturable=self.use_graph)
         self.graph_warmup = 11 if self.distributed else 3
@@ -104,7 +100,9 @@ class Trainer():
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the process group's watchdog thread polls its events while this thread captures; under the
+        # default (global) capture mode that hipEventQuery is an error that aborts the process
+        with torch.cuda.graph(g, capture_error_mode='thread_local' if self.distributed else 'global'):
             self._static_stats = self._step_body(self._static)
         self._graph = g
         torch.cuda.synchronize(dev)
