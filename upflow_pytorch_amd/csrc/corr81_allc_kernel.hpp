@@ -79,222 +79,253 @@ struct Task {      // two registers per task: NT = 8 tasks + their 64 raw-data r
 
 // out: [B,81,H,W] (batch stride out_bs).  !RAGGED requires W % 8 == 0 and 16-byte aligned pointers / strides.
 // ws1 / ws2 (NORM): (count, mean, M2) partials of normalize_stats, [B*C][nseg][3] for f1 / f2.
-template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM>
+// TPW (tiles per workgroup; the product instantiates 1): with 2 the workgroup issues the global loads of a SECOND tile
+// before the matrix work of the first and lands them in LDS afterwards.  Measured on MI355X and NOT used: 31.5 us instead
+// of 23.8 us at [8,32,96,320] (57.6 vs 39.4 at [16,32,112,256]) — the two tiles of a workgroup serialise (load, compute,
+// land, compute) while two rounds of independent workgroups, two resident per CU, overlap each other's phases for free.
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, int TPW = 1>
 __global__ __launch_bounds__(NTHREADS, 5)       // <= 102 VGPRs: two 9-wave workgroups per CU
 void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* __restrict__ out,
                         int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope,
-                        const float* __restrict__ ws1, const float* __restrict__ ws2, int nseg) {
+                        const float* __restrict__ ws1, const float* __restrict__ ws2, int nseg, int total_tiles) {
   using G = Geo<UW, NU>;
   extern __shared__ __attribute__((aligned(16))) uint2 lds[];
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = bid % tiles_x;
-  const int ty = (bid / tiles_x) % tiles_y;
-  const int n = bid / (tiles_x * tiles_y);
-  const int x0 = tx * G::TW, y0 = ty * G::TH;
+  const int ntiles = tiles_x * tiles_y;                                 // per batch item
   const int tid = threadIdx.x, lane = tid & 63;
   const int dyi = __builtin_amdgcn_readfirstlane(tid >> 6);            // 0..8 <-> dy = dyi-4
   const int KQ = (C + 3) >> 2;
   uint2* const lds_f1 = lds;
   uint2* const lds_f2 = lds + KQ * G::F1_E;
-
-  const size_t item = (size_t)n * C * H * W;
   const uint32_t plane = (uint32_t)H * (uint32_t)W * 2u;               // bytes per channel plane
   const uint32_t item_bytes = (uint32_t)C * plane;
-  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1 + item), 0, item_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f2 + item), 0, item_bytes, 0x00020000);
-
-  // ---- staging tasks: every load of the workgroup is issued before anything is consumed
   const int n1 = KQ * G::Q1, N1 = (n1 + 63) & ~63, n2 = KQ * G::Q2;
+  float2* const st = reinterpret_cast<float2*>(lds + KQ * G::E + (RAGGED ? 0 : NWAVES * PATCH_BYTES / 8));
+
   Task task[NT];
   u32x2 raw[NT][4];
+  // ---- staging: every load of a tile is issued before anything is consumed
+  auto issue = [&](int tile, bool live) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / ntiles;
+    const int x0 = tx * G::TW, y0 = ty * G::TH;
+    const size_t item = (size_t)n * C * H * W;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1 + item), 0, live ? item_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f2 + item), 0, live ? item_bytes : 0u, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int t = tid + j * NTHREADS;
-    const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;     // wave-uniform
-    Task s;
-    s.meta = -1; s.voff = 0x80000000u;
-    int kq = 0, gy = -1, gx = -1, lds_at = -1;
-    if (!from_f2) {
-      if (t < n1) {
-        kq = t / G::Q1;
-        const int rem = t - kq * G::Q1, r = rem / (G::TW / 4), g = rem - r * (G::TW / 4);
-        gy = y0 + r; gx = x0 + 4 * g;
-        lds_at = kq * G::F1_E + r * G::TW + 4 * g;
-      }
-    } else {
-      const int u = t - N1;
-      if (u < n2) {
-        kq = u / G::Q2;
-        const int rem = u - kq * G::Q2, r = rem / (G::F2W / 4), g = rem - r * (G::F2W / 4);
-        gy = y0 - R + r; gx = x0 - R + 4 * g;
-        lds_at = KQ * G::F1_E + kq * G::F2_E + r * G::F2W + 4 * g;
-      }
-    }
-    if (lds_at >= 0) s.meta = lds_at | (kq << 16);
-    if (lds_at >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      const int nv = min(W - gx, 4);                   // pixels of the quad inside the row
-      // RAGGED (W >= 4): the quad that straddles the row end is loaded shifted left so that it ENDS at the row end
-      // (every byte of every load then lies inside the row: nothing is read past the tensor, and the bounds check of
-      // the descriptor, which works in whole dwords, never cuts off an odd-sized tensor's last element); the shift is
-      // undone in registers below
-      s.voff = (uint32_t)((kq * 4 * H + gy) * W + gx - (RAGGED ? 4 - nv : 0)) * 2u;
-      s.meta |= nv << 24;
-    }
-    task[j] = s;
-    const __amdgpu_buffer_rsrc_t rs = from_f2 ? r2 : r1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) raw[j][k] = __builtin_amdgcn_raw_buffer_load_b64(rs, s.voff + k * plane, 0, 0);
-  }
-
-  // ---- NORM: merge the (count, mean, M2) partials of the 2 x C rows this workgroup needs -> (mean, rstd) in LDS
-  float2* const st = reinterpret_cast<float2*>(lds + KQ * G::E + (RAGGED ? 0 : NWAVES * PATCH_BYTES / 8));
-  if constexpr (NORM) {
-    const int c4 = KQ * 4;
-    if (tid < 2 * c4) {
-      const int sel = tid >= c4, c = tid - sel * c4;
-      float2 ms = make_float2(0.f, 0.f);               // channels >= C: (x - 0) * 0 keeps the zero padding of the quad
-      if (c < C) ms = norm_merge((sel ? ws2 : ws1) + ((size_t)n * C + c) * nseg * 3, nseg, H * W);
-      st[tid] = ms;
-    }
-    __syncthreads();
-  }
-
-  // ---- 4 channel rows x 4 pixels -> 4 pixel entries of 4 channels (v_perm), 2 ds_write_b128 per task
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    if (task[j].meta < 0) continue;
-    if constexpr (RAGGED) {                             // the quad that straddles the row end
-      const int nv = task[j].nv();                      // 0 (outside: loads returned zeros) or 1..4
-      if (nv > 0 && nv < 4) {                           // undo the left shift of the load: pixel i = loaded pixel i + (4 - nv)
-        const int sh = 16 * (4 - nv);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned long long q = (((unsigned long long)raw[j][k].y << 32) | raw[j][k].x) >> sh;
-          raw[j][k].x = (uint32_t)q; raw[j][k].y = (uint32_t)(q >> 32);
+    for (int j = 0; j < NT; ++j) {
+      const int t = tid + j * NTHREADS;
+      const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;     // wave-uniform
+      Task s;
+      s.meta = -1; s.voff = 0x80000000u;
+      int kq = 0, gy = -1, gx = -1, lds_at = -1;
+      if (!from_f2) {
+        if (t < n1) {
+          kq = t / G::Q1;
+          const int rem = t - kq * G::Q1, r = rem / (G::TW / 4), g = rem - r * (G::TW / 4);
+          gy = y0 + r; gx = x0 + 4 * g;
+          lds_at = kq * G::F1_E + r * G::TW + 4 * g;
+        }
+      } else {
+        const int u = t - N1;
+        if (u < n2) {
+          kq = u / G::Q2;
+          const int rem = u - kq * G::Q2, r = rem / (G::F2W / 4), g = rem - r * (G::F2W / 4);
+          gy = y0 - R + r; gx = x0 - R + 4 * g;
+          lds_at = KQ * G::F1_E + kq * G::F2_E + r * G::F2W + 4 * g;
         }
       }
+      if (lds_at >= 0) s.meta = lds_at | (kq << 16);
+      if (lds_at >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const int nv = min(W - gx, 4);                   // pixels of the quad inside the row
+        // RAGGED (W >= 4): the quad that straddles the row end is loaded shifted left so that it ENDS at the row end
+        // (every byte of every load then lies inside the row: nothing is read past the tensor, and the bounds check of
+        // the descriptor, which works in whole dwords, never cuts off an odd-sized tensor's last element); the shift
+        // is undone in registers when the task lands
+        s.voff = (uint32_t)((kq * 4 * H + gy) * W + gx - (RAGGED ? 4 - nv : 0)) * 2u;
+        s.meta |= nv << 24;
+      }
+      task[j] = s;
+      const __amdgpu_buffer_rsrc_t rs = from_f2 ? r2 : r1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) raw[j][k] = __builtin_amdgcn_raw_buffer_load_b64(rs, s.voff + k * plane, 0, 0);
     }
-    u32x2 v[4] = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
+  };
+  // ---- NORM: merge the (count, mean, M2) partials of the 2 x C rows of item n -> (mean, rstd) in LDS
+  auto merge_stats = [&](int n) {
     if constexpr (NORM) {
-      if (task[j].nv() != 0) {
-        const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;
-        const float2* sp = st + (from_f2 ? KQ * 4 : 0) + task[j].kq() * 4;
+      const int c4 = KQ * 4;
+      if (tid < 2 * c4) {
+        const int sel = tid >= c4, c = tid - sel * c4;
+        float2 ms = make_float2(0.f, 0.f);             // channels >= C: (x - 0) * 0 keeps the zero padding of the quad
+        if (c < C) ms = norm_merge((sel ? ws2 : ws1) + ((size_t)n * C + c) * nseg * 3, nseg, H * W);
+        st[tid] = ms;
+      }
+      __syncthreads();
+    }
+  };
+  // ---- 4 channel rows x 4 pixels -> 4 pixel entries of 4 channels (v_perm), 2 ds_write_b128 per task
+  auto land = [&]() {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float2 ms = sp[k];
-          // (x - mean) * rstd in separately rounded fp32 steps, then ONE rounding to the storage type (pack2), exactly
-          // like normalize_apply_kernel
-          v[k].x = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].x), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].x), ms.x), ms.y));
-          v[k].y = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].y), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].y), ms.x), ms.y));
+    for (int j = 0; j < NT; ++j) {
+      if (task[j].meta < 0) continue;
+      if constexpr (RAGGED) {                             // the quad that straddles the row end
+        const int nv = task[j].nv();                      // 0 (outside: loads returned zeros) or 1..4
+        if (nv > 0 && nv < 4) {                           // undo the left shift of the load: pixel i = loaded pixel i + (4 - nv)
+          const int sh = 16 * (4 - nv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const unsigned long long q = (((unsigned long long)raw[j][k].y << 32) | raw[j][k].x) >> sh;
+            raw[j][k].x = (uint32_t)q; raw[j][k].y = (uint32_t)(q >> 32);
+          }
         }
       }
-    }
-    if constexpr (RAGGED && NORM) {                     // pixels >= W were normalised zeros: drop them again
-      const int nv = task[j].nv();
-      const uint32_t mx = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
-      const uint32_t my = nv >= 4 ? 0xffffffffu : (nv == 3 ? 0x0000ffffu : 0u);
+      u32x2 v[4] = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
+      if constexpr (NORM) {
+        if (task[j].nv() != 0) {
+          const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;
+          const float2* sp = st + (from_f2 ? KQ * 4 : 0) + task[j].kq() * 4;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { v[k].x &= mx; v[k].y &= my; }
+          for (int k = 0; k < 4; ++k) {
+            const float2 ms = sp[k];
+            // (x - mean) * rstd in separately rounded fp32 steps, then ONE rounding to the storage type (pack2), exactly
+            // like normalize_apply_kernel
+            v[k].x = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].x), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].x), ms.x), ms.y));
+            v[k].y = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].y), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].y), ms.x), ms.y));
+          }
+        }
+      }
+      if constexpr (RAGGED && NORM) {                     // pixels >= W were normalised zeros: drop them again
+        const int nv = task[j].nv();
+        const uint32_t mx = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
+        const uint32_t my = nv >= 4 ? 0xffffffffu : (nv == 3 ? 0x0000ffffu : 0u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k].x &= mx; v[k].y &= my; }
+      }
+      uint4 lo, hi;                                       // pixels 0,1 | pixels 2,3
+      lo.x = __builtin_amdgcn_perm(v[1].x, v[0].x, 0x05040100u);  lo.y = __builtin_amdgcn_perm(v[3].x, v[2].x, 0x05040100u);
+      lo.z = __builtin_amdgcn_perm(v[1].x, v[0].x, 0x07060302u);  lo.w = __builtin_amdgcn_perm(v[3].x, v[2].x, 0x07060302u);
+      hi.x = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x05040100u);  hi.y = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x05040100u);
+      hi.z = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x07060302u);  hi.w = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x07060302u);
+      *reinterpret_cast<uint4*>(lds + task[j].lds()) = lo;
+      *reinterpret_cast<uint4*>(lds + task[j].lds() + 2) = hi;
     }
-    uint4 lo, hi;                                       // pixels 0,1 | pixels 2,3
-    lo.x = __builtin_amdgcn_perm(v[1].x, v[0].x, 0x05040100u);  lo.y = __builtin_amdgcn_perm(v[3].x, v[2].x, 0x05040100u);
-    lo.z = __builtin_amdgcn_perm(v[1].x, v[0].x, 0x07060302u);  lo.w = __builtin_amdgcn_perm(v[3].x, v[2].x, 0x07060302u);
-    hi.x = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x05040100u);  hi.y = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x05040100u);
-    hi.z = __builtin_amdgcn_perm(v[1].y, v[0].y, 0x07060302u);  hi.w = __builtin_amdgcn_perm(v[3].y, v[2].y, 0x07060302u);
-    *reinterpret_cast<uint4*>(lds + task[j].lds()) = lo;
-    *reinterpret_cast<uint4*>(lds + task[j].lds() + 2) = hi;
-  }
-  __syncthreads();
+  };
 
-  // ---- matrix work: NU units x KQ channel quads x 3 candidate quads; a finished unit is stored while the next computes
+  // ---- matrix work on the tile in LDS: NU units x KQ channel quads x 3 candidate quads; a finished unit is stored while
+  // the next computes
   const int rsel = lane / UW, pix = lane % UW;                          // pix = 4*quad + j
   const int p = lane & 3;
   const uint32_t m1 = (p & 1) ? 0xffffffffu : 0u, m2 = (p & 2) ? 0xffffffffu : 0u;   // per-lane select masks
   const float invC = 1.0f / (float)C;
   using st16 = uint16_t;
-  st16* obase = reinterpret_cast<st16*>(out) + (size_t)n * out_bs + (size_t)(dyi * D) * H * W;
   uint16_t* patch = reinterpret_cast<uint16_t*>(lds + KQ * G::E) + (tid >> 6) * (PATCH_BYTES / 2);
   auto sel = [](uint32_t mask, float a, float b) {
     return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
   };
-
+  auto compute = [&](int tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / ntiles;
+    const int x0 = tx * G::TW, y0 = ty * G::TH;
+    st16* obase = reinterpret_cast<st16*>(out) + (size_t)n * out_bs + (size_t)(dyi * D) * H * W;
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
-    const uint2* pb = lds_f1 + (u * G::UR + rsel) * G::TW + pix;                           // f1 (B operand)
-    const uint2* pa = lds_f2 + (u * G::UR + rsel + dyi) * G::F2W + pix;                    // f2 (A operand), q = 0
-    // channel quads four at a time (16 ds_read_b64 in flight for 12 MFMAs), written out because hipcc does not partially
-    // unroll the run-time-bounded loop around the MFMA builtins.  (A hand-pipelined version that loads group g+1 during
-    // the MFMAs of group g was measured SLOWER at every level — 13.9 -> 17.6 us at the 1/4-resolution level: twice the
-    // operand registers and a block of moves per group; the 2-3 waves per SIMD already hide the LDS latency.)
-    int kq = 0;
-    for (; kq + 4 <= KQ; kq += 4) {
-      uint2 bv[4], c0[4], c1[4], c2[4];
+    for (int u = 0; u < NU; ++u) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+      const uint2* pb = lds_f1 + (u * G::UR + rsel) * G::TW + pix;                           // f1 (B operand)
+      const uint2* pa = lds_f2 + (u * G::UR + rsel + dyi) * G::F2W + pix;                    // f2 (A operand), q = 0
+      // channel quads four at a time (16 ds_read_b64 in flight for 12 MFMAs), written out because hipcc does not
+      // partially unroll the run-time-bounded loop around the MFMA builtins.  (A hand-pipelined version that loads group
+      // g+1 during the MFMAs of group g was measured SLOWER at every level — 13.9 -> 17.6 us at the 1/4-resolution level:
+      // twice the operand registers and a block of moves per group; the 2-3 waves per SIMD already hide the LDS latency.)
+      int kq = 0;
+      for (; kq + 4 <= KQ; kq += 4) {
+        uint2 bv[4], c0[4], c1[4], c2[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bv[i] = pb[(kq + i) * G::F1_E];
-        c0[i] = pa[(kq + i) * G::F2_E]; c1[i] = pa[(kq + i) * G::F2_E + 4]; c2[i] = pa[(kq + i) * G::F2_E + 8];
+        for (int i = 0; i < 4; ++i) {
+          bv[i] = pb[(kq + i) * G::F1_E];
+          c0[i] = pa[(kq + i) * G::F2_E]; c1[i] = pa[(kq + i) * G::F2_E + 4]; c2[i] = pa[(kq + i) * G::F2_E + 8];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a0 = Mma<T>::mma(c0[i], bv[i], a0);
+          a1 = Mma<T>::mma(c1[i], bv[i], a1);
+          a2 = Mma<T>::mma(c2[i], bv[i], a2);
+        }
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a0 = Mma<T>::mma(c0[i], bv[i], a0);
-        a1 = Mma<T>::mma(c1[i], bv[i], a1);
-        a2 = Mma<T>::mma(c2[i], bv[i], a2);
+      for (; kq < KQ; ++kq) {
+        const uint2 bv = pb[kq * G::F1_E];
+        const uint2 c0 = pa[kq * G::F2_E], c1 = pa[kq * G::F2_E + 4], c2 = pa[kq * G::F2_E + 8];
+        a0 = Mma<T>::mma(c0, bv, a0);
+        a1 = Mma<T>::mma(c1, bv, a1);
+        a2 = Mma<T>::mma(c2, bv, a2);
       }
-    }
-    for (; kq < KQ; ++kq) {
-      const uint2 bv = pb[kq * G::F1_E];
-      const uint2 c0 = pa[kq * G::F2_E], c1 = pa[kq * G::F2_E + 4], c2 = pa[kq * G::F2_E + 8];
-      a0 = Mma<T>::mma(c0, bv, a0);
-      a1 = Mma<T>::mma(c1, bv, a1);
-      a2 = Mma<T>::mma(c2, bv, a2);
-    }
-    // candidates 0..11 of this lane's pixel; displacement t = dx+4 is candidate t + p: two-stage barrel shift by the
-    // lane's 2-bit position, as bit-selects on scalars (arrays indexed by a lane-dependent value go to scratch)
-    const float t0 = sel(m1, a0[1], a0[0]), t1 = sel(m1, a0[2], a0[1]), t2 = sel(m1, a0[3], a0[2]), t3 = sel(m1, a1[0], a0[3]);
-    const float t4 = sel(m1, a1[1], a1[0]), t5 = sel(m1, a1[2], a1[1]), t6 = sel(m1, a1[3], a1[2]), t7 = sel(m1, a2[0], a1[3]);
-    const float t8 = sel(m1, a2[1], a2[0]), t9 = sel(m1, a2[2], a2[1]), t10 = sel(m1, a2[3], a2[2]);
-    const float f[9] = {sel(m2, t2, t0), sel(m2, t3, t1), sel(m2, t4, t2), sel(m2, t5, t3), sel(m2, t6, t4),
-                        sel(m2, t7, t5), sel(m2, t8, t6), sel(m2, t9, t7), sel(m2, t10, t8)};
-    if constexpr (RAGGED) {
-      const int y = y0 + u * G::UR + rsel, x = x0 + pix;
-      if (y < H && x < W) {
-        st16* o = obase + (size_t)y * W + x;
+      // candidates 0..11 of this lane's pixel; displacement t = dx+4 is candidate t + p: two-stage barrel shift by the
+      // lane's 2-bit position, as bit-selects on scalars (arrays indexed by a lane-dependent value go to scratch)
+      const float t0 = sel(m1, a0[1], a0[0]), t1 = sel(m1, a0[2], a0[1]), t2 = sel(m1, a0[3], a0[2]), t3 = sel(m1, a1[0], a0[3]);
+      const float t4 = sel(m1, a1[1], a1[0]), t5 = sel(m1, a1[2], a1[1]), t6 = sel(m1, a1[3], a1[2]), t7 = sel(m1, a2[0], a1[3]);
+      const float t8 = sel(m1, a2[1], a2[0]), t9 = sel(m1, a2[2], a2[1]), t10 = sel(m1, a2[3], a2[2]);
+      const float f[9] = {sel(m2, t2, t0), sel(m2, t3, t1), sel(m2, t4, t2), sel(m2, t5, t3), sel(m2, t6, t4),
+                          sel(m2, t7, t5), sel(m2, t8, t6), sel(m2, t9, t7), sel(m2, t10, t8)};
+      if constexpr (RAGGED) {
+        const int y = y0 + u * G::UR + rsel, x = x0 + pix;
+        if (y < H && x < W) {
+          st16* o = obase + (size_t)y * W + x;
+#pragma unroll
+          for (int t = 0; t < D; ++t) {
+            float v = f[t] * invC;
+            v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
+            T tmp;
+            Elem<T>::store(&tmp, v);
+            o[(size_t)t * H * W] = tmp.v;
+          }
+        }
+      } else {
 #pragma unroll
         for (int t = 0; t < D; ++t) {
           float v = f[t] * invC;
           v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
           T tmp;
           Elem<T>::store(&tmp, v);
-          o[(size_t)t * H * W] = tmp.v;
+          patch[t * 64 + lane] = tmp.v;                                  // [t][row-in-unit][UW px]
         }
-      }
-    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 72 chunks of 8 pixels (16 B): chunk L = (t, row-in-unit, 8-px segment)
+        const int yb = y0 + u * G::UR;
 #pragma unroll
-      for (int t = 0; t < D; ++t) {
-        float v = f[t] * invC;
-        v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
-        T tmp;
-        Elem<T>::store(&tmp, v);
-        patch[t * 64 + lane] = tmp.v;                                  // [t][row-in-unit][UW px]
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // 72 chunks of 8 pixels (16 B): chunk L = (t, row-in-unit, 8-px segment)
-      const int yb = y0 + u * G::UR;
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int L = lane + 64 * pass;
-        if (L < D * 8) {
-          constexpr int SPR = UW / 8;
-          const int t = L >> 3, rr = (L / SPR) % G::UR, seg = L % SPR;
-          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(patch) + L * 16);
-          const int y = yb + rr, x = x0 + 8 * seg;
-          if (y < H && x < W) *reinterpret_cast<uint4*>(obase + ((size_t)t * H + y) * W + x) = v;
+        for (int pass = 0; pass < 2; ++pass) {
+          const int L = lane + 64 * pass;
+          if (L < D * 8) {
+            constexpr int SPR = UW / 8;
+            const int t = L >> 3, rr = (L / SPR) % G::UR, seg = L % SPR;
+            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(patch) + L * 16);
+            const int y = yb + rr, x = x0 + 8 * seg;
+            if (y < H && x < W) *reinterpret_cast<uint4*>(obase + ((size_t)t * H + y) * W + x) = v;
+          }
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
+  };
+
+  // tile order: consecutive workgroups (after the XCD remap) own consecutive tiles; with TPW = 2 a workgroup's two tiles
+  // are gridDim.x apart, so that both halves of the grid sweep the images in the same order
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  issue(bid, true);
+  merge_stats(bid / ntiles);
+  land();
+  __syncthreads();
+  if constexpr (TPW == 2) {
+    const int tile2 = bid + (int)gridDim.x;
+    const bool live2 = tile2 < total_tiles;                             // (workgroup-uniform)
+    issue(live2 ? tile2 : bid, live2);                                  // in flight during the matrix work of the first tile
+    compute(bid);
+    __syncthreads();                                                    // every wave is done reading the first tile
+    if (live2) {
+      merge_stats(tile2 / ntiles);
+      land();
+      __syncthreads();
+      compute(tile2);
+    }
+  } else {
+    compute(bid);
   }
 }
 

@@ -136,10 +136,10 @@ int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W
   UPF_REQUIRE(nblocks < (1ll << 31), UPF_EINVAL, "corr81_forward: grid too large");
   const size_t lds = corrx::lds_bytes<UW, NU>((C + 3) / 4, RAGGED, NORM);
   static LdsOptIn opt;
-  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM>;
+  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, 1>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipExtLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(corrx::NTHREADS), lds, stream, ev0, ev1, 0,
-                        f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg);
+                        f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg, (int)nblocks);
   return check_launch("corr81_forward");
 }
 
