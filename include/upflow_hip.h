@@ -218,6 +218,27 @@ int upf_conv_wgrad_supported(int Cin, int Cout, int H, int W, int kernel_size, i
 long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation);
 int upf_conv_wgrad(const void* x, long long x_batch_stride, const void* grad_pre, long long g_batch_stride, float* grad_w,
                    void* workspace, int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation, int dtype, void* stream);
+/* One weight gradient over SEVERAL uses of the same weights (the decoder is shared by the five pyramid levels,
+ * model/upflow.py:535-573): the pixels of every level are one K dimension, so the levels share the K-split launches, the
+ * partial blocks and the one ordered reduction (instead of a launch pair per level plus fp32 adds of the results).
+ * 1..6 levels of any sizes (each: upf_conv_wgrad_supported); aligned and ragged levels go in one launch each.  The
+ * workspace size depends on the pointers' alignment: query it with the same level array. */
+typedef struct {
+  const void* x;        long long x_batch_stride;      /* [B, Cin, H, W] slice, batch stride in elements (0 = dense) */
+  const void* grad_pre; long long g_batch_stride;      /* [B, Cout, H, W] slice */
+  int B, H, W;
+} upf_wgrad_level;
+long long upf_conv_wgrad_multi_workspace_bytes(const upf_wgrad_level* levels, int nlevels, int Cin, int Cout, int kernel_size, int dilation);
+int upf_conv_wgrad_multi(const upf_wgrad_level* levels /* host array */, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
+                         int kernel_size, int dilation, int dtype, void* stream);
+/* dst = (src + add) * (y > 0 ? 1 : slope) over channel-sliced [B, C, HW] tensors (add, y optional; dst may be src):
+ * the gradient entering a layer's pre-activation, with the first stage of the bias gradient (bias_partial: C x 32 fp32,
+ * optional) from the same pass; dst = NULL: the bias sums only.  upf_conv_bias_grad_finish sums the first-stage buffers of 1..8 uses in order. */
+int upf_act_grad(const void* src, long long src_batch_stride, const void* add, long long add_batch_stride, const void* y,
+                 long long y_batch_stride, void* dst, long long dst_batch_stride, float* bias_partial, int B, int C, int HW,
+                 float slope, int dtype, void* stream);
+int upf_conv_bias_grad_finish(const float* const* partials /* host array of device pointers */, int npartials, float* grad_bias,
+                              int Cout, void* stream);
 long long upf_conv_bias_grad_workspace_bytes(int Cout);
 int upf_conv_bias_grad(const void* grad_pre, long long g_batch_stride, float* grad_bias, void* workspace, int B, int Cout, int HW,
                        int dtype, void* stream);

@@ -94,3 +94,161 @@ def test_conv_train_unsupported_shapes_are_reported():
     assert ops.conv_train_supported(x, w, 1, 1) and ops.conv_train_supported(x, w, 2, 1) and not ops.conv_train_supported(x, w, 2, 2)
     assert ops.conv_wgrad_supported(x, w, 1, 1) and not ops.conv_wgrad_supported(x, w, 2, 1) and not ops.conv_wgrad_supported(x, w, 1, 3)
     assert ops.conv_wgrad_supported(torch.zeros(1, 8, 8, 12, dtype=torch.bfloat16, device='cuda'), w, 1, 1)
+
+
+# ---- the fused activation-gradient pass, the multi-level weight gradient, the in-buffer dense stack, the parameter sinks ----
+@pytest.mark.parametrize('shape', [(2, 32, 16, 52), (1, 7, 5, 9), (3, 64, 8, 32), (2, 2, 4, 13)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_act_grad_matches_torch(shape, dtype):
+    """dst = (src + add) * (y > 0 ? 1 : slope) on channel slices of wider buffers + the bias partial sums of the rounded
+    result (upf_act_grad / upf_conv_bias_grad_finish) vs the same arithmetic in torch."""
+    from upflow_pytorch_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    wide = lambda: torch.randn(B, C + 5, H, W, generator=g).to(dtype).cuda()
+    src, add, y = wide()[:, 2:2 + C], wide()[:, 1:1 + C], wide()[:, 5:]
+    for use_add in (False, True):
+        for use_y in (False, True):
+            dst, part = ops.act_grad(src, y if use_y else None, 0.1, add=add if use_add else None, want_bias=True)
+            ref = src.float()
+            if use_add:
+                ref = (ref + add.float()).to(dtype).float()
+            if use_y:
+                ref = torch.where(y.float() > 0, ref, ref * 0.1)
+            ref = ref.to(dtype)
+            assert torch.equal(dst, ref)
+            gb = ops.conv_bias_grad_finish([part], C)
+            gb_ref = ref.double().sum((0, 2, 3))
+            assert (gb.double() - gb_ref).abs().max() <= 1e-4 * max(1.0, float(gb_ref.abs().max()))
+    # in place, and the sums alone
+    buf = torch.cat([src, src], 1).contiguous()
+    want, _ = ops.act_grad(src, y, 0.1)
+    ops.act_grad(buf[:, C:], y, 0.1, dst=buf[:, C:])
+    assert torch.equal(buf[:, C:], want) and torch.equal(buf[:, :C], src)
+    none, part = ops.act_grad(src, dst=False, want_bias=True)
+    assert none is None and (ops.conv_bias_grad_finish([part, part], C) - 2 * src.float().sum((0, 2, 3))).abs().max() <= 1e-3 * max(1.0, float(src.float().abs().sum((0, 2, 3)).max()))
+
+
+@pytest.mark.parametrize('cfg', [(115, 128, 3, 1), (128, 96, 3, 8), (196, 32, 1, 1), (40, 70, 3, 2)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_wgrad_multi_level(cfg, dtype):
+    """One weight gradient over five uses of different sizes (aligned and ragged pyramid levels, channel slices of wider
+    buffers) == the sum of the per-use fp32 references; deterministic."""
+    from upflow_pytorch_amd import ops
+    Cin, Cout, k, d = cfg
+    g = torch.Generator().manual_seed(Cin + Cout + d)
+    sizes = [(2, 32, 104), (2, 16, 52), (2, 8, 26), (2, 4, 13), (2, 64, 208), (1, 24, 40), (1, 9, 16)]      # seven uses: two launches of <= 6
+    uses, ref = [], 0
+    for (B, H, W) in sizes:
+        xw = torch.randn(B, Cin + 3, H, W, generator=g).to(dtype).cuda()
+        gw_ = (torch.randn(B, Cout + 2, H, W, generator=g) * 0.25).to(dtype).cuda()
+        x, gy = xw[:, 3:], gw_[:, :Cout]
+        uses.append((x, gy))
+        ref = ref + torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin, k, k), gy.float(), padding=d * (k - 1) // 2, dilation=d)
+    got = ops.conv_wgrad_multi(uses, Cin, Cout, k, d)
+    assert got.shape == ref.shape and (got - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+    assert torch.equal(got, ops.conv_wgrad_multi(uses, Cin, Cout, k, d))
+    one = ops.conv_wgrad_multi(uses[:1], Cin, Cout, k, d)
+    ref1 = torch.nn.grad.conv2d_weight(uses[0][0].float(), (Cout, Cin, k, k), uses[0][1].float(), padding=d * (k - 1) // 2, dilation=d)
+    assert (one - ref1).abs().max() <= 2e-4 * max(1.0, float(ref1.abs().max()))
+
+
+def _dense_stack(ch_in, dev):
+    from upflow_pytorch_amd.model.pwc_modules import FlowEstimatorDense_v2
+    torch.manual_seed(ch_in)
+    m = FlowEstimatorDense_v2(ch_in).to(dev)
+    for p in m.parameters():
+        if p.dim() == 1:
+            torch.nn.init.normal_(p, std=0.05)
+    return m
+
+
+@pytest.mark.parametrize('geom', [(2, 16, 24), (2, 8, 26), (1, 4, 13), (2, 32, 104)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_dense_stack_in_buffer_matches_layerwise_autograd(geom, dtype):
+    """ops.DenseStackTrainFunction (one buffer, stacked data-gradient convolutions, no concatenations) vs the layer-by-layer
+    autograd schedule (ConvTrainFunction + torch.cat) and vs fp32 torch autograd of the reference's module structure
+    (model/pwc_modules.py:250-286) on the same rounded inputs."""
+    from upflow_pytorch_amd import ops
+    B, H, W = geom
+    m = _dense_stack(115, 'cuda')
+    g = torch.Generator().manual_seed(sum(geom))
+    mk = lambda c, dt: torch.randn(B, c, H, W, generator=g).to(dt).cuda().requires_grad_(True)
+    c, A, flow = mk(81, dtype), mk(32, dtype), mk(2, torch.float32)
+    g_buf = (torch.randn(B, m._n_total + 2, H, W, generator=g) * 0.1).to(dtype).cuda()
+    g_out = torch.randn(B, 2, H, W, generator=g).to(dtype).cuda()
+    params = list(m.parameters())
+
+    assert m.train_in_buffer_ok([c, A, flow])
+    buf, out = m.forward_train([c, A, flow], flow_tail=flow)
+    assert buf.shape == (B, m._n_total + 2, H, W) and out.shape == (B, 2, H, W)
+    grads = torch.autograd.grad((buf, out), [c, A, flow] + params, (g_buf, g_out))
+
+    # the same stack, layer by layer (16-bit tensor adds between the layers)
+    m._no_train_buffer = True
+    x = torch.cat([c, A, flow.to(dtype)], 1)
+    x5, out2 = m(x)
+    tail = (flow + out2.float()).to(dtype)
+    buf2 = torch.cat([x5, tail], 1)
+    assert torch.equal(out, out2) and torch.equal(buf, buf2)                     # forward: the same kernels on the same values
+    grads2 = torch.autograd.grad((buf2, out2), [c, A, flow] + params, (g_buf, g_out))
+    m._no_train_buffer = False
+
+    # fp32 reference of the module structure
+    import torch.nn.functional as F
+    xr = torch.cat([c.detach().float(), A.detach().float(), flow.detach().to(dtype).float()], 1).requires_grad_(True)
+    pr = [p.detach().clone().requires_grad_(True) for p in params]
+    h = xr
+    for i in range(5):
+        h = torch.cat([F.leaky_relu(F.conv2d(h, pr[2 * i].to(dtype).float(), pr[2 * i + 1], padding=1), 0.1), h], 1)
+    outr = F.conv2d(h, pr[10].to(dtype).float(), pr[11], padding=1)
+    flow_r = flow.detach().clone().requires_grad_(True)
+    bufr = torch.cat([h, flow_r + outr], 1)
+    gr = torch.autograd.grad((bufr, outr), [xr, flow_r] + pr, (g_buf.float(), g_out.float()))
+    gx_ref = gr[0]
+    refs = [gx_ref[:, :81], gx_ref[:, 81:113], gx_ref[:, 113:] + gr[1]] + list(gr[2:])
+    rel = lambda u, v: float((u.float() - v).norm() / v.norm().clamp_min(1e-20))
+    lim = 0.06 if dtype == torch.bfloat16 else 0.008          # six chained layers with 16-bit activations vs fp32
+    for i, (a, b, r) in enumerate(zip(grads, grads2, refs)):
+        assert a.shape == r.shape and a.dtype == ([c, A, flow] + params)[i].dtype
+        assert rel(a, r) <= lim, (i, rel(a, r), rel(b, r))
+        # the in-buffer schedule is at least as close to fp32 as the layer-wise one (fp32 accumulation across consumers)
+        assert rel(a, r) <= 1.1 * rel(b, r) + 1e-4, (i, rel(a, r), rel(b, r))
+    again = torch.autograd.grad(m.forward_train([c, A, flow], flow_tail=flow), [c, A, flow] + params, (g_buf, g_out))
+    assert all(torch.equal(a, b) for a, b in zip(grads, again))
+
+
+def test_shared_conv_grads_defers_to_one_contraction():
+    """Inside ops.shared_conv_grads the five uses of a shared decoder (pyramid levels of different sizes) hand their
+    (x, g) pairs to the parameters' sinks; the gradients equal the per-use ones summed by autograd (fp32 summation order
+    aside), inputs' gradients are identical, and nothing is left in the registry afterwards."""
+    from upflow_pytorch_amd import ops
+    from upflow_pytorch_amd.model.pwc_modules import ContextNetwork_v2_
+    dt = torch.bfloat16
+    est = _dense_stack(115, 'cuda')
+    ctxn = ContextNetwork_v2_(est._n_total + 2).cuda()
+    sizes = [(2, 4, 13), (2, 8, 26), (2, 16, 52), (2, 32, 104), (2, 64, 208)]
+    g = torch.Generator().manual_seed(3)
+    data = [[torch.randn(B, ch, H, W, generator=g).to(d).cuda().requires_grad_(True) for ch, d in ((81, dt), (32, dt), (2, torch.float32))] for B, H, W in sizes]
+    params = list(est.parameters()) + list(ctxn.parameters())
+
+    def run(shared):
+        convs = [m for m in list(est.modules()) + list(ctxn.modules()) if isinstance(m, torch.nn.Conv2d)]
+        total = 0
+        with ops.shared_conv_grads(convs if shared else []):
+            for c, A, flow in data:
+                buf, res = est.forward_train([c, A, flow], flow_tail=flow)
+                fine = ctxn(buf)
+                total = total + (res.float() + fine.float()).square().mean()
+        assert not ops._GATES
+        flat = [t for lvl in data for t in lvl]
+        return torch.autograd.grad(total, flat + params)
+
+    a, b = run(True), run(False)
+    n_in = 3 * len(sizes)
+    for x, y in zip(a[:n_in], b[:n_in]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[n_in:], b[n_in:]):
+        assert (x - y).abs().max() <= 1e-5 * max(1.0, float(y.abs().max())), float((x - y).abs().max())
+    a2 = run(True)
+    assert all(torch.equal(x, y) for x, y in zip(a, a2))

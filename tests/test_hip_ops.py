@@ -177,6 +177,25 @@ def test_corr_backward_vs_oracle(hip, shape, dtype):
     assert (g2.cpu().float() - w2).abs().max() <= tol
 
 
+@pytest.mark.parametrize('shape', [(1, 8, 12, 16), (1, 8, 14, 68), (2, 4, 11, 7)])
+def test_corr_backward_border_is_safe_against_nonfinite_neighbours(hip, shape):
+    """The tiled backward fetches 4-wide vectors of grad_out at displaced columns; where such a vector leaves the row it
+    covers elements of the neighbouring row.  Those terms are dropped by the reference (correlation_cuda_kernel.cu:228-262),
+    so an Inf / NaN elsewhere in grad_out must not leak into border pixels: poison one whole grad_out row and
+    compare every OTHER affected pixel with the oracle evaluated on the same input."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    f1, f2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    go = torch.randn(B, 81, H, W, generator=g)
+    go[:, :, H // 2, :] = float('inf')
+    w1, w2 = oracle.corr81_backward(f1, f2, go)
+    g1, g2 = hip.corr81_backward_raw(dev(f1), dev(f2), dev(go))
+    for got, want in ((g1.cpu(), w1), (g2.cpu(), w2)):
+        fin = torch.isfinite(want)
+        assert torch.equal(torch.isfinite(got), fin), 'non-finite values leaked into %d pixels' % int((torch.isfinite(got) != fin).sum())
+        assert fin.any() and (got[fin] - want[fin]).abs().max() <= 1e-5
+
+
 def test_corr_general_parameters(hip):
     """upf_correlation_forward with the reference's full parameter list; pinned only through the
     oracle's restatement of correlation_cuda_kernel.cu:41-114 for sets the model never uses."""

@@ -133,18 +133,24 @@ def test_graphed_training_step_equals_eager(mode):
         return net
     batch = {k: v.cuda() for k, v in _weights.make_train_batch().items()}
     res = []
-    for graph in (False, True):
+    for graph in (False, False, True):
         tr = Trainer(make(), lr=1e-4, device=torch.device('cuda', 0), distributed=False, graph=graph)
         stats = [tr.step(batch) for _ in range(5)]
         assert (tr._graph is not None) == graph
         res.append((stats, {n: p.detach().clone() for n, p in tr.raw_net.named_parameters()}))
-    (s0, p0), (s1, p1) = res
+    (s0, p0), (_, pe), (s1, p1) = res
     for a, b in zip(s0, s1):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
-    worst = max(float((p0[n] - p1[n]).abs().max()) for n in p0)
-    print('graphed vs eager after 5 steps (%s): worst parameter difference %.3g' % (mode, worst))
-    assert worst <= 5e-4                  # lr 1e-4, 5 Adam steps: parameters move by <= 5e-4 in total
+    diff = lambda u, v: (max(float((u[n] - v[n]).abs().max()) for n in u),
+                         sum(float((u[n] - v[n]).abs().sum()) for n in u) / sum(u[n].numel() for n in u))
+    (worst, mean), (noise_worst, noise_mean) = diff(p0, p1), diff(p0, pe)
+    print('graphed vs eager after 5 steps (%s): parameter difference worst %.3g mean %.3g; eager vs eager worst %.3g mean %.3g'
+          % (mode, worst, mean, noise_worst, noise_mean))
+    # lr 1e-4, 5 Adam steps: a parameter moves by <= 5e-4, two runs differ by <= 1e-3; the stride-2 layers' gradients come
+    # from MIOpen kernels with atomics, and Adam's first steps turn a sign flip of a near-zero gradient into +-lr — so the
+    # yardstick is the difference between two EAGER runs
+    assert worst <= 1e-3 and mean <= max(3.0 * noise_mean, 2e-5), (worst, mean, noise_worst, noise_mean)
 
 
 def test_bf16_training_mode_tracks_the_fp32_reference():

@@ -43,6 +43,9 @@ SIGNATURES = {
     'upf_leaky_backward': [_vp, _vp, _vp, _ll, _f, _i, _vp],
     'upf_conv_wgrad': [_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_bias_grad': [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp],
+    'upf_conv_wgrad_multi': [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_act_grad': [_vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _f, _i, _vp],
+    'upf_conv_bias_grad_finish': [_vp, _i, _vp, _i, _vp],
     'upf_census_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_census_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_boundary_warp_forward': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -53,6 +56,13 @@ SIGNATURES = {
     'upf_smooth_edge1_backward': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_occ_check': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
 }
+
+
+
+class WgradLevel(_c.Structure):
+    """upf_wgrad_level (include/upflow_hip.h): one use of a shared convolution in a multi-level weight gradient."""
+    _fields_ = [('x', _vp), ('x_batch_stride', _ll), ('grad_pre', _vp), ('g_batch_stride', _ll), ('B', _i), ('H', _i), ('W', _i)]
+
 
 _lib = None
 
@@ -93,6 +103,8 @@ def lib():
         L.upf_conv_wgrad_supported.restype = _i
         L.upf_conv_wgrad_workspace_bytes.argtypes = [_i] * 7
         L.upf_conv_wgrad_workspace_bytes.restype = _ll
+        L.upf_conv_wgrad_multi_workspace_bytes.argtypes = [_vp, _i, _i, _i, _i, _i]
+        L.upf_conv_wgrad_multi_workspace_bytes.restype = _ll
         L.upf_conv_bias_grad_workspace_bytes.argtypes = [_i]
         L.upf_conv_bias_grad_workspace_bytes.restype = _ll
         L.upf_loss_partials.argtypes = [_ll]

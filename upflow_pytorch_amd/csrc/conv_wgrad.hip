@@ -24,6 +24,7 @@
 // Requirements: stride 1, W >= 8 (rows that are not 16-byte aligned — the coarse levels of the 256x832 training crops are
 // 52, 26 and 13 pixels wide — take the RAGGED staging variant).
 #include "common.hpp"
+#include <cstring>
 
 namespace upf {
 namespace wgrad {
@@ -100,10 +101,25 @@ __device__ __forceinline__ u32x4 shr_pixels(u32x4 v, int sh) {            // 128
   return r;
 }
 
+// The K dimension of one launch may span several PYRAMID LEVELS: the decoder's weights are shared by all levels
+// (model/upflow.py:535-573 calls the same flow_estimators / context_networks five times), so their weight gradient is one
+// contraction over the pixels of every level.  A launch takes up to MAXL (x, g) pairs of different sizes; tile indices run
+// through the levels back to back (tile0 = first tile of a level) and a workgroup's tiles ks_id, ks_id + ksplit, ... are
+// spread over all of them.
+constexpr int MAXL = 6;
+struct KLevel {
+  const void* x; const void* g;
+  long long xbs, gbs;
+  int H, W, tiles_x, tiles_y, tile0, pad;
+};
+struct KLevels {
+  KLevel lv[MAXL];
+  int n, ntiles;
+};
+
 template <typename T, int D, bool RAGGED>
 __global__ __launch_bounds__(NTHREADS, 1)
-void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ g, long long gbs, float* __restrict__ partial,
-                  int B, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, int ntiles, int nci2) {
+void wgrad_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cout, int nci2) {
   using G = Geo<D>;
   constexpr int DD = (D == 0) ? 1 : D;
   constexpr int HALO = halo_of(D);
@@ -117,9 +133,9 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
   const int co2 = blockIdx.y / nci2, ci2 = blockIdx.y - co2 * nci2;      // 64-channel block pair of this workgroup
   const int cob = wave & 1, cib = wave >> 1;
   const int ch = lane & 31, kg = lane >> 5;
-  const uint32_t plane = (uint32_t)H * (uint32_t)W * 2u;
+  const int ntiles = L.ntiles;
   const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
-  const uint32_t xrec = (uint32_t)max(min(Cin - ci2 * 64, 64), 0) * plane, grec = (uint32_t)max(min(Cout - co2 * 64, 64), 0) * plane;
+  const uint32_t xnch = (uint32_t)max(min(Cin - ci2 * 64, 64), 0), gnch = (uint32_t)max(min(Cout - co2 * 64, 64), 0);
 
   // per-thread staging geometry (the same for every tile): channel, staged row, 8-pixel block -> LDS slot
   int xc[NXT], xsr[NXT], xb8[NXT], xl[NXT];
@@ -139,12 +155,24 @@ void wgrad_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ 
   u32x4 px[NXT], pg[NGT];
   int sx[RAGGED ? NXT : 1], sg[RAGGED ? NGT : 1];                         // RAGGED: left shift of each staged block
   auto issue = [&](int tile) {                                           // global loads of one tile -> registers
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    // the level this (uniform) tile index belongs to: scalar selects over the kernel arguments
+    const T* x = (const T*)L.lv[0].x; const T* g = (const T*)L.lv[0].g;
+    long long xbs = L.lv[0].xbs, gbs = L.lv[0].gbs;
+    int H = L.lv[0].H, W = L.lv[0].W, tiles_x = L.lv[0].tiles_x, tiles_y = L.lv[0].tiles_y, t0 = 0;
+#pragma unroll
+    for (int i = 1; i < MAXL; ++i)
+      if (i < L.n && tile >= L.lv[i].tile0) {
+        x = (const T*)L.lv[i].x; g = (const T*)L.lv[i].g; xbs = L.lv[i].xbs; gbs = L.lv[i].gbs;
+        H = L.lv[i].H; W = L.lv[i].W; tiles_x = L.lv[i].tiles_x; tiles_y = L.lv[i].tiles_y; t0 = L.lv[i].tile0;
+      }
+    const int lt = tile - t0;
+    const int tx = lt % tiles_x, ty = (lt / tiles_x) % tiles_y, n = lt / (tiles_x * tiles_y);
     const int phase = ty % DD, q = ty / DD;
     const int y0 = phase + DD * q * TR, x0 = tx * TWP;                  // output rows y0 + k*DD, k < TR
     const bool live = tile < ntiles;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs + (size_t)ci2 * 64 * H * W), 0, live ? xrec : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g + (size_t)n * gbs + (size_t)co2 * 64 * H * W), 0, live ? grec : 0u, 0x00020000);
+    const uint32_t plane = (uint32_t)H * (uint32_t)W * 2u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs + (size_t)ci2 * 64 * H * W), 0, live ? xnch * plane : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g + (size_t)n * gbs + (size_t)co2 * 64 * H * W), 0, live ? gnch * plane : 0u, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NXT; ++i) {
       const int gy = (D == 0) ? y0 + xsr[i] : y0 + (xsr[i] - 1) * DD, gx = x0 - HALO + 8 * xb8[i];
@@ -294,6 +322,83 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __
   db[co] = s;
 }
 
+// The gradient entering a layer's pre-activation, in ONE pass over a channel-sliced tensor (the dense stacks keep their
+// gradients in one buffer, see ops.DenseStackTrainFunction):
+//     dst = (src + add) * (y > 0 ? 1 : slope)        add, y optional
+// and, while the values are in registers, the first stage of the bias gradient: part[co][chunk] = sum of the ROUNDED dst
+// values over 1/BIAS_NCH of the channel's (image, pixel) range — the same (channel, chunk) grid and fixed summation
+// order as bias_grad_partial_kernel.  V = elements per access (4: rows of 4k pixels at 8-byte aligned slices, else 1).
+template <typename T> __device__ __forceinline__ float bits_f(unsigned short b) { T t; t.v = b; return Elem<T>::load(&t); }
+template <typename T> __device__ __forceinline__ float round16(float v) { T t; Elem<T>::store(&t, v); return Elem<T>::load(&t); }
+template <typename T, int V>
+__global__ __launch_bounds__(256)
+void act_grad_kernel(const T* __restrict__ src, long long sbs, const T* __restrict__ add, long long abs_, const T* __restrict__ y, long long ybs,
+                     T* __restrict__ dst, long long dbs, float* __restrict__ part, int B, int HW, float slope) {
+  __shared__ float sh[4];
+  const int co = blockIdx.x, chunk = blockIdx.y;
+  const long long total = (long long)B * (HW / V), per = (total + BIAS_NCH - 1) / BIAS_NCH;
+  const long long e0 = chunk * per, e1 = min(total, e0 + per);
+  const int hwv = HW / V;
+  float s = 0.f;
+  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const long long n = e / hwv;
+    const size_t o = (size_t)co * HW + (size_t)(e - n * hwv) * V;
+    float v[V];
+    if constexpr (V == 4) {
+      const uint2 r = *reinterpret_cast<const uint2*>(src + (size_t)n * sbs + o);
+      v[0] = bits_f<T>((unsigned short)r.x); v[1] = bits_f<T>((unsigned short)(r.x >> 16));
+      v[2] = bits_f<T>((unsigned short)r.y); v[3] = bits_f<T>((unsigned short)(r.y >> 16));
+      if (add) {
+        const uint2 a = *reinterpret_cast<const uint2*>(add + (size_t)n * abs_ + o);
+        // 16-bit sum, rounded like the tensor add it replaces
+        v[0] = round16<T>(v[0] + bits_f<T>((unsigned short)a.x)); v[1] = round16<T>(v[1] + bits_f<T>((unsigned short)(a.x >> 16)));
+        v[2] = round16<T>(v[2] + bits_f<T>((unsigned short)a.y)); v[3] = round16<T>(v[3] + bits_f<T>((unsigned short)(a.y >> 16)));
+      }
+      if (y) {
+        const uint2 q = *reinterpret_cast<const uint2*>(y + (size_t)n * ybs + o);
+        if (!(bits_f<T>((unsigned short)q.x) > 0.f)) v[0] *= slope;
+        if (!(bits_f<T>((unsigned short)(q.x >> 16)) > 0.f)) v[1] *= slope;
+        if (!(bits_f<T>((unsigned short)q.y) > 0.f)) v[2] *= slope;
+        if (!(bits_f<T>((unsigned short)(q.y >> 16)) > 0.f)) v[3] *= slope;
+      }
+      uint2 w;
+      w.x = pack2<T>(v[0], v[1]); w.y = pack2<T>(v[2], v[3]);
+      if (dst) *reinterpret_cast<uint2*>(dst + (size_t)n * dbs + o) = w;
+      s += (bits_f<T>((unsigned short)w.x) + bits_f<T>((unsigned short)(w.x >> 16))) +
+           (bits_f<T>((unsigned short)w.y) + bits_f<T>((unsigned short)(w.y >> 16)));
+    } else {
+      v[0] = Elem<T>::load(src + (size_t)n * sbs + o);
+      if (add) v[0] = round16<T>(v[0] + Elem<T>::load(add + (size_t)n * abs_ + o));
+      if (y && !(Elem<T>::load(y + (size_t)n * ybs + o) > 0.f)) v[0] *= slope;
+      if (dst) Elem<T>::store(dst + (size_t)n * dbs + o, v[0]);
+      s += round16<T>(v[0]);
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[co * BIAS_NCH + chunk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// second stage over the first-stage sums of several uses of one bias (the pyramid levels), in the order given
+constexpr int MAXP = 8;
+struct BiasParts { const float* p[MAXP]; int n; };
+__global__ void bias_grad_multi_final_kernel(const BiasParts P, float* __restrict__ db, int Cout) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Cout) return;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i)
+    if (i < P.n) {
+      float t = 0.f;
+      for (int k = 0; k < BIAS_NCH; ++k) t += P.p[i][co * BIAS_NCH + k];
+      s += t;
+    }
+  db[co] = s;
+}
+
 // K-splits: one workgroup per CU in total (the kernel keeps a whole tile in registers: 1 workgroup per CU is resident), as
 // long as the fp32 partial blocks (ksplit x taps x pad64(Cout) x pad64(Cin)) stay under 32 MB — small layers (a single
 // 64x64 block) then use all 256 CUs instead of 64, large ones are bounded by their own block count anyway.
@@ -306,22 +411,68 @@ static int pick_ksplit(int ntiles, int nblocks, int ntaps) {
   return ks < 1 ? 1 : ks;
 }
 
+// One group of levels (all aligned, or all through the RAGGED staging) -> `ksplit` partial blocks starting at `ws`.
 template <typename T, int D, bool RAGGED>
-int launch(const void* x, long long xbs, const void* g, long long gbs, float* dw, float* ws, int B, int Cin, int Cout, int H, int W,
-           hipStream_t stream) {
+void launch_group(const upf_wgrad_level* lv, const int* idx, int n, float* ws, int ksplit, int Cin, int Cout, hipStream_t stream) {
   using G = Geo<D>;
   constexpr int DD = (D == 0) ? 1 : D;
-  const int tiles_x = cdiv(W, TWP), tiles_y = DD * cdiv(cdiv(H, DD), TR);
-  const int ntiles = B * tiles_x * tiles_y;
+  KLevels L;
+  memset(&L, 0, sizeof(L));
+  int t0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const upf_wgrad_level& a = lv[idx[i]];
+    KLevel& k = L.lv[i];
+    k.x = a.x; k.g = a.grad_pre;
+    k.xbs = a.x_batch_stride ? a.x_batch_stride : (long long)Cin * a.H * a.W;
+    k.gbs = a.g_batch_stride ? a.g_batch_stride : (long long)Cout * a.H * a.W;
+    k.H = a.H; k.W = a.W;
+    k.tiles_x = cdiv(a.W, TWP); k.tiles_y = DD * cdiv(cdiv(a.H, DD), TR);
+    k.tile0 = t0;
+    t0 += a.B * k.tiles_x * k.tiles_y;
+  }
+  L.n = n; L.ntiles = t0;
   const int nco2 = cdiv(Cout, 64), nci2 = cdiv(Cin, 64);
-  const int ksplit = pick_ksplit(ntiles, nco2 * nci2, G::NT);
   static LdsOptIn opt;
   auto kern = &wgrad_kernel<T, D, RAGGED>;
   opt.ensure(reinterpret_cast<const void*>(kern), G::LDS_BYTES);
-  hipLaunchKernelGGL(kern, dim3(ksplit, nco2 * nci2), dim3(NTHREADS), G::LDS_BYTES, stream, (const T*)x, xbs, (const T*)g, gbs, ws,
-                     B, Cin, Cout, H, W, tiles_x, tiles_y, ntiles, nci2);
+  hipLaunchKernelGGL(kern, dim3(ksplit, nco2 * nci2), dim3(NTHREADS), G::LDS_BYTES, stream, L, ws, Cin, Cout, nci2);
+}
+
+static bool level_ragged(const upf_wgrad_level& a, int Cin, int Cout) {
+  const long long xbs = a.x_batch_stride ? a.x_batch_stride : (long long)Cin * a.H * a.W;
+  const long long gbs = a.g_batch_stride ? a.g_batch_stride : (long long)Cout * a.H * a.W;
+  return !(a.W % 8 == 0 && xbs % 8 == 0 && gbs % 8 == 0 && aligned_to(a.x, 16) && aligned_to(a.grad_pre, 16));
+}
+static int level_tiles(const upf_wgrad_level& a, int dd) { return a.B * cdiv(a.W, TWP) * dd * cdiv(cdiv(a.H, dd), TR); }
+
+// The plan of one multi-level weight gradient: aligned levels in one launch, ragged ones in a second, their K-splits
+// back to back in the workspace, one reduction over all of them.
+struct Plan {
+  int ia[MAXL], na = 0, ir[MAXL], nr = 0, ks_a = 0, ks_r = 0;
+};
+static Plan make_plan(const upf_wgrad_level* lv, int n, int Cin, int Cout, int kernel_size, int dilation) {
+  Plan p;
+  const int dd = kernel_size == 1 ? 1 : dilation, nt = kernel_size == 1 ? 1 : 9;
+  int ta = 0, tr = 0;
+  for (int i = 0; i < n; ++i) {
+    if (level_ragged(lv[i], Cin, Cout)) { p.ir[p.nr++] = i; tr += level_tiles(lv[i], dd); }
+    else { p.ia[p.na++] = i; ta += level_tiles(lv[i], dd); }
+  }
+  const int nblocks = cdiv(Cout, 64) * cdiv(Cin, 64);
+  if (p.na) p.ks_a = pick_ksplit(ta, nblocks, nt);
+  if (p.nr) p.ks_r = pick_ksplit(tr, nblocks, nt);
+  return p;
+}
+
+template <typename T, int D>
+int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cout, int kernel_size, int dilation, hipStream_t stream) {
+  using G = Geo<D>;
+  const Plan p = make_plan(lv, n, Cin, Cout, kernel_size, dilation);
+  const size_t per_split = (size_t)G::NT * (cdiv(Cout, 64) * 64) * (cdiv(Cin, 64) * 64);
+  if (p.na) launch_group<T, D, false>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
+  if (p.nr) launch_group<T, D, true>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
   const long long total = (long long)G::NT * Cout * (cdiv(Cin, 64) * 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws, dw, ksplit, G::NT, Cout, Cin);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws, dw, p.ks_a + p.ks_r, G::NT, Cout, Cin);
   return check_launch("conv_wgrad");
 }
 
@@ -333,35 +484,56 @@ extern "C" int upf_conv_wgrad_supported(int Cin, int Cout, int H, int W, int ker
          ((kernel_size == 1 && dilation == 1) || (kernel_size == 3 && (dilation == 1 || dilation == 2 || dilation == 4 || dilation == 8 || dilation == 16)));
 }
 
-extern "C" long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation) {
+static int wgrad_check_levels(const upf_wgrad_level* lv, int n, int Cin, int Cout, int kernel_size, int dilation, int dtype) {
   using namespace upf;
-  const int dd = kernel_size == 1 ? 1 : dilation, nt = kernel_size == 1 ? 1 : 9;
-  const int ntiles = B * cdiv(W, wgrad::TWP) * dd * cdiv(cdiv(H, dd), wgrad::TR);
-  const int ks = wgrad::pick_ksplit(ntiles, cdiv(Cout, 64) * cdiv(Cin, 64), nt);
-  return (long long)ks * nt * (cdiv(Cout, 64) * 64) * (cdiv(Cin, 64) * 64) * (long long)sizeof(float);
+  UPF_REQUIRE(lv && n >= 1 && n <= wgrad::MAXL, UPF_EINVAL, "conv_wgrad: 1..%d levels", wgrad::MAXL);
+  for (int i = 0; i < n; ++i) {
+    const upf_wgrad_level& a = lv[i];
+    UPF_REQUIRE(a.x && a.grad_pre && a.B > 0, UPF_EINVAL, "conv_wgrad: null pointer / empty batch (level %d)", i);
+    UPF_REQUIRE(upf_conv_wgrad_supported(Cin, Cout, a.H, a.W, kernel_size, dilation, 1, dtype), UPF_EUNSUPPORTED,
+                "conv_wgrad: bf16 / fp16, stride 1, W >= 8, 1x1 or 3x3 with dilation 1/2/4/8/16 only (k %d, d %d, W %d)", kernel_size, dilation, a.W);
+    const long long xbs = a.x_batch_stride ? a.x_batch_stride : (long long)Cin * a.H * a.W, gbs = a.g_batch_stride ? a.g_batch_stride : (long long)Cout * a.H * a.W;
+    UPF_REQUIRE(xbs >= (long long)Cin * a.H * a.W && gbs >= (long long)Cout * a.H * a.W, UPF_EINVAL, "conv_wgrad: bad batch stride");
+    UPF_REQUIRE((size_t)64 * a.H * a.W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "conv_wgrad: image too large");
+  }
+  return UPF_OK;
+}
+
+extern "C" long long upf_conv_wgrad_multi_workspace_bytes(const upf_wgrad_level* levels, int nlevels, int Cin, int Cout, int kernel_size, int dilation) {
+  using namespace upf;
+  if (!levels || nlevels < 1 || nlevels > wgrad::MAXL) return -1;
+  const int nt = kernel_size == 1 ? 1 : 9;
+  const wgrad::Plan p = wgrad::make_plan(levels, nlevels, Cin, Cout, kernel_size, kernel_size == 1 ? 1 : dilation);
+  return (long long)(p.ks_a + p.ks_r) * nt * (cdiv(Cout, 64) * 64) * (cdiv(Cin, 64) * 64) * (long long)sizeof(float);
+}
+
+extern "C" int upf_conv_wgrad_multi(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
+                                    int kernel_size, int dilation, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(grad_w && workspace, UPF_EINVAL, "conv_wgrad: null pointer");
+  if (int rc = wgrad_check_levels(levels, nlevels, Cin, Cout, kernel_size, dilation, dtype)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = kernel_size == 1 ? 0 : dilation;
+#define UPF_WG(DV) case DV: return dtype == UPF_BF16 ? wgrad::run<bf16_t, DV>(levels, nlevels, grad_w, (float*)workspace, Cin, Cout, kernel_size, dilation, s) \
+                                                     : wgrad::run<f16_t, DV>(levels, nlevels, grad_w, (float*)workspace, Cin, Cout, kernel_size, dilation, s);
+  switch (D) {
+    UPF_WG(0) UPF_WG(1) UPF_WG(2) UPF_WG(4) UPF_WG(8) UPF_WG(16)
+  }
+#undef UPF_WG
+  set_error("conv_wgrad: internal routing error");
+  return UPF_EUNSUPPORTED;
+}
+
+extern "C" long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation) {
+  // (alignment unknown here: aligned and ragged plans of ONE level use the same split count)
+  upf_wgrad_level a = {nullptr, 0, nullptr, 0, B, H, W};
+  return upf_conv_wgrad_multi_workspace_bytes(&a, 1, Cin, Cout, kernel_size, dilation);
 }
 
 extern "C" int upf_conv_wgrad(const void* x, long long x_batch_stride, const void* grad_y, long long g_batch_stride, float* grad_w,
                               void* workspace, int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation, int dtype, void* stream) {
-  using namespace upf;
-  UPF_REQUIRE(x && grad_y && grad_w && workspace, UPF_EINVAL, "conv_wgrad: null pointer");
-  UPF_REQUIRE(upf_conv_wgrad_supported(Cin, Cout, H, W, kernel_size, dilation, 1, dtype), UPF_EUNSUPPORTED,
-              "conv_wgrad: bf16 / fp16, stride 1, W >= 8, 1x1 or 3x3 with dilation 1/2/4/8/16 only (k %d, d %d, W %d)", kernel_size, dilation, W);
-  const long long xbs = x_batch_stride ? x_batch_stride : (long long)Cin * H * W, gbs = g_batch_stride ? g_batch_stride : (long long)Cout * H * W;
-  UPF_REQUIRE(xbs >= (long long)Cin * H * W && gbs >= (long long)Cout * H * W, UPF_EINVAL, "conv_wgrad: bad batch stride");
-  const bool ragged = !(W % 8 == 0 && xbs % 8 == 0 && gbs % 8 == 0 && aligned_to(x, 16) && aligned_to(grad_y, 16));
-  UPF_REQUIRE((size_t)64 * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "conv_wgrad: image too large");
-  hipStream_t s = (hipStream_t)stream;
-  const int D = kernel_size == 1 ? 0 : dilation;
-#define UPF_WG2(DV, TT) (ragged ? wgrad::launch<TT, DV, true>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s) : wgrad::launch<TT, DV, false>(x, xbs, grad_y, gbs, grad_w, (float*)workspace, B, Cin, Cout, H, W, s))
-#define UPF_WG(DV) case DV: return dtype == UPF_BF16 ? UPF_WG2(DV, bf16_t) : UPF_WG2(DV, f16_t);
-  switch (D) {
-    UPF_WG(0) UPF_WG(1) UPF_WG(2) UPF_WG(4) UPF_WG(8) UPF_WG(16)
-  }
-#undef UPF_WG2
-#undef UPF_WG
-  set_error("conv_wgrad: internal routing error");
-  return UPF_EUNSUPPORTED;
+  const upf_wgrad_level a = {x, x_batch_stride, grad_y, g_batch_stride, B, H, W};
+  return upf_conv_wgrad_multi(&a, 1, grad_w, workspace, Cin, Cout, kernel_size, dilation, dtype, stream);
 }
 
 extern "C" int upf_leaky_backward(const void* grad_y, const void* y, void* grad_pre, long long n, float slope, int dtype, void* stream) {
@@ -375,6 +547,40 @@ extern "C" int upf_leaky_backward(const void* grad_y, const void* y, void* grad_
   if (dtype == UPF_BF16) hipLaunchKernelGGL((wgrad::leaky_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad_y, (const bf16_t*)y, (bf16_t*)grad_pre, n8, slope);
   else hipLaunchKernelGGL((wgrad::leaky_bwd_kernel<f16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const f16_t*)grad_y, (const f16_t*)y, (f16_t*)grad_pre, n8, slope);
   return check_launch("leaky_backward");
+}
+
+extern "C" int upf_act_grad(const void* src, long long src_batch_stride, const void* add, long long add_batch_stride, const void* y,
+                            long long y_batch_stride, void* dst, long long dst_batch_stride, float* bias_partial, int B, int C, int HW,
+                            float slope, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(src && (dst || bias_partial) && B > 0 && C > 0 && HW > 0, UPF_EINVAL, "act_grad: bad arguments");
+  UPF_REQUIRE(dtype == UPF_F16 || dtype == UPF_BF16, UPF_EDTYPE, "act_grad: bf16 / fp16 only");
+  const long long chw = (long long)C * HW;
+  const long long sbs = src_batch_stride ? src_batch_stride : chw, abs_ = add_batch_stride ? add_batch_stride : chw;
+  const long long ybs = y_batch_stride ? y_batch_stride : chw, dbs = dst_batch_stride ? dst_batch_stride : chw;
+  const bool v4 = HW % 4 == 0 && sbs % 4 == 0 && abs_ % 4 == 0 && ybs % 4 == 0 && dbs % 4 == 0 && aligned_to(src, 8) && (!dst || aligned_to(dst, 8)) &&
+                  (!add || aligned_to(add, 8)) && (!y || aligned_to(y, 8));
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(C, wgrad::BIAS_NCH);
+#define UPF_AG(TT, VV) hipLaunchKernelGGL((wgrad::act_grad_kernel<TT, VV>), grid, dim3(256), 0, s, (const TT*)src, sbs, (const TT*)add, abs_, (const TT*)y, ybs, (TT*)dst, dbs, bias_partial, B, HW, slope)
+  if (dtype == UPF_BF16) { if (v4) UPF_AG(bf16_t, 4); else UPF_AG(bf16_t, 1); }
+  else { if (v4) UPF_AG(f16_t, 4); else UPF_AG(f16_t, 1); }
+#undef UPF_AG
+  return check_launch("act_grad");
+}
+
+extern "C" int upf_conv_bias_grad_finish(const float* const* partials, int npartials, float* grad_bias, int Cout, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(partials && grad_bias && Cout > 0 && npartials >= 1 && npartials <= wgrad::MAXP, UPF_EINVAL, "conv_bias_grad_finish: 1..%d partial buffers", wgrad::MAXP);
+  wgrad::BiasParts P;
+  memset(&P, 0, sizeof(P));
+  for (int i = 0; i < npartials; ++i) {
+    UPF_REQUIRE(partials[i], UPF_EINVAL, "conv_bias_grad_finish: null partial buffer");
+    P.p[i] = partials[i];
+  }
+  P.n = npartials;
+  hipLaunchKernelGGL(wgrad::bias_grad_multi_final_kernel, dim3(cdiv(Cout, 128)), dim3(128), 0, (hipStream_t)stream, P, grad_bias, Cout);
+  return check_launch("conv_bias_grad_finish");
 }
 
 extern "C" long long upf_conv_bias_grad_workspace_bytes(int Cout) { return (long long)Cout * upf::wgrad::BIAS_NCH * (long long)sizeof(float); }

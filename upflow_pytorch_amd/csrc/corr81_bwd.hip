@@ -120,8 +120,12 @@ void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ g
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[c][i] = 0.f;
   const bool live = y < H && x < W;
-  // weights of displacement row dyi: g1: gO[d] at the pixels themselves; g2: gO[d] at the displaced SOURCE pixels
-  // (columns of a displaced vector that leave the row meet the zero halo of the feature tile)
+  // weights of displacement row dyi: g1: gO[d] at the pixels themselves; g2: gO[d] at the displaced SOURCE pixels.
+  // Columns of a displaced 4-vector that leave the row [0, W) are elements of the NEIGHBOURING row in memory: they meet the
+  // zero halo of the feature tile, but 0 * (Inf / NaN of that other row) would still poison the border pixels (the
+  // reference drops those terms, correlation_cuda_kernel.cu:228-262), so they are zeroed here — only lanes within 4
+  // pixels of the left / right image border ever take that branch.
+  const bool edge = WHICH && (x < 4 || x + 8 > W);
   auto load_w = [&](int dyi, float (&w)[9][4]) {
     const int dy = dyi - 4;
 #pragma unroll
@@ -129,6 +133,10 @@ void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ g
       const int yy = WHICH ? y - dy : y, xx = WHICH ? x - (dxi - 4) : x;
       const bool in = live && yy >= 0 && yy < H;
       load4(gr, in ? (uint32_t)(((dyi * 9 + dxi) * H + yy) * W + xx) * ES : 0x80000000u, w[dxi]);
+      if (edge) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[dxi][i] = (xx + i >= 0 && xx + i < W) ? w[dxi][i] : 0.f;
+      }
     }
   };
   auto compute = [&](int dyi, const float (&w)[9][4]) {

@@ -11,6 +11,9 @@
 // x, so the y stores are fully coalesced and the four tap loads of neighbouring lanes fall into the
 // same or adjacent cache lines for smooth flows.
 //
+// Finite-input assumption: a clamped pair load may multiply a column that is not a tap by an exact zero weight, so a
+// non-finite FEATURE value next to an image-border tap can turn that output into NaN (ATen multiplies its in-bounds
+// zero-weight taps too; only which neighbour is touched differs).  Non-finite FLOWS are handled (positions are clamped).
 // Compiled with -ffp-contract=off (see sampling.hpp: the mask is bit-sensitive).
 #include "sampling.hpp"
 

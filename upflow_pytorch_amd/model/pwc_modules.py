@@ -270,11 +270,39 @@ class _DenseStack(tools.abstract_model):
         self._packed[5](x5, out)
         return x5, out
 
+    def _train_convs(self):
+        """conv1..conv5, conv_last as plain nn.Conv2d if every Sequential is Conv2d [+ LeakyReLU] (no norm layers)."""
+        seqs = [getattr(self, n) for n in self._NAMES] + [self.conv_last]
+        slope = None
+        for i, q in enumerate(seqs):
+            act = list(q)[1:]
+            if i < 5:
+                if len(act) != 1 or not isinstance(act[0], nn.LeakyReLU):
+                    return None, None
+                slope = float(act[0].negative_slope)
+            elif act:
+                return None, None
+        return [q[0] for q in seqs], slope
+
+    def train_in_buffer_ok(self, inputs):
+        convs, _ = self._train_convs()
+        return convs is not None and not getattr(self, '_no_train_buffer', False) and ops.dense_stack_train_supported(inputs, convs)
+
+    def forward_train(self, inputs, flow_tail=None):
+        """Training (16-bit activations, fp32 master weights): the whole stack as ONE autograd node in the inference path's
+        buffer layout (ops.DenseStackTrainFunction).  inputs: tensors whose concatenation is the stack's input.
+        -> (buf [B, n_total (+ tail), H, W], x_out); buf[:, :n_total] is the reference's x5."""
+        convs, slope = self._train_convs()
+        return ops.dense_stack_train(inputs, convs, slope, flow_tail)
+
     def forward(self, x):
         if _fast_conv_ok(x):
             buf, slot = self.alloc_buffer(x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device)
             slot.copy_(x)
             return self.forward_in_buffer(buf)
+        if self.train_in_buffer_ok([x]):
+            buf, out = self.forward_train([x])
+            return buf, out
         cache = self.__dict__.setdefault('_fast_cache', {})
         for name in self._NAMES:
             x = torch.cat([fast_conv_seq(getattr(self, name), x, cache), x], dim=1)

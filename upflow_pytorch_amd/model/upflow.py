@@ -349,7 +349,11 @@ class UPFlow_net(tools.abstract_model):
             if tdt is not None and torch.is_grad_enabled() and cdt == torch.float32:
                 # training on the matrix cores: 16-bit activations from the first layer on, fp32 master weights
                 # (flows, sampling positions, masks, statistics and the losses stay fp32)
-                return self._forward_stacked(X.to(tdt), B, tdt)
+                # (the decoder's convolutions are shared by the pyramid levels: their parameter gradients are deferred to
+                # one multi-level contraction per layer, ops.shared_conv_grads)
+                convs = [m for m in self.modules() if isinstance(m, nn.Conv2d)] if getattr(self, 'shared_grad_sinks', True) else []
+                with ops.shared_conv_grads(convs):
+                    return self._forward_stacked(X.to(tdt), B, tdt)
             return self._forward_stacked(X, B)
         x1_raw = x1_raw.to(cdt)
         x2_raw = x2_raw.to(cdt)
@@ -500,7 +504,16 @@ class UPFlow_net(tools.abstract_model):
             buf[:, est._n_total:] = flow_up + res
             fine = self.context_networks(buf).float()
             return res + fine
-        x = self._estimator_input(Fn, Fwn, A, flow_up)          # (autograd-aware: cat of differentiable pieces under grad)
+        if torch.is_grad_enabled() and (Fn.requires_grad or Fwn.requires_grad):
+            c = self.leakyRELU(self.correlation(Fn, Fwn))
+            if est.train_in_buffer_ok([c, A, flow_up]):
+                # training on the matrix cores: the estimator is one autograd node in the inference buffer layout; the
+                # refined flow is appended to its buffer, which the context network reads whole (no concatenations)
+                buf, res = est.forward_train([c, A, flow_up], flow_tail=flow_up)
+                return res.float() + self.context_networks(buf).float()
+            x = torch.cat([c, A, flow_up.to(c.dtype)], dim=1)
+        else:
+            x = self._estimator_input(Fn, Fwn, A, flow_up)
         feat, res = est(x)
         res = res.float()
         fine = self.context_networks(torch.cat([feat, (flow_up + res).to(feat.dtype)], dim=1)).float()

@@ -681,70 +681,390 @@ def conv_wgrad_supported(x, weight, stride, dilation):
     return bool(_lib.lib().upf_conv_wgrad_supported(Cin, Cout, x.shape[2], x.shape[3], k, dilation if k == 3 else 1, stride, _lib.dtype_code(x)))
 
 
+def _is_slice(t):
+    """[B,C,H,W] channel slice of a contiguous NCHW buffer (only the batch stride is free)."""
+    return t.dim() == 4 and t.stride()[1:] == (t.shape[2] * t.shape[3], t.shape[3], 1)
+
+
+def act_grad(src, y=None, slope=0.0, add=None, dst=None, want_bias=False):
+    """dst = (src + add) * (y > 0 ? 1 : slope) over [B,C,H,W] channel slices (add, y optional; dst None: a new tensor,
+    dst False: nothing stored) and, from the same pass, the first stage of the bias gradient ([C,32] fp32 partial sums;
+    `conv_bias_grad_finish`).  -> (dst, partial)"""
+    B, C, H, W = src.shape
+    for t in (src, add, y, dst):
+        if t is not None and t is not False and (not _is_slice(t) or tuple(t.shape) != (B, C, H, W) or t.dtype != src.dtype):
+            raise UpflowHipError('act_grad: operands must be [B,C,H,W] channel slices of one 16-bit dtype and shape')
+    if dst is None:
+        dst = torch.empty((B, C, H, W), dtype=src.dtype, device=src.device)
+    part = torch.empty((C, 32), dtype=torch.float32, device=src.device) if want_bias else None
+    dev = src.device
+    if not src.is_cuda:
+        raise UpflowHipError('act_grad: GPU tensors expected (there is no CPU fallback)')
+    st = lambda t: t.stride(0) if (t is not None and t is not False) else 0
+    pt = lambda t: _lib.ptr(t if t is not False else None)
+    with torch.cuda.device(dev):
+        _lib.call('upf_act_grad', _lib.ptr(src), st(src), pt(add), st(add), pt(y), st(y), pt(dst), st(dst), _lib.ptr(part),
+                  B, C, H * W, float(slope), _lib.dtype_code(src), _lib.stream_ptr(dev))
+    return (dst if dst is not False else None), part
+
+
+def conv_bias_grad_finish(parts, Cout):
+    """Second stage of the bias gradient over the first-stage sums of 1..n uses (fixed order)."""
+    gb = torch.empty((Cout,), dtype=torch.float32, device=parts[0].device)
+    dev = parts[0].device
+    total = None
+    with torch.cuda.device(dev):
+        for i in range(0, len(parts), 8):
+            chunk = parts[i:i + 8]
+            arr = (_lib._vp * len(chunk))(*[p.data_ptr() for p in chunk])
+            out = gb if i == 0 else torch.empty_like(gb)
+            _lib.call('upf_conv_bias_grad_finish', arr, len(chunk), _lib.ptr(out), Cout, _lib.stream_ptr(dev))
+            total = out if total is None else total + out
+    return total
+
+
+def conv_wgrad_multi(uses, Cin, Cout, k, dilation):
+    """fp32 [Cout,Cin,k,k] weight gradient over several uses [(x, g), ...] of one convolution (x: [B,Cin,H,W] slices,
+    g: [B,Cout,H,W] slices of the gradient entering the pre-activation; sizes may differ per use — the pyramid levels):
+    one K dimension, shared K-split launches and one ordered reduction (upf_conv_wgrad_multi)."""
+    dev = uses[0][0].device
+    d = dilation if k == 3 else 1
+    total = None
+    with torch.cuda.device(dev):
+        for i in range(0, len(uses), 6):
+            chunk = uses[i:i + 6]
+            arr = (_lib.WgradLevel * len(chunk))()
+            for a, (x, g) in zip(arr, chunk):
+                if not (_is_slice(x) and _is_slice(g)) or x.shape[1] != Cin or g.shape[1] != Cout or x.shape[0] != g.shape[0] or x.shape[2:] != g.shape[2:]:
+                    raise UpflowHipError('conv_wgrad_multi: x / g must be [B,Cin,H,W] / [B,Cout,H,W] channel slices')
+                a.x, a.x_batch_stride, a.grad_pre, a.g_batch_stride = x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0)
+                a.B, a.H, a.W = x.shape[0], x.shape[2], x.shape[3]
+            nbytes = _lib.lib().upf_conv_wgrad_multi_workspace_bytes(arr, len(chunk), Cin, Cout, k, d)
+            if nbytes < 0:
+                raise UpflowHipError('conv_wgrad_multi: bad level list')
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            gw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev)
+            _lib.call('upf_conv_wgrad_multi', arr, len(chunk), _lib.ptr(gw), _lib.ptr(ws), Cin, Cout, k, d, _lib.dtype_code(chunk[0][0]), _lib.stream_ptr(dev))
+            total = gw if total is None else total + gw
+    return total
+
+
+# ---- parameter gradients of SHARED convolutions: one contraction per step -----------------------------------------------
+# The decoder (flow estimator, context network, SGU estimator) is applied at every pyramid level with the same weights
+# (model/upflow.py:535-573).  Autograd would compute a weight gradient per use and add them; here every use only records
+# its (x, g) pair and its bias partial sums in the parameter's sink, and a gate node between the parameter and its uses —
+# which autograd runs after ALL uses — does the one multi-level contraction.
+class _ParamSink(object):
+    def __init__(self, weight, bias, dilation):
+        self.weight, self.bias, self.dilation = weight, bias, int(dilation)
+        self.uses, self.bias_parts = [], []
+
+    def finish(self):
+        Cout, Cin, k, _ = self.weight.shape
+        gw = conv_wgrad_multi(self.uses, Cin, Cout, k, self.dilation) if self.uses else None
+        gb = conv_bias_grad_finish(self.bias_parts, Cout) if self.bias_parts else None
+        self.uses, self.bias_parts = [], []
+        return gw, gb
+
+
+class _GateFunction(Function):
+    @staticmethod
+    def forward(ctx, sink, weight, bias):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)
+        return weight.view_as(weight), (bias.view_as(bias) if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, gw_in, gb_in):
+        gw, gb = ctx.sink.finish()                   # (gradients that a use could not defer arrive as gw_in / gb_in)
+        if gw_in is not None:
+            gw = gw_in if gw is None else gw + gw_in
+        if gb_in is not None:
+            gb = gb_in if gb is None else gb + gb_in
+        return None, gw, gb
+
+
+_GATES = {}
+
+
+class shared_conv_grads(object):
+    """with shared_conv_grads(conv_modules): every ops.conv_train / DenseStackTrainFunction use of these nn.Conv2d
+    parameters inside the block defers its parameter gradients to one multi-use contraction (see _ParamSink)."""
+
+    def __init__(self, convs):
+        self.convs = [c for c in convs if c.weight.requires_grad]
+        self.keys = []
+
+    def __enter__(self):
+        if torch.is_grad_enabled():
+            for c in self.convs:
+                if id(c.weight) in _GATES or not c.weight.is_cuda:
+                    continue
+                sink = _ParamSink(c.weight, c.bias, c.dilation[0])
+                wa, ba = _GateFunction.apply(sink, c.weight, c.bias)
+                _GATES[id(c.weight)] = (wa, ba, sink)
+                self.keys.append(id(c.weight))
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.keys:
+            _GATES.pop(k, None)
+        self.keys = []
+        return False
+
+
+def _gated(weight, bias):
+    """-> (weight, bias, sink) to hand to an autograd Function: the gate's aliases inside shared_conv_grads."""
+    hit = _GATES.get(id(weight))
+    return hit if hit is not None else (weight, bias, None)
+
+
 class ConvTrainFunction(Function):
     """y = LeakyReLU_slope(conv2d(x, weight, bias, padding = dilation * (k-1)/2, dilation, stride)) with 16-bit activations,
     fp32 master weights / bias and fp32 parameter gradients.  Forward on the MFMA kernel of csrc/conv3x3.hip; backward:
     the data gradient of a stride-1 layer is the same kernel on the flipped, transposed weights, the weight gradient is
-    csrc/conv_wgrad.hip (stride 1, W % 8 == 0), the LeakyReLU and bias gradients one launch each; the remaining cases
-    (stride-2 layers, ragged coarse levels) take PyTorch-ROCm's gradient kernels on fp32 copies.
+    csrc/conv_wgrad.hip (stride 1, W >= 8), the LeakyReLU gradient and the first stage of the bias gradient one launch
+    (upf_act_grad); the remaining cases (stride-2 layers) take PyTorch-ROCm's gradient kernels on fp32 copies.  Inside
+    `shared_conv_grads` the parameter gradients are deferred to the parameter's sink (one contraction over all uses).
     Replaces nn.Conv2d + nn.LeakyReLU (model/pwc_modules.py:10-49) in training."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dilation, slope, stride):
+    def forward(ctx, x, weight, bias, dilation, slope, stride, sink):
         x = x.contiguous()
+        master = sink.weight if sink is not None else weight
         Cout, Cin, k, _ = weight.shape
         B, _, H, W = x.shape
         _lib.check_gpu(x, weight)
         Ho, Wo = conv3x3_out_hw(H, W, stride)
         y = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device)
         b32 = bias.detach().float().contiguous() if bias is not None else torch.zeros(Cout, device=x.device)
-        conv3x3_forward_raw(x, conv_pack_from_master(weight, x.dtype), b32, y, dilation, slope, stride, k)
+        conv3x3_forward_raw(x, conv_pack_from_master(master, x.dtype), b32, y, dilation, slope, stride, k)
         ctx.save_for_backward(x, weight, y if slope != 0.0 else None)
         ctx.cfg = (int(dilation), float(slope), bias is not None, int(stride))
+        ctx.sink = sink
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
         dilation, slope, has_bias, stride = ctx.cfg
+        sink = ctx.sink
+        master = sink.weight if sink is not None else weight
         Cout, Cin, k, _ = weight.shape
-        B, _, H, W = x.shape
-        Ho, Wo = gy.shape[2:]
         gy = gy.to(x.dtype).contiguous()
-        dev = _lib.check_gpu(x, gy)
-        code = _lib.dtype_code(x)
+        _lib.check_gpu(x, gy)
         pad = dilation * (k - 1) // 2
-        with torch.cuda.device(dev):
-            st = _lib.stream_ptr(dev)
-            if y is None:
-                g = gy
-            elif gy.numel() % 8 == 0:
-                g = torch.empty_like(gy)
-                _lib.call('upf_leaky_backward', _lib.ptr(gy), _lib.ptr(y), _lib.ptr(g), gy.numel(), slope, code, st)
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if y is None:
+            g, part = gy, (act_grad(gy, dst=False, want_bias=True)[1] if want_b else None)
+        else:
+            g, part = act_grad(gy, y, slope, want_bias=want_b)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                gx = torch.empty_like(x)
+                zero = torch.zeros(Cin, dtype=torch.float32, device=x.device)
+                conv3x3_forward_raw(g, conv_pack_from_master(master, x.dtype, dgrad=True), zero, gx, dilation, 0.0, 1, k)
             else:
-                g = torch.where(y > 0, gy, gy * slope)
-            gx = gw = gb = None
-            if ctx.needs_input_grad[0]:
-                if stride == 1:
-                    gx = torch.empty_like(x)
-                    zero = torch.zeros(Cin, dtype=torch.float32, device=x.device)
-                    conv3x3_forward_raw(g, conv_pack_from_master(weight, x.dtype, dgrad=True), zero, gx, dilation, 0.0, 1, k)
+                gx = torch.nn.grad.conv2d_input(x.shape, weight.detach(), g.float(), stride=stride, padding=pad, dilation=dilation).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            if conv_wgrad_supported(x, weight, stride, dilation):
+                if sink is not None:
+                    sink.uses.append((x, g))
                 else:
-                    gx = torch.nn.grad.conv2d_input(x.shape, weight.detach(), g.float(), stride=stride, padding=pad, dilation=dilation).to(x.dtype)
-            if ctx.needs_input_grad[1]:
-                if conv_wgrad_supported(x, weight, stride, dilation):
-                    gw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
-                    d = dilation if k == 3 else 1
-                    ws = torch.empty((_lib.lib().upf_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, k, d),), dtype=torch.uint8, device=x.device)
-                    _lib.call('upf_conv_wgrad', _lib.ptr(x), 0, _lib.ptr(g), 0, _lib.ptr(gw), _lib.ptr(ws), B, Cin, Cout, H, W, k, d, code, st)
-                else:
-                    gw = torch.nn.grad.conv2d_weight(x.float(), weight.shape, g.float(), stride=stride, padding=pad, dilation=dilation)
-            if has_bias and ctx.needs_input_grad[2]:
-                gb = torch.empty((Cout,), dtype=torch.float32, device=x.device)
-                ws = torch.empty((_lib.lib().upf_conv_bias_grad_workspace_bytes(Cout),), dtype=torch.uint8, device=x.device)
-                _lib.call('upf_conv_bias_grad', _lib.ptr(g), 0, _lib.ptr(gb), _lib.ptr(ws), B, Cout, Ho * Wo, code, st)
-        return gx, gw, gb, None, None, None
+                    gw = conv_wgrad_multi([(x, g)], Cin, Cout, k, dilation)
+            else:
+                gw = torch.nn.grad.conv2d_weight(x.float(), weight.shape, g.float(), stride=stride, padding=pad, dilation=dilation)
+        if want_b:
+            if sink is not None:
+                sink.bias_parts.append(part)
+            else:
+                gb = conv_bias_grad_finish([part], Cout)
+        return gx, gw, gb, None, None, None, None
 
 
 def conv_train(x, weight, bias, dilation=1, slope=0.0, stride=1):
-    return ConvTrainFunction.apply(x, weight, bias, dilation, slope, stride)
+    w, b, sink = _gated(weight, bias)
+    return ConvTrainFunction.apply(x, w, b, dilation, slope, stride, sink)
+
+
+# ---- a whole dense stack (conv1..conv5 + conv_last) under autograd, in ONE buffer ---------------------------------------
+_STACK_PACK_CACHE = {}
+
+
+def _stacked_dgrad_pack(masters, lo, hi_of, lo_k, f_k, dtype):
+    """Packed data-gradient operand for the buffer channels [lo_k, lo_k + f_k) with respect to the pre-activation gradients
+    of the layers `masters` (ordered like the gradient buffer: last layer first): the rows of each layer's kernel that
+    read those channels, stacked along the (transposed) input dimension.  Cached per parameter versions."""
+    key = (tuple(id(w) for w in masters), tuple(w._version for w in masters), tuple(w.data_ptr() for w in masters), lo_k, f_k, dtype)
+    slot = _STACK_PACK_CACHE.get(key[0] + (lo_k, f_k, dtype))
+    if slot is not None and slot[0] == key:
+        return slot[1]
+    with torch.no_grad():
+        parts = [w.detach()[:, lo_k - h:lo_k - h + f_k] for w, h in zip(masters, hi_of)]
+        stacked = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=0)
+        packed = _conv_pack_from_master(stacked.float(), dtype, dgrad=True)
+    if len(_STACK_PACK_CACHE) > 1024:
+        _STACK_PACK_CACHE.clear()
+    _STACK_PACK_CACHE[key[0] + (lo_k, f_k, dtype)] = (key, packed)
+    return packed
+
+
+class DenseStackTrainFunction(Function):
+    """The dense estimator stacks (FlowEstimatorDense / the SGU mask estimator: `x = cat([conv_k(x), x])` five times, then
+    conv_last; model/pwc_modules.py:250-286) under autograd without a single concatenation, in the buffer layout of the
+    inference path:
+        buf = [conv5 | conv4 | conv3 | conv2 | conv1 | inputs... | flow tail]
+    forward: every layer reads a channel suffix of buf and writes its slice.  backward: the gradients entering the
+    pre-activations live in a second buffer P = [g_last | g5 | g4 | g3 | g2 | g1]; the gradient of buffer slice k is ONE
+    data-gradient convolution of the PREFIX of P that is known by then (the layers after k) with their stacked kernels —
+    the sum over consumers happens in the fp32 accumulators of the matrix cores instead of in 16-bit tensor adds — followed
+    by one pass (upf_act_grad) that adds the gradient arriving from outside the stack, applies the LeakyReLU mask and takes
+    the bias sums.  Weight gradients: (buf suffix, P slice) pairs, deferred to the parameter sinks inside
+    shared_conv_grads.  `flow_tail`: buf[:, nt:] = flow_tail + out (the refined flow the context network reads next to
+    the features, model/upflow.py:566-570).
+    apply(cfg, *inputs, [flow_tail], w1, b1, ..., w5, b5, w_last, b_last) -> (buf, out)"""
+
+    @staticmethod
+    def forward(ctx, cfg, *tensors):
+        nin, f, slope, sinks, has_tail = cfg['n_inputs'], tuple(cfg['f']), float(cfg['slope']), cfg['sinks'], cfg['flow_tail']
+        inputs = tensors[:nin]
+        tail = tensors[nin] if has_tail else None
+        params = tensors[nin + (1 if has_tail else 0):]
+        nl = len(f) + 1
+        weights, biases = params[0::2], params[1::2]
+        masters = [s.weight if s is not None else w for s, w in zip(sinks, weights)]
+        dt, dev = inputs[0].dtype, inputs[0].device
+        B, _, H, W = inputs[0].shape
+        cin = [t.shape[1] for t in inputs]
+        ch_in, nt = sum(cin), sum(cin) + sum(f)
+        oc = weights[-1].shape[0]
+        tailc = tail.shape[1] if has_tail else 0
+        buf = torch.empty((B, nt + tailc, H, W), dtype=dt, device=dev)
+        o = nt - ch_in
+        for t in inputs:
+            buf[:, o:o + t.shape[1]].copy_(t)
+            o += t.shape[1]
+        hi = nt - ch_in
+        for k in range(len(f)):
+            b32 = biases[k].detach().float().contiguous()
+            conv3x3_forward_raw(buf[:, hi:nt], conv_pack_from_master(masters[k], dt), b32, buf[:, hi - f[k]:hi], 1, slope, 1, 3)
+            hi -= f[k]
+        out = torch.empty((B, oc, H, W), dtype=dt, device=dev)
+        conv3x3_forward_raw(buf[:, :nt], conv_pack_from_master(masters[-1], dt), biases[-1].detach().float().contiguous(), out, 1, 0.0, 1, 3)
+        if has_tail:
+            flow_update(tail, out, out=buf[:, nt:])
+        ctx.save_for_backward(buf, *weights)
+        ctx.cfg = (nin, f, slope, has_tail, cin, [t.dtype for t in inputs], tail.dtype if has_tail else None, oc)
+        ctx.sinks = sinks
+        ctx.set_materialize_grads(False)
+        return buf, out
+
+    @staticmethod
+    def backward(ctx, g_buf, g_out):
+        buf = ctx.saved_tensors[0]
+        weights = ctx.saved_tensors[1:]
+        nin, f, slope, has_tail, cin, in_dtypes, tail_dtype, oc = ctx.cfg
+        sinks = ctx.sinks
+        masters = [s.weight if s is not None else w for s, w in zip(sinks, weights)]
+        dt, dev = buf.dtype, buf.device
+        B, _, H, W = buf.shape
+        ch_in, nf = sum(cin), len(f)
+        nt = ch_in + sum(f)
+        if g_buf is not None:
+            g_buf = g_buf.to(dt)
+            if not _is_slice(g_buf):
+                g_buf = g_buf.contiguous()
+        # buffer slot of layer k (k = 0..nf-1 = conv1..conv5): [lo[k], lo[k] + f[k]); its input: [lo[k] + f[k], nt)
+        lo = [sum(f[k + 1:]) for k in range(nf)]
+        pch = oc + sum(f)
+        P = torch.empty((B, pch, H, W), dtype=dt, device=dev)
+        parts = [None] * (nf + 1)
+        # the last layer's output gradient (+ what arrives through the flow tail)
+        if g_out is None:
+            g_out = torch.zeros((B, oc, H, W), dtype=dt, device=dev)
+        g_tail = g_buf[:, nt:] if (has_tail and g_buf is not None) else None
+        _, parts[nf] = act_grad(g_out.to(dt).contiguous(), None, 0.0, add=g_tail, dst=P[:, :oc], want_bias=True)
+        # layers in P order: last, conv5, ..., conv1;  hi_of = first buffer channel each one reads
+        order = [nf] + list(range(nf - 1, -1, -1))
+        hi_of = {nf: 0}
+        for k in range(nf):
+            hi_of[k] = lo[k] + f[k]
+        zero = torch.zeros(max(max(f), ch_in), dtype=torch.float32, device=dev)
+        filled = oc
+        for pos, k in enumerate(order[1:], start=1):
+            ms = [masters[j] for j in order[:pos]]
+            packed = _stacked_dgrad_pack(ms, lo, [hi_of[j] for j in order[:pos]], lo[k], f[k], dt)
+            dst = P[:, filled:filled + f[k]]
+            conv3x3_forward_raw(P[:, :filled], packed, zero, dst, 1, 0.0, 1, 3)
+            _, parts[k] = act_grad(dst, buf[:, lo[k]:lo[k] + f[k]], slope, add=(g_buf[:, lo[k]:lo[k] + f[k]] if g_buf is not None else None),
+                                   dst=dst, want_bias=True)
+            filled += f[k]
+        # gradient of the input slot
+        grads_in = [None] * nin
+        g_tail_in = None
+        if any(ctx.needs_input_grad[1:1 + nin]):
+            x0 = nt - ch_in
+            packed = _stacked_dgrad_pack([masters[j] for j in order], lo, [hi_of[j] for j in order], x0, ch_in, dt)
+            gx = torch.empty((B, ch_in, H, W), dtype=dt, device=dev)
+            conv3x3_forward_raw(P, packed, zero, gx, 1, 0.0, 1, 3)
+            o = 0
+            for i in range(nin):
+                if ctx.needs_input_grad[1 + i]:
+                    gi = gx[:, o:o + cin[i]]
+                    gi = (gi + g_buf[:, x0 + o:x0 + o + cin[i]]) if g_buf is not None else gi.contiguous()
+                    grads_in[i] = gi.to(in_dtypes[i])
+                o += cin[i]
+        if has_tail and ctx.needs_input_grad[1 + nin]:
+            g_tail_in = g_tail.to(tail_dtype) if g_tail is not None else None
+        # parameter gradients: x = the buffer suffix a layer read, g = its slice of P
+        gparams = []
+        poff = {nf: 0}
+        acc = oc
+        for k in range(nf - 1, -1, -1):
+            poff[k] = acc
+            acc += f[k]
+        for k in range(nf + 1):
+            xk = buf[:, hi_of[k]:nt]
+            gk = P[:, poff[k]:poff[k] + (oc if k == nf else f[k])]
+            Cout, Cin = weights[k].shape[0], weights[k].shape[1]
+            iw = 1 + nin + (1 if has_tail else 0) + 2 * k
+            gw = gb = None
+            if sinks[k] is not None:
+                if ctx.needs_input_grad[iw]:
+                    sinks[k].uses.append((xk, gk))
+                if ctx.needs_input_grad[iw + 1]:
+                    sinks[k].bias_parts.append(parts[k])
+            else:
+                if ctx.needs_input_grad[iw]:
+                    gw = conv_wgrad_multi([(xk, gk)], Cin, Cout, 3, 1)
+                if ctx.needs_input_grad[iw + 1]:
+                    gb = conv_bias_grad_finish([parts[k]], Cout)
+            gparams += [gw, gb]
+        return (None,) + tuple(grads_in) + ((g_tail_in,) if has_tail else ()) + tuple(gparams)
+
+
+def dense_stack_train_supported(inputs, convs):
+    """16-bit GPU inputs under autograd, 3x3 stride-1 undilated layers with bias, rows of >= 8 pixels (every layer then has
+    its forward, data-gradient and weight-gradient kernels)."""
+    x = inputs[0]
+    if not (torch.is_grad_enabled() and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.shape[3] >= 8):
+        return False
+    for c in convs:
+        if not (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.dilation == (1, 1) and c.padding == (1, 1) and c.groups == 1
+                and c.bias is not None and c.weight.dtype == torch.float32 and c.weight.is_cuda):
+            return False
+    return True
+
+
+def dense_stack_train(inputs, convs, slope, flow_tail=None):
+    """inputs: the tensors whose concatenation is the stack's input ([B,C_i,H,W], 16-bit or fp32 — cast on the way into
+    the buffer); convs: the nn.Conv2d modules conv1..conv5, conv_last.  -> (buf [B, sum(f) + sum(C_i) (+ tail), H, W], out)"""
+    gated = [_gated(c.weight, c.bias) for c in convs]
+    cfg = dict(n_inputs=len(inputs), f=[c.out_channels for c in convs[:-1]], slope=slope, sinks=[g[2] for g in gated],
+               flow_tail=flow_tail is not None)
+    params = []
+    for w, b, _ in gated:
+        params += [w, b]
+    args = list(inputs) + ([flow_tail] if flow_tail is not None else []) + params
+    return DenseStackTrainFunction.apply(cfg, *args)
