@@ -119,7 +119,7 @@ void blend_fwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(THREADS)
 void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__ x_out, const float* __restrict__ g_up,
-                      unsigned long long* __restrict__ g_init, unsigned long long* __restrict__ g_xo64, float* __restrict__ g_xo,
+                      unsigned long long* __restrict__ g_init, float* __restrict__ g_full, float* __restrict__ g_xo,
                       int h, int w, int Hf, int Wf) {
   const int HW = Hf * Wf, hw = h * w;
   const int p = blockIdx.x * THREADS + threadIdx.x;
@@ -162,31 +162,27 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
   const float my = ((float)(Hf - 1) * 0.5f) * (2.0f / (float)max(Hf - 1, 1));
   gix *= om * mx;
   giy *= om * my;
-  float* gx = g_xo + (size_t)n * 3 * hw;
-  unsigned long long* gx64 = g_xo64 + (size_t)n * 3 * hw;
   if (Hf == h && Wf == w) {
+    float* gx = g_xo + (size_t)n * 3 * hw;
     gx[p] = gix;
     gx[hw + p] = giy;
     gx[2 * hw + p] = gm * m * (1.0f - m);
     return;
   }
+  // final level: gradients of the UP-SAMPLED (inter_flow * ratio, mask) at full resolution; the resize gradient is a
+  // gather (upsample_bwd_kernel) and the sigmoid' factor is applied per low-resolution pixel afterwards.  (The first
+  // version scattered 12 fixed-point atomics per output pixel into the low-resolution map, ~64 colliding adds per
+  // address: 750 us of an 830 us launch.)
   const float su = (float)((double)Wf / (double)w), sv = (float)((double)Hf / (double)h);
-  const int q[4] = {ly.i0 * w + lx.i0, ly.i0 * w + lx.i1, ly.i1 * w + lx.i0, ly.i1 * w + lx.i1};
-  const float bw[4] = {ly.l0 * lx.l0, ly.l0 * lx.l1, ly.l1 * lx.l0, ly.l1 * lx.l1};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    fix_add(gx64 + q[k], gix * su * bw[k]);
-    fix_add(gx64 + hw + q[k], giy * sv * bw[k]);
-    const float s = sigmoidf(Elem<T>::load(xo + 2 * hw + q[k]));
-    fix_add(gx64 + 2 * hw + q[k], gm * bw[k] * s * (1.0f - s));
-  }
+  float* gf = g_full + (size_t)n * 3 * HW;
+  gf[p] = gix * su;
+  gf[HW + p] = giy * sv;
+  gf[2 * HW + p] = gm;
 }
 
-__global__ void blend_bwd_finish_kernel(const unsigned long long* __restrict__ gi64, float* __restrict__ g_init, long long n_init,
-                                        const unsigned long long* __restrict__ gx64, float* __restrict__ g_xo, long long n_xo) {
+__global__ void blend_bwd_finish_kernel(const unsigned long long* __restrict__ gi64, float* __restrict__ g_init, long long n_init) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i < n_init) g_init[i] = fix_get(gi64[i]);
-  if (gx64 && i < n_xo) g_xo[i] = fix_get(gx64[i]);
 }
 
 // ---- flow up-sampling -------------------------------------------------------------------------
@@ -232,12 +228,59 @@ __device__ __forceinline__ void upsample_bwd_range(int a, int in_size, int out_s
 __device__ __forceinline__ float upsample_bwd_weight(const Lerp& l, int a) {
   return (l.i0 == a ? l.l0 : 0.f) + (l.i1 == a ? l.l1 : 0.f);
 }
-template <bool WG>
+// Group variant (footprints up to a few hundred outputs): G lanes per input pixel, lane r takes the footprint rows
+// ilo + r, ilo + r + G, ...  The column weights depend only on (j, b) and the row weight only on (i, a): the <= MAXNJ column
+// weights are computed once per group into an LDS column and the row weight once per row, and the G partial sums are
+// combined by an xor-shuffle tree (fixed order).  (The first version: one thread per input pixel evaluating both
+// interpolations — two IEEE divisions each — for every footprint pixel, ~100 per input pixel at the 4x resize of the last
+// level and 361 at the 8x resize of the distillation loss: 117-138 us per launch.)
+constexpr int MAXNJ = 24;
+template <int G>
 __global__ __launch_bounds__(THREADS)
-void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate, long long total) {
+void upsample_bwd_group_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate, long long total) {
+  constexpr int NG = THREADS / G;
+  __shared__ float wxs[MAXNJ * NG];
+  const int grp = threadIdx.x / G, r = threadIdx.x % G;
+  const long long idx0 = blockIdx.x * (long long)NG + grp;
+  const bool live = idx0 < total;
+  const long long idx = live ? idx0 : total - 1;
+  const int b = (int)(idx % w), a = (int)((idx / w) % h);
+  const long long nc = idx / ((long long)w * h);
+  const int c = (int)(nc % C);
+  int ilo, ihi, jlo, jhi;
+  upsample_bwd_range(a, h, H, ilo, ihi);
+  upsample_bwd_range(b, w, W, jlo, jhi);
+  const float* g = gy + (size_t)nc * H * W;
+  const int nj = jhi - jlo + 1;
+  const bool table = nj <= MAXNJ;
+  float* wx = wxs + grp;
+  if (table)
+    for (int k = r; k < nj; k += G) wx[k * NG] = upsample_bwd_weight(make_lerp(jlo + k, w, W), b);
+  __syncthreads();
+  float acc = 0.f;
+  for (int i = ilo + r; i <= ihi; i += G) {
+    const float wy = upsample_bwd_weight(make_lerp(i, h, H), a);
+    if (wy == 0.f) continue;
+    const float* row = g + (size_t)i * W + jlo;
+    if (table) {
+      for (int k = 0; k < nj; ++k) acc += row[k] * wy * wx[k * NG];
+    } else {
+      for (int k = 0; k < nj; ++k) acc += row[k] * wy * upsample_bwd_weight(make_lerp(jlo + k, w, W), b);
+    }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (r != 0 || !live) return;
+  if (if_rate) acc *= (c == 0) ? (float)((double)W / (double)w) : (float)((double)H / (double)h);
+  gx[idx] = acc;
+}
+
+// Workgroup variant (large footprints: the pyramid-distillation loss resizes 4x13 flows to 256x832): the 256 threads stride
+// over the footprint, fixed-order LDS tree reduction.
+__global__ __launch_bounds__(THREADS)
+void upsample_bwd_wg_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate, long long total) {
   __shared__ float red[THREADS];
-  const long long idx = WG ? (long long)blockIdx.x : blockIdx.x * (long long)THREADS + threadIdx.x;
-  if (!WG && idx >= total) return;
+  const long long idx = (long long)blockIdx.x;
   const int b = (int)(idx % w), a = (int)((idx / w) % h);
   const long long nc = idx / ((long long)w * h);
   const int c = (int)(nc % C);
@@ -247,24 +290,33 @@ void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, i
   const float* g = gy + (size_t)nc * H * W;
   const int nj = jhi - jlo + 1, cnt = (ihi - ilo + 1) * nj;
   float acc = 0.f;
-  for (int t = WG ? (int)threadIdx.x : 0; t < cnt; t += WG ? THREADS : 1) {
+  for (int t = (int)threadIdx.x; t < cnt; t += THREADS) {
     const int i = ilo + t / nj, j = jlo + t % nj;
     const float wy = upsample_bwd_weight(make_lerp(i, h, H), a);
     const float wx = upsample_bwd_weight(make_lerp(j, w, W), b);
     if (wy != 0.f && wx != 0.f) acc += g[(size_t)i * W + j] * wy * wx;
   }
-  if (WG) {
-    red[threadIdx.x] = acc;
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = THREADS / 2; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
     __syncthreads();
-    for (int sft = THREADS / 2; sft > 0; sft >>= 1) {
-      if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
-      __syncthreads();
-    }
-    acc = red[0];
-    if (threadIdx.x != 0) return;
   }
+  if (threadIdx.x != 0) return;
+  acc = red[0];
   if (if_rate) acc *= (c == 0) ? (float)((double)W / (double)w) : (float)((double)H / (double)h);
   gx[idx] = acc;
+}
+
+// g_logit *= s (1 - s), s = sigmoid(logit): the mask channel of the final-level blend after its resize gradient
+template <typename T>
+__global__ void sigmoid_grad_kernel(const T* __restrict__ x_out, float* __restrict__ g_xo, int hw, long long total) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long n = i / hw;
+  const size_t o = (size_t)n * 3 * hw + 2 * hw + (i - n * hw);
+  const float sg = sigmoidf(Elem<T>::load(x_out + o));
+  g_xo[o] *= sg * (1.0f - sg);
 }
 
 // out[n, :] = cast(a + (b + c))  — the flow bookkeeping of one pyramid level (model/upflow.py:566-572:
@@ -319,7 +371,25 @@ extern "C" int upf_sgu_blend_forward(const float* flow_init, const void* x_out, 
 }
 
 extern "C" long long upf_sgu_blend_backward_workspace_bytes(int B, int h, int w, int Hf, int Wf) {
-  return ((long long)B * 2 * Hf * Wf + (long long)B * 3 * h * w) * (long long)sizeof(unsigned long long);
+  const bool final_level = !(Hf == h && Wf == w);
+  return (long long)B * 2 * Hf * Wf * (long long)sizeof(unsigned long long) + (final_level ? (long long)B * 3 * Hf * Wf * (long long)sizeof(float) : 0);
+}
+
+static int launch_upsample_backward(const float* grad_y, float* gx, long long BC, int C, int h, int w, int H, int W, int if_rate, hipStream_t stream) {
+  using namespace upf;
+  const long long total = BC * h * w;
+  // footprint of one input pixel ~ (2H/h) x (2W/w) outputs: 1 / 4 / 16 lanes per input pixel, a workgroup beyond a few hundred
+  const long long fp = (2LL * cdiv(H, h) + 2) * (2LL * cdiv(W, w) + 2);
+  auto groups = [&](int G) { return dim3((unsigned)((total + sgu::THREADS / G - 1) / (sgu::THREADS / G))); };
+  if (fp > 512 && total < (1LL << 31))
+    hipLaunchKernelGGL(sgu::upsample_bwd_wg_kernel, dim3((unsigned)total), dim3(sgu::THREADS), 0, stream, grad_y, gx, C, h, w, H, W, if_rate, total);
+  else if (fp > 200)
+    hipLaunchKernelGGL(sgu::upsample_bwd_group_kernel<16>, groups(16), dim3(sgu::THREADS), 0, stream, grad_y, gx, C, h, w, H, W, if_rate, total);
+  else if (fp > 16)
+    hipLaunchKernelGGL(sgu::upsample_bwd_group_kernel<4>, groups(4), dim3(sgu::THREADS), 0, stream, grad_y, gx, C, h, w, H, W, if_rate, total);
+  else
+    hipLaunchKernelGGL(sgu::upsample_bwd_group_kernel<1>, groups(1), dim3(sgu::THREADS), 0, stream, grad_y, gx, C, h, w, H, W, if_rate, total);
+  return 0;
 }
 
 extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out, const float* grad_flow_up,
@@ -330,18 +400,21 @@ extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out,
   UPF_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && Hf >= h && Wf >= w, UPF_EINVAL, "sgu_blend_backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const long long n_init = (long long)B * 2 * Hf * Wf, n_xo = (long long)B * 3 * h * w;
-  const bool final_level = !(Hf == h && Wf == w);           // the low-resolution map is a scatter target only then
+  const bool final_level = !(Hf == h && Wf == w);
   unsigned long long* gi64 = (unsigned long long*)workspace;
-  unsigned long long* gx64 = gi64 + n_init;
-  hipError_t e = hipMemsetAsync(gi64, 0, (size_t)(n_init + (final_level ? n_xo : 0)) * sizeof(unsigned long long), s);
+  float* g_full = (float*)(gi64 + n_init);                  // final level: [B, 3, Hf, Wf] gradients before the resize gradient
+  hipError_t e = hipMemsetAsync(gi64, 0, (size_t)n_init * sizeof(unsigned long long), s);
   UPF_REQUIRE(e == hipSuccess, (int)e, "sgu_blend_backward: memset failed: %s", hipGetErrorString(e));
   dim3 grid(cdiv(Hf * Wf, sgu::THREADS), B);
   UPF_DISPATCH(dtype, T,
                hipLaunchKernelGGL((sgu::blend_bwd_kernel<T>), grid, dim3(sgu::THREADS), 0, s,
-                                  flow_init, (const T*)x_out, grad_flow_up, gi64, gx64, g_x_out32, h, w, Hf, Wf));
-  const long long n_fin = n_init > n_xo ? n_init : n_xo;
-  hipLaunchKernelGGL(sgu::blend_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, s,
-                     gi64, g_flow_init32, n_init, final_level ? gx64 : nullptr, g_x_out32, n_xo);
+                                  flow_init, (const T*)x_out, grad_flow_up, gi64, g_full, g_x_out32, h, w, Hf, Wf));
+  hipLaunchKernelGGL(sgu::blend_bwd_finish_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, gi64, g_flow_init32, n_init);
+  if (final_level) {
+    launch_upsample_backward(g_full, g_x_out32, (long long)B * 3, 3, h, w, Hf, Wf, 0, s);
+    const long long nm = (long long)B * h * w;
+    UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((sgu::sigmoid_grad_kernel<T>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, (const T*)x_out, g_x_out32, h * w, nm));
+  }
   return check_launch("sgu_blend_backward");
 }
 
@@ -366,13 +439,7 @@ extern "C" int upf_flow_upsample_backward(const float* grad_y, float* gx, int B,
   UPF_REQUIRE(grad_y && gx, UPF_EINVAL, "flow_upsample_backward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && (long long)B * C <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, UPF_EINVAL, "flow_upsample_backward: bad shape");
   UPF_REQUIRE(!if_rate || C == 2, UPF_EINVAL, "flow_upsample_backward: if_rate needs a 2-channel flow, got C=%d", C);
-  const long long total = (long long)B * C * h * w;
-  // footprint of one input pixel ~ (2H/h) x (2W/w) outputs: a workgroup per input pixel once it exceeds a few hundred
-  const long long fp = (2LL * cdiv(H, h) + 2) * (2LL * cdiv(W, w) + 2);
-  if (fp > 512 && total < (1LL << 31))
-    hipLaunchKernelGGL(sgu::upsample_bwd_kernel<true>, dim3((unsigned)total), dim3(sgu::THREADS), 0, (hipStream_t)stream, grad_y, gx, C, h, w, H, W, if_rate, total);
-  else
-    hipLaunchKernelGGL(sgu::upsample_bwd_kernel<false>, dim3((unsigned)((total + sgu::THREADS - 1) / sgu::THREADS)), dim3(sgu::THREADS), 0, (hipStream_t)stream, grad_y, gx, C, h, w, H, W, if_rate, total);
+  launch_upsample_backward(grad_y, gx, (long long)B * C, C, h, w, H, W, if_rate, (hipStream_t)stream);
   return check_launch("flow_upsample_backward");
 }
 

@@ -3,6 +3,8 @@
 Each operator = one HIP launch on the current torch stream.  Flows, sampling positions and masks
 are fp32 whatever the feature dtype.  No CPU path: non-GPU tensors raise.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -636,17 +638,20 @@ def conv_pack_from_master(weight32, dtype, dgrad=False):
     (dgrad) for its data gradient (flipped, transposed kernel).  Cached per parameter VERSION: the decoder's layers are
     shared by the five pyramid levels, so a training step packs every layer once per direction instead of ten times
     (the optimiser's in-place update bumps the version; `.data` surgery needs conv_pack_cache_clear())."""
-    key = (id(weight32), weight32.data_ptr(), weight32._version, dtype, bool(dgrad))
-    hit = _PACK_CACHE.get(id(weight32), {}).get(key)
-    if hit is not None:
-        return hit
+    key = (weight32.data_ptr(), weight32._version, dtype, bool(dgrad))
+    slot = _PACK_CACHE.get(id(weight32))
+    if slot is not None and slot[0]() is not weight32:          # the id was recycled by another tensor: not our entry
+        slot = None
+    if slot is not None and key in slot[1]:
+        return slot[1][key]
     packed = _conv_pack_from_master(weight32, dtype, dgrad)
-    slot = _PACK_CACHE.setdefault(id(weight32), {})
-    for k in [k for k in slot if k[2] != weight32._version or k[1] != weight32.data_ptr()]:
-        del slot[k]
-    slot[key] = packed
-    if len(_PACK_CACHE) > 4096:
-        _PACK_CACHE.clear()
+    if slot is None:
+        if len(_PACK_CACHE) > 4096:
+            _PACK_CACHE.clear()
+        slot = _PACK_CACHE[id(weight32)] = (weakref.ref(weight32), {})
+    for k in [k for k in slot[1] if k[1] != weight32._version or k[0] != weight32.data_ptr()]:
+        del slot[1][k]
+    slot[1][key] = packed
     return packed
 
 
@@ -896,17 +901,18 @@ def _stacked_dgrad_pack(masters, lo, hi_of, lo_k, f_k, dtype):
     """Packed data-gradient operand for the buffer channels [lo_k, lo_k + f_k) with respect to the pre-activation gradients
     of the layers `masters` (ordered like the gradient buffer: last layer first): the rows of each layer's kernel that
     read those channels, stacked along the (transposed) input dimension.  Cached per parameter versions."""
-    key = (tuple(id(w) for w in masters), tuple(w._version for w in masters), tuple(w.data_ptr() for w in masters), lo_k, f_k, dtype)
-    slot = _STACK_PACK_CACHE.get(key[0] + (lo_k, f_k, dtype))
-    if slot is not None and slot[0] == key:
-        return slot[1]
+    ids = tuple(id(w) for w in masters) + (lo_k, f_k, dtype)
+    key = (tuple(w._version for w in masters), tuple(w.data_ptr() for w in masters))
+    slot = _STACK_PACK_CACHE.get(ids)
+    if slot is not None and slot[0] == key and all(r() is w for r, w in zip(slot[1], masters)):
+        return slot[2]
     with torch.no_grad():
         parts = [w.detach()[:, lo_k - h:lo_k - h + f_k] for w, h in zip(masters, hi_of)]
         stacked = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=0)
         packed = _conv_pack_from_master(stacked.float(), dtype, dgrad=True)
     if len(_STACK_PACK_CACHE) > 1024:
         _STACK_PACK_CACHE.clear()
-    _STACK_PACK_CACHE[key[0] + (lo_k, f_k, dtype)] = (key, packed)
+    _STACK_PACK_CACHE[ids] = (key, [weakref.ref(w) for w in masters], packed)
     return packed
 
 
