@@ -8,8 +8,7 @@
 //   g2[n,c,y,x] = (1/C) sum_d gO[n,d,y-dy,x-dx] * f1[n,c,y-dy,x-dx]      (out-of-range terms dropped)
 //
 // Both are "81 per-pixel weights times a 9x9 neighbourhood of one feature channel".  Two kernels: the LDS-tiled one
-// further down (W % 4 == 0: every level the trainer's crops produce except the two coarsest) and this gather kernel
-// (any shape), in which a thread owns
+// further down (W >= 4) and this gather kernel (any shape; the fallback), in which a thread owns
 // one pixel: it loads its 81 weights ONCE into registers (gO is the big tensor: 81 channels), then
 // walks its slice of the C channels gathering the neighbourhood (L1/L2 hits: neighbouring lanes read
 // neighbouring addresses).  gO is therefore read exactly once per direction from HBM; fp32
@@ -73,7 +72,10 @@ void corr81_bwd_kernel(const T* __restrict__ f1, const T* __restrict__ f2, const
 constexpr int BTH = 16, BTW = 64, BCC = 4;
 constexpr int BROWS = BTH + 8, BPITCH = BTW + 8;                 // tile incl. halo, floats
 
-template <typename T, bool WHICH>
+// RW (ragged width, W % 4 != 0 — the 13- and 26-pixel levels of the trainer's crops, which took the gather kernel at
+// 90 us per launch): the 4-column group that straddles the row end is loaded whole (2-byte-aligned 8-byte buffer loads are
+// legal on gfx950) and the columns beyond W are zeroed / not stored.
+template <typename T, bool WHICH, bool RW>
 __global__ __launch_bounds__(256, 4)
 void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ gO, T* __restrict__ gout,
                              int C, int H, int W, int tiles_x) {
@@ -100,14 +102,33 @@ void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ g
       for (int i = 0; i < 4; ++i) v[i] = Elem<T>::load(&e[i]);
     }
   };
-  // ---- stage the feature tile: groups of 4 columns (all in or all out of the row: x0 - 4 and W are multiples of 4)
+  // elements [xx, xx + 4) of the row that starts at element `row`; RW: a vector that straddles the row end is loaded
+  // SHIFTED LEFT so that it ends at the row end and shifted back in registers (zeros beyond the row): no load leaves its
+  // row, so nothing depends on what follows the tensor (a load straddling the end of the descriptor loses its last
+  // partial dword — the last pixel of the last plane).
+  auto load4r = [&](__amdgpu_buffer_rsrc_t r, int row, int xx, bool in, float (&v)[4]) {
+    int sh = 0;
+    if constexpr (RW) sh = (in && xx < W && xx + 4 > W) ? xx + 4 - W : 0;
+    load4(r, in ? (uint32_t)(row + xx - sh) * ES : 0x80000000u, v);
+    if constexpr (RW) {
+      if (sh) {
+        const float a = v[0], b = v[1], c = v[2], d = v[3];
+        (void)a;
+        v[0] = sh == 1 ? b : (sh == 2 ? c : d);
+        v[1] = sh == 1 ? c : (sh == 2 ? d : 0.f);
+        v[2] = sh == 1 ? d : 0.f;
+        v[3] = 0.f;
+      }
+    }
+  };
+  // ---- stage the feature tile: groups of 4 columns (!RW: all in or all out of the row: x0 - 4 and W are multiples of 4)
   constexpr int GPR = BPITCH / 4;                                // 18 groups per tile row
   for (int g = tid; g < BCC * BROWS * GPR; g += 256) {
     const int c = g / (BROWS * GPR), rem = g - c * (BROWS * GPR), r = rem / GPR, k = rem - r * GPR;
     const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * k;
     const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;      // (channels >= C fall off the descriptor)
     float v[4];
-    load4(fr, in ? (uint32_t)((c0 + c) * HW + gy * W + gx) * ES : 0x80000000u, v);
+    load4r(fr, (c0 + c) * HW + gy * W, gx, in, v);
     *reinterpret_cast<float4*>(&tile[(c * BROWS + r) * BPITCH + 4 * k]) = make_float4(v[0], v[1], v[2], v[3]);
   }
   __syncthreads();
@@ -132,7 +153,7 @@ void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ g
     for (int dxi = 0; dxi < 9; ++dxi) {
       const int yy = WHICH ? y - dy : y, xx = WHICH ? x - (dxi - 4) : x;
       const bool in = live && yy >= 0 && yy < H;
-      load4(gr, in ? (uint32_t)(((dyi * 9 + dxi) * H + yy) * W + xx) * ES : 0x80000000u, w[dxi]);
+      load4r(gr, ((dyi * 9 + dxi) * H + yy) * W, xx, in, w[dxi]);
       if (edge) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[dxi][i] = (xx + i >= 0 && xx + i < W) ? w[dxi][i] : 0.f;
@@ -166,7 +187,11 @@ void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ g
   for (int c = 0; c < BCC; ++c) {
     if (c0 + c >= C) break;
     T* dst = gout + ((size_t)n * C + c0 + c) * HW + (size_t)y * W + x;
-    if constexpr (ES == 4) {
+    if constexpr (RW) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (x + i < W) Elem<T>::store(dst + i, acc[c][i] * invC);
+    } else if constexpr (ES == 4) {
       *reinterpret_cast<float4*>(dst) = make_float4(acc[c][0] * invC, acc[c][1] * invC, acc[c][2] * invC, acc[c][3] * invC);
     } else {
       *reinterpret_cast<uint2*>(dst) = make_uint2(pack2<T>(acc[c][0] * invC, acc[c][1] * invC), pack2<T>(acc[c][2] * invC, acc[c][3] * invC));
@@ -184,13 +209,20 @@ extern "C" int upf_corr81_backward(const void* f1, const void* f2, const void* g
   UPF_REQUIRE(B > 0 && 2 * B <= 65535 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_backward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   const int HW = H * W;
   const size_t es = dtype == UPF_F32 ? 4 : 2;
-  if (W % 4 == 0 && (size_t)81 * HW * es < (1ull << 31) && (size_t)C * HW * es < (1ull << 31) && aligned_to(f1, 16) && aligned_to(f2, 16) &&
-      aligned_to(grad_out, 8) && aligned_to(g1, 16) && aligned_to(g2, 16) && getenv("UPF_CORR_BWD_GATHER") == nullptr) {
+  const bool fits = (size_t)81 * HW * es < (1ull << 31) && (size_t)C * HW * es < (1ull << 31) && getenv("UPF_CORR_BWD_GATHER") == nullptr;
+  const bool aligned = W % 4 == 0 && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(grad_out, 8) && aligned_to(g1, 16) && aligned_to(g2, 16);
+  if (fits && (aligned || W >= 4)) {
     const int tiles_x = cdiv(W, corr::BTW), tiles_y = cdiv(H, corr::BTH);
     dim3 grid(tiles_x * tiles_y, cdiv(C, corr::BCC), B);
-    UPF_DISPATCH(dtype, T,
-                 hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f2, (const T*)grad_out, (T*)g1, C, H, W, tiles_x);
-                 hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f1, (const T*)grad_out, (T*)g2, C, H, W, tiles_x));
+    if (aligned) {
+      UPF_DISPATCH(dtype, T,
+                   hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, false, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f2, (const T*)grad_out, (T*)g1, C, H, W, tiles_x);
+                   hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, true, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f1, (const T*)grad_out, (T*)g2, C, H, W, tiles_x));
+    } else {
+      UPF_DISPATCH(dtype, T,
+                   hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f2, (const T*)grad_out, (T*)g1, C, H, W, tiles_x);
+                   hipLaunchKernelGGL((corr::corr81_bwd_tiled_kernel<T, true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)f1, (const T*)grad_out, (T*)g2, C, H, W, tiles_x));
+    }
     return check_launch("corr81_backward");
   }
   // split channels over blockIdx.y until there are a few thousand waves in flight

@@ -194,7 +194,10 @@ void occ_check_kernel(const float* __restrict__ ff, const float* __restrict__ fb
 // and the backward is a GATHER (deterministic, no atomics): I(q) appears in dist(q) as the centre of all its terms and
 // in dist(q-k) as the neighbour of offset k, so  dI(q) = sum_k [ G(q-k) c_k(q-k) ] - G(q) sum_k c_k(q)  with
 // c_k(p) = d dist(p) / d u_k, every factor recomputed from the two grey images.
-__device__ __forceinline__ float census_t(float u) { return u / sqrtf(0.81f + u * u); }
+// t(u) = u / sqrt(0.81 + u^2) and dt/du = 0.81 / (0.81 + u^2)^(3/2) from ONE hardware reciprocal square root (1 ulp):
+// the first version spent most of its time in IEEE sqrt / division sequences (per neighbour 4 square roots and 5 divisions
+// in the backward pass); the loss tolerances of the reference's goldens (2e-6) leave three orders of magnitude of room.
+__device__ __forceinline__ float census_r(float u) { return __builtin_amdgcn_rsqf(0.81f + u * u); }
 
 __global__ __launch_bounds__(256)
 void census_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ dist, int H, int W, int R) {
@@ -214,26 +217,27 @@ void census_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g
       const int x = j + dx;
       const bool in = iny && x >= 0 && x < W;
       const float va = in ? a[y * W + x] : 0.f, vb = in ? b[y * W + x] : 0.f;
-      const float t = census_t(va - ca) - census_t(vb - cb);
+      const float u1 = va - ca, u2 = vb - cb;
+      const float t = u1 * census_r(u1) - u2 * census_r(u2);
       const float d = t * t;
-      acc += d / (0.1f + d);
+      acc += d * __builtin_amdgcn_rcpf(0.1f + d);
     }
   }
   dist[(size_t)n * HW + p] = acc;
 }
 
-// c(p, u1, u2, sign): d dist / d u of image `which` for one term; dt/du = 0.81 / (0.81 + u^2)^(3/2)
-__device__ __forceinline__ float census_c(float u1, float u2, bool wrt2) {
-  const float t1 = census_t(u1), t2 = census_t(u2);
-  const float df = t1 - t2, d = df * df;
-  const float dh = 0.1f / ((0.1f + d) * (0.1f + d));            // d/dd of d/(0.1+d)
-  const float u = wrt2 ? u2 : u1;
-  const float s = 0.81f + u * u;
-  const float dt = 0.81f / (s * sqrtf(s));
-  return dh * 2.f * df * (wrt2 ? -dt : dt);
+// d dist / d u1 and d dist / d u2 of one term
+__device__ __forceinline__ void census_c(float u1, float u2, float& c1, float& c2) {
+  const float r1 = census_r(u1), r2 = census_r(u2);
+  const float df = u1 * r1 - u2 * r2, d = df * df;
+  const float inv = __builtin_amdgcn_rcpf(0.1f + d);
+  const float k = (0.1f * inv * inv) * 2.f * df * 0.81f;         // d/dd of d/(0.1+d), times 2 df, times the 0.81 of dt/du
+  c1 = k * (r1 * r1 * r1);
+  c2 = -k * (r2 * r2 * r2);
 }
 
-// grad wrt g1 (gg1, may be null) and g2 (gg2, may be null); G = grad of dist [B,1,H,W]
+// grad wrt g1 (W1) and / or g2 (W2); G = grad of dist [B,1,H,W]
+template <bool W1, bool W2>
 __global__ __launch_bounds__(256)
 void census_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ G,
                        float* __restrict__ gg1, float* __restrict__ gg2, int H, int W, int R) {
@@ -249,29 +253,30 @@ void census_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g
   float s1 = 0.f, s2 = 0.f;
   for (int dy = -R; dy <= R; ++dy)
     for (int dx = -R; dx <= R; ++dx) {
+      float c1, c2;
       // (1) q as the CENTRE of its own term k = (dy,dx): neighbour value at q+k (zero outside), du/dI(q) = -1
       {
         const int y = i + dy, x = j + dx;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
         const float va = in ? a[y * W + x] : 0.f, vb = in ? b[y * W + x] : 0.f;
-        const float u1 = va - aq, u2 = vb - bq;
-        s1 -= Gq * census_c(u1, u2, false);
-        s2 -= Gq * census_c(u1, u2, true);
+        census_c(va - aq, vb - bq, c1, c2);
+        if (W1) s1 -= Gq * c1;
+        if (W2) s2 -= Gq * c2;
       }
       // (2) q as the NEIGHBOUR of offset k of the centre p = q - k (if p is inside the image), du/dI(q) = +1
       {
         const int y = i - dy, x = j - dx;
         if (y >= 0 && y < H && x >= 0 && x < W) {
           const int pp = y * W + x;
-          const float u1 = aq - a[pp], u2 = bq - b[pp];
+          census_c(aq - a[pp], bq - b[pp], c1, c2);
           const float Gp = Gn[pp];
-          s1 += Gp * census_c(u1, u2, false);
-          s2 += Gp * census_c(u1, u2, true);
+          if (W1) s1 += Gp * c1;
+          if (W2) s2 += Gp * c2;
         }
       }
     }
-  if (gg1) gg1[(size_t)n * HW + q] = s1;
-  if (gg2) gg2[(size_t)n * HW + q] = s2;
+  if (W1) gg1[(size_t)n * HW + q] = s1;
+  if (W2) gg2[(size_t)n * HW + q] = s2;
 }
 
 }  // namespace misc
@@ -360,6 +365,9 @@ extern "C" int upf_census_backward(const float* gray1, const float* gray2, const
   UPF_REQUIRE(gray1 && gray2 && grad_dist && (g_gray1 || g_gray2), UPF_EINVAL, "census_backward: null pointer");
   UPF_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && max_distance >= 1 && max_distance <= 8, UPF_EINVAL, "census_backward: bad shape / max_distance");
   dim3 grid(cdiv(H * W, 256), B);
-  hipLaunchKernelGGL(misc::census_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gray1, gray2, grad_dist, g_gray1, g_gray2, H, W, max_distance);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_gray1 && g_gray2) hipLaunchKernelGGL((misc::census_bwd_kernel<true, true>), grid, dim3(256), 0, s, gray1, gray2, grad_dist, g_gray1, g_gray2, H, W, max_distance);
+  else if (g_gray1) hipLaunchKernelGGL((misc::census_bwd_kernel<true, false>), grid, dim3(256), 0, s, gray1, gray2, grad_dist, g_gray1, g_gray2, H, W, max_distance);
+  else hipLaunchKernelGGL((misc::census_bwd_kernel<false, true>), grid, dim3(256), 0, s, gray1, gray2, grad_dist, g_gray1, g_gray2, H, W, max_distance);
   return check_launch("census_backward");
 }

@@ -824,6 +824,17 @@ def _gated(weight, bias):
     return hit if hit is not None else (weight, bias, None)
 
 
+_ZERO_BIAS = {}
+
+
+def _zero_bias(device, n):
+    """A read-only fp32 zero vector (the bias operand of the data-gradient convolutions), one allocation per device."""
+    z = _ZERO_BIAS.get(device)
+    if z is None or z.numel() < n:
+        z = _ZERO_BIAS[device] = torch.zeros(max(4096, n), dtype=torch.float32, device=device)
+    return z[:n]
+
+
 class ConvTrainFunction(Function):
     """y = LeakyReLU_slope(conv2d(x, weight, bias, padding = dilation * (k-1)/2, dilation, stride)) with 16-bit activations,
     fp32 master weights / bias and fp32 parameter gradients.  Forward on the MFMA kernel of csrc/conv3x3.hip; backward:
@@ -868,8 +879,7 @@ class ConvTrainFunction(Function):
         if ctx.needs_input_grad[0]:
             if stride == 1:
                 gx = torch.empty_like(x)
-                zero = torch.zeros(Cin, dtype=torch.float32, device=x.device)
-                conv3x3_forward_raw(g, conv_pack_from_master(master, x.dtype, dgrad=True), zero, gx, dilation, 0.0, 1, k)
+                conv3x3_forward_raw(g, conv_pack_from_master(master, x.dtype, dgrad=True), _zero_bias(x.device, Cin), gx, dilation, 0.0, 1, k)
             else:
                 gx = torch.nn.grad.conv2d_input(x.shape, weight.detach(), g.float(), stride=stride, padding=pad, dilation=dilation).to(x.dtype)
         if ctx.needs_input_grad[1]:
@@ -996,7 +1006,7 @@ class DenseStackTrainFunction(Function):
         hi_of = {nf: 0}
         for k in range(nf):
             hi_of[k] = lo[k] + f[k]
-        zero = torch.zeros(max(max(f), ch_in), dtype=torch.float32, device=dev)
+        zero = _zero_bias(dev, max(max(f), ch_in))
         filled = oc
         for pos, k in enumerate(order[1:], start=1):
             ms = [masters[j] for j in order[:pos]]
