@@ -276,10 +276,14 @@ void upsample_bwd_group_kernel(const float* __restrict__ gy, float* __restrict__
 }
 
 // Workgroup variant (large footprints: the pyramid-distillation loss resizes 4x13 flows to 256x832): the 256 threads stride
-// over the footprint, fixed-order LDS tree reduction.
+// over the footprint, fixed-order LDS tree reduction.  Row and column weights come from two LDS tables filled once per
+// workgroup (footprints up to WGT x WGT; the first version evaluated both interpolations for each of the ~17 K footprint
+// pixels: 30 us per launch) — the same products in the same order, so the same bits.
+constexpr int WGT = 160;
 __global__ __launch_bounds__(THREADS)
 void upsample_bwd_wg_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate, long long total) {
   __shared__ float red[THREADS];
+  __shared__ float wys[WGT], wxs[WGT];
   const long long idx = (long long)blockIdx.x;
   const int b = (int)(idx % w), a = (int)((idx / w) % h);
   const long long nc = idx / ((long long)w * h);
@@ -288,13 +292,19 @@ void upsample_bwd_wg_kernel(const float* __restrict__ gy, float* __restrict__ gx
   upsample_bwd_range(a, h, H, ilo, ihi);
   upsample_bwd_range(b, w, W, jlo, jhi);
   const float* g = gy + (size_t)nc * H * W;
-  const int nj = jhi - jlo + 1, cnt = (ihi - ilo + 1) * nj;
+  const int ni = ihi - ilo + 1, nj = jhi - jlo + 1, cnt = ni * nj;
+  const bool table = ni <= WGT && nj <= WGT;
+  if (table) {
+    for (int t = (int)threadIdx.x; t < ni; t += THREADS) wys[t] = upsample_bwd_weight(make_lerp(ilo + t, h, H), a);
+    for (int t = (int)threadIdx.x; t < nj; t += THREADS) wxs[t] = upsample_bwd_weight(make_lerp(jlo + t, w, W), b);
+  }
+  __syncthreads();
   float acc = 0.f;
   for (int t = (int)threadIdx.x; t < cnt; t += THREADS) {
-    const int i = ilo + t / nj, j = jlo + t % nj;
-    const float wy = upsample_bwd_weight(make_lerp(i, h, H), a);
-    const float wx = upsample_bwd_weight(make_lerp(j, w, W), b);
-    if (wy != 0.f && wx != 0.f) acc += g[(size_t)i * W + j] * wy * wx;
+    const int di = t / nj, dj = t - di * nj;
+    const float wy = table ? wys[di] : upsample_bwd_weight(make_lerp(ilo + di, h, H), a);
+    const float wx = table ? wxs[dj] : upsample_bwd_weight(make_lerp(jlo + dj, w, W), b);
+    if (wy != 0.f && wx != 0.f) acc += g[(size_t)(ilo + di) * W + jlo + dj] * wy * wx;
   }
   red[threadIdx.x] = acc;
   __syncthreads();

@@ -418,8 +418,7 @@ class UPFlow_net(tools.abstract_model):
                     Fn, Fwn = network_tools.normalize_features((Fm, Fw), **kw)
             else:
                 Fn, Fwn = Fm, Fw
-            total = self._level_update(Fn, Fwn, A, flow_up)
-            flow = flow_up + total
+            flow = self._level_update(Fn, Fwn, A, flow_up, add_to_flow=True)
             flows.append([flow[:B], flow[B:]])
         flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
         if sgu:
@@ -487,11 +486,13 @@ class UPFlow_net(tools.abstract_model):
             flow_out = sgi.forward_in_buffer(flow, sbuf, sslot, output_level_flow=flow_out, batch_shift=B)[1]
         return flow_out[:B], flow_out[B:], flows[::-1]
 
-    def _level_update(self, Fn, Fwn, A, flow_up):
-        """res + fine for all 2B stacked items (model/upflow.py:557-572)."""
+    def _level_update(self, Fn, Fwn, A, flow_up, add_to_flow=False):
+        """res + fine for all 2B stacked items (model/upflow.py:557-572); add_to_flow: flow_up + (res + fine), the level's
+        refined flow (:566-572)."""
         est = self.flow_estimators
         nb, _, H, W = Fn.shape
         nc = self.dim_corr
+        fin = (lambda t: flow_up + t) if add_to_flow else (lambda t: t)
         if _fast_conv_ok(Fn):
             # one [2B, 565, H, W] buffer: corr81 (+LeakyReLU) -> 448..528, 1x1 features and flow -> 529..562, each
             # dense conv reads a suffix and writes its slice, refined flow appended at 563..564 for the context net
@@ -503,21 +504,24 @@ class UPFlow_net(tools.abstract_model):
             res = res.float()
             buf[:, est._n_total:] = flow_up + res
             fine = self.context_networks(buf).float()
-            return res + fine
+            return fin(res + fine)
         if torch.is_grad_enabled() and (Fn.requires_grad or Fwn.requires_grad):
             c = self.leakyRELU(self.correlation(Fn, Fwn))
             if est.train_in_buffer_ok([c, A, flow_up]):
                 # training on the matrix cores: the estimator is one autograd node in the inference buffer layout; the
                 # refined flow is appended to its buffer, which the context network reads whole (no concatenations)
                 buf, res = est.forward_train([c, A, flow_up], flow_tail=flow_up)
-                return res.float() + self.context_networks(buf).float()
+                fine = self.context_networks(buf)
+                if add_to_flow and flow_up.dtype == torch.float32 and fine.dtype == res.dtype and res.dtype != torch.float32:
+                    return ops.flow_sum3(flow_up, res, fine)              # one launch each way
+                return fin(res.float() + fine.float())
             x = torch.cat([c, A, flow_up.to(c.dtype)], dim=1)
         else:
             x = self._estimator_input(Fn, Fwn, A, flow_up)
         feat, res = est(x)
         res = res.float()
         fine = self.context_networks(torch.cat([feat, (flow_up + res).to(feat.dtype)], dim=1)).float()
-        return res + fine
+        return fin(res + fine)
 
     def _estimator_input(self, f_a, f_b_warp, feat_1x1, flow):
         """cat[LeakyReLU(corr81(f_a, f_b_warp)), feat_1x1, flow]  (model/upflow.py:557-566).

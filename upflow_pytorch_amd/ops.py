@@ -257,6 +257,26 @@ def flow_update(a, b=None, c=None, out=None):
     return out
 
 
+class FlowSum3Function(Function):
+    """a + (b + c) in fp32 (a: fp32 flow, b / c: 16-bit convolution outputs) as ONE launch under autograd — the per-level
+    `flow_up + (res + fine)` of model/upflow.py:566-572, which as tensor arithmetic is two casts and two adds forward and
+    as many kernels backward.  Backward: the incoming gradient itself for a, one 16-bit cast shared by b and c."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.dt = b.dtype
+        return flow_update(a, b.contiguous(), c.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        g16 = g.to(ctx.dt) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        return (g if ctx.needs_input_grad[0] else None), (g16 if ctx.needs_input_grad[1] else None), (g16 if ctx.needs_input_grad[2] else None)
+
+
+def flow_sum3(a, b, c):
+    return FlowSum3Function.apply(a, b, c)
+
+
 # ------------------------------------------------------------------------------------------------
 # flow up-sampling
 # ------------------------------------------------------------------------------------------------
