@@ -231,6 +231,15 @@ typedef struct {
 long long upf_conv_wgrad_multi_workspace_bytes(const upf_wgrad_level* levels, int nlevels, int Cin, int Cout, int kernel_size, int dilation);
 int upf_conv_wgrad_multi(const upf_wgrad_level* levels /* host array */, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
                          int kernel_size, int dilation, int dtype, void* stream);
+/* Stride-2 3x3 layers (feature pyramid, SGU guidance; model/pwc_modules.py:95, model/upflow.py:53-55) take the stride-1
+ * gradient kernels through their space-to-depth form: xs[(ci,p,q), i, j] = x[ci, 2i+p, 2j+q] (upf_space_to_depth2; inverse = 1
+ * for the way back) convolved at stride 1 with a kernel that is w at 9 of its 36 (phase, tap) positions.
+ *   weight gradient: upf_conv_wgrad_s2d — levels hold xs ([B, 4*Cin, H/2, W/2]) and grad_pre; grad_w is [Cout, Cin, 3, 3]
+ *                    (workspace: upf_conv_wgrad_multi_workspace_bytes with Cin := 4*Cin)
+ *   data gradient:   upf_conv_pack_weights_f32(w, ..., dgrad = 2) (upf_conv_packed_bytes(Cout, 4*Cin, 3) bytes), then
+ *                    upf_conv_forward(grad_pre, ..., Cin := Cout, Cout := 4*Cin) and upf_space_to_depth2(inverse = 1). */
+int upf_space_to_depth2(const void* src, void* dst, int B, int C /* of x */, int H, int W /* of x, even */, int inverse, int dtype, void* stream);
+int upf_conv_wgrad_s2d(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout, int dtype, void* stream);
 /* dst = (src + add) * (y > 0 ? 1 : slope) over channel-sliced [B, C, HW] tensors (add, y optional; dst may be src):
  * the gradient entering a layer's pre-activation, with the first stage of the bias gradient (bias_partial: C x 32 fp32,
  * optional) from the same pass; dst = NULL: the bias sums only.  upf_conv_bias_grad_finish sums the first-stage buffers of 1..8 uses in order. */

@@ -252,3 +252,36 @@ def test_shared_conv_grads_defers_to_one_contraction():
         assert (x - y).abs().max() <= 1e-5 * max(1.0, float(y.abs().max())), float((x - y).abs().max())
     a2 = run(True)
     assert all(torch.equal(x, y) for x, y in zip(a, a2))
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64), (1, 3, 6, 20), (2, 5, 12, 26), (1, 32, 64, 208)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_space_to_depth_and_stride2_gradients(shape, dtype):
+    """upf_space_to_depth2 == F.pixel_unshuffle / F.pixel_shuffle (bit copies), and the stride-2 layer's gradients through its
+    space-to-depth form (upf_conv_wgrad_s2d, upf_conv_pack_weights_f32(dgrad = 2)) vs fp32 autograd of the strided convolution
+    on the same rounded operands (model/pwc_modules.py:95, model/upflow.py:53-55)."""
+    from upflow_pytorch_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(dtype).cuda()
+    xs = ops.space_to_depth2(x)
+    assert torch.equal(xs, F.pixel_unshuffle(x, 2))
+    assert torch.equal(ops.space_to_depth2(xs, inverse=True), x)
+    if W // 2 < 8:
+        return
+    Cout = 24
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda().requires_grad_(True)
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda().requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    gy = torch.randn(B, Cout, H // 2, W // 2, generator=g).to(dtype).cuda()
+    assert ops._s2d_ok(xg, w, 2, 1)
+    y = ops.conv_train(xg, w, b, 1, 0.1, 2)
+    gx, gw, gb = torch.autograd.grad(y, (xg, w, b), gy)
+    xr, wr = x.float(), w.detach().to(dtype).float()
+    gpre = (gy.float() * torch.where(y.detach().float() > 0, 1.0, 0.1)).to(dtype).float()
+    gx_ref = torch.nn.grad.conv2d_input(xr.shape, wr, gpre, stride=2, padding=1)
+    gw_ref = torch.nn.grad.conv2d_weight(xr, wr.shape, gpre, stride=2, padding=1)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert (gx.float() - gx_ref).abs().max() <= 2 * eps * max(1.0, float(gx_ref.abs().max()))
+    assert gw.shape == w.shape and (gw - gw_ref).abs().max() <= 2e-4 * max(1.0, float(gw_ref.abs().max())), float((gw - gw_ref).abs().max())
+    assert (gb - gpre.sum((0, 2, 3))).abs().max() <= 1e-4 * max(1.0, float(gpre.sum((0, 2, 3)).abs().max()))

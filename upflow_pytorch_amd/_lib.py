@@ -44,6 +44,8 @@ SIGNATURES = {
     'upf_conv_wgrad': [_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_bias_grad': [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_conv_wgrad_multi': [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_space_to_depth2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_conv_wgrad_s2d': [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
     'upf_act_grad': [_vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _f, _i, _vp],
     'upf_conv_bias_grad_finish': [_vp, _i, _vp, _i, _vp],
     'upf_census_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -94,9 +94,14 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
 // forward convolution (dgrad = 0) or for its DATA GRADIENT (dgrad = 1): gx = conv(g, w') with w'[ci][co][tap] =
 // w[co][ci][ntaps-1-tap] — the spatially flipped, channel-transposed kernel — so the packed operand has Cout' = Cin rows
 // and Cin' = Cout k-columns.
+// dgrad = 2: the data gradient of a STRIDE-2 3x3 layer in its space-to-depth form (ops.py: _s2d_ok).  The layer equals a
+// stride-1 convolution of xs[(ci,p,q), i, j] = x[ci, 2i+p, 2j+q] with the kernel w4[co][(ci,p,q)][a][b] = w[co][ci][ky][kx]
+// at (p, a) = s2d(ky), (q, b) = s2d(kx) (ky = 0: phase 1 of the row above; 1: phase 0; 2: phase 1 of the same row) and zero
+// elsewhere; packed here is w4's data-gradient operand (Cin' = Cout k-columns, Cout' = 4*Cin rows) straight from w.
+__device__ __forceinline__ int s2d_tap(int phase, int a) { return a == 0 ? (phase == 1 ? 0 : -1) : (a == 1 ? (phase == 0 ? 1 : 2) : -1); }
 template <typename T>
 __global__ void pack_weights_f32_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps, int dgrad) {
-  const int cinp = dgrad ? Cout : Cin, coutp = dgrad ? Cin : Cout;          // channel counts of the convolution being packed
+  const int cinp = dgrad ? Cout : Cin, coutp = dgrad == 2 ? 4 * Cin : (dgrad ? Cin : Cout);   // channel counts of the convolution being packed
   const int cip = pad32(cinp), cop = pad32(coutp), nk = cip / 16;
   const long long total = (long long)ntaps * cop * cip;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -105,8 +110,14 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, T* __restri
     const int tap = (int)(b % ntaps), kstep = (int)((b / ntaps) % nk), slab = (int)(b / ((long long)ntaps * nk));
     const int co = slab * 32 + px, ci = kstep * 16 + kg * 8 + j;
     float v = 0.f;
-    if (ci < cinp && co < coutp)
-      v = dgrad ? w[((size_t)ci * Cin + co) * ntaps + (ntaps - 1 - tap)] : w[((size_t)co * Cin + ci) * ntaps + tap];
+    if (ci < cinp && co < coutp) {
+      if (dgrad == 2) {
+        const int ft = ntaps - 1 - tap, ky = s2d_tap((co >> 1) & 1, ft / 3), kx = s2d_tap(co & 1, ft % 3);
+        if (ky >= 0 && kx >= 0) v = w[((size_t)ci * Cin + (co >> 2)) * 9 + ky * 3 + kx];
+      } else {
+        v = dgrad ? w[((size_t)ci * Cin + co) * ntaps + (ntaps - 1 - tap)] : w[((size_t)co * Cin + ci) * ntaps + tap];
+      }
+    }
     Elem<T>::store(wp + i, v);
   }
 }
@@ -734,8 +745,9 @@ extern "C" int upf_conv_pack_weights_f32(const float* w, void* w_packed, int Cin
   UPF_REQUIRE(w && w_packed && Cin > 0 && Cout > 0, UPF_EINVAL, "conv_pack_weights_f32: bad arguments");
   UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_pack_weights_f32: kernel_size %d (1 or 3)", kernel_size);
   UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_pack_weights_f32: packs to bf16 / fp16");
+  UPF_REQUIRE(dgrad >= 0 && dgrad <= 2 && (dgrad != 2 || kernel_size == 3), UPF_EINVAL, "conv_pack_weights_f32: dgrad 0 / 1 / 2 (2: 3x3 only)");
   const int ntaps = kernel_size * kernel_size;
-  const long long total = (long long)ntaps * conv::pad32(Cout) * conv::pad32(Cin);
+  const long long total = (long long)ntaps * conv::pad32(dgrad == 2 ? 4 * Cin : Cout) * conv::pad32(dgrad == 2 ? Cout : Cin);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == UPF_BF16)
     hipLaunchKernelGGL((conv::pack_weights_f32_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_packed, Cin, Cout, ntaps, dgrad);

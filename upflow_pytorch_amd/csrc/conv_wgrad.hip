@@ -329,7 +329,7 @@ void wgrad_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cou
 // chain of 4-byte loads over the splits, 36-byte-strided stores — ran at 1 TB/s: 36 us per layer, 1.15 ms per step.)
 template <int NT>
 __global__ __launch_bounds__(256)
-void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ksplit, int Cout, int Cin, int cop) {
+void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ksplit, int Cout, int Cin, int cop, int s2d) {
   __shared__ float4 sh[3][NT][64];
   const int cip = (Cin + 63) / 64 * 64, c4n = cip / 4;
   const int q = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -364,6 +364,23 @@ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ 
     out[1][t] = ((acc[t].y + a.y) + b.y) + c.y;
     out[2][t] = ((acc[t].z + a.z) + b.z) + c.z;
     out[3][t] = ((acc[t].w + a.w) + b.w) + c.w;
+  }
+  if constexpr (NT == 9) {
+    if (s2d) {
+      // space-to-depth form of a stride-2 layer (ops.py: _s2d_ok): this thread's 4 channels are the 4 phases (p, q) of input
+      // channel c4; dw[co][c4][ky][kx] = (phase (P[ky], P[kx]), tap (A[ky], A[kx])) with P = {1,0,1}, A = {0,1,1}
+      if (c4 * 4 < Cin) {
+        float* d = dw + ((size_t)co * (Cin / 4) + c4) * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int P[3] = {1, 0, 1}, A[3] = {0, 1, 1};
+            d[ky * 3 + kx] = out[P[ky] * 2 + P[kx]][A[ky] * 3 + A[kx]];
+          }
+      }
+      return;
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -565,7 +582,7 @@ static Plan make_plan(const upf_wgrad_level* lv, int n, int Cin, int Cout, int k
 }
 
 template <typename T, int D>
-int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cout, int kernel_size, int dilation, hipStream_t stream) {
+int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cout, int kernel_size, int dilation, hipStream_t stream, int s2d = 0) {
   using G = Geo<D>;
   const Plan p = make_plan(lv, n, Cin, Cout, kernel_size, dilation);
   const int cob = co_block(Cout), cop = cdiv(Cout, cob) * cob;
@@ -578,7 +595,7 @@ int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cou
     if (p.nr) launch_group<T, D, true, 1>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
   }
   const long long items = (long long)Cout * (cdiv(Cin, 64) * 16);
-  hipLaunchKernelGGL(wgrad_reduce_kernel<G::NT>, dim3((unsigned)((items + 63) / 64)), dim3(256), 0, stream, ws, dw, p.ks_a + p.ks_r, Cout, Cin, cop);
+  hipLaunchKernelGGL(wgrad_reduce_kernel<G::NT>, dim3((unsigned)((items + 63) / 64)), dim3(256), 0, stream, ws, dw, p.ks_a + p.ks_r, Cout, Cin, cop, s2d);
   return check_launch("conv_wgrad");
 }
 
@@ -629,6 +646,15 @@ extern "C" int upf_conv_wgrad_multi(const upf_wgrad_level* levels, int nlevels, 
 #undef UPF_WG
   set_error("conv_wgrad: internal routing error");
   return UPF_EUNSUPPORTED;
+}
+
+extern "C" int upf_conv_wgrad_s2d(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(grad_w && workspace, UPF_EINVAL, "conv_wgrad_s2d: null pointer");
+  if (int rc = wgrad_check_levels(levels, nlevels, 4 * Cin, Cout, 3, 1, dtype)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == UPF_BF16 ? wgrad::run<bf16_t, 1>(levels, nlevels, grad_w, (float*)workspace, 4 * Cin, Cout, 3, 1, s, 1)
+                           : wgrad::run<f16_t, 1>(levels, nlevels, grad_w, (float*)workspace, 4 * Cin, Cout, 3, 1, s, 1);
 }
 
 extern "C" long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation) {

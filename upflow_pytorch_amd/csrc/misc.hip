@@ -279,8 +279,64 @@ void census_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g
   if (W2) gg2[(size_t)n * HW + q] = s2;
 }
 
+// xs[n, c*4 + p*2 + q, i, j] = x[n, c, 2i+p, 2j+q] (F.pixel_unshuffle(x, 2)) and its inverse, 16-bit elements: the layout glue
+// of the stride-2 layers' gradients (ops.py: _s2d_ok).  A thread moves V input pixels of one row (V = 8: one 16-byte access
+// split into / merged from the two column phases; V = 2 for widths that are not multiples of 8).
+template <int V, bool INVERSE>
+__global__ void space_to_depth2_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int C, int H, int W, long long total) {
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int wv = W / V;
+  const int jv = (int)(t % wv), r = (int)((t / wv) % H);
+  const long long nc = t / ((long long)wv * H);               // n * C + c
+  const int i = r >> 1, p = r & 1, h2 = H / 2, w2 = W / 2;
+  const uint16_t* full = (INVERSE ? dst : src) + ((size_t)nc * H + r) * W + (size_t)jv * V;            // x row segment
+  const uint16_t* q0c = (INVERSE ? src : dst) + (((size_t)nc * 4 + p * 2) * h2 + i) * w2 + (size_t)jv * (V / 2);   // phase q = 0
+  const uint16_t* q1c = q0c + (size_t)h2 * w2;                                                                       // phase q = 1
+  uint16_t* fullw = const_cast<uint16_t*>(full); uint16_t* q0 = const_cast<uint16_t*>(q0c); uint16_t* q1 = const_cast<uint16_t*>(q1c);
+  if constexpr (V == 8) {
+    if constexpr (!INVERSE) {
+      const uint4 v = *reinterpret_cast<const uint4*>(full);
+      uint2 e, o;
+      e.x = __builtin_amdgcn_perm(v.y, v.x, 0x05040100u); o.x = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
+      e.y = __builtin_amdgcn_perm(v.w, v.z, 0x05040100u); o.y = __builtin_amdgcn_perm(v.w, v.z, 0x07060302u);
+      *reinterpret_cast<uint2*>(q0) = e;
+      *reinterpret_cast<uint2*>(q1) = o;
+    } else {
+      const uint2 e = *reinterpret_cast<const uint2*>(q0c), o = *reinterpret_cast<const uint2*>(q1c);
+      uint4 v;
+      v.x = (e.x & 0xffffu) | (o.x << 16); v.y = (e.x >> 16) | (o.x & 0xffff0000u);
+      v.z = (e.y & 0xffffu) | (o.y << 16); v.w = (e.y >> 16) | (o.y & 0xffff0000u);
+      *reinterpret_cast<uint4*>(fullw) = v;
+    }
+  } else {
+    if constexpr (!INVERSE) { q0[0] = full[0]; q1[0] = full[1]; }
+    else { fullw[0] = q0c[0]; fullw[1] = q1c[0]; }
+  }
+}
+
 }  // namespace misc
 }  // namespace upf
+
+extern "C" int upf_space_to_depth2(const void* src, void* dst, int B, int C, int H, int W, int inverse, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, UPF_EINVAL, "space_to_depth2: even H, W expected (H %d, W %d)", H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "space_to_depth2: bf16 / fp16 only");
+  const bool v8 = W % 16 == 0 && aligned_to(src, 16) && aligned_to(dst, 16);
+  const long long total = (long long)B * C * H * (W / (v8 ? 8 : 2));
+  UPF_REQUIRE((total + 255) / 256 < (1ll << 31), UPF_EINVAL, "space_to_depth2: tensor too large");
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  const uint16_t* a = (const uint16_t*)src; uint16_t* b = (uint16_t*)dst;
+  if (v8) {
+    if (inverse) hipLaunchKernelGGL((misc::space_to_depth2_kernel<8, true>), grid, dim3(256), 0, s, a, b, C, H, W, total);
+    else hipLaunchKernelGGL((misc::space_to_depth2_kernel<8, false>), grid, dim3(256), 0, s, a, b, C, H, W, total);
+  } else {
+    if (inverse) hipLaunchKernelGGL((misc::space_to_depth2_kernel<2, true>), grid, dim3(256), 0, s, a, b, C, H, W, total);
+    else hipLaunchKernelGGL((misc::space_to_depth2_kernel<2, false>), grid, dim3(256), 0, s, a, b, C, H, W, total);
+  }
+  return check_launch("space_to_depth2");
+}
 
 // segments per row: enough workgroups for ~4 per CU, at least 2048 elements per segment
 static int normalize_nseg(long long N, int HW) {

@@ -855,6 +855,73 @@ def _zero_bias(device, n):
     return z[:n]
 
 
+# ---- stride-2 layers (feature pyramid, SGU guidance) through the stride-1 gradient kernels --------------------------------
+# y[i] = sum_k w[k] x[2i + k - 1] reads rows 2i-1, 2i, 2i+1 = (row i-1, phase 1), (row i, phase 0), (row i, phase 1) of the
+# space-to-depth input xs[(c, p, q), i, j] = x[c, 2i+p, 2j+q] (F.pixel_unshuffle): a STRIDE-1 3x3 convolution of xs whose
+# kernel w4[co, (ci,p,q), a, b] is w[co, ci, ky, kx] at (p, a) = _S2D(ky), (q, b) = _S2D(kx) and zero elsewhere.  So the
+# weight gradient is the stride-1 weight gradient w.r.t. (xs, g) gathered at those positions (inside the split-K reduction,
+# upf_conv_wgrad_s2d), and the data gradient the stride-1 data gradient with w4 (packed straight from w,
+# upf_conv_pack_weights_f32(dgrad = 2)), shuffled back (upf_space_to_depth2).  4x the flops of the minimum on layers that hold 2 % of the step's
+# flops — against PyTorch-ROCm's fp32 gradient kernels, their casts and NCHW<->NHWC transposes (1.2 ms of a 13.3 ms step).
+_S2D_CACHE = {}
+
+
+def space_to_depth2(t, inverse=False):
+    """xs[n, c*4 + p*2 + q, i, j] = x[n, c, 2i+p, 2j+q] (= F.pixel_unshuffle(x, 2)); inverse: F.pixel_shuffle(xs, 2)."""
+    t = t.contiguous()
+    B, C, H, W = t.shape
+    if inverse:
+        C, H, W = C // 4, H * 2, W * 2
+    out = torch.empty((B, C, H, W) if inverse else (B, 4 * C, H // 2, W // 2), dtype=t.dtype, device=t.device)
+    dev = _lib.check_gpu(t)
+    with torch.cuda.device(dev):
+        _lib.call('upf_space_to_depth2', _lib.ptr(t), _lib.ptr(out), B, C, H, W, int(bool(inverse)), _lib.dtype_code(t), _lib.stream_ptr(dev))
+    return out
+
+
+def conv_wgrad_s2d(xs, g, Cin, Cout):
+    """Weight gradient [Cout,Cin,3,3] of a stride-2 3x3 layer from its space-to-depth input xs [B,4*Cin,H/2,W/2] and the
+    gradient g [B,Cout,H/2,W/2] entering its pre-activation (upf_conv_wgrad_s2d)."""
+    dev = _lib.check_gpu(xs, g)
+    arr = (_lib.WgradLevel * 1)()
+    a = arr[0]
+    a.x, a.x_batch_stride, a.grad_pre, a.g_batch_stride = xs.data_ptr(), xs.stride(0), g.data_ptr(), g.stride(0)
+    a.B, a.H, a.W = xs.shape[0], xs.shape[2], xs.shape[3]
+    nbytes = _lib.lib().upf_conv_wgrad_multi_workspace_bytes(arr, 1, 4 * Cin, Cout, 3, 1)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    gw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_wgrad_s2d', arr, 1, _lib.ptr(gw), _lib.ptr(ws), Cin, Cout, _lib.dtype_code(xs), _lib.stream_ptr(dev))
+    return gw
+
+
+def _s2d_ok(x, weight, stride, dilation):
+    Cout, Cin, k, _ = weight.shape
+    H, W = x.shape[2:]
+    return (stride == 2 and k == 3 and dilation == 1 and H % 2 == 0 and W % 2 == 0 and W // 2 >= 8 and x.dtype in (torch.bfloat16, torch.float16)
+            and bool(_lib.lib().upf_conv_wgrad_supported(4 * Cin, Cout, H // 2, W // 2, 3, 1, 1, _lib.dtype_code(x))))
+
+
+def _s2d_dgrad_pack(master, dtype):
+    """Packed data-gradient operand of the space-to-depth form of a stride-2 layer (cached per parameter version)."""
+    key = (master._version, master.data_ptr(), dtype)
+    slot = _S2D_CACHE.get(id(master))
+    if slot is not None and slot[0] == key and slot[1]() is master:
+        return slot[2]
+    Cout, Cin = master.shape[:2]
+    w = master.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    dev = _lib.check_gpu(w)
+    packed = torch.empty((_lib.lib().upf_conv_packed_bytes(Cout, 4 * Cin, 3) // 2,), dtype=dtype, device=w.device)
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_pack_weights_f32', _lib.ptr(w), _lib.ptr(packed), Cin, Cout, 3, _lib.dtype_code(packed), 2, _lib.stream_ptr(dev))
+    if len(_S2D_CACHE) > 1024:
+        _S2D_CACHE.clear()
+    _S2D_CACHE[id(master)] = (key, weakref.ref(master), packed)
+    return packed
+
+
 class ConvTrainFunction(Function):
     """y = LeakyReLU_slope(conv2d(x, weight, bias, padding = dilation * (k-1)/2, dilation, stride)) with 16-bit activations,
     fp32 master weights / bias and fp32 parameter gradients.  Forward on the MFMA kernel of csrc/conv3x3.hip; backward:
@@ -896,6 +963,22 @@ class ConvTrainFunction(Function):
         else:
             g, part = act_grad(gy, y, slope, want_bias=want_b)
         gx = gw = gb = None
+        if _s2d_ok(x, weight, stride, dilation):
+            # stride-2 layer as a stride-1 convolution of the space-to-depth input (see _s2d_ok): both gradients on the
+            # matrix-core kernels instead of PyTorch-ROCm's fp32 kernels + casts + layout transposes
+            B, _, H, W = x.shape
+            if ctx.needs_input_grad[0]:
+                gxs = torch.empty((B, 4 * Cin, H // 2, W // 2), dtype=x.dtype, device=x.device)
+                conv3x3_forward_raw(g, _s2d_dgrad_pack(master, x.dtype), _zero_bias(x.device, 4 * Cin), gxs, 1, 0.0, 1, 3)
+                gx = space_to_depth2(gxs, inverse=True)
+            if ctx.needs_input_grad[1]:
+                gw = conv_wgrad_s2d(space_to_depth2(x), g, Cin, Cout)
+            if want_b:
+                if sink is not None:
+                    sink.bias_parts.append(part)
+                else:
+                    gb = conv_bias_grad_finish([part], Cout)
+            return gx, gw, gb, None, None, None, None
         if ctx.needs_input_grad[0]:
             if stride == 1:
                 gx = torch.empty_like(x)
