@@ -14,8 +14,8 @@ for f in sorted(glob.glob('gpurun_out/prof_wgrad/*/*/*_counter_collection.csv'))
     rows = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(list)
     for r in rows:
-        if 'wgrad_kernel' in r['Kernel_Name']:
+        if 'wgrad_' in r['Kernel_Name'] and 'reduce' not in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
-    kt = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(f.replace('counter_collection', 'kernel_trace'))) if 'wgrad_kernel' in r['Kernel_Name']]
+    kt = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(f.replace('counter_collection', 'kernel_trace'))) if 'wgrad_' in r['Kernel_Name'] and 'reduce' not in r['Kernel_Name']]
     print(f.split('/')[2], 'dur us', [round(v, 1) for v in kt[-3:]], {k: round(sum(v[-2:]) / len(v[-2:])) for k, v in agg.items()})
 PY

@@ -25,6 +25,7 @@
 // 52, 26 and 13 pixels wide — take the RAGGED staging variant).
 #include "common.hpp"
 #include <cstring>
+#include <stdlib.h>
 
 namespace upf {
 namespace wgrad {
@@ -322,6 +323,239 @@ void wgrad_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cou
     }
 }
 
+// ---- producer / consumer form -------------------------------------------------------------------------------------------
+// PMC picture of wgrad_kernel (profiles/r02_wgrad_567_128_pmc.txt): 11 K cycles per tile and SIMD against 4.6 K of MFMA issue —
+// every wave stages (address arithmetic, loads, LDS writes), waits at a workgroup barrier, multiplies, waits again: the
+// phases of all waves coincide, so the matrix pipe idles while the tile is staged.  Here the roles are split: waves 0-3
+// (consumers) only read LDS and issue MFMAs, waves 4-7 (producers) only stage — loads of tile t+3 in flight in one of two
+// register sets while tile t+1 is written to the OTHER of two LDS buffers — so that a SIMD always holds one wave of each
+// kind and issues MFMAs and staging instructions side by side; one barrier per tile swaps the buffers.  64 co x 64 ci per
+// workgroup, same partial layout, same XCD-aware tile order as wgrad_kernel<.., MB = 1>.
+template <typename T, int D, bool RAGGED>
+__global__ __launch_bounds__(2 * NTHREADS, 2)
+void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cout, int nci2, int J, int co2_base) {
+  using G = Geo<D>;
+  constexpr int DD = (D == 0) ? 1 : D;
+  constexpr int HALO = halo_of(D);
+  constexpr int NXT = (64 * G::XR * G::XB + NTHREADS - 1) / NTHREADS;      // X staging tasks per producer thread
+  constexpr int NGT = (64 * TR * G::GB + NTHREADS - 1) / NTHREADS;         // g staging tasks per producer thread
+  constexpr int BUF = G::X_BLOCKS + G::G_BLOCKS;                            // 16-byte blocks per LDS buffer
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];            // two buffers: [X | g] [X | g]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblocks = gridDim.x / (8 * J);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bpair = slot % nblocks, jj = slot / nblocks;
+  const int ks_id = xcd * J + jj;
+  const int co2 = bpair / nci2 + co2_base, ci2 = bpair % nci2;
+  const int t_lo = (int)((long long)L.ntiles * xcd / 8), t_hi = (int)((long long)L.ntiles * (xcd + 1) / 8);
+  const int first = t_lo + jj;
+  const int niter = first < t_hi ? (t_hi - first + J - 1) / J : 0;       // tiles of this workgroup (uniform)
+  const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
+
+  if (wave >= 4) {
+    // ================= producers
+    const int ptid = tid - NTHREADS;
+    const uint32_t xnch = (uint32_t)max(min(Cin - ci2 * 64, 64), 0), gnch = (uint32_t)max(min(Cout - co2 * 64, 64), 0);
+    // staging tasks of this thread (the same for every tile): LDS slot, and — per pyramid level — the byte offset of the
+    // task's 16-byte block relative to the tile origin (y0, x0) plus its row / column relative to that origin, so that a
+    // tile costs one add and two unsigned range checks per task instead of the full index arithmetic
+    int xslot[NXT], xrow[NXT], xcol[NXT], gslot[NGT], grow[NGT], gcol[NGT];
+    uint32_t xrel[NXT], grel[NGT];
+    int xch[NXT], gch[NGT];
+#pragma unroll
+    for (int i = 0; i < NXT; ++i) {
+      const int t = ptid + i * NTHREADS;
+      const int c = t / (G::XR * G::XB), rem = t - c * (G::XR * G::XB), sr = rem / G::XB, bb = rem - sr * G::XB;
+      xslot[i] = (t < 64 * G::XR * G::XB) ? c * G::XCH + sr * G::XB + bb : -1;
+      xch[i] = c;
+      xrow[i] = (D == 0) ? sr : (sr - 1) * DD;
+      xcol[i] = 8 * bb - HALO;
+    }
+#pragma unroll
+    for (int i = 0; i < NGT; ++i) {
+      const int t = ptid + i * NTHREADS;
+      const int c = t / (TR * G::GB), rem = t - c * (TR * G::GB), k = rem / G::GB, bb = rem - k * G::GB;
+      gslot[i] = (t < 64 * TR * G::GB) ? c * G::GCH + k * G::GB + bb : -1;
+      gch[i] = c;
+      grow[i] = k * DD;
+      gcol[i] = 8 * bb;
+    }
+    // current pyramid level (tiles of a workgroup only ever move forward through the levels)
+    int lev = -1, next_t0 = 0;
+    const T* lx = nullptr; const T* lg = nullptr;
+    long long lxbs = 0, lgbs = 0;
+    int H = 1, W = 1, tiles_x = 1, tiles_y = 1, t0 = 0;
+    float rtx = 1.f, rtxy = 1.f;
+    uint32_t plane = 0;
+    auto enter_level = [&](int tile) {
+      while (lev + 1 < L.n && tile >= next_t0) {
+        ++lev;
+#pragma unroll
+        for (int i = 0; i < MAXL; ++i)
+          if (i == lev) {
+            lx = (const T*)L.lv[i].x; lg = (const T*)L.lv[i].g; lxbs = L.lv[i].xbs; lgbs = L.lv[i].gbs;
+            H = L.lv[i].H; W = L.lv[i].W; tiles_x = L.lv[i].tiles_x; tiles_y = L.lv[i].tiles_y; t0 = L.lv[i].tile0;
+          }
+        next_t0 = 0x7fffffff;
+#pragma unroll
+        for (int i = 1; i < MAXL; ++i)
+          if (i == lev + 1 && i < L.n) next_t0 = L.lv[i].tile0;
+        plane = (uint32_t)H * (uint32_t)W * 2u;
+        rtx = 1.0f / (float)tiles_x; rtxy = 1.0f / (float)(tiles_x * tiles_y);
+#pragma unroll
+        for (int i = 0; i < NXT; ++i) xrel[i] = (uint32_t)xch[i] * plane + (uint32_t)((xrow[i] * W + xcol[i]) * 2);
+#pragma unroll
+        for (int i = 0; i < NGT; ++i) grel[i] = (uint32_t)gch[i] * plane + (uint32_t)((grow[i] * W + gcol[i]) * 2);
+      }
+    };
+    // a / b for 0 <= a < 2^24 through the reciprocal (exact after one correction step either way)
+    auto fdiv = [](int a, int b, float rb) { int q = (int)((float)a * rb); int r = a - q * b; q += (r >= b) - (r < 0); return q; };
+    struct Set { u32x4 px[NXT], pg[NGT]; int sx[RAGGED ? NXT : 1], sg[RAGGED ? NGT : 1]; };
+    Set S0, S1;
+    auto issue = [&](int tile, Set& S) {
+      enter_level(tile);
+      const int lt = tile - t0;
+      const int n = fdiv(lt, tiles_x * tiles_y, rtxy), r2 = lt - n * tiles_x * tiles_y;
+      const int ty = fdiv(r2, tiles_x, rtx), tx = r2 - ty * tiles_x;
+      const int phase = ty % DD, q = ty / DD;                            // (compile-time divisor)
+      const int y0 = phase + DD * q * TR, x0 = tx * TWP;
+      const bool live = tile < t_hi;
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(lx + (size_t)n * lxbs + (size_t)ci2 * 64 * H * W), 0, live ? xnch * plane : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(lg + (size_t)n * lgbs + (size_t)co2 * 64 * H * W), 0, live ? gnch * plane : 0u, 0x00020000);
+      const uint32_t torg = (uint32_t)((y0 * W + x0) * 2);
+#pragma unroll
+      for (int i = 0; i < NXT; ++i) {
+        const int gy = y0 + xrow[i], gx = x0 + xcol[i];
+        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        int sh = 0;
+        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sx[i] = sh; }
+        const uint32_t off = in ? xrel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
+        S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NGT; ++i) {
+        const int gy = y0 + grow[i], gx = x0 + gcol[i];
+        const bool in = gy < H && gx < W;
+        int sh = 0;
+        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sg[i] = sh; }
+        const uint32_t off = in ? grel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
+        S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
+      }
+    };
+    auto land = [&](const Set& S, uint4* buf) {
+      uint4* xs = buf; uint4* gs = buf + G::X_BLOCKS;
+#pragma unroll
+      for (int i = 0; i < NXT; ++i)
+        if (xslot[i] >= 0) xs[xslot[i]] = __builtin_bit_cast(uint4, RAGGED ? shr_pixels(S.px[i], S.sx[RAGGED ? i : 0]) : S.px[i]);
+#pragma unroll
+      for (int i = 0; i < NGT; ++i)
+        if (gslot[i] >= 0) gs[gslot[i]] = __builtin_bit_cast(uint4, RAGGED ? shr_pixels(S.pg[i], S.sg[RAGGED ? i : 0]) : S.pg[i]);
+    };
+    // tile k of this workgroup = first + k * J (dead beyond niter: a null descriptor, zeros).  Set k & 1 carries tile k.
+    issue(first, S0);
+    issue(first + J, S1);
+    land(S0, smem);                                                      // tile 0 -> buffer 0
+    issue(first + 2 * J, S0);
+    __syncthreads();
+    for (int it = 0; it < niter; it += 2) {
+      // consumers multiply tile `it` out of buffer 0
+      land(S1, smem + BUF);                                              // tile it+1 -> buffer 1
+      issue(first + (it + 3) * J, S1);
+      __syncthreads();
+      if (it + 1 < niter) {
+        // consumers multiply tile it+1 out of buffer 1
+        land(S0, smem);                                                  // tile it+2 -> buffer 0
+        issue(first + (it + 4) * J, S0);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // ================= consumers
+  const int cob = wave & 1, cib = wave >> 1;
+  const int ch = lane & 31, kg = lane >> 5;
+  f32x16 acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  auto multiply = [&](const uint4* buf) {
+    const uint4* xw = buf + (cib * 32 + ch) * G::XCH;
+    const uint4* gw = buf + G::X_BLOCKS + (cob * 32 + ch) * G::GCH;
+    if constexpr (D == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int blk = 2 * ks + kg;
+#pragma unroll
+        for (int k = 0; k < TR; ++k) acc[0] = Mma32<T>::mma(gw[k * G::GB + blk], xw[k * G::XB + blk], acc[0]);
+      }
+    } else {
+      struct Row { uint4 p2, p1, c, n1, n2; };
+      auto rload = [&](int ks, int s2) {
+        const uint4* row = xw + s2 * G::XB + HALO / 8 + 2 * ks + kg;
+        Row r;
+        r.p2 = r.n2 = make_uint4(0, 0, 0, 0);
+        r.p1 = row[-1]; r.c = row[0]; r.n1 = row[1];
+        if constexpr (D == 16) { r.p2 = row[-2]; r.n2 = row[2]; }
+        return r;
+      };
+      uint4 a[2][TR];
+#pragma unroll
+      for (int k = 0; k < TR; ++k) a[0][k] = gw[k * G::GB + kg];
+      // rows are read TWO steps ahead of their MFMAs (a step is 3-9 MFMAs = 100-300 cycles, an LDS read under load more)
+      constexpr bool DEEP = (D != 16);
+      Row cur = rload(0, 0);
+      Row nx1 = rload(0, 1);
+#pragma unroll
+      for (int it = 0; it < 2 * G::XR; ++it) {
+        const int ks = it / G::XR, s2 = it % G::XR;
+        Row nxt = nx1;
+        if constexpr (DEEP) {
+          if (it + 2 < 2 * G::XR) nx1 = rload((it + 2) / G::XR, (it + 2) % G::XR);
+        } else {
+          if (it + 1 < 2 * G::XR) nxt = rload((it + 1) / G::XR, (it + 1) % G::XR);
+        }
+        if (ks == 0 && s2 == 0) {
+#pragma unroll
+          for (int k = 0; k < TR; ++k) a[1][k] = gw[k * G::GB + 2 + kg];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4 w0 = window<DD>(cur.p2, cur.p1, cur.c, cur.n1, cur.n2), w2 = window<-DD>(cur.p2, cur.p1, cur.c, cur.n1, cur.n2);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int k = s2 - ky;
+          if (k >= 0 && k < TR) {
+            acc[ky * 3 + 0] = Mma32<T>::mma(a[ks][k], w0, acc[ky * 3 + 0]);
+            acc[ky * 3 + 1] = Mma32<T>::mma(a[ks][k], cur.c, acc[ky * 3 + 1]);
+            acc[ky * 3 + 2] = Mma32<T>::mma(a[ks][k], w2, acc[ky * 3 + 2]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
+    }
+  };
+  __syncthreads();                                                       // tile 0 is in buffer 0
+  for (int it = 0; it < niter; it += 2) {
+    multiply(smem);
+    __syncthreads();
+    if (it + 1 < niter) {
+      multiply(smem + BUF);
+      __syncthreads();
+    }
+  }
+  float* pb = partial + (size_t)ks_id * G::NT * cop * cip;
+  const int ci = ci2 * 64 + cib * 32 + ch;
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co2 * 64 + cob * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+      pb[((size_t)t * cop + co) * cip + ci] = acc[t][e];
+    }
+}
+
 // dw[co][ci][tap] = sum over the K-splits, fixed order.  A thread owns 4 consecutive ci of one co for ALL taps: its reads
 // are 16-byte loads that a wave lays side by side (the partial layout is [split][tap][co][ci], ci fastest), NT independent
 // loads per split in flight, and its NT x 4 results are 36 consecutive floats of dw.  The four waves of a workgroup take
@@ -517,7 +751,13 @@ __global__ void bias_grad_multi_final_kernel(const BiasParts P, float* __restric
 // K-splits = 8 XCDs x J: J concurrent tiles per XCD such that J x (block pairs) workgroups fill its 32 CUs (the kernel
 // keeps a whole tile in registers: 1 workgroup per CU is resident), bounded by the tiles an XCD has and by 40 MB of fp32
 // partial blocks per 64 output channels of a workgroup.
-static int co_block(int Cout) { return Cout > 64 ? 128 : 64; }             // 128 co x 64 ci workgroups for the wide layers
+// kernel choice: 0 = producer / consumer kernel (64 co x 64 ci), 1 = wgrad_kernel (64 co, or 128 co for Cout > 64);
+// UPF_WGRAD_MODE overrides (A/B runs)
+static int wgrad_mode() {
+  static const int m = [] { const char* e = getenv("UPF_WGRAD_MODE"); return e ? atoi(e) : 0; }();
+  return m;
+}
+static int co_block(int Cout) { return (wgrad_mode() == 1 && Cout > 64) ? 128 : 64; }
 static int pick_ksplit(int ntiles, int nblocks, int ntaps, int cob) {
   int J = 32 / nblocks;
   const long long per_split = (long long)nblocks * ntaps * cob * 64 * 4;
@@ -555,6 +795,42 @@ void launch_group(const upf_wgrad_level* lv, const int* idx, int n, float* ws, i
   hipLaunchKernelGGL(kern, dim3(ksplit * nco2 * nci2), dim3(NTHREADS * MB), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8);
 }
 
+// More than 16 block pairs cannot run two tile lanes per XCD (32 CUs): a 567 -> 128 layer (18 pairs) would leave 14 of 32
+// CUs idle.  Its co blocks then go in separate launches (9 pairs, 3 lanes, 27 CUs per XCD); X is read once per launch.
+static bool pc_split_co(int nco2, int nci2) { return nco2 > 1 && nco2 * nci2 > 16 && nci2 <= 16; }
+
+template <typename T, int D, bool RAGGED>
+void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws, int ksplit, int Cin, int Cout, hipStream_t stream) {
+  using G = Geo<D>;
+  constexpr int DD = (D == 0) ? 1 : D;
+  KLevels L;
+  memset(&L, 0, sizeof(L));
+  int t0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const upf_wgrad_level& a = lv[idx[i]];
+    KLevel& k = L.lv[i];
+    k.x = a.x; k.g = a.grad_pre;
+    k.xbs = a.x_batch_stride ? a.x_batch_stride : (long long)Cin * a.H * a.W;
+    k.gbs = a.g_batch_stride ? a.g_batch_stride : (long long)Cout * a.H * a.W;
+    k.H = a.H; k.W = a.W;
+    k.tiles_x = cdiv(a.W, TWP); k.tiles_y = DD * cdiv(cdiv(a.H, DD), TR);
+    k.tile0 = t0;
+    t0 += a.B * k.tiles_x * k.tiles_y;
+  }
+  L.n = n; L.ntiles = t0;
+  const int nco2 = cdiv(Cout, 64), nci2 = cdiv(Cin, 64);
+  constexpr int lds_bytes = 2 * (G::X_BLOCKS + G::G_BLOCKS) * 16;
+  static LdsOptIn opt;
+  auto kern = &wgrad_pc_kernel<T, D, RAGGED>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds_bytes);
+  if (pc_split_co(nco2, nci2)) {                 // one launch per co block (see pc_split_co)
+    for (int c = 0; c < nco2; ++c)
+      hipLaunchKernelGGL(kern, dim3(ksplit * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, c);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(ksplit * nco2 * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, 0);
+  }
+}
+
 static bool level_ragged(const upf_wgrad_level& a, int Cin, int Cout) {
   const long long xbs = a.x_batch_stride ? a.x_batch_stride : (long long)Cin * a.H * a.W;
   const long long gbs = a.g_batch_stride ? a.g_batch_stride : (long long)Cout * a.H * a.W;
@@ -575,7 +851,9 @@ static Plan make_plan(const upf_wgrad_level* lv, int n, int Cin, int Cout, int k
     if (level_ragged(lv[i], Cin, Cout)) { p.ir[p.nr++] = i; tr += level_tiles(lv[i], dd); }
     else { p.ia[p.na++] = i; ta += level_tiles(lv[i], dd); }
   }
-  const int cob = co_block(Cout), nblocks = cdiv(Cout, cob) * cdiv(Cin, 64);
+  const int cob = co_block(Cout);
+  int nblocks = cdiv(Cout, cob) * cdiv(Cin, 64);
+  if (wgrad_mode() == 0 && pc_split_co(cdiv(Cout, 64), cdiv(Cin, 64))) nblocks = cdiv(Cin, 64);      // workgroups per launch
   if (p.na) p.ks_a = pick_ksplit(ta, nblocks, nt, cob);
   if (p.nr) p.ks_r = pick_ksplit(tr, nblocks, nt, cob);
   return p;
@@ -587,7 +865,10 @@ int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cou
   const Plan p = make_plan(lv, n, Cin, Cout, kernel_size, dilation);
   const int cob = co_block(Cout), cop = cdiv(Cout, cob) * cob;
   const size_t per_split = (size_t)G::NT * cop * (cdiv(Cin, 64) * 64);
-  if (cob == 128) {
+  if (wgrad_mode() == 0) {
+    if (p.na) launch_group_pc<T, D, false>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
+    if (p.nr) launch_group_pc<T, D, true>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
+  } else if (cob == 128) {
     if (p.na) launch_group<T, D, false, 2>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
     if (p.nr) launch_group<T, D, true, 2>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
   } else {
