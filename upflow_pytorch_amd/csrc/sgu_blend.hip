@@ -409,7 +409,7 @@ extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out,
   UPF_REQUIRE(flow_init && x_out && grad_flow_up && g_flow_init32 && g_x_out32 && workspace, UPF_EINVAL, "sgu_blend_backward: null pointer");
   UPF_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && Hf >= h && Wf >= w, UPF_EINVAL, "sgu_blend_backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  const long long n_init = (long long)B * 2 * Hf * Wf, n_xo = (long long)B * 3 * h * w;
+  const long long n_init = (long long)B * 2 * Hf * Wf;
   const bool final_level = !(Hf == h && Wf == w);
   unsigned long long* gi64 = (unsigned long long*)workspace;
   float* g_full = (float*)(gi64 + n_init);                  // final level: [B, 3, Hf, Wf] gradients before the resize gradient
