@@ -253,6 +253,40 @@ def train_main(args, rank, world, device):
         torch.distributed.destroy_process_group()
 
 
+def train_probe(device, steps=30):
+    """BASELINE config 3 at N = 1 as an extra object of the default line (so that the driver's own run carries a training
+    number): one unsupervised training step (forward, photometric / smooth / census / pyramid-distillation losses, backward,
+    Adam(amsgrad)) on the matrix cores (bf16 activations, fp32 master weights) inside one hipGraph — `--mode train` is the
+    full bench of the same step (any N, DDP)."""
+    from upflow_pytorch_amd import synthetic as _weights
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.train import Trainer, synthetic_train_batch
+    try:
+        conf = UPFlow_net.config()
+        d = dict(FLAGS)
+        d.update(TRAIN_FLAGS)
+        d['train_conv_dtype'] = 'bf16'
+        conf.update(d, verbose=False)
+        net = conf()
+        net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
+        tr = Trainer(net, device=device, graph=True)
+        batch = synthetic_train_batch(4, seed=0, device=device)
+        for _ in range(tr.graph_warmup + 1 + 20):
+            tr.step(batch)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stats = tr.step(batch, sync_stats=False)
+        torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        loss = float(stats.cpu()[tr._names.index('loss')]) if 'loss' in tr._names else None
+        return {'workload': 'config3: unsupervised training step, 256x832 crops, batch 4, bf16 activations / fp32 master weights, '
+                            'forward + losses + backward + Adam(amsgrad) in one hipGraph', 'ms_per_step': round(ms, 3),
+                'frame_pairs_per_s': round(4e3 / ms, 2), 'steps': steps, 'hip_graph': tr.use_graph, 'final_loss': loss}
+    except Exception as e:                                   # (an extra: it must never take the headline line down)
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it: re-execute this command under torch.distributed.run with
     one rank per GPU of this node (RCCL over xGMI; rendezvous on 127.0.0.1, a free port), pass the ranks' output
@@ -295,6 +329,7 @@ def main():
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train-probe', action='store_true', help='skip the config-3 training step reported as `train_step`')
     ap.add_argument('--torch-pyramid', action='store_true',
                     help="the north star's literal split: feature-pyramid convolutions through PyTorch-ROCm (MIOpen)")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train', 'launch-check'],
@@ -375,6 +410,8 @@ def main():
             line['roofline_conv'] = conv_rf
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.no_train_probe and args.workload == 'config2':
+            line['train_step'] = train_probe(device)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
