@@ -34,6 +34,35 @@ def graph_time(fn, iters=10):
     return best  # us per launch
 
 
+def train_kernels(res):
+    """The training-only kernels at the two fine levels of config 3 (B = 8: both directions stacked), bf16."""
+    dev, dt = 'cuda', torch.bfloat16
+    B = 8
+    lv = [(64, 208), (32, 104)]
+    for (Cin, Cout, d) in [(567, 128, 1), (531, 32, 1), (563, 2, 1), (243, 128, 1), (128, 128, 4), (96, 64, 16)]:
+        uses = [(torch.randn(B, Cin, H, W, device=dev).to(dt), (torch.randn(B, Cout, H, W, device=dev) * 0.1).to(dt)) for H, W in lv]
+        t = graph_time(lambda: ops.conv_wgrad_multi(uses, Cin, Cout, 3, d), iters=5)
+        flop = sum(2.0 * 9 * Cin * Cout * B * H * W for H, W in lv)
+        res.append(dict(op='wgrad+reduce', cfg=3, B=B, shape='%d->%d d%d 64x208+32x104' % (Cin, Cout, d), dtype='bfloat16', us=t, TFs=flop / t / 1e6))
+    for (C, H, W) in [(128, 64, 208), (32, 64, 208), (128, 32, 104)]:
+        a = torch.randn(B, C, H, W, device=dev).to(dt); b = torch.randn(B, C, H, W, device=dev).to(dt); y = torch.randn(B, C, H, W, device=dev).to(dt)
+        dst = torch.empty_like(a)
+        t = graph_time(lambda: ops.act_grad(a, y, 0.1, add=b, dst=dst, want_bias=True))
+        res.append(dict(op='act_grad', cfg=3, B=B, C=C, H=H, W=W, dtype='bfloat16', us=t, GBs=4 * 2 * B * C * H * W / t / 1e3))
+    for (C, H, W) in [(16, 256, 832), (32, 128, 416), (64, 64, 208)]:
+        a = torch.randn(B, C, H, W, device=dev).to(dt)
+        t = graph_time(lambda: ops.space_to_depth2(a))
+        res.append(dict(op='space_to_depth', cfg=3, B=B, C=C, H=H, W=W, dtype='bfloat16', us=t, GBs=2 * 2 * B * C * H * W / t / 1e3))
+    g1 = torch.rand(B // 2, 1, 256, 832, device=dev); g2 = (g1 + 0.05 * torch.randn_like(g1)).requires_grad_(True)
+    gout = torch.randn(B // 2, 1, 256, 832, device=dev)
+
+    def census():
+        d = ops.census_distance(g1, g2)
+        torch.autograd.grad(d, g2, gout)
+    t = graph_time(census, iters=5)
+    res.append(dict(op='census fwd+bwd', cfg=3, B=B // 2, C=1, H=256, W=832, dtype='float32', us=t, GBs=(B // 2) * 256 * 832 * 4 * 6 / t / 1e3))
+
+
 def main(only=None):
     dev = 'cuda'
     res = []
@@ -76,7 +105,12 @@ def main(only=None):
         res.append(dict(op='flow_upsample', cfg=cfg, B=B, C=2, H=Hf, W=Wf, dtype='float32', us=t, GBs=(B * Hf * Wf * 8 + B * H * W * 8) / t / 1e3))
         t = graph_time(lambda: ops.occ_check(olf, olf))
         res.append(dict(op='occ_check', cfg=cfg, B=B, C=2, H=Hf, W=Wf, dtype='float32', us=t, GBs=(B * Hf * Wf * 24) / t / 1e3))
+    if not only or 3 in only:
+        train_kernels(res)
     for r in res:
+        if 'TFs' in r:
+            print('%-15s cfg%d B%d %-28s %-9s %8.2f us %8.1f TFLOP/s %5.1f%% of 2.5 PF' % (r['op'], r['cfg'], r['B'], r['shape'], r['dtype'], r['us'], r['TFs'], r['TFs'] / 25.0))
+            continue
         print('%-15s cfg%d B%d C%3d %4dx%-4d %-9s %8.2f us %8.1f GB/s  %5.1f%% of 8TB/s' % (r['op'], r['cfg'], r['B'], r['C'], r['H'], r['W'], r['dtype'], r['us'], r['GBs'], r['GBs'] / 80.0))
     os.makedirs('gpurun_out', exist_ok=True)
     json.dump(res, open('gpurun_out/kbench.json', 'w'), indent=1)
