@@ -183,3 +183,60 @@ def test_bf16_training_mode_tracks_the_fp32_reference():
     rel = np.abs(got - want) / np.maximum(want, 1e-3)
     print('bf16 training mode: max rel grad-norm error %.3g (param %s), median %.3g' % (rel.max(), names[int(rel.argmax())], np.median(rel)))
     assert all(params[n].grad.dtype == torch.float32 for n in names) and rel.max() <= 6e-2
+
+
+@pytest.mark.parametrize('variant', ['no_sgu', 'per_direction', 'no_sinks', 'layerwise_stacks', 'fp16', 'frozen_pyramid'])
+def test_bf16_training_schedule_variants_agree(variant):
+    """The matrix-core training mode under the schedule / flag variants a user can select — without the self-guided upsampling,
+    the reference's per-direction schedule (stacked_training = False), without the parameter sinks, with the layer-wise dense
+    stacks, in fp16, with a frozen feature pyramid: every one gives the default schedule's losses (same arithmetic up to the
+    summation order of gradient accumulations) and finite gradients for every trainable parameter."""
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.model.pwc_modules import _DenseStack
+
+    def run(var):
+        conf = UPFlow_net.config()
+        d = dict(FLAGS)
+        d.update(_weights.TRAIN_FLAGS)
+        d['train_conv_dtype'] = 'fp16' if var == 'fp16' else 'bf16'
+        if var == 'no_sgu':
+            d['if_sgu_upsample'] = False
+        conf.update(d, verbose=False)
+        net = conf()
+        sd = _weights.make_state_dict(0, head_scale=0.1)
+        net.load_state_dict(sd, strict=(var != 'no_sgu'))
+        net = net.cuda().train()
+        if var == 'per_direction':
+            net.stacked_training = False
+        if var == 'no_sinks':
+            net.shared_grad_sinks = False
+        if var == 'layerwise_stacks':
+            for m in net.modules():
+                if isinstance(m, _DenseStack):
+                    m._no_train_buffer = True
+        if var == 'frozen_pyramid':
+            for p in net.feature_pyramid_extractor.parameters():
+                p.requires_grad_(False)
+        batch = {k: v.cuda() for k, v in _weights.make_train_batch().items()}
+        batch['if_loss'] = True
+        out = net(batch)
+        terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')}
+        sum(terms.values()).backward()
+        for n, p in net.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            else:
+                assert p.grad is None, n
+        gn = float(torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None]).norm())
+        return {k: float(v) for k, v in terms.items()}, gn
+    got, gn = run(variant)
+    if variant in ('no_sgu', 'fp16'):
+        ref, gn_ref = run(variant)                      # (different arithmetic: only reproducibility is checked)
+        tol = 1e-3
+    else:
+        ref, gn_ref = run('default')
+        tol = 5e-3                                     # bf16 intermediates summed in a different order
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+    if variant != 'frozen_pyramid':
+        assert abs(gn - gn_ref) <= 0.05 * gn_ref, (gn, gn_ref)
