@@ -418,7 +418,10 @@ def test_flow_update_matches_torch_chain(dtype):
 
 
 @pytest.mark.parametrize('shape', [((6, 20), (12, 40)), ((4, 13), (256, 832)), ((64, 208), (256, 832)), ((1, 3), (7, 9)),
-                                   ((5, 1), (11, 6)), ((24, 40), (9, 15)), ((3, 5), (3, 5))])
+                                   ((5, 1), (11, 6)), ((24, 40), (9, 15)), ((3, 5), (3, 5)),
+                                   # 8x (16 lanes per input pixel), 16x (workgroup variant with weight tables), footprints wider than the
+                                   # group kernel's column table / taller than the workgroup kernel's tables (their fallback loops)
+                                   ((32, 104), (256, 832)), ((16, 52), (256, 832)), ((6, 5), (6, 200)), ((2, 3), (400, 12))])
 @pytest.mark.parametrize('if_rate', [True, False])
 def test_flow_upsample_backward_matches_autograd(shape, if_rate):
     """upf_flow_upsample_backward (deterministic gather, both kernel variants) vs autograd through
@@ -694,3 +697,20 @@ def test_warp_backward_vs_oracle_with_batch_shift_and_collisions(hip, shape):
         xd, fd = dev(x).requires_grad_(True), dev(flow).requires_grad_(True)
         gx, gf = torch.autograd.grad(hip.warp(xd, fd, 'robust', shift), (xd, fd), dev(gy))
         assert relerr(gx.cpu(), gxw) <= 1e-5 and relerr(gf.cpu(), gfw) <= 1e-4
+
+
+def test_flow_sum3_autograd(hip):
+    """ops.flow_sum3 = a + (b + c) in fp32 as one launch each way (model/upflow.py:566-572): value and gradients vs the tensor
+    expression it replaces."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(2, 2, 9, 14, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(2, 2, 9, 14, generator=g).bfloat16().cuda().requires_grad_(True)
+    c = torch.randn(2, 2, 9, 14, generator=g).bfloat16().cuda().requires_grad_(True)
+    go = torch.randn(2, 2, 9, 14, generator=g).cuda()
+    y = hip.flow_sum3(a, b, c)
+    ga, gb, gc = torch.autograd.grad(y, (a, b, c), go)
+    ar, br, cr = (t.detach().clone().requires_grad_(True) for t in (a, b, c))
+    yr = ar + (br.float() + cr.float())
+    gar, gbr, gcr = torch.autograd.grad(yr, (ar, br, cr), go)
+    assert y.dtype == torch.float32 and torch.equal(y, yr)
+    assert torch.equal(ga, gar) and torch.equal(gb, gbr) and torch.equal(gc, gcr)
