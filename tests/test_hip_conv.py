@@ -12,7 +12,10 @@ CASES = [  # B, Cin, Cout, H, W, dilation
     (2, 64, 32, 17, 56, 1), (1, 184, 3, 8, 16, 1), (1, 7, 5, 3, 8, 1), (4, 96, 32, 96, 320, 1),
     # rows that are not 16-byte aligned (W % 8 != 0, odd W, odd channel-slice offsets) and Cout > 128
     (2, 115, 128, 6, 20, 1), (1, 565, 96, 6, 20, 1), (2, 64, 196, 6, 20, 1), (1, 96, 64, 6, 20, 16), (1, 128, 128, 12, 26, 4),
-    (1, 40, 33, 7, 13, 1), (1, 35, 2, 5, 9, 1), (2, 48, 64, 24, 52, 2), (1, 16, 160, 9, 75, 1), (1, 196, 196, 8, 24, 1)]
+    (1, 40, 33, 7, 13, 1), (1, 35, 2, 5, 9, 1), (2, 48, 64, 24, 52, 2), (1, 16, 160, 9, 75, 1), (1, 196, 196, 8, 24, 1),
+    # row-phase layers whose phases hold 6 / 3 / 12 rows (the 6- and 4-row tiles of round 3), odd heights (unequal phases)
+    (1, 128, 128, 48, 64, 4), (1, 128, 96, 48, 64, 8), (1, 96, 64, 48, 64, 16), (1, 96, 64, 96, 64, 16), (1, 128, 96, 24, 64, 8),
+    (1, 128, 96, 45, 64, 8), (1, 64, 64, 23, 40, 2), (1, 96, 64, 47, 45, 16), (2, 128, 128, 96, 32, 8), (1, 128, 96, 13, 27, 4)]
 
 
 # launch heuristics under which every case runs: the defaults (coarse grids -> split-K kernel), every grid

@@ -195,7 +195,6 @@ constexpr int EPI_WAVE_BYTES = 2 * 32 * EPI_PITCH;             // two tile rows 
 template <typename T, int RPW>
 __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned char* patch, T* y_img, int Cout, int Ho, int Wo,
                                               int slab, int lane, int x0, int gy0, int row_step, float slope) {
-  static_assert(RPW % 2 == 0, "two tile rows per pass");
   const int px = lane & 31, kg = lane >> 5;
   const bool odd = px & 1;
   const uint32_t sel = odd ? 0x03020706u : 0x05040100u;
@@ -210,11 +209,15 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
   const uint32_t goff = (gx < Wo) ? ((uint32_t)(slab * 32 + rc) * plane2 + (uint32_t)gx * 2u) : 0x80000000u;
 #pragma unroll
   for (int rb = 0; rb < RPW; rb += 2) {
+    const int nrr = (rb + 2 <= RPW) ? 2 : 1;         // (compile-time after unrolling: an odd RPW ends on a single row)
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float v0 = acc[rb + rr][2 * j], v1 = acc[rb + rr][2 * j + 1];
+        if (rr >= nrr) continue;
+        constexpr int RMAX = RPW - 1;
+        const int ri = (rb + rr < RPW) ? rb + rr : RMAX;
+        float v0 = acc[ri][2 * j], v1 = acc[ri][2 * j + 1];
         v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
         const uint32_t p = pack2<T>(v0, v1);
         const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);
@@ -222,6 +225,7 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
       }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
+      if (rr >= nrr) continue;
       const int gy = gy0 + (rb + rr) * row_step;               // uniform
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -672,7 +676,35 @@ int launch_sk(const Args& a) {
 }
 
 // launch heuristics (upf_conv_set_option)
-static int g_sk_grid = 96, g_small_grid = 256, g_rpw4_min = 256;
+static int g_sk_grid = 96, g_small_grid = 256, g_rpw4_min = 256, g_ph_fit = 1, g_force_mtw = 0, g_force_sk = -1;
+
+// Row-phase layers (compile-time dilation >= 2): a tile holds TH rows of ONE phase, and a phase has only ceil(Ho / d)
+// rows — 6 at the 1/4-resolution level of config 2 for dilation 16, 3 one level down — so 8-row tiles compute up to
+// 2.7x the rows that exist (round 2: the dilation-8 / -16 layers ran at 50-60 % of their neighbours' rate).  Pick the
+// tile height among those the wave split offers, by staged rows (TH + 2 per tile, + the fixed cost of a tile).
+static int ph_tile_rows(int Ho, int d, int mtw) {
+  const int rpp = cdiv(Ho, d);
+  int best = 8; float best_cost = 1e30f;
+  for (int th : {8, 6, 4}) {
+    if (mtw == 1 && th == 6) continue;               // (four row groups: TH = 4 * RPW)
+    const float cost = (float)cdiv(rpp, th) * ((float)th + 2.5f);
+    if (cost < best_cost - 1e-3f) { best_cost = cost; best = th; }
+  }
+  return best;
+}
+
+// the extra tile heights of the row-phase layers: D in {2, 4, 8, 16} only
+template <typename T, int MTW, int RPW, bool GEN>
+int launch_shape_ph(const Args& a, int slabs) {
+  switch (a.d) {
+    case 2: return launch_one<T, MTW, RPW, 1, wide_nocts<MTW, 2>(), 2, GEN>(a, slabs);
+    case 4: return launch_one<T, MTW, RPW, 1, wide_nocts<MTW, 4>(), 4, GEN>(a, slabs);
+    case 8: return launch_one<T, MTW, RPW, 1, wide_nocts<MTW, 8>(), 8, GEN>(a, slabs);
+    case 16: return launch_one<T, MTW, RPW, 1, wide_nocts<MTW, 16>(), 16, GEN>(a, slabs);
+  }
+  set_error("conv_forward: internal routing error (row-phase dilation %d)", a.d);
+  return UPF_EUNSUPPORTED;
+}
 
 // Cout and the grid size -> (MTW, RPW, slabs over blockIdx.y)
 template <typename T, bool GEN>
@@ -681,7 +713,8 @@ int launch(const Args& a) {
   const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
   const long long tiles = (long long)a.B * cdiv(Wo, TW) * cdiv(Ho, 8);
   const int small_grid = g_small_grid, sk_grid = g_sk_grid, rpw4_min = g_rpw4_min;
-  if (tiles <= (a.d == 4 ? sk_grid / 2 : sk_grid) && a.stride == 1 && a.Cin > 64 && (a.ntaps == 1 || a.d == 1 || a.d == 2 || a.d == 4))
+  const bool sk_ok = a.stride == 1 && a.Cin > 64 && (a.ntaps == 1 || a.d == 1 || a.d == 2 || a.d == 4);
+  if (sk_ok && (g_force_sk < 0 ? tiles <= (a.d == 4 ? sk_grid / 2 : sk_grid) : g_force_sk == 1))
     return launch_sk<T, GEN>(a);       // (dilation 4 stages 10 rows per wave for 2 output rows: only the coarsest grids gain)
   int mtw = mt >= 3 ? 4 : mt;
   if (tiles <= small_grid && mt > 1) {
@@ -689,6 +722,7 @@ int launch(const Args& a) {
     // (each re-stages the x tile, which is irrelevant when the grid is latency-bound)
     mtw = (tiles * cdiv(mt, 2) >= 384) ? 2 : 1;
   }
+  if (g_force_mtw == 1 || g_force_mtw == 2 || g_force_mtw == 4) mtw = g_force_mtw < (mt >= 3 ? 4 : mt) ? g_force_mtw : (mt >= 3 ? 4 : mt);
   // four-block workgroups keep 128 accumulator registers per wave: only the window-reuse loops fit beside them
   const bool reuse_d = a.ntaps == 1 || a.d == 1 || a.d == 2 || a.d == 4 || a.d == 8 || a.d == 16;
   if (mtw == 4 && (a.stride == 2 || !reuse_d)) mtw = 2;
@@ -696,6 +730,14 @@ int launch(const Args& a) {
   if (a.stride == 2) {
     if (mtw == 2) return launch_shape<T, 2, 4, 2, GEN>(a, slabs);
     return launch_shape<T, 1, 2, 2, GEN>(a, slabs);
+  }
+  if (g_ph_fit && a.ntaps == 9 && (a.d == 2 || a.d == 4 || a.d == 8 || a.d == 16)) {
+    const int th = ph_tile_rows(Ho, a.d, mtw);
+    if (mtw == 4 && th == 6) return launch_shape_ph<T, 4, 6, GEN>(a, slabs);
+    if (mtw == 4 && th == 4) return launch_shape_ph<T, 4, 4, GEN>(a, slabs);
+    if (mtw == 2 && th == 6) return launch_shape_ph<T, 2, 3, GEN>(a, slabs);
+    if (mtw == 2 && th == 4) return launch_shape_ph<T, 2, 2, GEN>(a, slabs);
+    if (mtw == 1 && th == 4) return launch_shape_ph<T, 1, 1, GEN>(a, slabs);
   }
   if (mtw == 4) return launch_shape<T, 4, 8, 1, GEN>(a, slabs);
   if (mtw == 2) return launch_shape<T, 2, 4, 1, GEN>(a, slabs);
@@ -715,6 +757,9 @@ extern "C" int upf_conv_set_option(const char* name, int value) {
   if (name && !strcmp(name, "sk_grid")) slot = &g_sk_grid;
   else if (name && !strcmp(name, "small_grid")) slot = &g_small_grid;
   else if (name && !strcmp(name, "rpw4_min")) slot = &g_rpw4_min;
+  else if (name && !strcmp(name, "ph_fit")) slot = &g_ph_fit;          // 0: row-phase layers always on 8-row tiles (round-2 behaviour)
+  else if (name && !strcmp(name, "force_mtw")) slot = &g_force_mtw;    // experiments: 0 = heuristic, 1 / 2 / 4
+  else if (name && !strcmp(name, "force_sk")) slot = &g_force_sk;      // experiments: -1 = heuristic, 0 = never, 1 = wherever eligible
   if (!slot) return -1;
   const int prev = *slot;
   *slot = value;
