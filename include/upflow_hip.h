@@ -190,7 +190,10 @@ int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd,
  *   "sk_grid"    (96)  grids of at most this many 8x32 pixel tiles use the split-K kernel (0 = never)
  *   "small_grid" (256) at most this many tiles: narrower workgroups, output channels over blockIdx.y
  *   "rpw4_min"   (256) at least this many 16x32 tiles: Cout <= 32 layers use 16-row tiles
- * returns the previous value, or -1 for an unknown name. */
+ *   "ph_fit"     (1)   dilated layers: tile height (8 / 6 / 4 rows) fitted to the rows of a row phase (0 = always 8)
+ *   "force_mtw"  (0)   experiments: 1 / 2 / 4 output-channel blocks per workgroup whatever the grid (0 = heuristic)
+ *   "force_sk"   (-1)  experiments: 0 = never the split-K kernel, 1 = wherever it applies (-1 = heuristic)
+ * returns the previous value, or INT32_MIN for an unknown name. */
 long long upf_conv_packed_bytes(int Cin, int Cout, int kernel_size);
 int upf_conv_pack_weights(const void* w /* [Cout,Cin,k,k] */, void* w_packed, int Cin, int Cout, int kernel_size,
                           int dtype, void* stream);

@@ -485,10 +485,120 @@ def golden_losses(upflow, tools):
         save('smooth1_%d' % i, img=img, pred=pred, loss=np.array([float(v)]), gpred=gp)
 
 
+def golden_eval(tools):
+    """Data / evaluation edge pinned on the reference's own code:
+      * tools.write_flo / write_flow / read_flo / read_flow (utils/tools.py:1557-1632, numpy only): the bytes the reference
+        writes for seeded flows, and — checked HERE, at generation time — that the reference's readers return the same array
+        from a file written by the build's writer;
+      * tools.write_flow_png / write_kitti_png_file (:1482-1525): the reference hands a uint16 array to pypng / cv2, which are
+        not installed; capturing stand-ins for `png.Writer` / `cv2.imwrite` record that array (the quantisation arithmetic is
+        the reference's, the PNG container is the codec's);
+      * img_func.read_png_flow / get_process_img_only_img / frame_name_to_num (dataset/kitti_dataset.py:67-147), with
+        `png.Reader` standing on the build's decoder (the decode arithmetic is the reference's);
+      * kitti_flow.Evaluation_bench.flow_error_avg / outlier_pct (:464-499, torch only) on seeded flows and masks, incl.
+        an empty mask, a full mask, every pixel an outlier, relative=None.
+    dataset/kitti_dataset.py imports tensorflow / torchvision / cv2 / png / imageio at module level: empty stub modules."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from upflow_pytorch_amd.utils import flow_io
+    for m in ['tensorflow', 'torchvision', 'rarfile', 'h5py', 'skimage', 'thop']:
+        sys.modules.setdefault(m, types.ModuleType(m))
+    tv = sys.modules['torchvision']
+    if not hasattr(tv, 'transforms'):
+        tv.transforms = types.ModuleType('torchvision.transforms')
+        sys.modules['torchvision.transforms'] = tv.transforms
+    if not hasattr(np, 'float'):
+        np.float = float                                   # (numpy < 1.24 spelling used at kitti_dataset.py:143)
+    import dataset.kitti_dataset as kd
+    import utils.tools as tmod
+    d = {}
+    tmp = tempfile.mkdtemp()
+    # ---- .flo
+    rng = np.random.default_rng(4100)
+    for i, (h, w) in enumerate([(7, 13), (1, 1), (5, 3)]):
+        flow = (rng.normal(size=(h, w, 2)) * 20).astype(np.float32)
+        pr, pb = os.path.join(tmp, 'r%d.flo' % i), os.path.join(tmp, 'b%d.flo' % i)
+        (tools.write_flo if i != 1 else tools.write_flow)(flow, pr)
+        flow_io.write_flo(flow, pb)
+        # the reference's reader on the BUILD's file (tools.read_flow, :1583-1599, passes a numpy array as `count`, which
+        # numpy 2 rejects; read_flo is the same code with int())
+        assert np.array_equal(tools.read_flo(pb), flow)
+        d['flo_flow_%d' % i] = flow
+        d['flo_bytes_%d' % i] = np.frombuffer(open(pr, 'rb').read(), dtype=np.uint8)
+    # ---- KITTI flow PNG: what the reference hands to pypng / cv2
+    captured = {}
+
+    class Writer(object):
+        def __init__(self, **kw):
+            captured['pypng_args'] = kw
+
+        def write(self, f, rows):
+            captured['pypng'] = np.array(rows)
+
+    tmod.png.Writer = Writer
+    tmod.cv2.imwrite = lambda fn, img: captured.__setitem__('cv2', np.array(img))
+    uv = rng.normal(size=(9, 11, 2)) * 30
+    uv[0, 0] = (600.0, -600.0)                              # outside the 16-bit range: write_flow_png clips
+    uv[0, 1] = (0.0078125, -0.0078125)                      # half a quantisation step
+    mask = (rng.random((9, 11)) > 0.4).astype(np.uint16)
+    tools.write_flow_png(os.path.join(tmp, 'a.png'), uv, mask=mask)
+    d['png_uv'], d['png_mask'], d['png_raw_pypng'] = uv, mask, captured['pypng'].reshape(9, 11, 3)
+    assert captured['pypng_args'] == dict(width=11, height=9, bitdepth=16, compression=3, greyscale=False)
+    tools.write_flow_png(os.path.join(tmp, 'a.png'), uv[:, :, 0], uv[:, :, 1])
+    d['png_raw_pypng_nomask'] = captured['pypng'].reshape(9, 11, 3)
+    uv2 = np.clip(uv, -500, 500)
+    tools.write_kitti_png_file(os.path.join(tmp, 'b.png'), uv2, mask)
+    d['png_uv_cv2'], d['png_raw_cv2_bgr'] = uv2, captured['cv2']
+    # ---- reading: the reference's decode arithmetic on the raw samples of a file the build wrote
+    pk = os.path.join(tmp, 'k.png')
+    flow_io.write_kitti_png_file(pk, uv2, mask)
+
+    class Reader(object):
+        def __init__(self, path):
+            self.raw = flow_io.read_png(path)
+
+        def asDirect(self):
+            h, w, c = self.raw.shape
+            return w, h, [row.reshape(-1) for row in self.raw], {}
+
+    kd.png.Reader = Reader
+    f, m = kd.img_func.read_png_flow(pk)
+    d['png_file_bytes'] = np.frombuffer(open(pk, 'rb').read(), dtype=np.uint8)
+    d['png_read_flow'], d['png_read_mask'] = np.asarray(f, dtype=np.float64), m
+    # ---- frame normalisation / names
+    img = rng.integers(0, 256, size=(6, 10, 3)).astype(np.uint8)
+    d['img'] = img
+    d['img_norm'] = kd.img_func.get_process_img_only_img(img, normalize=True, if_horizontal_flip=False)
+    d['img_norm_flip'] = kd.img_func.get_process_img_only_img(img, normalize=True, if_horizontal_flip=True)
+    d['img_raw'] = kd.img_func.get_process_img_only_img(img, normalize=False, if_horizontal_flip=False)
+    names = ['000000.png', '000123.png', '10.png', '0.png', '000.jpg']     # (the reference parses what precedes the first dot)
+    d['frame_nums'] = np.array([kd.img_func.frame_name_to_num(n) for n in names])
+    d['frame_names'] = np.array(names)
+    # ---- EPE / F1
+    EB = kd.kitti_flow.Evaluation_bench
+    g = gen(4200)
+    gt = torch.randn(3, 2, 12, 17, generator=g) * 20
+    pred = gt + torch.randn(3, 2, 12, 17, generator=g) * 3
+    masks = {'rand': (torch.rand(3, 1, 12, 17, generator=g) > 0.4).float(), 'full': torch.ones(3, 1, 12, 17),
+             'empty': torch.zeros(3, 1, 12, 17)}
+    d['ev_gt'], d['ev_pred'] = gt, pred
+    for k, mk in masks.items():
+        d['ev_mask_' + k] = mk
+        d['ev_epe_' + k] = np.array([float(EB.flow_error_avg(gt, pred, mk))])
+        d['ev_f1_' + k] = np.array([float(EB.outlier_pct(gt, pred, mk))])            # (empty mask: 0 / 0 = nan)
+    d['ev_f1_rand_abs'] = np.array([float(EB.outlier_pct(gt, pred, masks['rand'], threshold=2.0, relative=None))])
+    d['ev_f1_rand_t1'] = np.array([float(EB.outlier_pct(gt, pred, masks['rand'], threshold=1.0, relative=0.1))])
+    far = gt + 100.0
+    d['ev_epe_all_outliers'] = np.array([float(EB.flow_error_avg(gt, far, masks['rand']))])
+    d['ev_f1_all_outliers'] = np.array([float(EB.outlier_pct(gt, far, masks['rand']))])
+    d['ev_f1_exact'] = np.array([float(EB.outlier_pct(gt, gt, masks['rand']))])
+    save('eval_edge', **d)
+
+
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'net', 'net384', 'train']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'eval', 'net', 'net384', 'train']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -505,6 +615,8 @@ def main():
         golden_census()
     if 'losses' in which:
         golden_losses(upflow, tools)
+    if 'eval' in which:
+        golden_eval(tools)
     if 'net' in which:
         golden_net(upflow, pwc, tools)
     if 'net384' in which:

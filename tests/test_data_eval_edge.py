@@ -205,3 +205,76 @@ def test_training_dataset_crops(tmp_path):
     assert im1.shape == (3, 96, 160) and c1.shape == (3, 64, 128) and start.shape == (2, 1, 1)
     x, y = int(start[0]), int(start[1])
     assert torch.equal(c1, im1[:, y:y + 64, x:x + 128]) and x >= 8 and y >= 8
+
+
+# ---- pinned on the reference (tests/golden/eval_edge.npz, generated by make_golden.py `eval` from the imported
+# /root/reference/utils/tools.py:1482-1632 and dataset/kitti_dataset.py:67-147, :464-499) ---------------------------------
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'eval_edge.npz')
+
+
+@pytest.fixture(scope='module')
+def edge():
+    return np.load(GOLD)
+
+
+def test_flo_bytes_equal_the_references(edge, tmp_path):
+    """The build's writer produces the reference's bytes, and its reader returns the reference's array from them."""
+    for i in range(3):
+        flow, ref_bytes = edge['flo_flow_%d' % i], edge['flo_bytes_%d' % i].tobytes()
+        p = str(tmp_path / ('w%d.flo' % i))
+        for wr in (tools.write_flo, tools.write_flow, flow_io.write_flo):
+            wr(flow, p)
+            assert open(p, 'rb').read() == ref_bytes
+        open(p, 'wb').write(ref_bytes)
+        for rd in (tools.read_flo, tools.read_flow, flow_io.read_flo):
+            got = rd(p)
+            assert got.dtype == np.float32 and np.array_equal(got, flow)
+
+
+def test_kitti_png_quantisation_equals_the_references(edge, tmp_path):
+    """What the reference hands to pypng (write_flow_png, RGB) / cv2 (write_kitti_png_file, BGR) == the samples in our file."""
+    p = str(tmp_path / 'q.png')
+    uv, mask = edge['png_uv'], edge['png_mask']
+    tools.write_flow_png(p, uv, mask=mask)
+    assert np.array_equal(flow_io.read_png(p), edge['png_raw_pypng'])
+    tools.write_flow_png(p, uv[:, :, 0], uv[:, :, 1])
+    assert np.array_equal(flow_io.read_png(p), edge['png_raw_pypng_nomask'])
+    tools.write_kitti_png_file(p, edge['png_uv_cv2'], mask)
+    assert np.array_equal(flow_io.read_png(p), edge['png_raw_cv2_bgr'][:, :, ::-1])      # cv2 stores BGR -> the file's RGB
+
+
+def test_kitti_png_decode_equals_the_references(edge, tmp_path):
+    p = str(tmp_path / 'k.png')
+    open(p, 'wb').write(edge['png_file_bytes'].tobytes())
+    for rd in (img_func.read_png_flow, img_func.read_flow, flow_io.read_kitti_png_flow):
+        f, m = rd(p)
+        assert f.dtype == np.float64 and np.array_equal(f, edge['png_read_flow'])
+        assert m.dtype == np.uint8 and np.array_equal(m, edge['png_read_mask'])
+
+
+def test_frame_normalisation_and_names_equal_the_references(edge):
+    img = edge['img']
+    for key, kw in (('img_norm', dict(normalize=True)), ('img_norm_flip', dict(normalize=True, if_horizontal_flip=True)),
+                    ('img_raw', dict(normalize=False))):
+        got = img_func.get_process_img_only_img(img, **kw)
+        assert got.shape == edge[key].shape and np.array_equal(np.asarray(got, dtype=np.float64), edge[key].astype(np.float64))
+    assert [img_func.frame_name_to_num(str(n)) for n in edge['frame_names']] == list(edge['frame_nums'])
+
+
+def test_epe_and_f1_equal_the_references(edge):
+    EB = kitti_flow.Evaluation_bench
+    gt, pred = torch.from_numpy(edge['ev_gt']), torch.from_numpy(edge['ev_pred'])
+
+    def same(got, want):
+        got, want = float(got), float(want[0])
+        return (np.isnan(got) and np.isnan(want)) or got == pytest.approx(want, rel=1e-6, abs=1e-7)
+    for k in ('rand', 'full', 'empty'):
+        m = torch.from_numpy(edge['ev_mask_' + k])
+        assert same(EB.flow_error_avg(gt, pred, m), edge['ev_epe_' + k]), k
+        assert same(EB.outlier_pct(gt, pred, m), edge['ev_f1_' + k]), k          # empty mask: nan on both sides (0 / 0)
+    m = torch.from_numpy(edge['ev_mask_rand'])
+    assert same(EB.outlier_pct(gt, pred, m, threshold=2.0, relative=None), edge['ev_f1_rand_abs'])
+    assert same(EB.outlier_pct(gt, pred, m, threshold=1.0, relative=0.1), edge['ev_f1_rand_t1'])
+    assert same(EB.flow_error_avg(gt, gt + 100.0, m), edge['ev_epe_all_outliers'])
+    assert same(EB.outlier_pct(gt, gt + 100.0, m), edge['ev_f1_all_outliers']) and float(edge['ev_f1_all_outliers'][0]) == pytest.approx(100.0)
+    assert same(EB.outlier_pct(gt, gt, m), edge['ev_f1_exact']) and float(edge['ev_f1_exact'][0]) == 0.0

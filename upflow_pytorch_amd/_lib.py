@@ -121,7 +121,7 @@ def lib():
         # tuning hook: UPF_CONV_OPTS="sk_grid=48,rpw4_min=512" -> upf_conv_set_option (include/upflow_hip.h)
         for item in filter(None, os.environ.get('UPF_CONV_OPTS', '').split(',')):
             k, v = item.split('=')
-            if L.upf_conv_set_option(k.strip().encode(), int(v)) < 0:
+            if L.upf_conv_set_option(k.strip().encode(), int(v)) == -2 ** 31:
                 raise UpflowHipError('UPF_CONV_OPTS: unknown option %r' % k)
     return _lib
 

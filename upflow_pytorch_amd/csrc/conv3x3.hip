@@ -34,6 +34,7 @@
 //   * epilogue: + bias, LeakyReLU, convert, lane pairs exchange so that every lane stores two adjacent pixels.
 #include "common.hpp"
 #include <cstring>
+#include <cstdint>
 
 namespace upf {
 namespace conv {
@@ -403,7 +404,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int r = 0; r < RPW; ++r) {
-            const uint4 b = xs[((2 * ks + kg) * rows + S * (RPW * rg + r) + ky * d) * XWP + col];
+            const uint4 b = xs[((2 * ks + kg) * rows + S * (RPW * rg + r) + ky * (PH ? 1 : d)) * XWP + col];   // (PH: kernel rows are adjacent staged rows)
             acc[r] = Mma32<T>::mma(wa[tap][ks], b, acc[r]);
           }
 #pragma unroll
@@ -760,7 +761,7 @@ extern "C" int upf_conv_set_option(const char* name, int value) {
   else if (name && !strcmp(name, "ph_fit")) slot = &g_ph_fit;          // 0: row-phase layers always on 8-row tiles (round-2 behaviour)
   else if (name && !strcmp(name, "force_mtw")) slot = &g_force_mtw;    // experiments: 0 = heuristic, 1 / 2 / 4
   else if (name && !strcmp(name, "force_sk")) slot = &g_force_sk;      // experiments: -1 = heuristic, 0 = never, 1 = wherever eligible
-  if (!slot) return -1;
+  if (!slot) return INT32_MIN;
   const int prev = *slot;
   *slot = value;
   return prev;

@@ -449,7 +449,7 @@ def conv_set_option(name, value):
     """Launch heuristics of the convolution (include/upflow_hip.h: "sk_grid", "small_grid", "rpw4_min");
     returns the previous value."""
     prev = _lib.lib().upf_conv_set_option(name.encode(), int(value))
-    if prev < 0:
+    if prev == -2 ** 31:
         raise UpflowHipError('unknown convolution option %r' % name)
     return prev
 
