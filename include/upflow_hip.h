@@ -187,12 +187,14 @@ int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd,
  * done once per layer).  Any Cout; any W >= 8 (rows that are not 16-byte aligned take a slightly slower
  * staging path); Cin*H*W*2 < 2^31.
  * upf_conv_set_option: launch heuristics, for tuning and for the tests to reach every kernel variant:
- *   "sk_grid"    (96)  grids of at most this many 8x32 pixel tiles use the split-K kernel (0 = never)
+ *   "sk_grid"    (48)  grids of at most this many 8x32 pixel tiles use the split-K kernel (0 = never);
+ *   "sk_grid_narrow" (96) the same bound for layers with Cout <= 64;  "sk_grid_d4" (16) for dilation 4
  *   "small_grid" (256) at most this many tiles: narrower workgroups, output channels over blockIdx.y
  *   "rpw4_min"   (256) at least this many 16x32 tiles: Cout <= 32 layers use 16-row tiles
  *   "ph_fit"     (1)   dilated layers: tile height (8 / 6 / 4 rows) fitted to the rows of a row phase (0 = always 8)
  *   "force_mtw"  (0)   experiments: 1 / 2 / 4 output-channel blocks per workgroup whatever the grid (0 = heuristic)
  *   "force_sk"   (-1)  experiments: 0 = never the split-K kernel, 1 = wherever it applies (-1 = heuristic)
+ *   "ablate"     (0)   experiments: bit mask — 1 no matrix phase, 2 no x loads, 4 no LDS staging writes, 8 no weight loads
  * returns the previous value, or INT32_MIN for an unknown name. */
 long long upf_conv_packed_bytes(int Cin, int Cout, int kernel_size);
 int upf_conv_pack_weights(const void* w /* [Cout,Cin,k,k] */, void* w_packed, int Cin, int Cout, int kernel_size,
@@ -201,6 +203,28 @@ int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_pack
                      void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
                      int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
+
+/* ---- the same convolutions with operands in the channel-octet layout  (round 3; csrc/conv_c8.hip) -----------------------
+ * "C8": [n][ceil(C/8)][H][W][8] — the 8 channels of a pixel are one 16-byte entry, which is one entry of the kernel's LDS
+ * tile image and one k-octet of an MFMA operand.  Between the convolutions of a dense stack (model/pwc_modules.py:279-286,
+ * model/upflow.py:53-60) and of the context network (:396-412) this layout removes the register transposition on the way
+ * into LDS and the LDS transposition on the way out, and the tile image is filled by LDS-DMA into the other of two LDS buffers
+ * under the matrix phase of the current chunk.  Tensors that other operators write or read plane-wise stay NCHW:
+ *   input  = a C8 slice (x8: first octet plane, n8_oct octets; may be absent) followed — in the K order of the packed
+ *            weights — by an NCHW part (x2, C2 planes; may be absent);  K = pad32(8*n8_oct) + pad32(C2) = upf_conv_c8_k()
+ *   output = C8 octets (y_is_c8; channels that pad the last octet are written as zeros) or NCHW planes.
+ * upf_conv_pack_weights_kmap gathers the input channels of w through kmap[K] (-1 = zero) into that K order.
+ * stride 1, W % 8 == 0, 16-byte aligned operands; kernel 3x3 with dilation 1 (any layout combination) or 2 / 4 / 8 / 16 (C8 in,
+ * C8 out), or 1x1 (NCHW in, C8 out, Cout <= 32).  Everything else: upf_conv_forward. */
+long long upf_conv_packed_bytes_k(int K, int Cout, int kernel_size);
+int upf_conv_c8_k(int n8_oct, int C2);
+int upf_conv_pack_weights_kmap(const void* w /* [Cout,Cin,k,k] */, void* w_packed, int Cin, int Cout, int kernel_size,
+                               const int* kmap /* device, [K] */, int K, int dtype, void* stream);
+int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, int n8_oct, const void* x2, long long x2_batch_stride, int C2,
+                        const void* w_packed, const float* bias, void* y, long long y_batch_stride, int y_is_c8,
+                        int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
+                        int dtype, void* stream);
+int upf_conv_c8_set_option(const char* name, int value);   /* "rpw4" (1): Cout <= 32 on large grids: 16-row tiles */
 
 /* ---- the same convolutions under autograd: training on the matrix cores  (model/pwc_modules.py:250-286, :396-412) ----
  * forward      upf_conv_forward on weights packed straight from the fp32 master copy: upf_conv_pack_weights_f32(dgrad=0)

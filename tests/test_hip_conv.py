@@ -20,8 +20,10 @@ CASES = [  # B, Cin, Cout, H, W, dilation
 
 # launch heuristics under which every case runs: the defaults (coarse grids -> split-K kernel), every grid
 # through the tiled kernel with 4 / 2 / 1 channel blocks per workgroup by Cout (and 16-row tiles for Cout <= 32),
-# and every grid through 32-channel slabs over blockIdx.y
-MODES = {'auto': {}, 'tiled': {'sk_grid': 0, 'small_grid': 0, 'rpw4_min': 0}, 'slabs': {'sk_grid': 0, 'small_grid': 1 << 30, 'rpw4_min': 1 << 30}}
+# every grid through 32-channel slabs over blockIdx.y, and the split-K kernel wherever it applies (with the row-phase
+# layers on their 8-row tiles)
+MODES = {'auto': {}, 'tiled': {'force_sk': 0, 'small_grid': 0, 'rpw4_min': 0},
+         'slabs': {'force_sk': 0, 'force_mtw': 1, 'rpw4_min': 1 << 30}, 'splitk': {'force_sk': 1, 'ph_fit': 0}}
 
 
 @pytest.fixture(params=sorted(MODES))

@@ -85,7 +85,61 @@ def bench_layer(B, Cin, Cout, k, d, stride, H, W, dt=torch.bfloat16):
     return t, flop / t / 1e6, byt / t / 1e3
 
 
+def bench_layer_c8(B, C8c, C2, Cout, d, H, W, y_c8, dt=torch.bfloat16):
+    """The same layer through upf_conv_forward_c8: input channels [0, C8c) in a C8 buffer, the last C2 as NCHW planes."""
+    Cin = C8c + C2
+    x8 = torch.randn(B, (C8c + 7) // 8, H, W, 8, device='cuda').to(dt)
+    x2 = torch.randn(B, C2, H, W, device='cuda').to(dt) if C2 else None
+    w = (torch.randn(Cout, Cin, 3, 3, device='cuda') * 0.02).to(dt)
+    b = torch.randn(Cout, device='cuda')
+    y = ops.c8_empty(B, Cout, H, W, dt, 'cuda') if y_c8 else torch.empty(B, Cout, H, W, device='cuda', dtype=dt)
+    c8_map = list(range(C8c)) + [-1] * ((C8c + 7) // 8 * 8 - C8c)
+    packed = ops.conv_c8_pack(w, c8_map, list(range(C8c, Cin)))
+    t = graph_time(lambda: ops.conv_c8_forward_raw(x8, x2, packed, b, y, d, 0.1))
+    flop = 2.0 * B * H * W * Cin * Cout * 9
+    return t, flop / t / 1e6, 2.0 * B * H * W * (Cin + Cout) / t / 1e3
+
+
+def main_c8():
+    """Decoder layers at the two fine levels in the mixed layout: est.* read [C8 suffix | corr81 + flow planes]."""
+    B = 8
+    rows = []
+    for (H, W) in [(96, 320), (48, 160)]:
+        items = []
+        c8 = 32
+        for i, f in enumerate((128, 128, 96, 64, 32)):
+            items.append(('est.conv%d' % (i + 1), c8, 83, f, 1, True)); c8 += f
+        items.append(('est.conv_last', c8, 83, 2, 1, False))
+        items.append(('ctx.conv0', 480, 85, 128, 1, True))
+        ch = (128, 128, 128, 96, 64, 32, 2)
+        for i, d in enumerate((2, 4, 8, 16, 1)):
+            items.append(('ctx.conv%d' % (i + 1), ch[i], 0, ch[i + 1], d, True))
+        items.append(('ctx.conv6', 32, 0, 2, 1, False))
+        cin = 64
+        for i, f in enumerate((32, 32, 32, 16, 8)):
+            items.append(('sgu.conv%d' % (i + 1), cin, 0, f, 1, True)); cin += f
+        items.append(('sgu.conv_last', cin, 0, 3, 1, False))
+        tot_c8 = tot_nchw = 0.0
+        for (name, C8c, C2, Cout, d, y_c8) in items:
+            t, tf, gb = bench_layer_c8(B, C8c, C2, Cout, d, H, W, y_c8)
+            t0, tf0, gb0 = bench_layer(B, C8c + C2, Cout, 3, d, 1, H, W)
+            alt = ''
+            if Cout <= 32:
+                prev = ops.conv_c8_set_option('rpw4', 0)
+                alt = '  (8-row tiles %.1f us)' % bench_layer_c8(B, C8c, C2, Cout, d, H, W, y_c8)[0]
+                ops.conv_c8_set_option('rpw4', prev)
+            tot_c8 += t; tot_nchw += t0
+            rows.append(dict(level='%dx%d' % (H, W), layer=name, C8=C8c, C2=C2, Cout=Cout, d=d, us_c8=t, us_nchw=t0, TFs_c8=tf))
+            print('%4dx%-4d %-14s %3d+%2d->%3d d%-2d  C8 %7.1f us %7.1f TF/s (%4.1f%%) %6.0f GB/s | NCHW %7.1f us  x%.2f%s' %
+                  (H, W, name, C8c, C2, Cout, d, t, tf, tf / 25.0, gb, t0, t0 / t, alt), flush=True)
+        print('sum %dx%d: C8 %.1f us, NCHW %.1f us' % (H, W, tot_c8, tot_nchw))
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(rows, open('gpurun_out/conv_layers_c8.json', 'w'), indent=1)
+
+
 def main():
+    if '--c8' in sys.argv:
+        return main_c8()
     sweep = '--sweep' in sys.argv
     B = 8
     levels = [(96, 320), (48, 160), (24, 80), (12, 40), (6, 20)]

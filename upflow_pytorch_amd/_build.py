@@ -18,6 +18,7 @@ SOURCES = [
     ('corr81_fwd.hip', ['-ffp-contract=off']),      # (the fused normalisation must round like misc.hip's)
     ('corr81_bwd.hip', []),
     ('conv3x3.hip', []),
+    ('conv_c8.hip', []),
     ('conv_wgrad.hip', []),
     ('warp.hip', ['-ffp-contract=off']),
     ('sgu_blend.hip', ['-ffp-contract=off']),

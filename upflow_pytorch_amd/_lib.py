@@ -40,6 +40,8 @@ SIGNATURES = {
     'upf_conv_pack_weights': [_vp, _vp, _i, _i, _i, _i, _vp],
     'upf_conv_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_conv_pack_weights_f32': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_conv_pack_weights_kmap': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp],
+    'upf_conv_forward_c8': [_vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_leaky_backward': [_vp, _vp, _vp, _ll, _f, _i, _vp],
     'upf_conv_wgrad': [_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_bias_grad': [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -115,6 +117,12 @@ def lib():
         L.upf_conv_packed_bytes.restype = _ll
         L.upf_conv_set_option.argtypes = [_c.c_char_p, _i]
         L.upf_conv_set_option.restype = _i
+        L.upf_conv_c8_set_option.argtypes = [_c.c_char_p, _i]
+        L.upf_conv_c8_set_option.restype = _i
+        L.upf_conv_packed_bytes_k.argtypes = [_i, _i, _i]
+        L.upf_conv_packed_bytes_k.restype = _ll
+        L.upf_conv_c8_k.argtypes = [_i, _i]
+        L.upf_conv_c8_k.restype = _i
         L.upf_version.restype = _c.c_char_p
         L.upf_last_error.restype = _c.c_char_p
         _lib = L

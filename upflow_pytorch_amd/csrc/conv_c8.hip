@@ -1,0 +1,185 @@
+// Convolution on the matrix cores with operands in the CHANNEL-OCTET layout ("C8": [n][c/8][y][x][8], the 8 channels of a
+// pixel are one 16-byte entry) — gfx950.  The kernel is conv_kernel of conv_kernel.hpp (XL / YC8 template arguments: LDS-DMA
+// staging into two LDS buffers, 8-byte stores straight from the accumulators); this file holds its instantiations, the
+// weight packing for a mixed K order and the C-ABI entry.
+//
+// Why a second layout: the dense estimator / context / SGU stacks of UPFlow
+// (/root/reference/model/pwc_modules.py:250-286, :396-412, model/upflow.py:24-60) are chains of convolutions that read what
+// convolutions wrote.  In NCHW every consumer transposes 8 channel rows x 8 pixels in registers on the way into LDS (8 loads,
+// 32 v_perm, 8 LDS stores per 128 bytes, 32 staging registers per thread), and every producer transposes back through an LDS
+// patch.  With the octet layout between them both passes vanish and the staging becomes asynchronous DMA.  The tensors that
+// other operators produce or consume plane-wise (the cost volume, flows, pyramid features, the 2- / 3-channel outputs) stay
+// NCHW: a layer's input is a C8 slice followed by an NCHW tail, its output either layout.
+#include "conv_kernel.hpp"
+
+namespace upf {
+namespace conv {
+
+// w [Cout, Cin, k, k] -> the packed MFMA-lane-order operand of conv3x3.hip, with the K axis (input channels) gathered through
+// kmap: packed channel kk reads w[:, kmap[kk]] (kmap[kk] < 0 or kk >= K: zero) — the K order [C8 slice | NCHW tail] of a
+// mixed-layout layer, each part padded to 32 channels.
+template <typename T>
+__global__ void pack_weights_kmap_kernel(const T* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps, const int* __restrict__ kmap, int K) {
+  const int cop = pad32(Cout), nk = K / 16;
+  const long long total = (long long)ntaps * cop * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), px = (int)((i >> 3) & 31), kg = (int)((i >> 8) & 1);
+    const long long b = i >> 9;                      // (slab * nk + kstep) * ntaps + tap
+    const int tap = (int)(b % ntaps), kstep = (int)((b / ntaps) % nk), slab = (int)(b / ((long long)ntaps * nk));
+    const int co = slab * 32 + px, kk = kstep * 16 + kg * 8 + j;
+    const int ci = kmap[kk];
+    T v; v.v = 0;
+    if (ci >= 0 && ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ntaps + tap];
+    wp[i] = v;
+  }
+}
+
+struct ArgsC8 {
+  const void* x8; long long x8bs; int n8oct;       // C8 slice of the input (XL >= 1)
+  const void* x2; long long x2bs; int C2;          // NCHW part of the input (XL == 0 or 2)
+  const void* wp; const float* bias; void* y; long long ybs;
+  int B, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
+};
+
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, int XL, bool YC8>
+int launch_one_c8(const ArgsC8& a, int slabs) {
+  constexpr int TH = (4 / MTW) * RPW;
+  constexpr bool PH = (D >= 2 && S == 1);
+  constexpr int DV = PH ? 1 : D;
+  constexpr int rowsC = S * (TH - 1) + 2 * DV + 1;
+  constexpr int XWP = xw(S, margin_of(D)) + xw(S, margin_of(D)) / 16;
+  constexpr int EB = NOCTS * rowsC * XWP, EBP = (EB + 63) & ~63;
+  const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const int tiles_x = cdiv(Wo, TW), tiles_y = PH ? cdiv(Ho, D * TH) * D : cdiv(Ho, TH);
+  size_t lds = (XL >= 1) ? (size_t)2 * EBP * 16 : (size_t)EB * 16;
+  if (!YC8 && lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;
+  UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward_c8: tile does not fit LDS (dilation %d)", a.d);
+  static LdsOptIn opt;
+  auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, false, false, XL, YC8>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x2, a.x2bs,
+                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.C2, a.Cout, a.H, a.W, Ho, Wo, g_ablate, tiles_x, tiles_y, a.slope,
+                     (const T*)a.x8, a.x8bs, a.n8oct);
+  return check_launch("conv_forward_c8");
+}
+
+inline int g_c8_rpw4 = 1;      // Cout <= 32 layers on large grids: 16-row tiles (1) or 8-row tiles (0)
+
+// (MTW, tile rows) by Cout and grid like launch() of conv3x3.hip; stride 1; the instantiated subset:
+//   dilation 1 (and 1x1 with an NCHW input): any XL, both output layouts;  dilation 2 / 4 / 8 / 16: C8 in, C8 out
+template <typename T, int XL, bool YC8>
+int launch_c8(const ArgsC8& a) {
+  const int mt = cdiv(a.Cout, 32);
+  const long long tiles = (long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 8);
+  int mtw = mt >= 3 ? 4 : mt;
+  if (tiles <= g_small_grid && mt > 1) mtw = 2;
+  if (g_force_mtw == 1 || g_force_mtw == 2 || g_force_mtw == 4) mtw = g_force_mtw < (mt >= 3 ? 4 : mt) ? g_force_mtw : (mt >= 3 ? 4 : mt);
+  const int slabs = cdiv(mt, mtw);
+  if (a.ntaps == 1) {
+    if constexpr (XL == 0 && YC8) {
+      if (mtw == 1) return launch_one_c8<T, 1, 2, 1, 4, 0, 0, true>(a, slabs);
+    }
+    set_error("conv_forward_c8: 1x1 kernels take an NCHW input, a C8 output and Cout <= 32");
+    return UPF_EUNSUPPORTED;
+  }
+  if (a.d == 1) {
+    if constexpr (XL >= 1) {
+      if (mtw == 4) return launch_one_c8<T, 4, 8, 1, 2, 1, XL, YC8>(a, slabs);
+      if (mtw == 2) return launch_one_c8<T, 2, 4, 1, 4, 1, XL, YC8>(a, slabs);
+      if (g_c8_rpw4 && (long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 16) >= g_rpw4_min) return launch_one_c8<T, 1, 4, 1, 2, 1, XL, YC8>(a, slabs);
+      return launch_one_c8<T, 1, 2, 1, 4, 1, XL, YC8>(a, slabs);
+    }
+  }
+  if constexpr (XL == 1 && YC8) {
+    if (a.d == 2 || a.d == 4 || a.d == 8 || a.d == 16) {
+      const int th = g_ph_fit ? ph_tile_rows(a.H, a.d, mtw) : 8;
+#define UPF_C8_PH(MT, RP)                                                              \
+      switch (a.d) {                                                                   \
+        case 2: return launch_one_c8<T, MT, RP, 1, wide_nocts<MT, 2>(), 2, 1, true>(a, slabs);   \
+        case 4: return launch_one_c8<T, MT, RP, 1, wide_nocts<MT, 4>(), 4, 1, true>(a, slabs);   \
+        case 8: return launch_one_c8<T, MT, RP, 1, wide_nocts<MT, 8>(), 8, 1, true>(a, slabs);   \
+        default: return launch_one_c8<T, MT, RP, 1, wide_nocts<MT, 16>(), 16, 1, true>(a, slabs); \
+      }
+      if (mtw == 4) { if (th == 6) { UPF_C8_PH(4, 6) } if (th == 4) { UPF_C8_PH(4, 4) } UPF_C8_PH(4, 8) }
+      if (mtw == 2) { if (th == 6) { UPF_C8_PH(2, 3) } if (th == 4) { UPF_C8_PH(2, 2) } UPF_C8_PH(2, 4) }
+      if (th == 4) { UPF_C8_PH(1, 1) }
+      UPF_C8_PH(1, 2)
+#undef UPF_C8_PH
+    }
+  }
+  set_error("conv_forward_c8: no kernel for this combination (kernel %d taps, dilation %d, input layout %d, output C8 %d)", a.ntaps, a.d, XL, (int)YC8);
+  return UPF_EUNSUPPORTED;
+}
+
+template <typename T>
+int dispatch_c8(const ArgsC8& a, bool y_c8) {
+  const int xl = a.x8 ? (a.x2 ? 2 : 1) : 0;
+  if (xl == 2) return y_c8 ? launch_c8<T, 2, true>(a) : launch_c8<T, 2, false>(a);
+  if (xl == 1) return y_c8 ? launch_c8<T, 1, true>(a) : launch_c8<T, 1, false>(a);
+  if (y_c8) return launch_c8<T, 0, true>(a);
+  set_error("conv_forward_c8: NCHW in, NCHW out is upf_conv_forward");
+  return UPF_EINVAL;
+}
+
+}  // namespace conv
+}  // namespace upf
+
+extern "C" long long upf_conv_packed_bytes_k(int K, int Cout, int kernel_size) {
+  return (long long)kernel_size * kernel_size * upf::conv::pad32(Cout) * (long long)K * 2;
+}
+
+extern "C" int upf_conv_c8_k(int n8_oct, int C2) {
+  return (n8_oct > 0 ? upf::conv::pad32(n8_oct * 8) : 0) + (C2 > 0 ? upf::conv::pad32(C2) : 0);
+}
+
+extern "C" int upf_conv_pack_weights_kmap(const void* w, void* w_packed, int Cin, int Cout, int kernel_size, const int* kmap, int K,
+                                          int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(w && w_packed && kmap && Cin > 0 && Cout > 0, UPF_EINVAL, "conv_pack_weights_kmap: bad arguments");
+  UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_pack_weights_kmap: kernel_size %d (1 or 3)", kernel_size);
+  UPF_REQUIRE(K > 0 && K % 32 == 0, UPF_EINVAL, "conv_pack_weights_kmap: K = %d must be a positive multiple of 32", K);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv: bf16 / fp16 only");
+  const int ntaps = kernel_size * kernel_size;
+  const long long total = (long long)ntaps * conv::pad32(Cout) * K;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == UPF_BF16)
+    hipLaunchKernelGGL((conv::pack_weights_kmap_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)w_packed, Cin, Cout, ntaps, kmap, K);
+  else
+    hipLaunchKernelGGL((conv::pack_weights_kmap_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)w, (f16_t*)w_packed, Cin, Cout, ntaps, kmap, K);
+  return check_launch("conv_pack_weights_kmap");
+}
+
+extern "C" int upf_conv_c8_set_option(const char* name, int value) {
+  using namespace upf::conv;
+  int* slot = nullptr;
+  if (name && !strcmp(name, "rpw4")) slot = &g_c8_rpw4;
+  if (!slot) return INT32_MIN;
+  const int prev = *slot;
+  *slot = value;
+  return prev;
+}
+
+extern "C" int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, int n8_oct, const void* x2, long long x2_batch_stride, int C2,
+                                   const void* w_packed, const float* bias, void* y, long long y_batch_stride, int y_is_c8,
+                                   int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
+                                   int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE((x8 || x2) && w_packed && bias && y, UPF_EINVAL, "conv_forward_c8: null pointer");
+  UPF_REQUIRE((x8 != nullptr) == (n8_oct > 0) && (x2 != nullptr) == (C2 > 0), UPF_EINVAL, "conv_forward_c8: a pointer and its channel count disagree");
+  UPF_REQUIRE(B > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_forward_c8: bad shape B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_c8: bf16 / fp16 only");
+  UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_forward_c8: kernel_size %d (1 or 3)", kernel_size);
+  UPF_REQUIRE(stride == 1, UPF_EUNSUPPORTED, "conv_forward_c8: stride %d (1)", stride);
+  UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_forward_c8: dilation %d not in [1,%d]", dilation, conv::MAXD);
+  UPF_REQUIRE(W % 8 == 0, UPF_EUNSUPPORTED, "conv_forward_c8: W = %d is not a multiple of 8 (use upf_conv_forward)", W);
+  UPF_REQUIRE(!x8 || (aligned_to(x8, 16) && x8_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the C8 input must be 16-byte aligned");
+  UPF_REQUIRE(!x2 || (aligned_to(x2, 16) && x2_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the NCHW input must be 16-byte aligned");
+  UPF_REQUIRE(!y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the C8 output must be 16-byte aligned");
+  UPF_REQUIRE(y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EUNSUPPORTED, "conv_forward_c8: the NCHW output must be 16-byte aligned");
+  UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31) && (long long)C2 * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: image too large for one buffer descriptor");
+  UPF_REQUIRE((long long)((Cout + 7) / 8) * H * W * 16 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: output too large for one buffer descriptor");
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward_c8: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, x2, x2_batch_stride, C2, w_packed, bias, y, y_batch_stride,
+                 B, Cout, H, W, kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};
+  return dtype == UPF_BF16 ? conv::dispatch_c8<bf16_t>(a, y_is_c8 != 0) : conv::dispatch_c8<f16_t>(a, y_is_c8 != 0);
+}

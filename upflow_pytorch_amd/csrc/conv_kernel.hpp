@@ -1,0 +1,513 @@
+// Shared device code of the matrix-core convolution (csrc/conv3x3.hip: NCHW operands; csrc/conv_c8.hip: operands in the
+// channel-octet layout): MFMA wrappers, staging helpers, epilogues, conv_kernel, launch_one and the launch heuristics' state.
+#pragma once
+#include "common.hpp"
+#include <cstring>
+#include <cstdint>
+
+namespace upf {
+namespace conv {
+
+constexpr int TW = 32, NTHREADS = 256;
+constexpr int MAXD = 16;                  // dilation limit (the context network's largest)
+// D template values: 0 = 1x1; 1,2,4,8,16 = 3x3 with that dilation; -1 = 3x3, run-time dilation (1..16)
+__host__ __device__ constexpr int margin_of(int D) { return (D == 16 || D < 0) ? 16 : 8; }
+// staged columns [S*x0 - marg, S*x0 + S*32 + marg): whole 8-pixel groups -> 16-byte global loads
+__host__ __device__ constexpr int xw(int S, int marg) { return S * TW + 2 * marg; }
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <typename T> struct Mma32;
+template <> struct Mma32<bf16_t> {
+  static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma32<f16_t> {
+  static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+__host__ __device__ constexpr int pad32(int v) { return (v + 31) / 32 * 32; }
+
+// LDS x tile: row pitch XW + XW/16 entries, and inside every 8-pixel group the pixel slots are ROTATED by group/2:
+// a staging write phase (16 lanes = consecutive 8-pixel groups of a few rows, each lane writing pixel q of its group)
+// then hits 16 different bank quads (tools: brute-force search over rotations and pitches) instead of piling onto two
+// of them, while the global loads stay coalesced (lanes adjacent along the row).  A 16-column read window that starts
+// inside a group sees one 2-way conflict at most.  swz(col) = position of staged column `col` inside its row.
+__device__ __forceinline__ int swz(int col) { return (col & ~7) | ((col + (col >> 4)) & 7); }
+
+// ---- x staging helpers shared by both kernels -------------------------------------------------------------------------
+// 8 channel rows x 8 pixels (eight 16-byte loads of one 8-pixel group) -> 8 LDS entries of 8 channels x 1 pixel.
+// `enc` = (entry index of the group's first pixel) * 8 + slot rotation (see swz); GEN: `sh` = pixels the load window was
+// shifted left so that it ends at the row end — pixel q sits at column q - sh, columns >= 8 - sh are zero padding.
+template <bool GEN>
+__device__ __forceinline__ void stage_store(uint4* tile, int enc, int sh, const u32x4 (&ch)[8]) {
+  uint4* dst = tile + (enc >> 3);
+  const int rot = enc & 7;
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
+    uint4 e0, e1;
+    e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
+    e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
+    e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
+    e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
+    if constexpr (GEN) {
+      const uint32_t m0 = (2 * pp >= sh) ? 0xffffffffu : 0u, m1 = (2 * pp + 1 >= sh) ? 0xffffffffu : 0u;
+      e0.x &= m0; e0.y &= m0; e0.z &= m0; e0.w &= m0;
+      e1.x &= m1; e1.y &= m1; e1.z &= m1; e1.w &= m1;
+      dst[(2 * pp - sh + rot) & 7] = e0;
+      dst[(2 * pp + 1 - sh + rot) & 7] = e1;
+    } else {
+      dst[(2 * pp + rot) & 7] = e0;
+      dst[(2 * pp + 1 + rot) & 7] = e1;
+    }
+  }
+}
+
+// ---- epilogue: accumulators -> LeakyReLU -> 16-bit -> y.  D[co][pixel]: lane -> pixel column px, register e ->
+// output channel (e&3) + 8*(e>>2) + 4*kg of the 32-channel block.  Lane pairs (px, px^1) swap halves (one DPP move +
+// one v_perm): the even lane stores pixels (px, px+1) of the even registers' channels, the odd lane pixels (px-1, px) of
+// the odd registers' — 4-byte stores, half as many.  Stores go through a buffer descriptor over the image's Cout output
+// planes, so channels >= Cout and columns >= Wo are dropped by the bounds check instead of by branches.
+struct Epilogue {
+  __amdgpu_buffer_rsrc_t yr;
+  uint32_t off32, off16;   // this lane's byte offset at (first channel of its pair set, row 0, its pixel pair) or 0x80000000
+  uint32_t sel;            // v_perm selector merging own and partner halves
+  uint32_t plane2;         // bytes per output plane
+};
+template <typename T, bool GEN>
+__device__ __forceinline__ void epilogue_init(Epilogue& ep, T* y_img, int Cout, int Ho, int Wo, int slab, int lane, int x0) {
+  const int px = lane & 31, kg = lane >> 5;
+  const bool odd = px & 1;
+  const int gx = x0 + (px & ~1);
+  ep.plane2 = (uint32_t)(Ho * Wo) * 2u;
+  ep.yr = __builtin_amdgcn_make_buffer_rsrc(y_img, 0, (uint32_t)Cout * ep.plane2, 0x00020000);
+  const uint32_t off = (uint32_t)(slab * 32 + 4 * kg + (odd ? 1 : 0)) * ep.plane2 + (uint32_t)gx * 2u;
+  ep.off32 = (gx + 1 < Wo) ? off : 0x80000000u;
+  ep.off16 = (GEN && gx + 1 == Wo) ? off : 0x80000000u;     // odd Wo: the last column is a 2-byte store
+  ep.sel = odd ? 0x03020706u : 0x05040100u;
+}
+// v0, v1: channels c and c+1 of this lane's pixel (registers e = 2j, 2j+1); soff: uniform byte offset of
+// (channel offset of register 2j, output row) = ({0,2,8,10,16,18,24,26}[j] * Ho*Wo + gy*Wo) * 2
+template <typename T, bool GEN>
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, float v0, float v1, uint32_t soff, float slope) {
+  v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);                  // slope = 1 -> identity
+  const uint32_t p = pack2<T>(v0, v1);                                     // lo = channel c, hi = channel c+1 of pixel px
+  const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  const uint32_t out = __builtin_amdgcn_perm(recv, p, ep.sel);
+  __builtin_amdgcn_raw_buffer_store_b32(out, ep.yr, ep.off32 + soff, 0, 0);
+  if constexpr (GEN) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)out, ep.yr, ep.off16 + soff, 0, 0);
+}
+__device__ __forceinline__ uint32_t epilogue_choff(int j) { return (uint32_t)((2 * j & 3) + 8 * (2 * j >> 2)); }   // channel offset of register 2j
+
+// Wide epilogue (Wo % 8 == 0, 16-byte aligned rows): 4-byte stores issue at ~4 B/clk/CU, which bounds every layer with a
+// large output (the 3->16 full-resolution layer wrote 126 MB in 94 us).  So each wave transposes its tile through a
+// private LDS patch, two tile rows at a time — [row][channel][32 px] with an 80-byte channel pitch — and writes 16 bytes
+// (8 pixels) per lane: 4x fewer store instructions, each covering whole 64-byte row segments.
+constexpr int EPI_PITCH = 80;                                  // bytes per (row, channel) in the patch
+constexpr int EPI_WAVE_BYTES = 2 * 32 * EPI_PITCH;             // two tile rows of one wave
+template <typename T, int RPW>
+__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned char* patch, T* y_img, int Cout, int Ho, int Wo,
+                                              int slab, int lane, int x0, int gy0, int row_step, float slope) {
+  const int px = lane & 31, kg = lane >> 5;
+  const bool odd = px & 1;
+  const uint32_t sel = odd ? 0x03020706u : 0x05040100u;
+  const uint32_t plane2 = (uint32_t)(Ho * Wo) * 2u;
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y_img, 0, (uint32_t)Cout * plane2, 0x00020000);
+  // write side: this lane's pixel pair of channel (its register pair's channel) -> patch[row][channel][pixel pair]
+  unsigned char* wbase = patch + (4 * kg + (odd ? 1 : 0)) * EPI_PITCH + (px & ~1) * 2;
+  // read side: lane -> (channel l/4 of a 16-channel half, 8-pixel segment l%4)
+  const int rc = lane >> 2, seg = lane & 3;
+  const unsigned char* rbase = patch + rc * EPI_PITCH + seg * 16;
+  const int gx = x0 + seg * 8;
+  const uint32_t goff = (gx < Wo) ? ((uint32_t)(slab * 32 + rc) * plane2 + (uint32_t)gx * 2u) : 0x80000000u;
+#pragma unroll
+  for (int rb = 0; rb < RPW; rb += 2) {
+    const int nrr = (rb + 2 <= RPW) ? 2 : 1;         // (compile-time after unrolling: an odd RPW ends on a single row)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (rr >= nrr) continue;
+        constexpr int RMAX = RPW - 1;
+        const int ri = (rb + rr < RPW) ? rb + rr : RMAX;
+        float v0 = acc[ri][2 * j], v1 = acc[ri][2 * j + 1];
+        v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
+        const uint32_t p = pack2<T>(v0, v1);
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);
+        *reinterpret_cast<uint32_t*>(wbase + (rr * 32 + (int)epilogue_choff(j)) * EPI_PITCH) = __builtin_amdgcn_perm(recv, p, sel);
+      }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      if (rr >= nrr) continue;
+      const int gy = gy0 + (rb + rr) * row_step;               // uniform
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(rbase + (rr * 32 + h * 16) * EPI_PITCH);
+        if (gy < Ho) __builtin_amdgcn_raw_buffer_store_b128(v, yr, goff + (uint32_t)(h * 16) * plane2 + (uint32_t)(gy * Wo) * 2u, 0, 0);
+      }
+    }
+  }
+}
+
+// MTW: 32-channel output blocks per workgroup (1, 2, 4) = waves along Cout;  RPW: tile rows per wave
+// (tile height TH = (4/MTW)*RPW);  S: stride;  NOCTS: channel octets per chunk (4 = 32 channels, 2 = 16);
+// D: compile-time dilation (see margin_of);  GEN: the staged rows need not be 16-byte aligned (W % 8 != 0, or x is an
+// odd channel slice): the 8-pixel group that would cross the end of its image row is loaded SHIFTED LEFT so that it
+// ends at the row end (gfx950 executes the 2-byte-aligned 16-byte load; tools/unaligned_b128_probe.hip), and the
+// shift is undone by the LDS entry index each transposed pixel is written to — no load ever leaves its row, so
+// nothing depends on what follows the buffer.
+// ONE: Cin <= 16 = a single 16-channel chunk (the RGB and 16-channel layers at full / half resolution: pure
+// bandwidth, thousands of short-lived workgroups): no chunk loop, nothing loop-carried, so the register budget allows
+// four workgroups per CU to overlap their load / store latencies.
+//
+// XL / YC8 (round 3) — operands in the CHANNEL-OCTET layout [n][c/8][y][x][8] ("C8": the 8 channels of a pixel are one
+// 16-byte entry — exactly one LDS entry of the tile image and one k-octet of an MFMA operand):
+//   XL = 1: x is a C8 tensor slice (x8: first octet plane, n8oct octets);  XL = 2: the C8 slice is followed, in the K order
+//   of the packed weights, by an NCHW tail (x, Cin planes: the cost volume and the flow, whose producers write planes);
+//   XL = 0: NCHW only (the round-1/2 path, unchanged).  YC8: y is written as C8 octets.
+// Staging a C8 chunk needs no registers, no transposition and no LDS store instructions: the tile image is filled by
+// LDS-DMA (`buffer_load_dwordx4 ... lds`, 64 entries = 1 KB per wave instruction; lanes outside the image or past the last
+// octet get zeros from the descriptor's bounds check), into the OTHER of two LDS buffers while the matrix phase of the
+// current chunk runs — one barrier per chunk, every load of chunk c+1 in flight under the MFMAs of chunk c.  The round-2
+// ablations (profiles/r03_conv_ablate.txt) had shown the NCHW form's phases adding up instead of overlapping: 565->128
+// at 96x320 took 266 us against 181 us for its matrix phase alone and 115 us for its staging alone.
+// The YC8 epilogue is 8-byte stores straight from the accumulators (a lane holds 4 consecutive channels of its pixel
+// per octet): no LDS patch, no lane exchange.
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false>
+__global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
+void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
+                 T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
+                 int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct) {
+  static_assert(XL == 0 || (D >= 0 && !GEN && !ONE), "C8 input: compile-time dilation, aligned rows");
+  constexpr int ntaps = (D == 0) ? 1 : 9;
+  constexpr int marg = margin_of(D);
+  constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
+  constexpr int RG = 4 / MTW, TH = RG * RPW;
+  constexpr int XW = xw(S, marg);
+  constexpr int XWP = XW + XW / 16;                  // LDS row pitch in entries (with the rotated pixel slots of swz: the
+                                                     // staging writes of a 16-lane phase hit 16 different bank quads)
+  // PH (compile-time dilation >= 2): ROW-PHASE decomposition.  A workgroup's TH output rows are D image rows apart
+  // (rows y0 + D*r of one phase y0 % D), so the three kernel rows read ADJACENT staged rows — the vertical halo is 2
+  // rows instead of 2*D (dilation 8: 10 staged rows per 8 output rows instead of 24), and only the horizontal taps
+  // keep the dilation, as a window shift inside the LDS row.
+  constexpr bool PH = (D >= 2 && S == 1);
+  constexpr int RS = PH ? D : 1;                     // image rows between consecutive tile rows
+  constexpr int DV = PH ? 1 : D;                     // staged rows between consecutive kernel rows (D >= 0)
+  const int d = (D >= 0) ? D : d_rt;
+  // experiments (upf_conv_set_option "ablate", compile-time dilations only): 1 = no matrix phase, 2 = no x loads, 4 = no LDS staging writes, 8 = no weight loads
+  const int abl = (D >= 0) ? d_rt : 0;
+  const int rows = (D >= 0) ? S * (TH - 1) + 2 * DV + 1 : S * (TH - 1) + 2 * d + 1;         // staged input rows
+  extern __shared__ __attribute__((aligned(16))) uint4 xs[];   // [octet][rows][XWP] entries of 8 channels x 1 pixel
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int x0 = tx * TW, y0 = PH ? (ty / RS) * (RS * TH) + ty % RS : ty * TH;     // PH: tiles_y counts (row block, phase) pairs
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 31, kg = lane >> 5;          // MFMA operand lane: column / row index, k-octet within the k-step
+  const int cb = wave % MTW, rg = wave / MTW;
+  const int slab = blockIdx.y * MTW + cb;            // this wave's 32-channel output block
+  // K order of the packed weights: [C8 part, padded to 32 channels | NCHW part, padded to 32 channels]
+  const int c8p = (XL >= 1) ? pad32(n8oct * 8) : 0;
+  const int cip = c8p + ((XL == 1) ? 0 : pad32(Cin));
+  const int n8c = c8p / KCH;                                  // chunks staged from the C8 slice
+  const int nchunks = ONE ? 1 : cip / KCH, nksteps = cip / 16;
+  const int HW = H * W;
+
+  // buffer descriptor over this image's Cin input planes: rows/cols outside the image get offset
+  // 0x80000000, channel planes >= Cin fall off the end -> the hardware returns the zero padding
+  const uint32_t plane = (uint32_t)HW * 2u;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 2u, 0x00020000);
+
+  // accumulators start at the bias (channels >= Cout read 0 through the descriptor)
+  __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, (uint32_t)Cout * 4u, 0x00020000);
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r][e] = bv;
+  }
+
+  // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
+  constexpr int ngroups = XW / 8;
+  const int ntasks = NOCTS * rows * ngroups;
+  // task t -> buffer-load offset of channel 0 of its octet in chunk 0 (0x80000000 = outside the image), the LDS
+  // entry it fills, and (GEN) the pixels by which the load window is shifted left to end at the row end
+  auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
+    const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;   // group fastest: coalesced loads
+    const int gy = PH ? y0 + (r - 1) * RS : S * y0 - d + r, gx = S * x0 - marg + 8 * g;
+    const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W && !(abl & 2);      // !GEN: W % 8 == 0, a group is all in or all out
+    sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
+    off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
+    dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);   // entry index * 8 + slot rotation of the group
+  };
+  auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
+    const uint32_t o = off + (uint32_t)cc * KCH * plane;                           // stays >= 2^31 for outside tasks
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ch[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + k * plane, 0, 0);
+  };
+  auto task_store = [&](int enc, int sh, const u32x4 (&ch)[8]) { if (!(abl & 4)) stage_store<GEN>(xs, enc, sh, ch); };
+  // this thread's first x task of chunk cc+1 is loaded into registers BEFORE the matrix phase of chunk cc and
+  // lands in LDS after it
+  constexpr bool PRE = (XL == 2) || (XL == 0 && !(MTW == 1 && RPW == 4 && NOCTS == 4));     // (that one would spill)
+  uint32_t off0 = 0x80000000u; int dst0 = 0, sh0 = 0;
+  u32x4 pre[8];
+  if constexpr (PRE) {
+    task_geom(tid, off0, dst0, sh0);
+    if constexpr (XL == 0) task_load(off0, 0, pre);
+  }
+
+  // this lane's A operands (row px of the weight tile, k-octet kg of each k-step) for every tap of a chunk
+  uint4 wa[ntaps][KS];
+  auto wload = [&](int cc, int tap, int ks) {
+    const uint32_t off = (cc < nchunks && !(abl & 8)) ? (uint32_t)(((slab * nksteps + cc * KS + ks) * ntaps + tap) * 1024 + lane * 16) : 0x80000000u;
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+  };
+#pragma unroll
+  for (int tap = 0; tap < ntaps; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(0, tap, ks);
+
+  constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * DV) * 3 < 9 * RPW);
+  const int colx[3] = {swz(marg + px - (D > 0 ? D : 0)), swz(marg + px), swz(marg + px + (D > 0 ? D : 0))};   // REUSE windows
+
+  // ---- the matrix phase of chunk cc on the tile image at xb (also fetches the weights of chunk cc + 1)
+  auto matrix_phase = [&](const uint4* __restrict__ xb, int cc) {
+    // matrix phase at raised wave priority: the CU's other workgroup is usually in its staging phase, and the arbiter then
+    // serves the MFMA stream first (A/B on one box, three runs each: 1165 -> 1173 frame-pairs/s)
+    __builtin_amdgcn_s_setprio(2);
+
+    if (abl & 1) {
+    } else if constexpr (REUSE) {
+      // staged row sr of this wave's strip feeds output rows r = sr - ky*DV.  The three windows (kx) of row sr+1 are
+      // read from LDS while the (up to 9*KS) MFMAs of row sr run: left to itself hipcc issues each ds_read right
+      // before its first use and the ~130-cycle LDS latency stalls the matrix pipe twice per row.
+      constexpr int NR = RPW + 2 * DV;
+      uint4 bq[2][3 * KS];
+      auto bload = [&](int sr, uint4 (&b)[3 * KS]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) b[kx * KS + ks] = xb[((2 * ks + kg) * rows + RPW * rg + sr) * XWP + colx[kx]];
+      };
+      constexpr bool PIPEB = !ONE;                   // (the single-chunk variants run 4 workgroups per CU on 128 registers)
+      if constexpr (PIPEB) bload(0, bq[0]);
+#pragma unroll
+      for (int sr = 0; sr < NR; ++sr) {
+        if constexpr (PIPEB) { if (sr + 1 < NR) bload(sr + 1, bq[(sr + 1) & 1]); }
+        else bload(sr, bq[sr & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+              if (sr - ky * DV >= 0 && sr - ky * DV < RPW)
+                acc[sr - ky * DV] = Mma32<T>::mma(wa[ky * 3 + kx][ks], bq[sr & 1][kx * KS + ks], acc[sr - ky * DV]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+          if (sr == ky * DV + RPW - 1) {              // kernel row ky is finished: fetch the next chunk's
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+              for (int ks = 0; ks < KS; ++ks) wa[ky * 3 + kx][ks] = wload(cc + 1, ky * 3 + kx, ks);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < ntaps; ++tap) {
+        const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
+        // shifted window: output pixel (row, px) reads staged entry (S*row + ky*d, marg + S*px + (kx-1)*d)
+        const int col = swz(marg + S * px + (kx - 1) * d);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            const uint4 b = xb[((2 * ks + kg) * rows + S * (RPW * rg + r) + ky * (PH ? 1 : d)) * XWP + col];   // (PH: kernel rows are adjacent staged rows)
+            acc[r] = Mma32<T>::mma(wa[tap][ks], b, acc[r]);
+          }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(cc + 1, tap, ks);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  if constexpr (XL >= 1) {
+    // ---- C8 input: two LDS buffers, chunk cc + 1 staged under the matrix phase of chunk cc
+    constexpr int rowsC = S * (TH - 1) + 2 * DV + 1;
+    constexpr int EB = NOCTS * rowsC * XWP, EBP = (EB + 63) & ~63;      // entries per buffer (whole 64-entry DMA pieces)
+    constexpr int NSL = (EBP / 64 + 3) / 4;                              // DMA pieces per wave and chunk
+    constexpr int DH = (D > 0) ? D : 0;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    __amdgpu_buffer_rsrc_t x8r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x8 + (size_t)n * x8bs), 0, (uint32_t)n8oct * (uint32_t)HW * 16u, 0x00020000);
+    // this lane's entry of each of its wave's pieces: LDS position -> (octet, row, column) -> byte offset in chunk 0
+    uint32_t voff8[NSL];
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+      const int p = (j * 4 + wave_u) * 64 + lane;
+      const int oct = p / (rowsC * XWP), rem = p - oct * (rowsC * XWP), r = rem / XWP, pos = rem - r * XWP;
+      const int grp = pos & ~7, col = grp | ((pos - (grp >> 4)) & 7);   // inverse of swz
+      const int gy = PH ? y0 + (r - 1) * RS : S * y0 - DV + r, gx = S * x0 - marg + col;
+      const bool in = p < EB && pos < XW && col >= marg - DH && col < marg + S * TW + DH && gy >= 0 && gy < H && gx >= 0 && gx < W && !(abl & 2);
+      voff8[j] = in ? (uint32_t)((oct * HW + gy * W + gx) * 16) : 0x80000000u;
+    }
+    auto land = [&](int cc) {                           // NCHW chunks: registers -> transposed LDS entries
+      if constexpr (XL == 2) {
+        if (cc >= n8c && cc < nchunks) {
+          uint4* xb = xs + (cc & 1) * EBP;
+          if (tid < ntasks) stage_store<false>(xb, dst0, sh0, pre);
+          for (int t = tid + NTHREADS; t < ntasks; t += NTHREADS) {
+            uint32_t off; int dsti, sh;
+            task_geom(t, off, dsti, sh);
+            u32x4 ch[8];
+            task_load(off, cc - n8c, ch);
+            stage_store<false>(xb, dsti, sh, ch);
+          }
+        }
+      }
+    };
+    // (iteration -1 is the prologue: chunk 0 is staged, nothing multiplied)
+    for (int cc = -1; cc < nchunks; ++cc) {
+      const int nx = cc + 1;                              // chunk nx -> buffer nx & 1
+      if (nx < n8c) {
+        const uint32_t cadd = (uint32_t)nx * (uint32_t)(NOCTS * 16) * (uint32_t)HW;     // (offsets >= 2^31 stay there: outside)
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+          const int piece = j * 4 + wave_u;
+          if (piece * 64 < EBP)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x8r, (__attribute__((address_space(3))) void*)(xs + ((nx & 1) * EBP + piece * 64)), 16, (int)(voff8[j] + cadd), 0, 0, 0);   // (the explicit int cast matters: without it hipcc's HOST pass silently drops this kernel template and the launch fails to link)
+        }
+      } else if constexpr (XL == 2) {
+        if (nx < nchunks) task_load(off0, nx - n8c, pre);
+      }
+      if (cc >= 0) matrix_phase(xs + (cc & 1) * EBP, cc);
+      land(nx);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces of chunk cc + 1 have landed
+      __syncthreads();                                    // ... in every wave, and chunk cc is fully consumed
+    }
+  } else {
+  for (int cc = 0; cc < nchunks; ++cc) {
+      __syncthreads();                                 // previous chunk fully consumed
+      // ---- stage the x tile (+halo) of channels [KCH*cc, KCH*cc + KCH)
+      if constexpr (PRE) { if (tid < ntasks) task_store(dst0, sh0, pre); }
+      for (int t = tid + (PRE ? NTHREADS : 0); t < ntasks; t += NTHREADS) {
+        uint32_t off; int dsti, sh;
+        task_geom(t, off, dsti, sh);
+        u32x4 ch[8];
+        task_load(off, cc, ch);
+        task_store(dsti, sh, ch);
+      }
+      __syncthreads();
+      if constexpr (PRE) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
+      matrix_phase(xs, cc);
+    }
+  }
+
+  // ---- epilogue (bias is already in the accumulators)
+  const int gy0 = __builtin_amdgcn_readfirstlane(y0 + RPW * rg * RS);
+  if constexpr (YC8) {
+    // y as octets [c/8][Ho][Wo][8]: register e of this lane is channel (e&3) + 8*(e>>2) + 4*kg of the wave's 32-block, so
+    // registers 4g..4g+3 are bytes [8*kg, 8*kg + 8) of the entry (octet g, pixel): one 8-byte store; the two half-waves
+    // together write 32 whole entries = 512 contiguous bytes per (octet, row).  Octets past ceil(Cout / 8) fall off the
+    // descriptor; the channels that pad the last octet are exact zeros (zero weights, zero bias).
+    const uint32_t plane16 = (uint32_t)(Ho * Wo) * 16u;
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * ybs, 0, (uint32_t)((Cout + 7) / 8) * plane16, 0x00020000);
+    const int gx = x0 + px;
+    const uint32_t lane_off = (gx < Wo) ? (uint32_t)(slab * 4) * plane16 + (uint32_t)gx * 16u + (uint32_t)kg * 8u : 0x80000000u;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int gy = gy0 + r * RS;                   // uniform
+      if (gy < Ho) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v[q] = acc[r][4 * g + q]; v[q] = fmaxf(v[q], v[q] * slope); }
+          u32x2 o;
+          o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]);
+          __builtin_amdgcn_raw_buffer_store_b64(o, yr, lane_off + (uint32_t)g * plane16 + (uint32_t)(gy * Wo) * 16u, 0, 0);
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (!GEN) {
+    if ((Wo & 7) == 0) {                             // uniform: 16-byte stores through a per-wave LDS patch
+      __syncthreads();                               // every wave is done with the x tile
+      epilogue_wide<T, RPW>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
+                            slab, lane, x0, gy0, RS, slope);
+      return;
+    }
+  }
+  Epilogue ep;
+  epilogue_init<T, GEN>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    if (gy0 + r * RS < Ho) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        epilogue_store<T, GEN>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * Wo) * 2u, slope);
+    }
+  }
+}
+
+// launch heuristics and experiment switches (upf_conv_set_option)
+inline int g_sk_grid = 48, g_sk_grid_narrow = 96, g_sk_grid_d4 = 16, g_small_grid = 256, g_rpw4_min = 256, g_ph_fit = 1, g_force_mtw = 0, g_force_sk = -1, g_ablate = 0;
+
+struct Args {
+  const void* x; long long xbs; const void* wp; const float* bias; void* y; long long ybs;
+  int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
+};
+
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false>
+int launch_one(const Args& a, int slabs) {
+  constexpr int TH = (4 / MTW) * RPW;
+  constexpr bool PH = (D >= 2 && S == 1);            // row-phase decomposition (see the kernel)
+  const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const int tiles_x = cdiv(Wo, TW), tiles_y = PH ? cdiv(Ho, D * TH) * D : cdiv(Ho, TH);
+  const int rows = PH ? TH + 2 : S * (TH - 1) + 2 * a.d + 1;
+  size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + xw(S, margin_of(D)) / 16) * 16;
+  if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;        // the wide epilogue's patches reuse the region
+  UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
+  static LdsOptIn opt;
+  auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN, ONE>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, D >= 0 ? g_ablate : a.d, tiles_x, tiles_y, a.slope,
+                     (const T*)nullptr, 0ll, 0);
+  return check_launch("conv_forward");
+}
+
+// run-time (kernel size, dilation, Cin) -> compile-time (D, NOCTS).  16-channel chunks (NOCTS = 2) where 72 weight
+// registers + the accumulators would spill (four channel blocks per workgroup: 128 accumulator registers per wave),
+// where the halo of the dilation would not fit LDS, and for the RGB / 16-channel layers (half the staging).
+template <int MTW, int D> constexpr int wide_nocts() { return (MTW == 4 || D < 0 || (MTW == 2 && D == 16)) ? 2 : 4; }
+
+// Row-phase layers (compile-time dilation >= 2): a tile holds TH rows of ONE phase, and a phase has only ceil(Ho / d)
+// rows — 6 at the 1/4-resolution level of config 2 for dilation 16, 3 one level down — so 8-row tiles compute up to
+// 2.7x the rows that exist (round 2: the dilation-8 / -16 layers ran at 50-60 % of their neighbours' rate).  Pick the
+// tile height among those the wave split offers, by staged rows (TH + 2 per tile, + the fixed cost of a tile).
+inline int ph_tile_rows(int Ho, int d, int mtw) {
+  const int rpp = cdiv(Ho, d);
+  int best = 8; float best_cost = 1e30f;
+  for (int th : {8, 6, 4}) {
+    if (mtw == 1 && th == 6) continue;               // (four row groups: TH = 4 * RPW)
+    const float cost = (float)cdiv(rpp, th) * ((float)th + 2.5f);
+    if (cost < best_cost - 1e-3f) { best_cost = cost; best = th; }
+  }
+  return best;
+}
+
+}  // namespace conv
+}  // namespace upf

@@ -476,6 +476,108 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
 
 
 # ------------------------------------------------------------------------------------------------
+# the same convolutions with operands in the channel-octet layout (csrc/conv_c8.hip; include/upflow_hip.h)
+# ------------------------------------------------------------------------------------------------
+def c8_empty(B, C, H, W, dtype, device):
+    """A C8 tensor [B, ceil(C/8), H, W, 8]: the 8 channels of a pixel are one 16-byte entry."""
+    return torch.empty((B, (C + 7) // 8, H, W, 8), dtype=dtype, device=device)
+
+
+def to_c8(x):
+    """NCHW -> C8 (zero padded to whole octets); plain torch ops — tests and slow paths only."""
+    B, C, H, W = x.shape
+    n = (C + 7) // 8
+    if n * 8 != C:
+        x = torch.cat([x, x.new_zeros(B, n * 8 - C, H, W)], 1)
+    return x.view(B, n, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def from_c8(x8, C=None):
+    """C8 -> NCHW (the first C channels)."""
+    B, n, H, W, _ = x8.shape
+    x = x8.permute(0, 1, 4, 2, 3).reshape(B, n * 8, H, W)
+    return x if C is None else x[:, :C]
+
+
+def conv_c8_k(n8_oct, C2):
+    return _lib.lib().upf_conv_c8_k(int(n8_oct), int(C2))
+
+
+def conv_c8_pack(weight, c8_channels=(), tail_channels=()):
+    """[Cout,Cin,k,k] bf16/fp16 -> packed operand for a layer whose input is a C8 slice followed by an NCHW tail.
+    c8_channels: for every channel position of the C8 slice (a whole number of octets) the input channel of `weight` it
+    carries, -1 for padding; tail_channels: the same for the planes of the NCHW tail."""
+    w = weight.detach().contiguous()
+    Cout, Cin, kh, kw = w.shape
+    if kh != kw or kh not in (1, 3):
+        raise UpflowHipError('conv pack: 3x3 or 1x1 kernels only')
+    c8_channels, tail_channels = list(c8_channels), list(tail_channels)
+    if len(c8_channels) % 8:
+        raise UpflowHipError('conv_c8_pack: the C8 slice must be whole octets')
+    K = conv_c8_k(len(c8_channels) // 8, len(tail_channels))
+    p8 = (len(c8_channels) + 31) // 32 * 32 if c8_channels else 0
+    kmap = [-1] * K
+    kmap[:len(c8_channels)] = c8_channels
+    kmap[p8:p8 + len(tail_channels)] = tail_channels
+    dev = _lib.check_gpu(w)
+    kmap_t = torch.tensor(kmap, dtype=torch.int32, device=w.device)
+    nbytes = _lib.lib().upf_conv_packed_bytes_k(K, Cout, kh)
+    packed = torch.empty((nbytes // 2,), dtype=w.dtype, device=w.device)
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_pack_weights_kmap', _lib.ptr(w), _lib.ptr(packed), Cin, Cout, kh, _lib.ptr(kmap_t), K,
+                  _lib.dtype_code(w), _lib.stream_ptr(dev))
+    return packed
+
+
+def _c8_view_ok(t):
+    B, n, H, W, e = t.shape
+    return e == 8 and t.stride()[1:] == (H * W * 8, W * 8, 8, 1)
+
+
+def conv_c8_supported(H, W, dtype, Cout, dilation, kernel_size, has_c8_in, has_tail, y_is_c8):
+    """What upf_conv_forward_c8 takes (stride 1)."""
+    if dtype not in (torch.bfloat16, torch.float16) or W % 8:
+        return False
+    if kernel_size == 1:
+        return (not has_c8_in) and has_tail and y_is_c8 and Cout <= 32
+    if dilation == 1:
+        return has_c8_in
+    return dilation in (2, 4, 8, 16) and has_c8_in and not has_tail and y_is_c8
+
+
+def conv_c8_forward_raw(x8, x2, packed, bias32, y, dilation=1, leaky_slope=0.0, kernel_size=3):
+    """x8: C8 view [B, n_oct, H, W, 8] (an octet slice of a C8 buffer) or None; x2: NCHW channel slice [B, C2, H, W] or None;
+    y: a C8 view [B, n_oct_out, H, W, 8] with Cout = its channel count given by bias32, or an NCHW channel slice."""
+    ref = x8 if x8 is not None else x2
+    B, H, W = ref.shape[0], ref.shape[2], ref.shape[3]
+    Cout = bias32.shape[0]
+    y_is_c8 = y.dim() == 5
+    if x8 is not None and not _c8_view_ok(x8):
+        raise UpflowHipError('conv_c8: x8 must be an octet slice of a contiguous C8 buffer')
+    if x2 is not None and x2.stride()[1:] != (H * W, W, 1):
+        raise UpflowHipError('conv_c8: x2 must be a channel slice of a contiguous NCHW buffer')
+    if y_is_c8:
+        if not _c8_view_ok(y) or tuple(y.shape) != (B, (Cout + 7) // 8, H, W, 8):
+            raise UpflowHipError('conv_c8: C8 output must be [%d,%d,%d,%d,8], got %s' % (B, (Cout + 7) // 8, H, W, tuple(y.shape)))
+    elif tuple(y.shape) != (B, Cout, H, W) or y.stride()[1:] != (H * W, W, 1):
+        raise UpflowHipError('conv_c8: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, H, W))
+    dev = ref.device
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_forward_c8', _lib.ptr(x8), x8.stride(0) if x8 is not None else 0, x8.shape[1] if x8 is not None else 0,
+                  _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, x2.shape[1] if x2 is not None else 0,
+                  _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y), y.stride(0), int(y_is_c8), B, Cout, H, W, int(kernel_size),
+                  int(dilation), 1, float(leaky_slope), _lib.dtype_code(ref), _lib.stream_ptr(dev))
+    return y
+
+
+def conv_c8_set_option(name, value):
+    prev = _lib.lib().upf_conv_c8_set_option(name.encode(), int(value))
+    if prev == -2 ** 31:
+        raise UpflowHipError('unknown C8 convolution option %r' % name)
+    return prev
+
+
+# ------------------------------------------------------------------------------------------------
 # soft census distance (photometric loss, utils/loss.py:50-91)
 # ------------------------------------------------------------------------------------------------
 class CensusFunction(Function):
