@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""A/B of convolution launch options on ONE box, in ONE process: the config-2 inference step is captured once per option set
+(launch shapes are baked into a hipGraph at capture time) and the graphs are replayed alternately, so box-to-box and
+thermal differences cancel.    python tools/ab_bench.py "il=0" "il=1" ["sk_grid=96,il=0" ...]    ("" = defaults)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from upflow_pytorch_amd import ops, synthetic
+from upflow_pytorch_amd.runtime import GraphedInference
+
+B, H, W, dname = bench.WORKLOADS[os.environ.get('UPF_AB_WORKLOAD', 'config2')]
+dev = torch.device('cuda', 0)
+net = bench.build_net(bench.DT[dname], dev)
+im1, im2 = synthetic.make_images(2, B, H, W)
+im1, im2 = im1.to(dev), im2.to(dev)
+variants = sys.argv[1:] or ['', '']
+runners = []
+for v in variants:
+    opts = dict(kv.split('=') for kv in v.split(',') if kv)
+    prev = {k: ops.conv_set_option(k, int(val)) for k, val in opts.items()}
+    r = GraphedInference(net, B, H, W, device=dev)
+    r.load(im1, im2)
+    r.replay(); torch.cuda.synchronize()
+    runners.append(r)
+    for k, val in prev.items():
+        ops.conv_set_option(k, val)
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 1.0:
+    for r in runners:
+        r.replay()
+    torch.cuda.synchronize()
+best = [1e9] * len(runners); tot = [0.0] * len(runners)
+ROUNDS, N = 12, 20
+for _ in range(ROUNDS):
+    for i, r in enumerate(runners):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(N):
+            r.replay()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / N
+        best[i] = min(best[i], dt); tot[i] += dt
+for i, v in enumerate(variants):
+    print('%-40s mean %.3f ms (%.1f pairs/s)   best %.3f ms' % (v or '(defaults)', tot[i] / ROUNDS * 1e3, B / (tot[i] / ROUNDS), best[i] * 1e3), flush=True)

@@ -10,6 +10,8 @@ Cin, Cout, H, W, d = a[:5]
 B = a[5] if len(a) > 5 else 8
 N = a[6] if len(a) > 6 else 20
 x = torch.randn(B, Cin, H, W, device='cuda').bfloat16()
+if os.environ.get('UPF_ZERO_X'):
+    x.zero_()
 w = (torch.randn(Cout, Cin, 3, 3, device='cuda') * 0.02).bfloat16()
 b = torch.randn(Cout, device='cuda')
 y = torch.empty(B, Cout, H, W, device='cuda', dtype=torch.bfloat16)
