@@ -191,9 +191,6 @@ int upf_normalize_backward(const void* y, const void* grad_y, const float* rstd,
  *   "sk_grid_narrow" (96) the same bound for layers with Cout <= 64;  "sk_grid_d4" (16) for dilation 4
  *   "small_grid" (256) at most this many tiles: narrower workgroups, output channels over blockIdx.y
  *   "rpw4_min"   (256) at least this many 16x32 tiles: Cout <= 32 layers use 16-row tiles
- *   "il"         (1)   interleaved staging (two LDS buffers, the next chunk written between the MFMAs of the current one,
- *                      one barrier per chunk) for stride-1 3x3 layers on aligned rows;  "il_min_wgs" (200): only on
- *                      grids of at least this many workgroups
  *   "ph_fit"     (1)   dilated layers: tile height (8 / 6 / 4 rows) fitted to the rows of a row phase (0 = always 8)
  *   "force_mtw"  (0)   experiments: 1 / 2 / 4 output-channel blocks per workgroup whatever the grid (0 = heuristic)
  *   "force_sk"   (-1)  experiments: 0 = never the split-K kernel, 1 = wherever it applies (-1 = heuristic)
@@ -206,7 +203,6 @@ int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_pack
                      void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
                      int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
-int upf_conv_set_debug_buffer(void* device_buffer);   /* experiments: >= 16 KB; time stamps of "ablate" bit 16 */
 
 /* ---- the same convolutions with operands in the channel-octet layout  (round 3; csrc/conv_c8.hip) -----------------------
  * "C8": [n][ceil(C/8)][H][W][8] — the 8 channels of a pixel are one 16-byte entry, which is one entry of the kernel's LDS

@@ -21,14 +21,10 @@ CASES = [  # B, Cin, Cout, H, W, dilation
 # launch heuristics under which every case runs: the defaults (coarse grids -> split-K kernel), every grid
 # through the tiled kernel with 4 / 2 / 1 channel blocks per workgroup by Cout (and 16-row tiles for Cout <= 32),
 # every grid through 32-channel slabs over blockIdx.y, the split-K kernel wherever it applies (with the row-phase
-# layers on their 8-row tiles), and the interleaved-staging kernels (two LDS buffers, one barrier per chunk)
-# in each of their workgroup shapes
-MODES = {'auto': {}, 'tiled': {'force_sk': 0, 'small_grid': 0, 'rpw4_min': 0, 'il': 0},
-         'slabs': {'force_sk': 0, 'force_mtw': 1, 'rpw4_min': 1 << 30, 'il': 0}, 'splitk': {'force_sk': 1, 'ph_fit': 0},
-         'interleaved': {'force_sk': 0, 'small_grid': 0, 'rpw4_min': 0, 'il_min_wgs': 1},
-         'interleaved_slabs': {'force_sk': 0, 'force_mtw': 1, 'rpw4_min': 1 << 30, 'il_min_wgs': 1},
-         'interleaved_mtw2_th8': {'force_sk': 0, 'force_mtw': 2, 'ph_fit': 0, 'il_min_wgs': 1},
-         'interleaved_1set': {'force_sk': 0, 'force_mtw': 1, 'il_min_wgs': 1, 'il_npre': 1}}
+# layers on their 8-row tiles), and 64-channel workgroups with 8-row tiles everywhere
+MODES = {'auto': {}, 'tiled': {'force_sk': 0, 'small_grid': 0, 'rpw4_min': 0},
+         'slabs': {'force_sk': 0, 'force_mtw': 1, 'rpw4_min': 1 << 30}, 'splitk': {'force_sk': 1, 'ph_fit': 0},
+         'mtw2_th8': {'force_sk': 0, 'force_mtw': 2, 'ph_fit': 0}}
 
 
 @pytest.fixture(params=sorted(MODES))

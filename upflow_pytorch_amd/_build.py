@@ -19,7 +19,6 @@ SOURCES = [
     ('corr81_bwd.hip', []),
     ('conv3x3.hip', []),
     ('conv_c8.hip', []),
-    ('conv_il.hip', []),
     ('conv_wgrad.hip', []),
     ('warp.hip', ['-ffp-contract=off']),
     ('sgu_blend.hip', ['-ffp-contract=off']),

@@ -344,11 +344,6 @@ int launch(const Args& a) {
     if (mtw == 2) return launch_shape<T, 2, 4, 2, GEN>(a, slabs);
     return launch_shape<T, 1, 2, 2, GEN>(a, slabs);
   }
-  if constexpr (!GEN) {
-    // interleaved staging (two LDS buffers, one barrier per chunk) wherever the grid fills the chip
-    const bool il_d = a.d == 1 || a.d == 2 || a.d == 4 || a.d == 8 || a.d == 16;
-    if (g_il && a.stride == 1 && a.ntaps == 9 && il_d && a.Cin > 16 && tiles * slabs >= g_il_min_wgs) return launch_il<T>(a, mtw, slabs);
-  }
   if (g_ph_fit && a.ntaps == 9 && (a.d == 2 || a.d == 4 || a.d == 8 || a.d == 16)) {
     const int th = ph_tile_rows(Ho, a.d, mtw);
     if (mtw == 4 && th == 6) return launch_shape_ph<T, 4, 6, GEN>(a, slabs);
@@ -376,9 +371,6 @@ extern "C" int upf_conv_set_option(const char* name, int value) {
   else if (name && !strcmp(name, "sk_grid_narrow")) slot = &g_sk_grid_narrow;
   else if (name && !strcmp(name, "sk_grid_d4")) slot = &g_sk_grid_d4;
   else if (name && !strcmp(name, "ablate")) slot = &g_ablate;            // experiments: see conv_kernel
-  else if (name && !strcmp(name, "il")) slot = &g_il;                    // 0: never the interleaved-staging kernels
-  else if (name && !strcmp(name, "il_min_wgs")) slot = &g_il_min_wgs;
-  else if (name && !strcmp(name, "il_npre")) slot = &g_il_npre;          // Cout <= 32: register sets in flight (1 / 2)
   else if (name && !strcmp(name, "small_grid")) slot = &g_small_grid;
   else if (name && !strcmp(name, "rpw4_min")) slot = &g_rpw4_min;
   else if (name && !strcmp(name, "ph_fit")) slot = &g_ph_fit;          // 0: row-phase layers always on 8-row tiles (round-2 behaviour)
@@ -388,11 +380,6 @@ extern "C" int upf_conv_set_option(const char* name, int value) {
   const int prev = *slot;
   *slot = value;
   return prev;
-}
-
-extern "C" int upf_conv_set_debug_buffer(void* device_buffer) {
-  upf::conv::g_dbg_buffer = device_buffer;
-  return 0;
 }
 
 extern "C" long long upf_conv_packed_bytes(int Cin, int Cout, int kernel_size) {

@@ -181,25 +181,25 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
 // The YC8 epilogue is 8-byte stores straight from the accumulators (a lane holds 4 consecutive channels of its pixel
 // per octet): no LDS patch, no lane exchange.
 //
-// IL (round 3) — INTERLEAVED staging, two LDS buffers, one barrier per chunk.  The ablations of the round-2 kernel
-// (profiles/r03_conv_ablate.txt) showed its two phases adding up instead of overlapping: 565->128 at 96x320 takes 266 us, its
-// matrix phase alone 181 us (= the MFMA pipe saturated at the ~1.8 GHz the power limit allows), its staging alone 115 us:
-// every wave stages, waits at a barrier, multiplies, waits again, and the CU's two workgroups overlap only by chance.
-// Measured and NOT kept: "ping-pong" workgroups of 8 waves whose two 4-wave groups alternate matrix and staging phases by
-// construction — no gain (271 us), and the in-kernel time stamps (tools/conv_timeline.py) say why: ONE wave per SIMD issues
-// a 32x32x16 MFMA every ~40 cycles, not every 32 — a single wave's MFMA stream caps at ~80 % of the pipe; only two waves
-// per SIMD that are BOTH multiplying fill it.  So the staging must not be a phase at all: with IL the registers of chunk
-// c + 1 (loaded a whole chunk earlier) are transposed and written to the OTHER LDS buffer between the MFMAs of chunk c, the
-// loads of chunk c + 2 are issued right behind them, and the only barrier is the buffer swap.  The non-MFMA instructions
-// issue in the shadow of the wave's own MFMAs.  NPRE = 2 (narrow layers, which are bound by the bytes they keep in flight, not
-// by the matrix pipe): TWO register sets, the loads of chunk c + 3 issued while chunk c multiplies.
-template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false, bool IL = false, int NPRE = 1>
+// Measured and NOT kept (round 3; evidence: profiles/r03_conv_ablate.txt, r03_conv_timeline.txt, r03_conv_pmc_il_power.txt).
+// The ablations showed the two phases of the NCHW loop adding up instead of overlapping (565->128 at 96x320: 266 us; matrix
+// phase alone 181 us, staging alone 115 us), so two restructurings were built, tested bit-identical, and measured:
+//   * "ping-pong" workgroups of 8 waves whose two 4-wave groups alternate matrix and staging turns by construction: 271 us.
+//     The in-kernel time stamps say why: ONE wave per SIMD issues a 32x32x16 MFMA every ~40 cycles, not every 32 — a single
+//     wave's MFMA stream caps at ~80 % of the pipe; only two waves per SIMD that are both multiplying fill it.
+//   * interleaved staging (two LDS buffers, chunk c + 1 transposed and written between the MFMAs of chunk c, loads of chunk
+//     c + 2 — or c + 3 from a second register set — right behind them, one barrier per chunk): 255-270 us, and 3.347 vs
+//     3.349 ms for the whole step (tools/ab_bench.py, same box).  PMC: the MFMA utilisation rises (60.5 -> 66.1 %) and the clock
+//     falls (1.88 -> 1.70 GHz) — utilisation x clock is constant.  With an all-zero input (no operand toggling) the same
+//     kernels hold 2.1 GHz and the interleaved form IS 10 % faster.  The wide layers are POWER-bound at ~1.1 PFLOP/s on
+//     random bf16 data; a better schedule buys nothing there, and the narrow layers (Cout <= 32) did not move either
+//     (their ~2.8 TB/s is set by the 96-byte row segments of a 32-pixel tile: two cache lines each).
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false>
 __global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
 void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                  T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
                  int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct) {
   static_assert(XL == 0 || (D >= 0 && !GEN && !ONE), "C8 input: compile-time dilation, aligned rows");
-  static_assert(!IL || (XL == 0 && D >= 0 && !ONE), "interleaved staging: NCHW input, compile-time dilation");
   constexpr int ntaps = (D == 0) ? 1 : 9;
   constexpr int marg = margin_of(D);
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
@@ -271,7 +271,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   auto task_store = [&](int enc, int sh, const u32x4 (&ch)[8]) { if (!(abl & 4)) stage_store<GEN>(xs, enc, sh, ch); };
   // this thread's first x task of chunk cc+1 is loaded into registers BEFORE the matrix phase of chunk cc and
   // lands in LDS after it
-  constexpr bool PRE = IL || (XL == 2) || (XL == 0 && !(MTW == 1 && RPW == 4 && NOCTS == 4));     // (that one would spill)
+  constexpr bool PRE = (XL == 2) || (XL == 0 && !(MTW == 1 && RPW == 4 && NOCTS == 4));     // (that one would spill)
   uint32_t off0 = 0x80000000u; int dst0 = 0, sh0 = 0;
   u32x4 pre[8];
   if constexpr (PRE) {
@@ -293,31 +293,8 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * DV) * 3 < 9 * RPW);
   const int colx[3] = {swz(marg + px - (D > 0 ? D : 0)), swz(marg + px), swz(marg + px + (D > 0 ? D : 0))};   // REUSE windows
 
-  // IL: entries per LDS buffer (the whole tile image, at least the wide epilogue's patches)
-  constexpr int IL_EB = (D >= 0) ? ((NOCTS * (S * (TH - 1) + 2 * DV + 1) * XWP * 16 < 4 * EPI_WAVE_BYTES) ? 4 * EPI_WAVE_BYTES / 16 : NOCTS * (S * (TH - 1) + 2 * DV + 1) * XWP) : 0;
-  auto il_land = [&](int c, const u32x4 (&regs)[8]) {  // chunk c (in `regs` since an earlier matrix phase) -> LDS buffer c & 1
-    if constexpr (IL) {
-      if (c < nchunks) {
-        uint4* xb = xs + (c & 1) * IL_EB;
-        if (tid < ntasks && !(abl & 4)) stage_store<GEN>(xb, dst0, sh0, regs);
-        for (int t = tid + NTHREADS; t < ntasks; t += NTHREADS) {     // (tile shapes with more tasks than threads: not prefetched)
-          uint32_t off; int dsti, sh;
-          task_geom(t, off, dsti, sh);
-          u32x4 ch[8];
-          task_load(off, c, ch);
-          if (!(abl & 4)) stage_store<GEN>(xb, dsti, sh, ch);
-        }
-      }
-    }
-  };
-  auto il_issue = [&](int c, u32x4 (&regs)[8]) {       // the loads of chunk c
-    if constexpr (IL) { if (c < nchunks) task_load(off0, c, regs); }
-  };
-  u32x4 pre2[(IL && NPRE == 2) ? 8 : 1];               // NPRE = 2: the register set of the odd chunks
-
-  // ---- the matrix phase of chunk cc on the tile image at xb (also fetches the weights of chunk cc + 1; IL: lands chunk
-  // cc + 1 in the other buffer and issues the loads of chunk cc + 2 between its MFMAs)
-  auto matrix_phase = [&](const uint4* __restrict__ xb, int cc, auto& regs) {      // regs (IL): the register set of chunk cc + 1
+  // ---- the matrix phase of chunk cc on the tile image at xb (also fetches the weights of chunk cc + 1)
+  auto matrix_phase = [&](const uint4* __restrict__ xb, int cc) {
     // matrix phase at raised wave priority: the CU's other workgroup is usually in its staging phase, and the arbiter then
     // serves the MFMA stream first (A/B on one box, three runs each: 1165 -> 1173 frame-pairs/s)
     __builtin_amdgcn_s_setprio(2);
@@ -358,10 +335,6 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 #pragma unroll
               for (int ks = 0; ks < KS; ++ks) wa[ky * 3 + kx][ks] = wload(cc + 1, ky * 3 + kx, ks);
           }
-        if constexpr (IL) {
-          if (sr == 1) il_land(cc + 1, regs);
-          if (sr == (NR > 4 ? 3 : NR - 1)) il_issue(cc + 1 + NPRE, regs);
-        }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -379,10 +352,6 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
           }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(cc + 1, tap, ks);
-        if constexpr (IL) {
-          if (tap == (ntaps > 1 ? 2 : 0)) il_land(cc + 1, regs);
-          if (tap == (ntaps > 1 ? 5 : 0)) il_issue(cc + 1 + NPRE, regs);
-        }
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -436,41 +405,10 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
       } else if constexpr (XL == 2) {
         if (nx < nchunks) task_load(off0, nx - n8c, pre);
       }
-      if (cc >= 0) matrix_phase(xs + (cc & 1) * EBP, cc, pre);
+      if (cc >= 0) matrix_phase(xs + (cc & 1) * EBP, cc);
       land(nx);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces of chunk cc + 1 have landed
       __syncthreads();                                    // ... in every wave, and chunk cc is fully consumed
-    }
-  } else if constexpr (IL) {
-    // ---- interleaved staging: prologue = chunk 0 in buffer 0, chunk 1 (and 2) in flight
-    // experiments ("ablate" bit 16): per-wave time stamps of the first 24 chunks of workgroups 0 and 100 into the buffer
-    // passed as x8: [wg][wave 0..3][chunk][start, end of the matrix phase, after the barrier]
-    long long* const dbg = (abl & 16) && (blockIdx.x == 0 || blockIdx.x == 100) && blockIdx.y == 0 ?
-        reinterpret_cast<long long*>(const_cast<T*>(x8)) + ((blockIdx.x ? 1 : 0) * 4 + wave) * 24 * 4 : nullptr;
-    auto step = [&](int cc, auto& regs) {
-      const long long t0 = dbg ? __builtin_readcyclecounter() : 0;
-      matrix_phase(xs + (cc & 1) * IL_EB, cc, regs);
-      const long long t1 = dbg ? __builtin_readcyclecounter() : 0;
-      __syncthreads();                                 // buffer (cc + 1) & 1 is complete, buffer cc & 1 is free
-      if (dbg && cc < 24 && lane == 0) {
-        long long* q = dbg + cc * 4;
-        q[0] = t0; q[1] = t1; q[2] = __builtin_readcyclecounter(); q[3] = 0;
-      }
-    };
-    if constexpr (NPRE == 2) {
-      il_issue(1, pre2);                               // even chunks live in `pre`, odd ones in `pre2`
-      il_land(0, pre);
-      il_issue(2, pre);
-      __syncthreads();
-      for (int cc = 0; cc < nchunks; cc += 2) {
-        step(cc, pre2);                                // lands chunk cc + 1 from pre2, then loads chunk cc + 3 into it
-        if (cc + 1 < nchunks) step(cc + 1, pre);
-      }
-    } else {
-      il_land(0, pre);                                 // (`pre` holds chunk 0: loaded above)
-      il_issue(1, pre);
-      __syncthreads();
-      for (int cc = 0; cc < nchunks; ++cc) step(cc, pre);
     }
   } else {
   for (int cc = 0; cc < nchunks; ++cc) {
@@ -486,7 +424,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
       }
       __syncthreads();
       if constexpr (PRE) { if (cc + 1 < nchunks) task_load(off0, cc + 1, pre); }
-      matrix_phase(xs, cc, pre);
+      matrix_phase(xs, cc);
     }
   }
 
@@ -539,8 +477,6 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 }
 
 // launch heuristics and experiment switches (upf_conv_set_option)
-inline void* g_dbg_buffer = nullptr;          // experiments: device buffer for the time stamps of "ablate" bit 16 (upf_conv_set_debug_buffer)
-inline int g_il = 1, g_il_min_wgs = 200, g_il_npre = 2;       // interleaved staging: on / at least this many workgroups
 inline int g_sk_grid = 48, g_sk_grid_narrow = 96, g_sk_grid_d4 = 16, g_small_grid = 256, g_rpw4_min = 256, g_ph_fit = 1, g_force_mtw = 0, g_force_sk = -1, g_ablate = 0;
 
 struct Args {
@@ -571,9 +507,6 @@ int launch_one(const Args& a, int slabs) {
 // registers + the accumulators would spill (four channel blocks per workgroup: 128 accumulator registers per wave),
 // where the halo of the dilation would not fit LDS, and for the RGB / 16-channel layers (half the staging).
 template <int MTW, int D> constexpr int wide_nocts() { return (MTW == 4 || D < 0 || (MTW == 2 && D == 16)) ? 2 : 4; }
-
-// interleaved-staging launch (csrc/conv_il.hip): stride 1, 3x3, aligned rows, compile-time dilation
-template <typename T> int launch_il(const Args& a, int mtw, int slabs);
 
 // Row-phase layers (compile-time dilation >= 2): a tile holds TH rows of ONE phase, and a phase has only ceil(Ho / d)
 // rows — 6 at the 1/4-resolution level of config 2 for dilation 16, 3 one level down — so 8-row tiles compute up to
