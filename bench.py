@@ -213,9 +213,9 @@ def train_main(args, rank, world, device):
     conf = UPFlow_net.config()
     d = dict(FLAGS)
     d.update(TRAIN_FLAGS)
-    dname = args.dtype or 'fp32'
-    d['train_conv_dtype'] = dname           # fp32: every convolution PyTorch-ROCm (the parity mode); bf16 / fp16: decoder
-    conf.update(d, verbose=False)           # convolutions (fwd, dgrad, wgrad) on the MFMA kernels, fp32 master weights
+    dname = args.dtype or 'bf16'            # bf16 / fp16 (the default): activations in that type, fp32 master weights, forward /
+    d['train_conv_dtype'] = dname           # data gradient / weight gradient on the MFMA kernels;  --dtype fp32: every convolution
+    conf.update(d, verbose=False)           # PyTorch-ROCm (the parity mode, ~4x slower)
     net = conf()
     net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
     tr = Trainer(net, device=device, graph=not args.no_graph)
@@ -237,6 +237,22 @@ def train_main(args, rank, world, device):
     barrier()
     stats = {k: float(v) for k, v in zip(tr._names, stats.cpu())}
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    # the ONE exchange step of the path, timed on its own (outside the timed region): an all-reduce of a gradient-sized
+    # fp32 buffer on the process group DDP uses, HIP events around 10 back-to-back calls
+    allreduce_ms = None
+    if world > 1:
+        n_grad = sum(p.numel() for p in tr.raw_net.parameters() if p.requires_grad)
+        buf = torch.zeros(n_grad, dtype=torch.float32, device=device)
+        for _ in range(3):
+            torch.distributed.all_reduce(buf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        e0.record()
+        for _ in range(10):
+            torch.distributed.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize(device)
+        allreduce_ms = parallel.max_over_ranks(e0.elapsed_time(e1) / 10, device)
     if rank == 0:
         print(json.dumps({
             'metric': 'training frame-pairs/sec (unsupervised step, 256x832 crops)', 'value': round(world * B * args.steps / elapsed, 3),
@@ -246,7 +262,10 @@ def train_main(args, rank, world, device):
             'config': {'workload': 'config3: photometric + smooth + census + pyramid-distillation loss, fwd+bwd+Adam(amsgrad), '
                                    '256x832 crops of 288x864 frames, batch 4 per GPU', 'global_batch': world * B,
                        'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world, 'hip_graph': tr.use_graph,
-                       'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None},
+                       'capture_fallback': tr.capture_fallback,      # True: the hipGraph capture failed and the steps ran eagerly
+                       'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
+                       'gradient_allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 4),
+                       'gradient_bytes': 4 * sum(p.numel() for p in tr.raw_net.parameters() if p.requires_grad)},
             'final_loss': stats}), flush=True)
     if world > 1:
         torch.distributed.barrier()
@@ -282,7 +301,7 @@ def train_probe(device, steps=30):
         loss = float(stats.cpu()[tr._names.index('loss')]) if 'loss' in tr._names else None
         return {'workload': 'config3: unsupervised training step, 256x832 crops, batch 4, bf16 activations / fp32 master weights, '
                             'forward + losses + backward + Adam(amsgrad) in one hipGraph', 'ms_per_step': round(ms, 3),
-                'frame_pairs_per_s': round(4e3 / ms, 2), 'steps': steps, 'hip_graph': tr.use_graph, 'final_loss': loss}
+                'frame_pairs_per_s': round(4e3 / ms, 2), 'steps': steps, 'hip_graph': tr.use_graph, 'capture_fallback': tr.capture_fallback, 'final_loss': loss}
     except Exception as e:                                   # (an extra: it must never take the headline line down)
         return {'error': '%s: %s' % (type(e).__name__, e)}
 
@@ -356,7 +375,7 @@ def main():
     dtype = DT[dname]
     from upflow_pytorch_amd import synthetic as _weights
     net = build_net(dtype, device, hip_pyramid_convs=not args.torch_pyramid)
-    im1, im2 = _weights.make_images(2, B, H, W)
+    im1, im2 = _weights.make_images(2 + rank, B, H, W)                      # every rank its own image pairs (the path shards by pair)
     im1, im2 = im1.to(device), im2.to(device)                               # inputs resident in HBM
 
     if args.no_graph:
@@ -401,7 +420,7 @@ def main():
                                    '%dx%d, batch %d per GPU, random-init weights' % (args.workload, H, W, B),
                        'global_batch': world * B, 'parallelism': 'replicas x%d (image pairs sharded, no collective)' % world,
                        'ranks': world, 'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
-                       'hip_graph': not args.no_graph,
+                       'hip_graph': not args.no_graph, 'capture_fallback': False,
                        'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or dtype == torch.float32 else 'HIP (MFMA kernel)'},
             'roofline': roofline_probe(B, H, W, dtype, device),
         }

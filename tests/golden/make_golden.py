@@ -416,12 +416,76 @@ def golden_train(upflow, pwc, tools):
         names = sorted(n for n, _ in net.named_parameters())
         params = dict(net.named_parameters())
         gnorm = np.array([float(params[n].grad.norm()) for n in names], dtype=np.float64)
+        # direction, not only size: 64 seeded random projections of every gradient, and every bias gradient in full
+        proj = _weights.grad_projections({n: params[n].grad for n in names})
+        bias = {'gbias_%d' % i: params[n].grad for i, n in enumerate(names) if n.endswith('.bias')}
         save('train_128x192', loss=np.array([float(loss)]), **{k: np.array([float(v)]) for k, v in terms.items()},
-             grad_norms=gnorm, flow_f_out=out['flow_f_out'], occ_fw=out['occ_fw'].to(torch.uint8))
+             grad_norms=gnorm, grad_proj=proj, flow_f_out=out['flow_f_out'], occ_fw=out['occ_fw'].to(torch.uint8), **bias)
         print({k: float(v) for k, v in terms.items()}, 'grad norm sum', gnorm.sum())
+        # the reference's OWN directional sensitivity to a 16-bit-sized perturbation: the same step with the four input frames
+        # rounded to bf16 (nothing else changes: fp32 network, fp32 arithmetic).  The hard masks of the model (warp validity,
+        # occlusion thresholds) make its gradients discontinuous, so this — not 1.0 — is the yardstick for the bf16 / fp16
+        # training modes of the build (tests/test_hip_train.py).
+        net.zero_grad()
+        b16 = {k: (v.bfloat16().float() if k in ('im1', 'im2', 'im1_raw', 'im2_raw') else v) for k, v in batch.items()}
+        out16 = net(b16)
+        sum(out16[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')).backward()
+        proj16 = _weights.grad_projections({n: params[n].grad for n in names})
+        cos = (proj * proj16).sum(1) / (np.linalg.norm(proj, axis=1) * np.linalg.norm(proj16, axis=1))
+        print('reference vs reference-with-bf16-rounded-frames: gradient cosine min %.5f median %.5f' % (cos.min(), np.median(cos)))
+        z = dict(np.load(os.path.join(HERE, 'train_128x192.npz')))
+        z['grad_proj_bf16_frames'] = proj16
+        np.savez_compressed(os.path.join(HERE, 'train_128x192.npz'), **z)
     finally:
         pwc.WarpingLayer_no_div.forward = old_fwd
         mu.upsample2d_flow_as = old_up
+
+
+def golden_train_trajectory(upflow, pwc, tools):
+    """The reference's OWN optimisation trajectory: 121 steps of the unsupervised recipe (Adam(amsgrad), lr 1e-4, weight decay
+    1e-4: scripts/simple_train.py:121-122; loss = the four terms of model/upflow.py:394-491) on one synthetic batch
+    (upflow_pytorch_amd.train.synthetic_train_batch: two 128x192 crops, 2-pixel horizontal motion), with the full set of loss
+    terms and with the pyramid distillation switched off (its weight defaults to 0 in the reference, model/upflow.py:312).  The
+    loss terms every 20 steps -> train_traj_128x192.json: tests/test_hip_train.py runs the SAME steps on the GPU and must stay
+    on this trajectory (the recipe is chaotic on this pair — the reference itself leaves it after ~200 steps — so the test
+    stops at 100).  ~4 minutes on 8 CPU threads."""
+    import model.upflow as mu
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from upflow_pytorch_amd.train import synthetic_train_batch
+    old_fwd = robust_mask_patch(pwc)
+    old_up = mu.upsample2d_flow_as
+    mu.upsample2d_flow_as = oop_upsample2d_flow_as
+    res = {}
+    try:
+        for tag, extra in (('full', {}), ('no_distillation', {'multi_scale_distillation_weight': 0})):
+            flags = dict(_weights.TRAIN_FLAGS)
+            flags.update(extra)
+            net = build_net(upflow, extra=flags, head_scale=0.1)
+            net.train()
+            batch = synthetic_train_batch(2, crop_hw=(128, 192), raw_hw=(160, 256))
+            batch['if_loss'] = True
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True, weight_decay=1e-4)
+            gt = torch.zeros(2, 2, 128, 192)
+            gt[:, 0] = 2.0
+            rows = []
+            for i in range(121):
+                opt.zero_grad()
+                out = net(batch)
+                terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss') if out.get(k) is not None}
+                loss = sum(terms.values())
+                loss.backward()
+                opt.step()
+                if i % 20 == 0:
+                    f = out['flow_f_out'].detach()[:, :, 16:-16, 16:-16]
+                    row = {k: float(v) for k, v in terms.items()}
+                    row.update(step=i, loss=float(loss), epe_vs_motion=float((f - gt[:, :, 16:-16, 16:-16]).pow(2).sum(1).sqrt().mean()))
+                    rows.append(row)
+                    print(tag, row, flush=True)
+            res[tag] = rows
+    finally:
+        pwc.WarpingLayer_no_div.forward = old_fwd
+        mu.upsample2d_flow_as = old_up
+    json.dump(res, open(os.path.join(HERE, 'train_traj_128x192.json'), 'w'), indent=1)
 
 
 def golden_census():
@@ -598,7 +662,7 @@ def golden_eval(tools):
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'eval', 'net', 'net384', 'train']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'eval', 'net', 'net384', 'train', 'traj']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -623,6 +687,8 @@ def main():
         golden_net_headline(upflow, pwc, tools)
     if 'train' in which:
         golden_train(upflow, pwc, tools)
+    if 'traj' in which:
+        golden_train_trajectory(upflow, pwc, tools)
 
 
 if __name__ == '__main__':

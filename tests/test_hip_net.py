@@ -73,7 +73,7 @@ def test_free_running_literal_vs_noise_floor():
     e = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
     floor = META['net_64x128_literal_self_sensitivity_epe']
     print('P3a literal free-running EPE %.3g px; reference self-sensitivity under 1e-7 input noise %.3g px (ratio %.2f)' % (e, floor, e / floor))
-    assert e <= 3 * floor
+    assert e <= 1.5 * floor
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

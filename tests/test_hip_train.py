@@ -44,7 +44,25 @@ def test_train_losses_and_gradients_match_reference():
     rel = np.abs(got - want) / np.maximum(want, 1e-3)
     print('max rel grad-norm error %.3g (param %s)' % (rel.max(), names[int(rel.argmax())]))
     assert (got > 0).all(), 'every parameter must receive a gradient'
-    assert rel.max() <= 2e-2
+    assert rel.max() <= 2e-3
+    # direction, not only size: cosine of the 64-projection fingerprint of every gradient with the reference's, and every
+    # bias gradient element by element
+    cos, worst = grad_direction_check({n: params[n].grad for n in names}, g)
+    print('gradient direction: min cosine %.7f (param %s), worst bias-gradient error %.3g' % (cos.min(), names[int(cos.argmin())], worst))
+    assert cos.min() >= 0.9999 and worst <= 5e-3
+
+
+def grad_direction_check(named_grads, g):
+    """-> (cosine of the projection fingerprints per parameter, worst relative error of a bias gradient)."""
+    names = sorted(named_grads)
+    got, want = _weights.grad_projections(named_grads), g['grad_proj'].numpy()
+    cos = (got * want).sum(1) / np.maximum(np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1), 1e-30)
+    worst = 0.0
+    for i, n in enumerate(names):
+        if n.endswith('.bias'):
+            w = g['gbias_%d' % i].double()
+            worst = max(worst, float((named_grads[n].detach().double().cpu() - w).norm() / w.norm().clamp_min(1e-12)))
+    return cos, worst
 
 
 def test_trainer_step_updates_every_parameter():
@@ -156,8 +174,9 @@ def test_graphed_training_step_equals_eager(mode):
 def test_bf16_training_mode_tracks_the_fp32_reference():
     """train_conv_dtype='bf16' (decoder + pyramid activations in bf16, fp32 master weights, forward / dgrad / wgrad on the
     matrix cores) against the REFERENCE's fp32 losses and gradient norms (tests/golden/train_128x192.npz): new behaviour
-    (the reference trains in fp32 only), so the bound is the bf16 rounding envelope, not 2e-4: losses within 0.5 %, every
-    parameter's gradient norm within 6 %, the flow within 0.02 px."""
+    (the reference trains in fp32 only), so the bound is the bf16 rounding envelope, not 2e-4: losses within 0.2 %, every
+    parameter's gradient norm within 4 %, its direction no further from the reference's gradient than the reference's own
+    gradient moves when its input frames are rounded to bf16, the flow within 0.02 px."""
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     g = load_golden('train_128x192')
     conf = UPFlow_net.config()
@@ -173,7 +192,7 @@ def test_bf16_training_mode_tracks_the_fp32_reference():
     out = net(batch)
     terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')}
     for k, v in terms.items():
-        assert abs(float(v) - float(g[k])) <= 5e-3 * max(1.0, abs(float(g[k]))), (k, float(v), float(g[k]))
+        assert abs(float(v) - float(g[k])) <= 2e-3 * max(1.0, abs(float(g[k]))), (k, float(v), float(g[k]))
     assert oracle.epe(out['flow_f_out'].detach().cpu(), g['flow_f_out']) <= 0.02
     sum(terms.values()).backward()
     names = sorted(n for n, _ in net.named_parameters())
@@ -182,7 +201,16 @@ def test_bf16_training_mode_tracks_the_fp32_reference():
     want = g['grad_norms'].numpy()
     rel = np.abs(got - want) / np.maximum(want, 1e-3)
     print('bf16 training mode: max rel grad-norm error %.3g (param %s), median %.3g' % (rel.max(), names[int(rel.argmax())], np.median(rel)))
-    assert all(params[n].grad.dtype == torch.float32 for n in names) and rel.max() <= 6e-2
+    assert all(params[n].grad.dtype == torch.float32 for n in names) and rel.max() <= 4e-2
+    # direction: the model's hard masks make its gradients discontinuous, so the yardstick is the REFERENCE's own sensitivity
+    # to a 16-bit-sized perturbation — its fp32 step with nothing but the input frames rounded to bf16 (golden
+    # grad_proj_bf16_frames: cosine to its exact gradients min 0.987, median 0.9987; fp16 activations land on the same floor)
+    cos, worst = grad_direction_check({n: params[n].grad for n in names}, g)
+    ref, r16 = g['grad_proj'].numpy(), g['grad_proj_bf16_frames'].numpy()
+    floor = (ref * r16).sum(1) / (np.linalg.norm(ref, axis=1) * np.linalg.norm(r16, axis=1))
+    print('bf16 training mode: gradient cosine min %.5f (param %s) median %.5f | reference with bf16-rounded frames: min %.5f median %.5f'
+          % (cos.min(), names[int(cos.argmin())], np.median(cos), floor.min(), np.median(floor)))
+    assert np.median(cos) >= np.median(floor) - 1e-3 and cos.min() >= floor.min() - 0.01 and (cos >= floor - 0.02).all()
 
 
 @pytest.mark.parametrize('variant', ['no_sgu', 'per_direction', 'no_sinks', 'layerwise_stacks', 'fp16', 'frozen_pyramid'])
@@ -240,3 +268,175 @@ def test_bf16_training_schedule_variants_agree(variant):
         assert abs(got[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (k, got[k], ref[k])
     if variant != 'frozen_pyramid':
         assert abs(gn - gn_ref) <= 0.05 * gn_ref, (gn, gn_ref)
+
+
+def _config3_trainer(mode, graph, B=4, seed=0):
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.train import Trainer
+    conf = UPFlow_net.config()
+    d = dict(FLAGS)
+    d.update(_weights.TRAIN_FLAGS)
+    d['train_conv_dtype'] = mode
+    conf.update(d, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(seed, head_scale=0.1))
+    return Trainer(net, lr=1e-4, device=torch.device('cuda', 0), distributed=False, graph=graph)
+
+
+def test_config3_full_size_step_graphed_equals_eager_and_bf16_tracks_fp32():
+    """BASELINE config 3 at its real size (256x832 crops of 288x864 frames, batch 4 per GPU,
+    /root/reference/dataset/kitti_dataset.py:268-342): six steps eager and six steps with the step captured as one hipGraph give
+    the same loss trajectory, and the bf16 matrix-core mode stays inside 0.5 % of the fp32 mode's loss terms at the first step (same
+    weights) and 3 % over the following five (two trajectories of a model with hard masks)."""
+    from upflow_pytorch_amd.train import synthetic_train_batch
+    batch = synthetic_train_batch(4, device='cuda')
+    traj = {}
+    for mode, graph in (('bf16', False), ('bf16', True), ('fp32', False)):
+        tr = _config3_trainer(mode, graph)
+        traj[(mode, graph)] = [tr.step(batch) for _ in range(6)]
+        assert (tr._graph is not None) == graph
+        del tr
+        torch.cuda.empty_cache()
+    for a, b in zip(traj[('bf16', False)], traj[('bf16', True)]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), ('graph vs eager', k, a[k], b[k])
+    for i, (a, b) in enumerate(zip(traj[('bf16', False)], traj[('fp32', False)])):
+        print('step %d  bf16 %s | fp32 %s' % (i, {k: round(v, 4) for k, v in a.items()}, {k: round(v, 4) for k, v in b.items()}))
+        for k in a:       # same weights at step 0: the 16-bit rounding envelope; afterwards two trajectories that drift apart
+            assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= (5e-3 if i == 0 else 3e-2) * max(1.0, abs(b[k])), ('bf16 vs fp32', i, k, a[k], b[k])
+
+
+def _traj_trainer(mode, graph, distill):
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.train import Trainer
+    conf = UPFlow_net.config()
+    d = dict(FLAGS)
+    d.update(_weights.TRAIN_FLAGS)
+    d['train_conv_dtype'] = mode
+    if not distill:
+        d['multi_scale_distillation_weight'] = 0          # (the reference's default, model/upflow.py:312)
+    conf.update(d, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))
+    return Trainer(net, lr=1e-4, device=torch.device('cuda', 0), distributed=False, graph=graph)
+
+
+@pytest.mark.parametrize('mode,graph', [('fp32', False), ('fp32', True), ('bf16', True)])
+def test_training_learns_a_known_motion_like_the_reference(mode, graph):
+    """Training must REDUCE something, not only move parameters.  One synthetic pair whose true motion is a
+    2-pixel horizontal shift; the unsupervised recipe of the reference (photometric + smoothness + census,
+    model/upflow.py:394-491; Adam(amsgrad) lr 1e-4 wd 1e-4, scripts/simple_train.py:121-122; pyramid distillation at its
+    default weight 0).  200 steps: the loss falls to < 0.3x, the photometric term to < 0.55x, the end-point error against
+    the KNOWN motion below 0.15 px — and the loss terms stay on the trajectory the REFERENCE itself follows on this batch
+    (tests/golden/train_traj_128x192.json, generated by make_golden.py `traj` from the imported reference on CPU).
+    This test is what exposed the hipMemsetAsync-in-hipGraph ordering fault (csrc/common.hpp: zero_fill_u64): before that
+    fix the graphed step diverged after a timing-dependent number of replays while the eager step was fine."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from upflow_pytorch_amd.train import synthetic_train_batch
+    ref = {r['step']: r for r in json.load(open(os.path.join(GOLDEN, 'train_traj_128x192.json')))['no_distillation']}
+    batch = synthetic_train_batch(2, crop_hw=(128, 192), raw_hw=(160, 256), device='cuda')
+    tr = _traj_trainer(mode, graph, distill=False)
+    gt = torch.zeros(2, 2, 128, 192, device='cuda')
+    gt[:, 0] = 2.0                                          # im2(x) = im1(x - 2): the forward flow is (+2, 0)
+    first = last = None
+    for i in range(201):
+        s = tr.step(batch, sync_stats=(i % 20 == 0))
+        if i % 20 == 0:
+            first = first or s
+            last = s
+            if i in ref:                                    # on the reference's trajectory (steps 0 .. 120)
+                tol = (2e-4 if i == 0 else 0.05) if mode == 'fp32' else (2e-3 if i == 0 else 0.06)
+                for k in ('photo_loss', 'smooth_loss', 'census_loss'):
+                    assert abs(s[k] - ref[i][k]) <= tol * max(abs(ref[i][k]), 0.05), (i, k, s[k], ref[i][k])
+    tr.raw_net.eval()
+    with torch.no_grad():
+        f = tr.raw_net(dict(batch, if_loss=False))['flow_f_out'].float()[:, :, 16:-16, 16:-16]
+    epe = float((f - gt[:, :, 16:-16, 16:-16]).pow(2).sum(1).sqrt().mean())
+    print('%s %s: loss %.4f -> %.4f, photo %.4f -> %.4f, census %.4f -> %.4f, EPE vs the known 2-px motion %.3f px (mean u %.3f)'
+          % (mode, 'graph' if graph else 'eager', first['loss'], last['loss'], first['photo_loss'], last['photo_loss'],
+             first['census_loss'], last['census_loss'], epe, float(f[:, 0].mean())))
+    assert (tr._graph is not None) == graph
+    assert last['loss'] <= 0.3 * first['loss'] and last['photo_loss'] <= 0.55 * first['photo_loss'] and epe <= 0.15
+
+
+def test_training_trajectory_with_distillation_follows_the_reference():
+    """The FULL loss (with the pyramid-distillation term, weight 1) on the same batch: chaotic — the reference's own run leaves
+    a loss of 10.6 for 37 at step 20 and comes back — and the fp32 HIP path goes through the same excursion: loss terms within
+    8 % of the reference's at steps 0, 20 ... 100."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from upflow_pytorch_amd.train import synthetic_train_batch
+    ref = {r['step']: r for r in json.load(open(os.path.join(GOLDEN, 'train_traj_128x192.json')))['full']}
+    batch = synthetic_train_batch(2, crop_hw=(128, 192), raw_hw=(160, 256), device='cuda')
+    tr = _traj_trainer('fp32', True, distill=True)
+    for i in range(101):
+        s = tr.step(batch, sync_stats=(i % 20 == 0))
+        if i % 20 == 0:
+            print('step %3d  build %s | reference %s' % (i, {k: round(v, 4) for k, v in s.items()}, {k: round(v, 4) for k, v in ref[i].items() if k in s}))
+            for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss'):
+                assert abs(s[k] - ref[i][k]) <= (2e-4 if i == 0 else 0.08) * max(abs(ref[i][k]), 0.05), (i, k, s[k], ref[i][k])
+
+
+def test_graph_mode_follows_the_lr_scheduler():
+    """capturable Adam bakes a python-float lr into the captured graph, so ExponentialLR was silently ignored in
+    graph mode.  The lr is a device tensor now: after end_epoch() with gamma 0.1 a replayed step moves the parameters ~10x less."""
+    from upflow_pytorch_amd.train import Trainer
+    net = build()
+    tr = Trainer(net, lr=1e-3, scheduler_gamma=0.1, device=torch.device('cuda', 0), distributed=False, graph=True)
+    batch = {k: v.cuda() for k, v in _weights.make_train_batch().items()}
+    for _ in range(tr.graph_warmup + 1):
+        tr.step(batch)
+    assert tr._graph is not None
+
+    def delta():
+        before = torch.cat([p.detach().flatten().clone() for p in tr.raw_net.parameters()])
+        tr.step(batch)
+        return float((torch.cat([p.detach().flatten() for p in tr.raw_net.parameters()]) - before).abs().mean())
+    d0 = delta()
+    tr.end_epoch()
+    d1 = delta()
+    print('mean parameter step %.3g -> %.3g after one ExponentialLR(0.1) epoch' % (d0, d1))
+    assert d1 <= 0.2 * d0 and d1 >= 0.05 * d0
+
+
+def test_capture_failure_leaves_no_poisoned_caches(monkeypatch):
+    """a failed capture had put packed-weight cache entries into graph-pool memory that was never written.  The
+    caches are dropped after every capture attempt now: steps after a forced failure equal pure eager steps."""
+    from upflow_pytorch_amd import train as train_mod
+    batch = {k: v.cuda() for k, v in _weights.make_train_batch().items()}
+    ref = _config3_trainer('bf16', False)
+    want = [ref.step(batch) for _ in range(6)]
+    tr = _config3_trainer('bf16', True)
+    real = tr._step_body
+    calls = {'n': 0}
+
+    def failing(b):
+        calls['n'] += 1
+        out = real(b)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('forced capture failure')
+        return out
+    monkeypatch.setattr(tr, '_step_body', failing)
+    with pytest.warns(UserWarning):
+        got = [tr.step(batch) for _ in range(6)]
+    assert tr._graph is None and tr.capture_fallback and not tr.use_graph
+    for a, b in zip(got, want):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+
+
+def test_replay_rejects_a_different_batch_shape():
+    from upflow_pytorch_amd.train import Trainer
+    tr = Trainer(build(), lr=1e-4, device=torch.device('cuda', 0), distributed=False, graph=True)
+    batch = {k: v.cuda() for k, v in _weights.make_train_batch().items()}
+    for _ in range(tr.graph_warmup + 1):
+        tr.step(batch)
+    assert tr._graph is not None
+    small = {k: v[:1] for k, v in batch.items()}
+    with pytest.warns(UserWarning):
+        s = tr.step(small)                                  # a last partial batch: one eager step, the graph stays
+    assert all(np.isfinite(v) for v in s.values()) and tr._graph is not None
+    assert all(np.isfinite(v) for v in tr.step(batch).values())

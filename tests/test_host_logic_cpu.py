@@ -71,6 +71,22 @@ def test_training_losses_and_gradient_norms_vs_reference_golden(stub):
     got = np.array([float(params[n].grad.norm()) for n in names])
     want = g['grad_norms'].numpy()
     assert len(names) == 80 and (np.abs(got - want) / np.maximum(want, 1e-3)).max() <= 2e-3
+    # direction, not only size: 64 seeded projections of every gradient, every bias gradient in full
+    cos, worst = _grad_direction_check({n: params[n].grad for n in names}, g)
+    assert cos.min() >= 0.99999 and worst <= 2e-3, (float(cos.min()), names[int(cos.argmin())], worst)
+
+
+def _grad_direction_check(named_grads, g):
+    """-> (cosine of the projection fingerprints per parameter, worst relative error of a bias gradient)."""
+    names = sorted(named_grads)
+    got, want = _weights.grad_projections(named_grads), g['grad_proj'].numpy()
+    cos = (got * want).sum(1) / np.maximum(np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1), 1e-30)
+    worst = 0.0
+    for i, n in enumerate(names):
+        if n.endswith('.bias'):
+            w = g['gbias_%d' % i].double()
+            worst = max(worst, float((named_grads[n].detach().double().cpu() - w).norm() / w.norm().clamp_min(1e-12)))
+    return cos, worst
 
 
 def test_loss_manager_handles_python_zero_terms(stub):

@@ -21,6 +21,17 @@ int check_launch(const char* what) {
   return UPF_OK;
 }
 
+__global__ void zero_fill_u64_kernel(unsigned long long* __restrict__ p, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0ull;
+}
+
+int zero_fill_u64(void* p, long long n, hipStream_t s) {
+  if (n <= 0) return UPF_OK;
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(zero_fill_u64_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, s, (unsigned long long*)p, n);
+  return check_launch("zero_fill");
+}
+
 }  // namespace upf
 
 extern "C" const char* upf_version(void) { return "upflow_hip 0.1.0 gfx950"; }

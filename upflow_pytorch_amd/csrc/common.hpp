@@ -161,6 +161,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 
 }  // namespace upf
 
+// Zero-fill as a KERNEL (n 8-byte words).  Not hipMemsetAsync: captured into a hipGraph (train.Trainer(graph=True)) the memset
+// node ahead of the 64-bit fixed-point accumulations of the scatter gradients was observed NOT to be ordered reliably before
+// its consumers on replay (ROCm 7.0 / MI355X): the accumulators then start from the previous replay's sums, the warp / SGU
+// gradients grow replay by replay (max |grad| 3e9 within a few dozen steps) and training diverges — in graph mode only, at a
+// step that depends on timing.  A kernel node is ordered like every other launch.  (round 3; tests/test_hip_train.py)
+namespace upf {
+__global__ void zero_fill_u64_kernel(unsigned long long* __restrict__ p, long long n);
+int zero_fill_u64(void* p, long long n, hipStream_t s);
+}  // namespace upf
+
 // dtype dispatch for host launchers
 #define UPF_DISPATCH(dtype, T, ...)                                              \
   switch (dtype) {                                                               \

@@ -413,8 +413,7 @@ extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out,
   const bool final_level = !(Hf == h && Wf == w);
   unsigned long long* gi64 = (unsigned long long*)workspace;
   float* g_full = (float*)(gi64 + n_init);                  // final level: [B, 3, Hf, Wf] gradients before the resize gradient
-  hipError_t e = hipMemsetAsync(gi64, 0, (size_t)n_init * sizeof(unsigned long long), s);
-  UPF_REQUIRE(e == hipSuccess, (int)e, "sgu_blend_backward: memset failed: %s", hipGetErrorString(e));
+  { const int zrc = zero_fill_u64(gi64, n_init, s); if (zrc) return zrc; }      // (a kernel, not a memset node: common.hpp)
   dim3 grid(cdiv(Hf * Wf, sgu::THREADS), B);
   UPF_DISPATCH(dtype, T,
                hipLaunchKernelGGL((sgu::blend_bwd_kernel<T>), grid, dim3(sgu::THREADS), 0, s,

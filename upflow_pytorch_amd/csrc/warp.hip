@@ -273,8 +273,7 @@ extern "C" int upf_warp_backward(const void* x, const float* flow, const void* g
   unsigned long long* gf64 = gx64 + n_gx;
   const int cpt = warp::pick_cpt(B, C, HW);
   const bool split = cdiv(C, cpt) > 1;
-  hipError_t e = hipMemsetAsync(gx64, 0, (size_t)(n_gx + (split ? n_gf : 0)) * sizeof(unsigned long long), s);
-  UPF_REQUIRE(e == hipSuccess, (int)e, "warp_backward: memset failed: %s", hipGetErrorString(e));
+  { const int zrc = zero_fill_u64(gx64, n_gx + (split ? n_gf : 0), s); if (zrc) return zrc; }      // (a kernel, not a memset node: common.hpp)
   dim3 grid(cdiv(HW, warp::THREADS), cdiv(C, cpt), B);
   const long long n_fin = n_gx > n_gf ? n_gx : n_gf;
   UPF_REQUIRE((n_fin + 255) / 256 < (1ll << 31), UPF_EINVAL, "warp_backward: tensor too large");

@@ -685,11 +685,15 @@ class RobustLossFunction(Function):
         sums = partials.sum(0)                               # fixed order: deterministic
         ctx.save_for_backward(x, y, occ)
         ctx.qe = (float(q), float(eps))
-        ctx.mark_non_differentiable(sums[1])
-        return sums[0], sums[1]
+        s_loss, s_occ = sums.unbind(0)                       # (mark and return the SAME view objects: ADVICE r2)
+        ctx.mark_non_differentiable(s_occ)
+        return s_loss, s_occ
 
     @staticmethod
     def backward(ctx, g, _g_occ):
+        if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]:
+            raise UpflowHipError('robust_loss: the occlusion weights are treated as constants (hard masks); a mask that '
+                                 'requires grad would silently get a zero gradient')
         x, y, occ = ctx.saved_tensors
         q, eps = ctx.qe
         B, C, H, W = x.shape
@@ -779,6 +783,16 @@ def conv_pack_from_master(weight32, dtype, dgrad=False):
 
 def conv_pack_cache_clear():
     _PACK_CACHE.clear()
+
+
+def train_caches_clear():
+    """Drop every cache of packed / derived weights of the training path (per-parameter-version packs, stride-2 data-gradient
+    packs, stacked data-gradient packs, the zero-bias buffer).  train.Trainer calls it after every hipGraph capture attempt:
+    entries made DURING a capture live in graph-pool memory whose packing kernels were recorded, not run."""
+    _PACK_CACHE.clear()
+    _S2D_CACHE.clear()
+    _STACK_PACK_CACHE.clear()
+    _ZERO_BIAS.clear()
 
 
 def _conv_pack_from_master(weight32, dtype, dgrad=False):

@@ -111,3 +111,21 @@ def make_train_batch(B=2, crop_hw=(128, 192), raw_hw=(160, 256), seed=0):
 TRAIN_FLAGS = {'photo_loss_census_weight': 1, 'multi_scale_distillation_weight': 1, 'multi_scale_distillation_style': 'upup',
                'multi_scale_distillation_occ': True, 'smooth_order_1_weight': 1, 'photo_loss_type': 'abs_robust',
                'photo_loss_delta': 0.4, 'photo_loss_use_occ': False, 'if_use_boundary_warp': True}
+
+
+def grad_projections(named_grads, ndir=64, seed=9000):
+    """Direction-sensitive fingerprint of a set of per-parameter gradients: for the parameters in sorted-name order, the
+    inner products of the flattened gradient with `ndir` seeded N(0,1) directions (one CPU generator per parameter index),
+    [P, ndir] float64.  Two gradients with the same norm but a different direction have different fingerprints — the cosine of
+    two fingerprints estimates the cosine of the gradients (Johnson-Lindenstrauss) — so tests compare these, not norms.
+    The golden generator applies it to the reference's gradients, the tests to the build's."""
+    import numpy as np
+    names = sorted(named_grads)
+    out = np.zeros((len(names), ndir), dtype=np.float64)
+    for i, n in enumerate(names):
+        g = named_grads[n].detach().double().cpu().reshape(-1)
+        gen = torch.Generator().manual_seed(seed + i)
+        for lo in range(0, ndir, 8):                                         # (8 directions at a time: bounded memory)
+            d = torch.randn(min(8, ndir - lo), g.numel(), generator=gen, dtype=torch.float64)
+            out[i, lo:lo + d.shape[0]] = (d @ g).numpy()
+    return out

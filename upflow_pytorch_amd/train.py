@@ -63,7 +63,12 @@ class Trainer():
         # Under DDP the capture follows PyTorch's whole-network recipe: DDP built on a side stream, 11 eager warm-up steps
         # (the reducer finalises its buckets), then fwd + bwd (incl. the bucket's RCCL all-reduce) + Adam captured.
         self.use_graph = bool(graph) and (device is not None) and torch.device(device).type == 'cuda'
-        self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr, amsgrad=True,
+        self.capture_fallback = False        # True once a capture failed and the trainer went back to eager steps
+        # graph mode: the learning rate is a DEVICE TENSOR — capturable Adam then reads it inside the captured step and the
+        # scheduler updates it in place; a python float would be baked into the graph at capture time and every later
+        # scheduler.step() silently ignored
+        lr_arg = torch.tensor(float(lr), dtype=torch.float32, device=device) if self.use_graph else lr
+        self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr_arg, amsgrad=True,
                                           weight_decay=weight_decay, capturable=self.use_graph)
         self.graph_warmup = 11 if self.distributed else 3
         self._graph = None
@@ -99,11 +104,18 @@ class Trainer():
         dev = torch.device(self.device)
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         self.optimizer.zero_grad(set_to_none=True)
+        from . import ops
         g = torch.cuda.CUDAGraph()
         # thread_local: the process group's watchdog thread polls its events while this thread captures; under the
         # default (global) capture mode that hipEventQuery is an error that aborts the process
-        with torch.cuda.graph(g, capture_error_mode='thread_local' if self.distributed else 'global'):
-            self._static_stats = self._step_body(self._static)
+        try:
+            with torch.cuda.graph(g, capture_error_mode='thread_local' if self.distributed else 'global'):
+                self._static_stats = self._step_body(self._static)
+        finally:
+            # packed-weight cache entries made during the capture point into graph-pool memory whose packing kernels were
+            # only RECORDED: an eager step that found them would multiply by garbage.  The captured step itself
+            # re-runs its packing kernels at every replay, so it does not need them.
+            ops.train_caches_clear()
         self._graph = g
         torch.cuda.synchronize(dev)
 
@@ -111,7 +123,12 @@ class Trainer():
         """One optimisation step on this rank's shard; returns the loss terms averaged over ranks
         (sync_stats=False: the device tensor of the terms, no host synchronisation)."""
         self.net.train()
-        if self.use_graph and self._graph is not None:
+        if self.use_graph and self._graph is not None and not self._matches_static(batch):
+            import warnings
+            warnings.warn('batch differs from the captured one (keys / shapes / non-tensor values): this step runs eagerly')
+            self.optimizer.zero_grad(set_to_none=True)
+            stats = self._step_body(batch)
+        elif self.use_graph and self._graph is not None:
             for k, v in batch.items():
                 if torch.is_tensor(v):
                     self._static[k].copy_(v, non_blocking=True)
@@ -128,11 +145,29 @@ class Trainer():
                     import warnings
                     warnings.warn('hipGraph capture of the training step failed (%s: %s); continuing with eager steps' % (type(e).__name__, e))
                     self.use_graph = False
+                    self.capture_fallback = True
                     self._graph = None
+                    self._static = self._static_stats = None
                     torch.cuda.synchronize(torch.device(self.device))
         if not sync_stats:
             return stats
         return {k: float(v) for k, v in zip(self._names, stats.cpu())}
+
+    def _matches_static(self, batch):
+        """The captured step replays on the tensors it was captured with: same keys, same shapes / dtypes, same non-tensor
+        values (a last partial batch of an epoch, a changed flag ... must not be copied into them)."""
+        st = self._static
+        if set(batch) - {'if_loss'} != set(st) - {'if_loss'}:
+            return False
+        for k, v in batch.items():
+            if k == 'if_loss':
+                continue
+            if torch.is_tensor(v):
+                if not torch.is_tensor(st[k]) or v.shape != st[k].shape or v.dtype != st[k].dtype:
+                    return False
+            elif torch.is_tensor(st[k]) or v != st[k]:
+                return False
+        return True
 
     def end_epoch(self):
         self.scheduler.step()
