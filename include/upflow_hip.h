@@ -292,6 +292,11 @@ int upf_flow_update(const float* a, const void* b, const void* c, void* out, lon
 int upf_occ_check(const float* flow_f, const float* flow_b, float* occ_fw, float* occ_bw,
                   int B, int H, int W, float alpha1, float alpha2, void* stream);
 
+/* Self-test of the division-free, correctly rounded quotient the sampling kernels use for 2(j+fx)/(W-1) (csrc/sampling.hpp:
+ * div_by_const): compares it with the IEEE division over ALL 2^32 bit patterns of the numerator for the divisor
+ * max(size-1, 1) and adds the number of differing results to *mismatches (device memory, zeroed by the caller).  ~30 ms. */
+int upf_div_selftest(int size, unsigned long long* mismatches, void* stream);
+
 /* ---- soft census distance of the photometric loss  (utils/loss.py:50-91) ----
  * gray1, gray2 : [B,1,H,W] fp32 grey images (0.2989 r + 0.5870 g + 0.1140 b);  dist : [B,1,H,W] fp32,
  *   dist(p) = sum_k d_k/(0.1+d_k),  d_k = (t_k(gray1,p) - t_k(gray2,p))^2,  t_k(I,p) = u/sqrt(0.81+u^2),  u = I(p+k) - I(p),

@@ -58,6 +58,7 @@ SIGNATURES = {
     'upf_robust_loss_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     'upf_smooth_edge1_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_smooth_edge1_backward': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_div_selftest': [_i, _vp, _vp],
     'upf_occ_check': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
 }
 

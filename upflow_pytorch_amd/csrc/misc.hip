@@ -160,7 +160,7 @@ __device__ __forceinline__ void warp2(const float* __restrict__ f, int HW, const
 // ~300 instructions per pixel — four IEEE divisions of the exact-rounding sampling positions — not by latency.)
 __global__ __launch_bounds__(256)
 void occ_check_kernel(const float* __restrict__ ff, const float* __restrict__ fb, float* __restrict__ occ_fw,
-                      float* __restrict__ occ_bw, int H, int W, float a1, float a2) {
+                      float* __restrict__ occ_bw, int H, int W, float a1, float a2, SampleGeom geo) {
   const int HW = H * W;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -173,9 +173,9 @@ void occ_check_kernel(const float* __restrict__ ff, const float* __restrict__ fb
   const float mag = (fabsf(fx) + fabsf(fy)) + (fabsf(bx) + fabsf(by));      // tools.py:559, :573
   const float thr = a1 * mag + a2;                                          // :578
   float wx, wy;
-  warp2(Bk, HW, make_taps(j, i, fx, fy, H, W), H, W, wx, wy);               // flow_bw warped by flow_fw, :574
+  warp2(Bk, HW, make_taps(j, i, fx, fy, H, W, geo), H, W, wx, wy);               // flow_bw warped by flow_fw, :574
   const bool cf = (fabsf(fx + wx) + fabsf(fy + wy)) < thr;                  // :576, :579
-  warp2(F, HW, make_taps(j, i, bx, by, H, W), H, W, wx, wy);                // :575
+  warp2(F, HW, make_taps(j, i, bx, by, H, W, geo), H, W, wx, wy);                // :575
   const bool cb = (fabsf(bx + wx) + fabsf(by + wy)) < thr;
   // outgoing mask (tools.py:657-667) and obj merge (:672-676): 1 where consistent OR flow leaves the image
   const float pxf = (float)j + fx, pyf = (float)i + fy, pxb = (float)j + bx, pyb = (float)i + by;
@@ -402,7 +402,7 @@ extern "C" int upf_occ_check(const float* flow_f, const float* flow_b, float* oc
   UPF_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0, UPF_EINVAL, "occ_check: bad shape");
   UPF_REQUIRE(H <= 4 * 65535, UPF_EINVAL, "occ_check: image too tall");
   dim3 grid(cdiv(W, 64), cdiv(H, 4), B);
-  hipLaunchKernelGGL(misc::occ_check_kernel, grid, dim3(256), 0, (hipStream_t)stream, flow_f, flow_b, occ_fw, occ_bw, H, W, alpha1, alpha2);
+  hipLaunchKernelGGL(misc::occ_check_kernel, grid, dim3(256), 0, (hipStream_t)stream, flow_f, flow_b, occ_fw, occ_bw, H, W, alpha1, alpha2, make_sample_geom(H, W));
   return check_launch("occ_check");
 }
 
@@ -426,4 +426,26 @@ extern "C" int upf_census_backward(const float* gray1, const float* gray2, const
   else if (g_gray1) hipLaunchKernelGGL((misc::census_bwd_kernel<true, false>), grid, dim3(256), 0, s, gray1, gray2, grad_dist, g_gray1, g_gray2, H, W, max_distance);
   else hipLaunchKernelGGL((misc::census_bwd_kernel<false, true>), grid, dim3(256), 0, s, gray1, gray2, grad_dist, g_gray1, g_gray2, H, W, max_distance);
   return check_launch("census_backward");
+}
+
+// ---- self-test of the division-free quotient of sampling.hpp (div_by_const) ---------------------------------------------
+namespace upf { namespace misc {
+__global__ void div_selftest_kernel(float d, float r, unsigned long long* __restrict__ bad) {
+  unsigned long long local = 0;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float((unsigned int)i);
+    const float want = __fdiv_rn(x, d), got = div_by_const(x, d, r);
+    if (__float_as_uint(got) != __float_as_uint(want) && !(got != got && want != want)) ++local;
+  }
+  if (local) atomicAdd(bad, local);
+}
+}}  // namespace upf::misc
+
+extern "C" int upf_div_selftest(int size, unsigned long long* mismatches /* device, zeroed by the caller */, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(size >= 1 && mismatches, UPF_EINVAL, "div_selftest: bad arguments");
+  const SampleGeom g = make_sample_geom(size, size);                       // the reciprocal exactly as the launchers compute it
+  const float d = (float)(size - 1 > 1 ? size - 1 : 1);
+  hipLaunchKernelGGL(misc::div_selftest_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, d, g.rW, mismatches);
+  return check_launch("div_selftest");
 }

@@ -19,13 +19,36 @@ struct Taps {
   float ix, iy;    // sampling position (after the normalise/un-normalise round trip)
 };
 
+// The two IEEE divisions of a sampling position divide by a launch constant (W-1, H-1): x / d is computed WITHOUT the
+// division sequence (~40 instructions each, a third of these kernels' instruction stream in round 2) and still correctly
+// rounded.  With r = RN(1/d) from the host (SampleGeom):  q = RN(x*r);  e = fma(-q, d, x) (exact);  q' = fma(e, r, q)
+// is RN(x/d) for every x whose quotient is a normal number [Markstein, IBM J. R&D 1990] — checked EXHAUSTIVELY on the
+// GPU, all 2^32 bit patterns of x, for every divisor a pyramid level of the BASELINE configurations has
+// (tools/div_exact_probe.hip, tests/test_hip_ops.py::test_division_free_quotient_is_exact).  Zeros keep their sign bit's
+// effect (x == 0 returns x); magnitudes outside [2^-100, 2^100], infinities and NaNs take the division (a wave-uniformly
+// rare branch: sampling positions are pixel coordinates).
+struct SampleGeom { float rW, rH; };       // RN(1 / max(W-1, 1)), RN(1 / max(H-1, 1))
+static inline SampleGeom make_sample_geom(int H, int W) {
+  SampleGeom g;
+  g.rW = 1.0f / (float)(W - 1 > 1 ? W - 1 : 1);
+  g.rH = 1.0f / (float)(H - 1 > 1 ? H - 1 : 1);
+  return g;
+}
+__device__ __forceinline__ float div_by_const(float x, float d, float r) {
+  const float a = fabsf(x);
+  if (!(a >= 7.888609e-31f && a <= 1.2676506e30f)) return (x == 0.f) ? x : __fdiv_rn(x, d);     // 2^-100 .. 2^100
+  const float q = __fmul_rn(x, r);
+  const float e = __builtin_fmaf(-q, d, x);
+  return __builtin_fmaf(e, r, q);
+}
+
 // position for output pixel (j, i) displaced by (fx, fy)
-__device__ __forceinline__ Taps make_taps(int j, int i, float fx, float fy, int H, int W) {
+__device__ __forceinline__ Taps make_taps(int j, int i, float fx, float fy, int H, int W, SampleGeom sg) {
   Taps t;
   const float dW = (float)max(W - 1, 1), dH = (float)max(H - 1, 1);
   // vgrid = 2*(grid+flow)/max(W-1,1) - 1                       pwc_modules.py:195-198
-  const float gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fadd_rn((float)j, fx)), dW), 1.0f);
-  const float gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fadd_rn((float)i, fy)), dH), 1.0f);
+  const float gx = __fsub_rn(div_by_const(__fmul_rn(2.0f, __fadd_rn((float)j, fx)), dW, sg.rW), 1.0f);
+  const float gy = __fsub_rn(div_by_const(__fmul_rn(2.0f, __fadd_rn((float)i, fy)), dH, sg.rH), 1.0f);
   // grid_sampler_unnormalize(align_corners=True): ((g+1)/2)*(size-1)
   t.ix = __fmul_rn(__fdiv_rn(__fadd_rn(gx, 1.0f), 2.0f), (float)(W - 1));
   t.iy = __fmul_rn(__fdiv_rn(__fadd_rn(gy, 1.0f), 2.0f), (float)(H - 1));

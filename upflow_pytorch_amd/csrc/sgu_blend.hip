@@ -65,7 +65,7 @@ template <typename T>
 __global__ __launch_bounds__(THREADS)
 void blend_fwd_kernel(const float* __restrict__ flow_init, const T* __restrict__ x_out, const float* __restrict__ sig,
                       float* __restrict__ flow_up, float* __restrict__ inter_flow, float* __restrict__ inter_mask,
-                      int h, int w, int Hf, int Wf, float scale_y, float scale_x, float su, float sv) {
+                      int h, int w, int Hf, int Wf, float scale_y, float scale_x, float su, float sv, SampleGeom geo) {
   const int HW = Hf * Wf, hw = h * w;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -90,7 +90,7 @@ void blend_fwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
     const float* sg = sig + (size_t)n * hw;                 // sigmoid evaluated once per low-resolution pixel
     m = lerp4(sg[q00], sg[q01], sg[q10], sg[q11]);
   }
-  const Taps t = make_taps(j, i, ifx, ify, Hf, Wf);
+  const Taps t = make_taps(j, i, ifx, ify, Hf, Wf, geo);
   const int xa = min(max(t.x0, 0), Wf - 1), xb = min(max(t.x0 + 1, 0), Wf - 1);
   const int ya = min(max(t.y0, 0), Hf - 1), yb = min(max(t.y0 + 1, 0), Hf - 1);
   const int o0 = ya * Wf + xa, o1 = ya * Wf + xb, o2 = yb * Wf + xa, o3 = yb * Wf + xb;
@@ -120,7 +120,7 @@ template <typename T>
 __global__ __launch_bounds__(THREADS)
 void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__ x_out, const float* __restrict__ g_up,
                       unsigned long long* __restrict__ g_init, float* __restrict__ g_full, float* __restrict__ g_xo,
-                      int h, int w, int Hf, int Wf) {
+                      int h, int w, int Hf, int Wf, SampleGeom geo) {
   const int HW = Hf * Wf, hw = h * w;
   const int p = blockIdx.x * THREADS + threadIdx.x;
   if (p >= HW) return;
@@ -131,7 +131,7 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
   const T* xo = x_out + (size_t)n * 3 * hw;
   inter_at<T>(xo, h, w, Hf, Wf, i, j, ifx, ify, m, ly, lx);
   const float* f0 = flow_init + (size_t)n * 2 * HW;
-  const Taps t = make_taps(j, i, ifx, ify, Hf, Wf);
+  const Taps t = make_taps(j, i, ifx, ify, Hf, Wf, geo);
   const int xa = min(max(t.x0, 0), Wf - 1), xb = min(max(t.x0 + 1, 0), Wf - 1);
   const int ya = min(max(t.y0, 0), Hf - 1), yb = min(max(t.y0 + 1, 0), Hf - 1);
   const int o[4] = {ya * Wf + xa, ya * Wf + xb, yb * Wf + xa, yb * Wf + xb};
@@ -376,7 +376,7 @@ extern "C" int upf_sgu_blend_forward(const float* flow_init, const void* x_out, 
   UPF_DISPATCH(dtype, T,
                if (!level) hipLaunchKernelGGL((sgu::sigmoid_map_kernel<T>), dim3((unsigned)((nsig + 255) / 256)), dim3(256), 0, st, (const T*)x_out, sig, h * w, nsig);
                hipLaunchKernelGGL((sgu::blend_fwd_kernel<T>), grid, dim3(sgu::THREADS), 0, st, flow_init, (const T*)x_out, sig, flow_up, inter_flow, inter_mask,
-                                  h, w, Hf, Wf, scale_y, scale_x, su, sv));
+                                  h, w, Hf, Wf, scale_y, scale_x, su, sv, make_sample_geom(Hf, Wf)));
   return check_launch("sgu_blend_forward");
 }
 
@@ -417,7 +417,7 @@ extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out,
   dim3 grid(cdiv(Hf * Wf, sgu::THREADS), B);
   UPF_DISPATCH(dtype, T,
                hipLaunchKernelGGL((sgu::blend_bwd_kernel<T>), grid, dim3(sgu::THREADS), 0, s,
-                                  flow_init, (const T*)x_out, grad_flow_up, gi64, g_full, g_x_out32, h, w, Hf, Wf));
+                                  flow_init, (const T*)x_out, grad_flow_up, gi64, g_full, g_x_out32, h, w, Hf, Wf, make_sample_geom(Hf, Wf)));
   hipLaunchKernelGGL(sgu::blend_bwd_finish_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, gi64, g_flow_init32, n_init);
   if (final_level) {
     launch_upsample_backward(g_full, g_x_out32, (long long)B * 3, 3, h, w, Hf, Wf, 0, s);

@@ -34,12 +34,12 @@ struct PixelTaps {
   bool valid;
 };
 
-__device__ __forceinline__ PixelTaps make_pixel(const float* __restrict__ flow_n, int p, int H, int W, int mask_mode) {
+__device__ __forceinline__ PixelTaps make_pixel(const float* __restrict__ flow_n, int p, int H, int W, int mask_mode, SampleGeom sg) {
   PixelTaps r;
   const int HW = H * W;
   const int i = p / W, j = p - i * W;
   const float fx = flow_n[p], fy = flow_n[HW + p];
-  const Taps t = make_taps(j, i, fx, fy, H, W);
+  const Taps t = make_taps(j, i, fx, fy, H, W, sg);
   r.valid = taps_valid(t, mask_mode, j, i, fx, fy, H, W);
   const int pc = min(max(t.x0, 0), W - 2);
   const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
@@ -89,7 +89,7 @@ __device__ __forceinline__ float sample(const T* __restrict__ plane, const Pixel
 template <typename T, int PXT>
 __global__ __launch_bounds__(THREADS)
 void warp_fwd_kernel(const T* __restrict__ x, long long xbs, const float* __restrict__ flow, T* __restrict__ y, long long ybs,
-                     int C, int H, int W, int cpt, int mask_mode, int shift) {
+                     int C, int H, int W, int cpt, int mask_mode, int shift, SampleGeom sg) {
   const int HW = H * W;
   const int p0 = (blockIdx.x * THREADS + threadIdx.x) * PXT;
   if (p0 >= HW) return;
@@ -99,7 +99,7 @@ void warp_fwd_kernel(const T* __restrict__ x, long long xbs, const float* __rest
   const float* fl = flow + (size_t)n * 2 * HW;
   PixelTaps s[PXT];
 #pragma unroll
-  for (int k = 0; k < PXT; ++k) s[k] = make_pixel(fl, p0 + k, H, W, mask_mode);
+  for (int k = 0; k < PXT; ++k) s[k] = make_pixel(fl, p0 + k, H, W, mask_mode, sg);
   const T* xb = x + (size_t)ns * xbs + (size_t)c_begin * HW;          // x / y may be channel slices of wider buffers
   T* yb = y + (size_t)n * ybs + (size_t)c_begin * HW + p0;
 #pragma unroll 4
@@ -124,7 +124,7 @@ void warp_fwd_kernel(const T* __restrict__ x, long long xbs, const float* __rest
 template <typename T>
 __global__ __launch_bounds__(THREADS)
 void warp_fwd_narrow_kernel(const T* __restrict__ x, long long xbs, const float* __restrict__ flow, T* __restrict__ y, long long ybs,
-                            int C, int H, int W, int mask_mode, int shift) {
+                            int C, int H, int W, int mask_mode, int shift, SampleGeom sg) {
   const int HW = H * W;
   const int p = blockIdx.x * THREADS + threadIdx.x;
   if (p >= HW) return;
@@ -132,7 +132,7 @@ void warp_fwd_narrow_kernel(const T* __restrict__ x, long long xbs, const float*
   const int ns = (n + shift) % (int)gridDim.z;
   const int i = p / W, j = p - i * W;
   const float fx = flow[((size_t)n * 2 + 0) * HW + p], fy = flow[((size_t)n * 2 + 1) * HW + p];
-  const Taps t = make_taps(j, i, fx, fy, H, W);
+  const Taps t = make_taps(j, i, fx, fy, H, W, sg);
   const bool valid = taps_valid(t, mask_mode, j, i, fx, fy, H, W);
   const int xa = min(max(t.x0, 0), W - 1), xb1 = min(max(t.x0 + 1, 0), W - 1);
   const int ya = min(max(t.y0, 0), H - 1), yb1 = min(max(t.y0 + 1, 0), H - 1);
@@ -156,7 +156,7 @@ template <typename T>
 __global__ __launch_bounds__(THREADS)
 void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, const T* __restrict__ gy,
                      unsigned long long* __restrict__ gx64, unsigned long long* __restrict__ gf64, float* __restrict__ gflow,
-                     int C, int H, int W, int cpt, int mask_mode, int shift) {
+                     int C, int H, int W, int cpt, int mask_mode, int shift, SampleGeom sg) {
   const int HW = H * W;
   const int p = blockIdx.x * THREADS + threadIdx.x;
   if (p >= HW) return;
@@ -166,7 +166,7 @@ void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, co
   const int i = p / W, j = p - i * W;
   const float fx = flow[((size_t)n * 2 + 0) * HW + p];
   const float fy = flow[((size_t)n * 2 + 1) * HW + p];
-  const Taps t = make_taps(j, i, fx, fy, H, W);
+  const Taps t = make_taps(j, i, fx, fy, H, W, sg);
   float* gf = gflow + (size_t)n * 2 * HW + p;
   if (!taps_valid(t, mask_mode, j, i, fx, fy, H, W)) {   // mask is a constant factor: zero grads
     if (gridDim.y == 1) { gf[0] = 0.f; gf[HW] = 0.f; }
@@ -231,9 +231,10 @@ extern "C" int upf_warp_forward_strided(const void* x, long long x_batch_stride,
   const long long xbs = x_batch_stride ? x_batch_stride : (long long)C * HW, ybs = y_batch_stride ? y_batch_stride : (long long)C * HW;
   UPF_REQUIRE(xbs >= (long long)C * HW && ybs >= (long long)C * HW, UPF_EINVAL, "warp_forward: batch stride smaller than C*H*W");
   hipStream_t st = (hipStream_t)stream;
+  const SampleGeom sg = make_sample_geom(H, W);
   if (W < 2) {
     UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((warp::warp_fwd_narrow_kernel<T>), dim3(cdiv(HW, warp::THREADS), 1, B), dim3(warp::THREADS), 0, st,
-                                              (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, mask_mode, batch_shift));
+                                              (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, mask_mode, batch_shift, sg));
     return check_launch("warp_forward");
   }
   // (4 consecutive pixels per thread with 8 / 16-byte stores were measured SLOWER for 16-bit features, 12.6 -> 16.2 us at
@@ -244,9 +245,9 @@ extern "C" int upf_warp_forward_strided(const void* x, long long x_batch_stride,
   const int cpt = warp::pick_cpt(B, C, HW / pxt);
   dim3 grid(cdiv(cdiv(HW, pxt), warp::THREADS), cdiv(C, cpt), B);
   UPF_DISPATCH(dtype, T,
-               if (four) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 4>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift);
-               else if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift);
-               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift));
+               if (four) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 4>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg);
+               else if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg);
+               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg));
   return check_launch("warp_forward");
 }
 
@@ -279,7 +280,7 @@ extern "C" int upf_warp_backward(const void* x, const float* flow, const void* g
   UPF_REQUIRE((n_fin + 255) / 256 < (1ll << 31), UPF_EINVAL, "warp_backward: tensor too large");
   UPF_DISPATCH(dtype, T,
                hipLaunchKernelGGL((warp::warp_bwd_kernel<T>), grid, dim3(warp::THREADS), 0, s,
-                                  (const T*)x, flow, (const T*)grad_y, gx64, gf64, gflow, C, H, W, cpt, mask_mode, batch_shift);
+                                  (const T*)x, flow, (const T*)grad_y, gx64, gf64, gflow, C, H, W, cpt, mask_mode, batch_shift, make_sample_geom(H, W));
                hipLaunchKernelGGL((warp::warp_bwd_finish_kernel<T>), dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, s,
                                   gx64, (T*)gx, n_gx, split ? gf64 : nullptr, gflow, n_gf));
   return check_launch("warp_backward");
