@@ -71,13 +71,18 @@ def roofline_probe(B, H, W, dtype, device):
     f1 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
     f2 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
     out = torch.empty(B, 81, h, w, device=device, dtype=dtype)
-    ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=20)                      # warm
-    avg_us, min_us = ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=200)
+    # the kernel INSIDE the timed step is the variant whose loader normalises the features (upf_corr81_norm_forward: 16-bit
+    # inference); the plain variant (training, fp32) is reported beside it
+    norm = dtype != torch.float32 and ops.corr81_norm_supported(f1)
+    timed = ops.corr81_norm_forward_timed if norm else ops.corr81_forward_timed
+    timed(f1, f2, out, 0.1, nrep=20)                                         # warm
+    avg_us, min_us = timed(f1, f2, out, 0.1, nrep=200)
+    plain_us = ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=200)[0] if norm else avg_us
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
     cold = []
     for _ in range(30):
         flush.fill_(1)
-        cold.append(ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=1)[0])
+        cold.append(timed(f1, f2, out, 0.1, nrep=1)[0])
     del flush
     cold_us = sum(cold) / len(cold)
     s = f1.element_size()
@@ -93,16 +98,17 @@ def roofline_probe(B, H, W, dtype, device):
             continue
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))['summary']
-            if pmc['shape'] == [B, C, h, w] and pmc['dtype'] == dn:
+            if pmc['shape'] == [B, C, h, w] and pmc['dtype'] == dn and pmc.get('variant', 'plain') == ('norm' if norm else 'plain'):
                 traffic = int(pmc['traffic_bytes'])
                 break
         except Exception:
             pass
-    return {'bound': 'hbm', 'kernel': 'corr81_allc_kernel<8x32 tile>' if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w],
+    return {'bound': 'hbm', 'kernel': ('corr81_allc_kernel<8x32 tile, NORM: normalisation fused into the loader> (the launch inside the step)' if norm else 'corr81_allc_kernel<8x32 tile>') if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w],
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2),
             'timing': 'HIP events around each of 200 back-to-back launches (inputs resident in the infinity cache)',
-            'cold_kernel_us': round(cold_us, 2), 'frac_cold': round(alg_bytes / (cold_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            'cold_kernel_us': round(cold_us, 2), 'frac_cold': round(alg_bytes / (cold_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            'plain_variant_us': round(plain_us, 2), 'plain_variant_frac': round(alg_bytes / (plain_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def conv_roofline_probe(B, H, W, dtype, device):

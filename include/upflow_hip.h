@@ -78,6 +78,12 @@ long long upf_corr81_norm_workspace_bytes(int B, int C, int H, int W);
 int upf_corr81_norm_forward(const void* f1, const void* f2, void* out,
                             int B, int C, int H, int W, int dtype,
                             long long out_batch_stride, float leaky_slope, void* workspace, void* stream);
+/* measurement helper (bench.py): one statistics launch, then nrep launches of the normalising cost volume, each between
+ * its own pair of HIP events on `stream` — the kernel that runs inside the inference step */
+int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out,
+                                  int B, int C, int H, int W, int dtype,
+                                  long long out_batch_stride, float leaky_slope, void* workspace, void* stream,
+                                  int nrep, float* avg_us, float* min_us);
 
 /* Launch heuristics of the 16-bit cost volume, for tuning and for the tests to reach every kernel variant:
  *   "variant"  (-1)  -1 = choose by shape; 0..3 = force tile geometry 8x32 / 4x32 / 2x32 / 4x16 where C fits

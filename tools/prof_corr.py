@@ -11,6 +11,8 @@ from upflow_pytorch_amd import ops
 
 B, C, H, W = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (4, 32, 96, 320)))
 dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[sys.argv[5] if len(sys.argv) > 5 else 'bf16']
+norm = len(sys.argv) > 6 and sys.argv[6] == 'norm'      # the normalising variant (upf_corr81_norm_forward): the kernel inside the step
+fwd = (lambda: ops.corr81_norm_forward_raw(f1, f2, out=out, leaky_slope=0.1)) if norm else (lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1))
 g = torch.Generator().manual_seed(2004)
 f1 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
 f2 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
@@ -19,10 +21,10 @@ out = torch.empty(B, 81, H, W, device='cuda', dtype=dt)
 junk = torch.empty(320 * 1024 * 1024, dtype=torch.uint8, device='cuda')
 for i in range(20):
     junk.add_(1)
-    ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)
+    fwd()
 torch.cuda.synchronize()
 # back-to-back (inputs/outputs warm in the infinity cache, as inside the network right after their producer)
 for i in range(20):
-    ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)
+    fwd()
 torch.cuda.synchronize()
 print('done')

@@ -345,6 +345,46 @@ extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out
   return rc;
 }
 
+// The NORM cost volume — the variant inside the inference step — timed like upf_corr81_forward_timed: one (untimed) statistics
+// launch, then nrep launches of the cost-volume kernel, each between its own pair of HIP events on the launch stream.
+extern "C" int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
+                                             long long out_batch_stride, float leaky_slope, void* workspace, void* stream, int nrep,
+                                             float* avg_us, float* min_us) {
+  using namespace upf;
+  UPF_REQUIRE(f1 && f2 && out && workspace && avg_us, UPF_EINVAL, "corr81_norm_forward_timed: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nrep > 0 && nrep <= 1024, UPF_EINVAL, "corr81_norm_forward_timed: bad arguments");
+  UPF_REQUIRE(upf_corr81_norm_supported(C, dtype) && (size_t)C * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward_timed: unsupported shape / dtype");
+  if (out_batch_stride == 0) out_batch_stride = (long long)corr::ND * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const long long N = (long long)B * C;
+  const int nseg = misc::launch_stats2(f1, f2, ws, N, H * W, dtype, s);
+  int rc = check_launch("corr81_norm_forward_timed (statistics)");
+  if (rc != UPF_OK) return rc;
+  const float* ws1 = ws;
+  const float* ws2 = ws + (size_t)N * nseg * 3;
+  hipEvent_t* ev = new hipEvent_t[2 * nrep];
+  for (int i = 0; i < 2 * nrep; ++i) (void)hipEventCreate(&ev[i]);
+  for (int i = 0; i < nrep && rc == UPF_OK; ++i) {
+    if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
+    else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
+    if (rc == 1) { set_error("corr81_norm_forward_timed: no kernel variant fits C=%d W=%d", C, W); rc = UPF_EUNSUPPORTED; }
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  if (rc == UPF_OK && e != hipSuccess) { set_error("corr81_norm_forward_timed: %s", hipGetErrorString(e)); rc = (int)e; }
+  double sum = 0.0, mn = 1e30;
+  if (rc == UPF_OK)
+    for (int i = 0; i < nrep; ++i) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+      sum += ms; if (ms < mn) mn = ms;
+    }
+  for (int i = 0; i < 2 * nrep; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  if (rc == UPF_OK) { *avg_us = (float)(sum / nrep * 1e3); if (min_us) *min_us = (float)(mn * 1e3); }
+  return rc;
+}
+
 extern "C" int upf_corr_set_option(const char* name, int value) {
   using namespace upf::corr;
   int* slot = nullptr;

@@ -99,6 +99,21 @@ def corr81_forward_timed(f1, f2, out, leaky_slope=0.0, nrep=50):
     return avg.value, mn.value
 
 
+def corr81_norm_forward_timed(f1, f2, out, leaky_slope=0.0, nrep=50):
+    """-> (avg_us, min_us) of `nrep` launches of the NORMALISING cost volume (the kernel inside the inference step), each
+    between its own pair of HIP events; the statistics launch runs once, untimed.  Measurement helper for bench.py."""
+    import ctypes
+    B, C, H, W = f1.shape
+    dev = _lib.check_gpu(f1, f2, out)
+    ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
+    avg, mn = ctypes.c_float(), ctypes.c_float()
+    with torch.cuda.device(dev):
+        _lib.call('upf_corr81_norm_forward_timed', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(out), B, C, H, W,
+                  _lib.dtype_code(f1), 0, float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev), int(nrep),
+                  ctypes.byref(avg), ctypes.byref(mn))
+    return avg.value, mn.value
+
+
 def corr81_backward_raw(f1, f2, grad_out):
     B, C, H, W = f1.shape
     grad_out = grad_out.contiguous()
