@@ -131,6 +131,10 @@ int upf_warp_forward(const void* x, const float* flow, void* y,
  * inference path warps straight out of / into the concatenation buffers the convolutions read (no slot copies). */
 int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
                              int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
+/* same on CHANNEL-OCTET tensors ("C8": [n][C/8][H][W][8], see upf_conv_forward_c8; bf16 / fp16): x8 / y8 point at the first
+ * octet plane of octet slices of C8 buffers (batch strides in elements), n_oct octets.  Values equal the NCHW kernel's. */
+int upf_warp_forward_c8(const void* x8, long long x_batch_stride, const float* flow, void* y8, long long y_batch_stride,
+                        int B, int n_oct, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
 /* Gradients of the warp: gx [B,C,H,W] of `dtype` (wrt x; with batch_shift it lands on the item that was sampled) and
  * gflow [B,2,H,W] fp32.  The scatter into gx is accumulated in 64-bit fixed point (value * 2^44, integer atomics), so the
  * result is bit-reproducible run to run; `workspace`: upf_warp_backward_workspace_bytes(B,C,H,W) bytes of device memory
@@ -221,7 +225,8 @@ int upf_conv_set_option(const char* name, int value);
  *   output = C8 octets (y_is_c8; channels that pad the last octet are written as zeros) or NCHW planes.
  * upf_conv_pack_weights_kmap gathers the input channels of w through kmap[K] (-1 = zero) into that K order.
  * stride 1, W % 8 == 0, 16-byte aligned operands; kernel 3x3 with dilation 1 (any layout combination) or 2 / 4 / 8 / 16 (C8 in,
- * C8 out), or 1x1 (NCHW in, C8 out, Cout <= 32).  Everything else: upf_conv_forward. */
+ * C8 out), or 1x1 (NCHW in, C8 out, Cout <= 32); stride 2 for a 3x3 with an NCHW input of > 16 channels and a C8 output of
+ * <= 32 (W % 16 == 0).  Everything else: upf_conv_forward. */
 long long upf_conv_packed_bytes_k(int K, int Cout, int kernel_size);
 int upf_conv_c8_k(int n8_oct, int C2);
 int upf_conv_pack_weights_kmap(const void* w /* [Cout,Cin,k,k] */, void* w_packed, int Cin, int Cout, int kernel_size,

@@ -102,3 +102,68 @@ def test_conv_c8_rejects_unsupported():
     x8 = ops.c8_empty(1, 32, 8, 16, torch.bfloat16, 'cuda')
     with pytest.raises(RuntimeError):                                  # dilation 2 needs a C8 output
         ops.conv_c8_forward_raw(x8, None, w, torch.zeros(8, device='cuda'), torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda'), dilation=2)
+
+
+@pytest.mark.parametrize('mask_mode', ['literal', 'robust', None])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_warp_c8_equals_the_nchw_warp(mask_mode, dtype):
+    """upf_warp_forward_c8 (octet tensors, 16-byte gathers) == upf_warp_forward_strided bit for bit, incl. batch_shift, flows
+    that leave the frame, NaN flows, and octet slices of wider buffers."""
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, C, H, W = 4, 32, 24, 40
+    x = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+    flow = (torch.randn(B, 2, H, W, generator=g) * 6).cuda()
+    flow[0, :, 0, :3] = float('nan')
+    flow[1, 0, 2, 5] = float('inf')
+    flow[2] = 0
+    want = torch.empty_like(x)
+    ops.warp_into(x, flow, want, mask_mode, batch_shift=2)
+    buf = torch.full((B, 11, H, W, 8), 5.0, dtype=dtype, device='cuda')
+    buf[:, 2:6] = ops.to_c8(x)
+    ops.warp_c8_into(buf[:, 2:6], flow, buf[:, 6:10], mask_mode, batch_shift=2)
+    got = ops.from_c8(buf[:, 6:10])
+    if mask_mode is None:       # (no mask: a tap outside the frame contributes value * 0 = +-0; the sign of that zero may differ)
+        assert torch.equal(got.float(), want.float())
+    else:
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert bool((buf[:, :2] == 5).all()) and bool((buf[:, 10:] == 5).all())
+
+
+def test_whole_net_c8_levels_are_bit_identical_to_nchw():
+    """The channel-octet SGU stack / context network of the large pyramid levels (UPFlow_net._forward_stacked_fast, c8_level_ok)
+    change the layout, not the arithmetic or its summation order: the whole config-2 forward is bit-identical with `_no_c8`."""
+    import _weights
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.model.pwc_modules import c8_level_ok
+    conf = UPFlow_net.config()
+    conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False, 'norm_moments_across_images': False,
+                 'if_sgu_upsample': True}, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0))
+    net = net.cuda().bfloat16().eval()
+    im1, im2 = _weights.make_images(2, 2, 384, 1280)
+    assert c8_level_ok(4, 96, 320, torch.bfloat16) and not c8_level_ok(4, 24, 80, torch.bfloat16)
+    with torch.no_grad():
+        a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        net._no_c8 = True
+        b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    for k in ('flow_f_out', 'flow_b_out', 'occ_fw', 'occ_bw'):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.isfinite(a['flow_f_out']).all() and float(a['flow_f_out'].abs().mean()) > 0
+
+
+def test_conv3x3_stride2_nchw_to_c8():
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Cin, Cout, H, W = 2, 32, 32, 48, 64
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).bfloat16().cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    want = F.leaky_relu(F.conv2d(x.float(), w.float(), b, padding=1, stride=2), 0.1)
+    y = ops.c8_empty(B, Cout, H // 2, W // 2, torch.bfloat16, 'cuda')
+    ops.conv_c8_forward_raw(None, x, ops.conv3x3_pack(w), b, y, dilation=1, leaky_slope=0.1, stride=2)
+    assert (ops.from_c8(y).float() - want).abs().max() <= 2.0 ** -8 * float(want.abs().max()) + 1e-3
+    ref = torch.empty(B, Cout, H // 2, W // 2, dtype=torch.bfloat16, device='cuda')
+    ops.conv3x3_forward_raw(x, ops.conv3x3_pack(w), b, ref, 1, 0.1, 2)
+    assert torch.equal(ops.from_c8(y), ref)            # the same kernel with another epilogue: bit-identical to the NCHW output

@@ -57,8 +57,8 @@ def test_conv_train_matches_fp32_autograd(case, dtype):
 @pytest.mark.parametrize('case', [(2, 16, 32, 16, 52, 3, 1, 0.1, 1), (2, 96, 64, 8, 26, 3, 1, 0.1, 1), (1, 196, 32, 4, 13, 1, 1, 0.1, 1),
                                   (2, 3, 16, 32, 64, 3, 1, 0.1, 2), (2, 16, 32, 17, 30, 3, 1, 0.1, 2), (1, 32, 32, 9, 21, 3, 1, 0.0, 1)])
 def test_conv_train_ragged_and_strided_layers(case):
-    """Ragged-width levels (weight gradient through PyTorch-ROCm) and the stride-2 layers of the pyramid / SGU guidance
-    (forward on the MFMA kernel, gradients through PyTorch-ROCm): same check as above."""
+    """Ragged-width levels (the ragged launch of the multi-level weight gradient) and the stride-2 layers of the pyramid / SGU
+    guidance (gradients through their space-to-depth form on the stride-1 kernels): same check as above."""
     from upflow_pytorch_amd import ops
     B, Cin, Cout, H, W, k, d, slope, stride = case
     dtype = torch.bfloat16

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of convolution launch options on ONE box, in ONE process: the config-2 inference step is captured once per option set
 (launch shapes are baked into a hipGraph at capture time) and the graphs are replayed alternately, so box-to-box and
-thermal differences cancel.    python tools/ab_bench.py "il=0" "il=1" ["sk_grid=96,il=0" ...]    ("" = defaults)"""
+thermal differences cancel.    python tools/ab_bench.py "" "no_c8=1" ["sk_grid=96,ph_fit=0" ...]    ("" = defaults; no_c8: model switch)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,7 @@ variants = sys.argv[1:] or ['', '']
 runners = []
 for v in variants:
     opts = dict(kv.split('=') for kv in v.split(',') if kv)
+    net._no_c8 = bool(int(opts.pop('no_c8', 0)))          # (model switch, not a library option: NCHW at every level)
     prev = {k: ops.conv_set_option(k, int(val)) for k, val in opts.items()}
     r = GraphedInference(net, B, H, W, device=dev)
     r.load(im1, im2)

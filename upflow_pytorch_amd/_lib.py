@@ -30,6 +30,7 @@ SIGNATURES = {
     'upf_correlation_out_shape': [_i, _i, _i, _i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],
     'upf_warp_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_warp_forward_strided': [_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_warp_forward_c8': [_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_update': [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp],
     'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_forward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -66,7 +66,8 @@ int launch_one_c8(const ArgsC8& a, int slabs) {
 inline int g_c8_rpw4 = 1;      // Cout <= 32 layers on large grids: 16-row tiles (1) or 8-row tiles (0)
 
 // (MTW, tile rows) by Cout and grid like launch() of conv3x3.hip; stride 1; the instantiated subset:
-//   dilation 1 (and 1x1 with an NCHW input): any XL, both output layouts;  dilation 2 / 4 / 8 / 16: C8 in, C8 out
+//   dilation 1 (and 1x1 with an NCHW input): any input layout, both output layouts (NCHW in -> NCHW out is conv3x3.hip's);
+//   dilation 2 / 4 / 8 / 16: C8 in, C8 out
 template <typename T, int XL, bool YC8>
 int launch_c8(const ArgsC8& a) {
   const int mt = cdiv(a.Cout, 32);
@@ -82,7 +83,19 @@ int launch_c8(const ArgsC8& a) {
     set_error("conv_forward_c8: 1x1 kernels take an NCHW input, a C8 output and Cout <= 32");
     return UPF_EUNSUPPORTED;
   }
+  if (a.stride == 2) {                               // NCHW in, C8 out, stride 2: the last layer of the SGU guidance stem
+    if constexpr (XL == 0 && YC8) {
+      if (a.d == 1 && a.Cout <= 32 && a.C2 > 16) return launch_one_c8<T, 1, 2, 2, 4, 1, 0, true>(a, 1);
+    }
+    set_error("conv_forward_c8: stride 2 takes an NCHW input of more than 16 channels, a C8 output of at most 32 channels, dilation 1");
+    return UPF_EUNSUPPORTED;
+  }
   if (a.d == 1) {
+    if constexpr (XL == 0 && YC8) {                  // NCHW in, C8 out: the first layer of a C8 chain (context network conv0)
+      if (mtw == 4) return launch_one_c8<T, 4, 8, 1, 2, 1, 0, true>(a, slabs);
+      if (mtw == 2) return launch_one_c8<T, 2, 4, 1, 4, 1, 0, true>(a, slabs);
+      return launch_one_c8<T, 1, 2, 1, 4, 1, 0, true>(a, slabs);
+    }
     if constexpr (XL >= 1) {
       if (mtw == 4) return launch_one_c8<T, 4, 8, 1, 2, 1, XL, YC8>(a, slabs);
       if (mtw == 2) return launch_one_c8<T, 2, 4, 1, 4, 1, XL, YC8>(a, slabs);
@@ -169,15 +182,15 @@ extern "C" int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, in
   UPF_REQUIRE(B > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_forward_c8: bad shape B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
   UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_c8: bf16 / fp16 only");
   UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_forward_c8: kernel_size %d (1 or 3)", kernel_size);
-  UPF_REQUIRE(stride == 1, UPF_EUNSUPPORTED, "conv_forward_c8: stride %d (1)", stride);
+  UPF_REQUIRE(stride == 1 || (stride == 2 && kernel_size == 3 && dilation == 1 && !x8), UPF_EUNSUPPORTED, "conv_forward_c8: stride %d (1, or 2 for a 3x3 with an NCHW input)", stride);
   UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_forward_c8: dilation %d not in [1,%d]", dilation, conv::MAXD);
-  UPF_REQUIRE(W % 8 == 0, UPF_EUNSUPPORTED, "conv_forward_c8: W = %d is not a multiple of 8 (use upf_conv_forward)", W);
+  UPF_REQUIRE(W % (8 * stride) == 0, UPF_EUNSUPPORTED, "conv_forward_c8: W = %d is not a multiple of %d (use upf_conv_forward)", W, 8 * stride);
   UPF_REQUIRE(!x8 || (aligned_to(x8, 16) && x8_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the C8 input must be 16-byte aligned");
   UPF_REQUIRE(!x2 || (aligned_to(x2, 16) && x2_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the NCHW input must be 16-byte aligned");
   UPF_REQUIRE(!y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the C8 output must be 16-byte aligned");
   UPF_REQUIRE(y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EUNSUPPORTED, "conv_forward_c8: the NCHW output must be 16-byte aligned");
   UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31) && (long long)C2 * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: image too large for one buffer descriptor");
-  UPF_REQUIRE((long long)((Cout + 7) / 8) * H * W * 16 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: output too large for one buffer descriptor");
+  UPF_REQUIRE((long long)((Cout + 7) / 8) * (H / stride + 1) * (W / stride + 1) * 16 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: output too large for one buffer descriptor");
   UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward_c8: leaky_slope %g not in [0,1]", (double)leaky_slope);
   conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, x2, x2_batch_stride, C2, w_packed, bias, y, y_batch_stride,
                  B, Cout, H, W, kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};

@@ -217,6 +217,54 @@ static int pick_cpt(int B, int C, int HW) {
   return cdiv(C, split);
 }
 
+
+// ---- the same warp on CHANNEL-OCTET tensors ([n][c/8][H][W][8], include/upflow_hip.h "C8"): the SGU stack's input is a C8
+// buffer whose first half (feature_1) a convolution wrote as octets; the warped other frame goes straight into its second half.
+// One thread per pixel: position, weights and mask once, then per octet four 16-byte gathers (8 channels of a tap each — the
+// NCHW form needs 2 x 4-byte gathers per CHANNEL) and one 16-byte store.  Same arithmetic per channel as sample():
+// ((nw*w0 + ne*w1) + sw*w2) + se*w3 with exact-zero weights for taps outside the image, so the values equal the NCHW kernel's.
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t v, float& lo, float& hi) { lo = __uint_as_float(v << 16); hi = __uint_as_float(v & 0xffff0000u); }
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t v, float& lo, float& hi) { lo = f16_bits_to_f32(v & 0xffffu); hi = f16_bits_to_f32(v >> 16); }
+
+template <typename T>
+__global__ __launch_bounds__(THREADS)
+void warp_c8_kernel(const T* __restrict__ x, long long xbs, const float* __restrict__ flow, T* __restrict__ y, long long ybs,
+                    int noct, int H, int W, int mask_mode, int shift, SampleGeom sg) {
+  const int HW = H * W;
+  const int p = blockIdx.x * THREADS + threadIdx.x;
+  if (p >= HW) return;
+  const int n = blockIdx.z;
+  const int ns = (n + shift) % (int)gridDim.z;
+  const int i = p / W, j = p - i * W;
+  const float fx = flow[((size_t)n * 2 + 0) * HW + p], fy = flow[((size_t)n * 2 + 1) * HW + p];
+  const Taps t = make_taps(j, i, fx, fy, H, W, sg);
+  const bool valid = taps_valid(t, mask_mode, j, i, fx, fy, H, W);
+  const int xa = min(max(t.x0, 0), W - 1), xb1 = min(max(t.x0 + 1, 0), W - 1);
+  const int ya = min(max(t.y0, 0), H - 1), yb1 = min(max(t.y0 + 1, 0), H - 1);
+  const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
+  const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f, w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
+  const uint4* xo = reinterpret_cast<const uint4*>(x + (size_t)ns * xbs);
+  uint4* yo = reinterpret_cast<uint4*>(y + (size_t)n * ybs) + (size_t)blockIdx.y * HW + p;
+  for (int g = blockIdx.y; g < noct; g += gridDim.y, yo += (size_t)gridDim.y * HW) {
+    uint4 out = make_uint4(0u, 0u, 0u, 0u);
+    if (valid) {
+      const uint4* xp = xo + (size_t)g * HW;
+      const uint4 a = xp[o0], b = xp[o1], c = xp[o2], d = xp[o3];
+      const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
+      uint32_t r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float lo[4], hi[4];
+        unpack2<T>(av[q], lo[0], hi[0]); unpack2<T>(bv[q], lo[1], hi[1]); unpack2<T>(cv[q], lo[2], hi[2]); unpack2<T>(dv[q], lo[3], hi[3]);
+        r[q] = pack2<T>(((lo[0] * w0 + lo[1] * w1) + lo[2] * w2) + lo[3] * w3, ((hi[0] * w0 + hi[1] * w1) + hi[2] * w2) + hi[3] * w3);
+      }
+      out = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+    *yo = out;
+  }
+}
+
 }  // namespace warp
 }  // namespace upf
 
@@ -284,4 +332,24 @@ extern "C" int upf_warp_backward(const void* x, const float* flow, const void* g
                hipLaunchKernelGGL((warp::warp_bwd_finish_kernel<T>), dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, s,
                                   gx64, (T*)gx, n_gx, split ? gf64 : nullptr, gflow, n_gf));
   return check_launch("warp_backward");
+}
+
+extern "C" int upf_warp_forward_c8(const void* x8, long long x_batch_stride, const float* flow, void* y8, long long y_batch_stride,
+                                   int B, int n_oct, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x8 && flow && y8, UPF_EINVAL, "warp_forward_c8: null pointer");
+  UPF_REQUIRE(B > 0 && B <= 65535 && n_oct > 0 && H > 0 && W > 0, UPF_EINVAL, "warp_forward_c8: bad shape B=%d octets=%d H=%d W=%d", B, n_oct, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "warp_forward_c8: bf16 / fp16 only (C8 tensors are 16-bit)");
+  UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_forward_c8: bad mask_mode %d", mask_mode);
+  UPF_REQUIRE(batch_shift >= 0 && batch_shift < B, UPF_EINVAL, "warp_forward_c8: batch_shift %d not in [0,%d)", batch_shift, B);
+  UPF_REQUIRE(aligned_to(x8, 16) && aligned_to(y8, 16) && x_batch_stride % 8 == 0 && y_batch_stride % 8 == 0, UPF_EINVAL, "warp_forward_c8: 16-byte aligned octet tensors expected");
+  const int HW = H * W;
+  const int gy = n_oct < 4 ? n_oct : 4;                 // octets over blockIdx.y (each thread loops over its share)
+  dim3 grid(cdiv(HW, warp::THREADS), gy, B);
+  const SampleGeom sg = make_sample_geom(H, W);
+  if (dtype == UPF_BF16)
+    hipLaunchKernelGGL((warp::warp_c8_kernel<bf16_t>), grid, dim3(warp::THREADS), 0, (hipStream_t)stream, (const bf16_t*)x8, x_batch_stride, flow, (bf16_t*)y8, y_batch_stride, n_oct, H, W, mask_mode, batch_shift, sg);
+  else
+    hipLaunchKernelGGL((warp::warp_c8_kernel<f16_t>), grid, dim3(warp::THREADS), 0, (hipStream_t)stream, (const f16_t*)x8, x_batch_stride, flow, (f16_t*)y8, y_batch_stride, n_oct, H, W, mask_mode, batch_shift, sg);
+  return check_launch("warp_forward_c8");
 }

@@ -178,6 +178,42 @@ class _PackedConv3x3(object):
                                        self.conv.kernel_size[0])
 
 
+class _PackedConvC8(object):
+    """_PackedConv3x3 for the channel-octet entry (ops.conv_c8_forward_raw): weights packed through a channel map — for every
+    channel position of the layer's C8 input slice and for every plane of its NCHW tail the input channel of the Conv2d it
+    carries (-1: padding)."""
+
+    def __init__(self, seq, c8_channels=(), tail_channels=()):
+        self.conv = seq[0]
+        self.slope = 0.1 if any(isinstance(m, nn.LeakyReLU) for m in seq) else 0.0
+        self.maps = (tuple(c8_channels), tuple(tail_channels))
+        self.key = None
+        self.packed = None
+        self.bias = None
+
+    def get(self):
+        w, b = self.conv.weight, self.conv.bias
+        key = (w._version, w.dtype, w.device, w.data_ptr(), b._version, b.data_ptr())
+        if key != self.key:
+            self.packed = ops.conv_c8_pack(w, self.maps[0], self.maps[1])
+            self.bias = self.conv.bias.detach().float().contiguous()
+            self.key = key
+        return self.packed, self.bias
+
+    def invalidate(self):
+        self.key = None
+
+    def __call__(self, x8, x2, y):
+        packed, bias = self.get()
+        return ops.conv_c8_forward_raw(x8, x2, packed, bias, y, self.conv.dilation[0], self.slope, self.conv.kernel_size[0], self.conv.stride[0])
+
+
+def c8_level_ok(nb, H, W, dtype):
+    """Levels whose dense stacks run in the channel-octet layout (ops.conv_c8_*): 16-bit, rows of whole 8-pixel groups, and a
+    grid that fills the chip (the C8 kernels have no split-K form for the coarse levels)."""
+    return dtype in (torch.bfloat16, torch.float16) and W % 8 == 0 and nb * ((W + 31) // 32) * ((H + 7) // 8) >= 200
+
+
 def fast_conv_seq(seq, x, cache, out=None, allow_hip=True):
     """Run one `conv(...)` Sequential (Conv2d [+ LeakyReLU]) — through the matrix-core kernel when it is a
     3x3 (stride 1/2, dilation <= 16) or 1x1 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
@@ -270,6 +306,32 @@ class _DenseStack(tools.abstract_model):
         self._packed[5](x5, out)
         return x5, out
 
+    def c8_ok(self):
+        """The whole stack can live in a channel-octet buffer: every width a whole number of octets."""
+        return self._ch_in % 8 == 0 and all(f % 8 == 0 for f in self._f)
+
+    def forward_in_buffer_c8(self, buf8, out=None):
+        """forward_in_buffer on a channel-octet buffer [B, n_total / 8, H, W, 8] (ops.c8_empty) whose input octets are
+        filled: the same layout in octets, every layer reads an octet suffix by LDS-DMA and writes its octets straight from
+        the accumulators; conv_last writes NCHW planes -> x_out [B, out_channels, H, W]."""
+        if getattr(self, '_packed8', None) is None:
+            nt = self._n_total
+            packed, hi = [], nt - self._ch_in
+            for name, f in zip(self._NAMES, self._f):
+                packed.append(_PackedConvC8(getattr(self, name), range(nt - hi)))      # input = channels [hi, nt) in this order
+                hi -= f
+            packed.append(_PackedConvC8(self.conv_last, range(nt)))
+            self._packed8 = packed
+        no = self._n_total // 8
+        hi = (self._n_total - self._ch_in) // 8
+        for pc, f in zip(self._packed8[:5], self._f):
+            pc(buf8[:, hi:no], None, buf8[:, hi - f // 8:hi])
+            hi -= f // 8
+        if out is None:
+            out = torch.empty((buf8.shape[0], self.conv_last[0].out_channels) + tuple(buf8.shape[2:4]), dtype=buf8.dtype, device=buf8.device)
+        self._packed8[5](buf8[:, :no], None, out)
+        return out
+
     def _train_convs(self):
         """conv1..conv5, conv_last as plain nn.Conv2d if every Sequential is Conv2d [+ LeakyReLU] (no norm layers)."""
         seqs = [getattr(self, n) for n in self._NAMES] + [self.conv_last]
@@ -349,6 +411,22 @@ class ContextNetwork_v2_(nn.Module):
         for seq in self.convs:                      # the dilation-16 layer falls back to MIOpen inside
             x = fast_conv_seq(seq, x, cache)
         return x
+
+    def forward_c8(self, x):
+        """Inference on a large grid (c8_level_ok): the chain in the channel-octet layout — conv0 reads the NCHW estimator
+        buffer and writes octets, conv1..5 read and write octets (LDS-DMA staging), conv6 writes the two NCHW flow planes."""
+        if getattr(self, '_packed8', None) is None:
+            chans = [s_[0].in_channels for s_ in self.convs]
+            self._packed8 = [_PackedConvC8(self.convs[0], (), range(chans[0]))] + \
+                            [_PackedConvC8(self.convs[i], range(chans[i])) for i in range(1, 7)]
+        B, _, H, W = x.shape
+        t = None
+        for i, pc in enumerate(self._packed8):
+            co = self.convs[i][0].out_channels
+            y = ops.c8_empty(B, co, H, W, x.dtype, x.device) if i < 6 else torch.empty((B, co, H, W), dtype=x.dtype, device=x.device)
+            pc(None if i == 0 else t, x if i == 0 else None, y)
+            t = y
+        return t
 
 
 class ContextNetwork(ContextNetwork_v2_):

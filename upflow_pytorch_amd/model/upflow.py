@@ -31,7 +31,7 @@ from ..utils.tools import tools
 from ..utils.loss import loss_functions
 from .pwc_modules import (conv, initialize_msra, upsample2d_flow_as, upsample_flow, FlowEstimatorDense_v2,
                           ContextNetwork_v2_, WarpingLayer_no_div, FeatureExtractor, _DenseStack, _fast_conv_ok,
-                          fast_conv_seq)
+                          fast_conv_seq, c8_level_ok, _PackedConvC8)
 from .correlation_package.correlation import Correlation
 
 
@@ -82,10 +82,27 @@ class network_tools():
             _, x_out = self.dense_estimator_mask.forward_in_buffer(buf)
             return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)   # (flow_init, flow_up, None, None)
 
-        def output_conv(self, x, out=None):
+        def forward_in_buffer_c8(self, flow_init, buf8, output_level_flow=None, batch_shift=0):
+            """forward_in_buffer with the estimator's buffer in the channel-octet layout (pwc_modules.c8_level_ok): feature_1 is
+            already in its octets (written there by the 1x1 convolution); the other frame's features are warped from those
+            octets into the second half, the stack runs on octets, x_out comes back as NCHW planes for the blend."""
+            est = self.dense_estimator_mask
+            o0 = (est._n_total - est._ch_in) // 8
+            half = est._ch_in // 16
+            ops.warp_c8_into(buf8[:, o0:o0 + half], flow_init, buf8[:, o0 + half:o0 + 2 * half], self.warping_layer.mask_mode, batch_shift)
+            x_out = est.forward_in_buffer_c8(buf8)
+            return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)
+
+        def output_conv(self, x, out=None, out8=None):
+            """out8: octet slice of a channel-octet buffer the LAST layer writes instead of `out` (forward_in_buffer_c8)."""
             cache = self.__dict__.setdefault('_fast_cache', {})
             n = len(self.upsample_output_conv)
             for i, seq in enumerate(self.upsample_output_conv):       # matrix-core kernel when eligible
+                if i == n - 1 and out8 is not None:
+                    pc = cache.get('c8_last')
+                    if pc is None:
+                        pc = cache['c8_last'] = _PackedConvC8(seq, (), range(seq[0].in_channels))
+                    return pc(None, x, out8)
                 x = fast_conv_seq(seq, x, cache, out=out if i == n - 1 else None)
             return x
 
@@ -450,7 +467,20 @@ class UPFlow_net(tools.abstract_model):
             C, H, W = shapes[level]
             buf, slot = est.alloc_buffer(nb, H, W, dt, dev, tail=2)
             use_sgu = sgu and level > 0
-            if use_sgu:
+            # large grids: the SGU stack and the context network run in the channel-octet layout (same arithmetic, same
+            # summation order: bit-identical outputs; `_no_c8 = True` keeps NCHW everywhere)
+            c8 = c8_level_ok(nb, H, W, dt) and not getattr(self, '_no_c8', False)
+            sbuf8 = None
+            if use_sgu and c8 and sgi.dense_estimator_mask.c8_ok():
+                em = sgi.dense_estimator_mask
+                sbuf8 = ops.c8_empty(nb, em._n_total, H, W, dt, dev)
+                o0 = (em._n_total - em._ch_in) // 8
+                pc = cache.get(('c8_1x1', level))
+                if pc is None:
+                    pc = cache[('c8_1x1', level)] = _PackedConvC8(self.conv_1x1[level], (), range(C))
+                pc(None, Fm, sbuf8[:, o0:o0 + 4])                               # feature_1 as octets for the SGU stack
+                fast_conv_seq(self.conv_1x1[level], Fm, cache, out=slot[:, nc:nc + 32])   # ... and as planes for the estimator
+            elif use_sgu:
                 sbuf, sslot = sgi.dense_estimator_mask.alloc_buffer(nb, H, W, dt, dev)
                 A = fast_conv_seq(self.conv_1x1[level], Fm, cache, out=sslot[:, :32])
                 slot[:, nc:nc + 32].copy_(A)
@@ -461,7 +491,9 @@ class UPFlow_net(tools.abstract_model):
                 pair[1, :B].copy_(Fm[B:])
                 pair[1, B:].copy_(Fm[:B])
             else:
-                if use_sgu:
+                if sbuf8 is not None:
+                    flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B)[1]
+                elif use_sgu:
                     flow_up = sgi.forward_in_buffer(flow_up, sbuf, sslot, batch_shift=B)[1]
                 ops.warp_into(Fm, flow_up, pair[1], self.warping_layer.mask_mode, B)
             if ops.corr81_norm_supported(pair) and not getattr(self, '_no_fused_norm', False):
@@ -473,17 +505,27 @@ class UPFlow_net(tools.abstract_model):
             ops.flow_update(flow_up, out=slot[:, nc + 32:])
             _, res = est.forward_in_buffer(buf)
             ops.flow_update(flow_up, res, out=buf[:, est._n_total:])          # flow_up + res -> context network input
-            fine = self.context_networks(buf)
+            fine = self.context_networks.forward_c8(buf) if c8 else self.context_networks(buf)
             flow = ops.flow_update(flow_up, res, fine)                        # flow_up + (res + fine)
             flows.append([flow[:B], flow[B:]])
         flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
         if sgu:
             H4, W4 = flow.shape[2:]
-            sbuf, sslot = sgi.dense_estimator_mask.alloc_buffer(nb, H4, W4, dt, dev)
-            G = sgi.output_conv(X, out=sslot[:, :32])
-            if tuple(G.shape[2:]) != (H4, W4):
-                raise RuntimeError('sgu output_conv / flow size mismatch %s vs %s' % (tuple(G.shape), tuple(flow.shape)))
-            flow_out = sgi.forward_in_buffer(flow, sbuf, sslot, output_level_flow=flow_out, batch_shift=B)[1]
+            em = sgi.dense_estimator_mask
+            last = sgi.upsample_output_conv[-1][0]
+            if (c8_level_ok(nb, H4, W4, dt) and not getattr(self, '_no_c8', False) and em.c8_ok() and X.shape[3] % 32 == 0
+                    and last.stride[0] == 2 and last.in_channels > 16 and last.out_channels == em._ch_in // 2
+                    and ops.conv3x3_out_hw(X.shape[2] // 2, X.shape[3] // 2, 2) == (H4, W4) and X.shape[2] % 2 == 0):
+                sbuf8 = ops.c8_empty(nb, em._n_total, H4, W4, dt, dev)
+                o0 = (em._n_total - em._ch_in) // 8
+                sgi.output_conv(X, out8=sbuf8[:, o0:o0 + em._ch_in // 16])          # the guidance stem's last layer writes octets
+                flow_out = sgi.forward_in_buffer_c8(flow, sbuf8, output_level_flow=flow_out, batch_shift=B)[1]
+            else:
+                sbuf, sslot = em.alloc_buffer(nb, H4, W4, dt, dev)
+                G = sgi.output_conv(X, out=sslot[:, :32])
+                if tuple(G.shape[2:]) != (H4, W4):
+                    raise RuntimeError('sgu output_conv / flow size mismatch %s vs %s' % (tuple(G.shape), tuple(flow.shape)))
+                flow_out = sgi.forward_in_buffer(flow, sbuf, sslot, output_level_flow=flow_out, batch_shift=B)[1]
         return flow_out[:B], flow_out[B:], flows[::-1]
 
     def _level_update(self, Fn, Fwn, A, flow_up, add_to_flow=False):

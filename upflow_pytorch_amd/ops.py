@@ -246,6 +246,23 @@ def warp_into(x_view, flow, y_view, mask_mode='literal', batch_shift=0):
     return y_view
 
 
+def warp_c8_into(x8, flow, y8, mask_mode='literal', batch_shift=0):
+    """warp_into on channel-octet tensors: x8 / y8 are octet slices [B, n_oct, H, W, 8] of C8 buffers (conv_c8_forward_raw)."""
+    if x8.shape != y8.shape or not _c8_view_ok(x8) or not _c8_view_ok(y8) or x8.dtype != y8.dtype:
+        raise UpflowHipError('warp_c8_into: x8 / y8 must be equal-shape octet slices of contiguous C8 buffers')
+    flow = _f32(flow).contiguous()
+    B, n, H, W, _ = x8.shape
+    if flow.shape != (B, 2, H, W):
+        raise UpflowHipError('warp_c8_into: flow [B,2,H,W] expected, got %s' % (tuple(flow.shape),))
+    dev = x8.device
+    if not (x8.is_cuda and y8.is_cuda and flow.is_cuda):
+        raise UpflowHipError('warp_c8_into: GPU tensors expected (there is no CPU fallback)')
+    with torch.cuda.device(dev):
+        _lib.call('upf_warp_forward_c8', _lib.ptr(x8), x8.stride(0), _lib.ptr(flow), _lib.ptr(y8), y8.stride(0),
+                  B, n, H, W, _lib.dtype_code(x8), _MASKS[mask_mode], int(batch_shift), _lib.stream_ptr(dev))
+    return y8
+
+
 def flow_update(a, b=None, c=None, out=None):
     """out = cast(a + (b + c)) in fp32 (b, c optional 16-bit conv outputs): the per-level flow bookkeeping
     (model/upflow.py:566-572) in one launch.  a: fp32 [N,C,H,W]; out: None (new fp32 tensor), or an fp32 / 16-bit
@@ -556,32 +573,33 @@ def conv_c8_supported(H, W, dtype, Cout, dilation, kernel_size, has_c8_in, has_t
     if kernel_size == 1:
         return (not has_c8_in) and has_tail and y_is_c8 and Cout <= 32
     if dilation == 1:
-        return has_c8_in
+        return has_c8_in or (has_tail and y_is_c8)
     return dilation in (2, 4, 8, 16) and has_c8_in and not has_tail and y_is_c8
 
 
-def conv_c8_forward_raw(x8, x2, packed, bias32, y, dilation=1, leaky_slope=0.0, kernel_size=3):
+def conv_c8_forward_raw(x8, x2, packed, bias32, y, dilation=1, leaky_slope=0.0, kernel_size=3, stride=1):
     """x8: C8 view [B, n_oct, H, W, 8] (an octet slice of a C8 buffer) or None; x2: NCHW channel slice [B, C2, H, W] or None;
     y: a C8 view [B, n_oct_out, H, W, 8] with Cout = its channel count given by bias32, or an NCHW channel slice."""
     ref = x8 if x8 is not None else x2
     B, H, W = ref.shape[0], ref.shape[2], ref.shape[3]
     Cout = bias32.shape[0]
     y_is_c8 = y.dim() == 5
+    Ho, Wo = conv3x3_out_hw(H, W, stride)
     if x8 is not None and not _c8_view_ok(x8):
         raise UpflowHipError('conv_c8: x8 must be an octet slice of a contiguous C8 buffer')
     if x2 is not None and x2.stride()[1:] != (H * W, W, 1):
         raise UpflowHipError('conv_c8: x2 must be a channel slice of a contiguous NCHW buffer')
     if y_is_c8:
-        if not _c8_view_ok(y) or tuple(y.shape) != (B, (Cout + 7) // 8, H, W, 8):
-            raise UpflowHipError('conv_c8: C8 output must be [%d,%d,%d,%d,8], got %s' % (B, (Cout + 7) // 8, H, W, tuple(y.shape)))
-    elif tuple(y.shape) != (B, Cout, H, W) or y.stride()[1:] != (H * W, W, 1):
-        raise UpflowHipError('conv_c8: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, H, W))
+        if not _c8_view_ok(y) or tuple(y.shape) != (B, (Cout + 7) // 8, Ho, Wo, 8):
+            raise UpflowHipError('conv_c8: C8 output must be [%d,%d,%d,%d,8], got %s' % (B, (Cout + 7) // 8, Ho, Wo, tuple(y.shape)))
+    elif tuple(y.shape) != (B, Cout, Ho, Wo) or y.stride()[1:] != (Ho * Wo, Wo, 1):
+        raise UpflowHipError('conv_c8: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, Ho, Wo))
     dev = ref.device
     with torch.cuda.device(dev):
         _lib.call('upf_conv_forward_c8', _lib.ptr(x8), x8.stride(0) if x8 is not None else 0, x8.shape[1] if x8 is not None else 0,
                   _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, x2.shape[1] if x2 is not None else 0,
                   _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y), y.stride(0), int(y_is_c8), B, Cout, H, W, int(kernel_size),
-                  int(dilation), 1, float(leaky_slope), _lib.dtype_code(ref), _lib.stream_ptr(dev))
+                  int(dilation), int(stride), float(leaky_slope), _lib.dtype_code(ref), _lib.stream_ptr(dev))
     return y
 
 
