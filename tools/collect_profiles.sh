@@ -1,16 +1,16 @@
 #!/bin/bash
-# Everything under profiles/r02_* in one go (run on the GPU box; results land in gpurun_out/profiles/).
+# Everything under profiles/${ROUND}_* in one go (run on the GPU box; results land in gpurun_out/profiles/).
 R=$(pwd); export TMPDIR=/tmp
 P=$R/gpurun_out/profiles; mkdir -p $P
 # 1. the default bench command under rocprofv3 (kernel trace + stats), and the same bench line un-profiled
-python bench.py > $P/r02_bench_config2_default.json 2> /dev/null
+python bench.py > $P/r03_bench_config2_default.json 2> /dev/null
 rm -rf $R/gpurun_out/prof_bench; mkdir -p $R/gpurun_out/prof_bench
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_bench/bench.log 2>&1)
 python - <<PY
 import csv, glob
 f = glob.glob('$R/gpurun_out/prof_bench/*/*kernel_stats.csv')[0]
 rows = list(csv.DictReader(open(f)))
-out = open('$P/r02_bench_default_rocprof_stats.txt', 'w')
+out = open('$P/r03_bench_default_rocprof_stats.txt', 'w')
 out.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline   (MI355X; config 2, hipGraph replay, 10 warm-up + 50 timed steps,\n# then the roofline probes: 220 + 30 launches of the cost volume at [8,32,96,320], 55 of the 565->128 convolution)\n')
 out.write('# bench line of this run: ' + [l for l in open('$R/gpurun_out/prof_bench/bench.log').read().split('\\n') if l.startswith('{')][-1] + '\\n')
 out.write('%-150s %8s %14s %12s %8s\\n' % ('kernel', 'calls', 'total_ns', 'avg_ns', 'pct'))
@@ -19,21 +19,24 @@ for r in rows[:45]:
 PY
 # 2. one steady-state forward, eager (per-kernel table)
 rm -rf $R/gpurun_out/prof_eager; mkdir -p $R/gpurun_out/prof_eager
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_eager -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_eager/bench.log 2>&1)
-(echo "# rocprofv3 --kernel-trace --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph   (tools/steady_profile.py on the trace)"; python tools/steady_profile.py $(ls $R/gpurun_out/prof_eager/*/*kernel_trace.csv | head -1)) > $P/r02_bench_config2_eager_kernel_stats.txt
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_eager -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-probe --no-graph > $R/gpurun_out/prof_eager/bench.log 2>&1)
+(echo "# rocprofv3 --kernel-trace --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-probe --no-graph   (tools/steady_profile.py on the trace)"; python tools/steady_profile.py $(ls $R/gpurun_out/prof_eager/*/*kernel_trace.csv | head -1)) > $P/r03_bench_config2_eager_kernel_stats.txt
 # 3. training steps
-tools/train_profile.sh train_bf16 --dtype bf16 --no-graph > /dev/null 2>&1
-tools/train_profile.sh train_fp32 --no-graph > /dev/null 2>&1
-python bench.py --mode train --dtype bf16 > $P/r02_train_bf16_bench.json 2>/dev/null
-python bench.py --mode train > $P/r02_train_fp32_bench.json 2>/dev/null
-# 4. cost volume: rocprof + PMC at the 1/4-resolution level of configs 2, 4, 5; level table
-tools/prof_corr_run.sh 8 32 96 320 bf16 l4_cfg2_stacked_bf16 > /dev/null 2>&1
-tools/prof_corr_run.sh 4 32 96 320 bf16 l4_cfg2_bf16 > /dev/null 2>&1
-tools/prof_corr_run.sh 2 32 240 720 bf16 l4_cfg5_stacked_bf16 > /dev/null 2>&1
-tools/prof_corr_run.sh 1 32 240 720 bf16 l4_cfg5_bf16 > /dev/null 2>&1
-tools/prof_corr_run.sh 16 32 112 256 fp16 l4_cfg4_stacked_fp16 > /dev/null 2>&1
-python tools/corr_levels.py > $R/gpurun_out/corr_levels.log 2>&1
-python tools/corr_levels.py 2 --stacked >> $R/gpurun_out/corr_levels.log 2>&1
+tools/train_profile.sh train_bf16 --no-graph > /dev/null 2>&1
+tools/train_profile.sh train_fp32 --dtype fp32 --no-graph > /dev/null 2>&1
+python bench.py --mode train > $P/r03_train_bf16_bench.json 2>/dev/null
+python bench.py --mode train --dtype fp32 > $P/r03_train_fp32_bench.json 2>/dev/null
+# 4. cost volume: rocprof + PMC of the NORMALISING variant (the kernel inside the step) at the 1/4-resolution level of configs 2 and 5
+if [ -z "$SKIP_CORR" ]; then
+tools/prof_corr_run.sh 8 32 96 320 bf16 norm_l4_cfg2_stacked_bf16 norm > /dev/null 2>&1
+tools/prof_corr_run.sh 2 32 240 720 bf16 norm_l4_cfg5_stacked_bf16 norm > /dev/null 2>&1
+fi
 # 5. every other operator at the level shapes
-python tools/kbench.py > $P/r02_kbench.txt 2>&1
+python tools/kbench.py > $P/r03_kbench.txt 2>&1
+# 6. every convolution of one config-2 step, per layer (and the C8 variants of the layers the model runs in C8)
+python tools/conv_layers.py > $P/r03_conv_layers.txt 2>&1
+python tools/conv_layers.py --c8 > $P/r03_conv_layers_c8.txt 2>&1
+# the raw traces are hundreds of MB: only the summaries travel back (gpurun merges <= 64 MiB)
+rm -rf $R/gpurun_out/prof_bench/*/ $R/gpurun_out/prof_eager/*/ $R/gpurun_out/prof_train_bf16/trace $R/gpurun_out/prof_train_fp32/trace
+du -sh $R/gpurun_out
 ls -la $P

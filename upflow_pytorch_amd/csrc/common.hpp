@@ -137,7 +137,9 @@ template <> struct VecIO<f16_t> {
 // ---- deterministic scatter-add: 64-bit fixed point (value * 2^44) through native integer atomics ---------------------
 // Integer addition is associative, so the accumulated value does not depend on the arrival order of the workgroups
 // (fp32 atomicAdd does).  Quantum 2^-44 = 5.7e-14, range +-2^19.  Used by the backward kernels whose inverse map is
-// unbounded (warp, SGU blend).
+// unbounded (warp, SGU blend).  LIMITS: one contribution is clamped to +-4e18 * 2^-44 = +-2.3e5, but the SUM is
+// not: two or more contributions whose total passes +-2^19 = 5.2e5 wrap around silently.  Gradient elements of that size only
+// occur once a training run has diverged (the loss terms are O(1) means); INTEGRATION.md states the range.
 constexpr float FIX_SCALE = 17592186044416.0f;        // 2^44
 constexpr float FIX_INV = 1.0f / 17592186044416.0f;
 __device__ __forceinline__ void fix_add(unsigned long long* p, float v) {
