@@ -24,6 +24,10 @@
 #include "common.hpp"
 #include "norm_merge.hpp"
 
+#ifndef UPF_ALLC_ABL
+#define UPF_ALLC_ABL 0     // tools/corr_norm_ablate.hip: 1 no normalisation arithmetic, 2 no merge arithmetic, 4 no statistics loads, 8 no barrier after the merge
+#endif
+
 namespace upf {
 namespace corrx {
 
@@ -150,16 +154,46 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
     }
   };
   // ---- NORM: merge the (count, mean, M2) partials of the 2 x C rows of item n -> (mean, rstd) in LDS
-  auto merge_stats = [&](int n) {
+  // Two steps around issue(): the partials are LOADED first (older than the feature loads, so the wait for them does not
+  // wait for the features: vmcnt retires in order) and MERGED — two IEEE divisions per segment, a square root and a
+  // reciprocal — while the feature loads are in flight.  (Round 2 loaded them after issue(): the merge then started only
+  // when every feature load had landed, ~2 us of a 28 us launch.)
+  constexpr int PRE = 4;                                  // segments held in registers; further ones (rare: one huge plane) are read in the merge
+  float pw[PRE * 3];
+  const float* wrow = nullptr;
+  auto load_stats = [&](int n) {
+    if constexpr (NORM) {
+      const int c4 = KQ * 4;
+      wrow = nullptr;
+      if (tid < 2 * c4) {
+        const int sel = tid >= c4, c = tid - sel * c4;
+        if (c < C && !(UPF_ALLC_ABL & 4)) {
+          wrow = (sel ? ws2 : ws1) + ((size_t)n * C + c) * nseg * 3;
+#pragma unroll
+          for (int k = 0; k < PRE; ++k)
+            if (k < nseg) { pw[3 * k] = wrow[3 * k]; pw[3 * k + 1] = wrow[3 * k + 1]; pw[3 * k + 2] = wrow[3 * k + 2]; }
+        }
+      }
+    }
+  };
+  auto merge_stats = [&]() {
     if constexpr (NORM) {
       const int c4 = KQ * 4;
       if (tid < 2 * c4) {
-        const int sel = tid >= c4, c = tid - sel * c4;
         float2 ms = make_float2(0.f, 0.f);             // channels >= C: (x - 0) * 0 keeps the zero padding of the quad
-        if (c < C) ms = norm_merge((sel ? ws2 : ws1) + ((size_t)n * C + c) * nseg * 3, nseg, H * W);
+        if ((UPF_ALLC_ABL & 2) && wrow) ms = make_float2(pw[1], pw[2]);
+        else if (wrow) {
+          MergeState s = {pw[0], pw[1], pw[2]};
+#pragma unroll
+          for (int k = 1; k < PRE; ++k)
+            if (k < nseg) norm_merge_add(s, pw[3 * k], pw[3 * k + 1], pw[3 * k + 2]);
+          for (int k = PRE; k < nseg; ++k) norm_merge_add(s, wrow[3 * k], wrow[3 * k + 1], wrow[3 * k + 2]);
+          const RowStats r = norm_merge_finish(s, H * W);
+          ms = make_float2(r.mean, r.rstd);
+        }
         st[tid] = ms;
       }
-      __syncthreads();
+      if (!(UPF_ALLC_ABL & 8)) __syncthreads();
     }
   };
   // ---- 4 channel rows x 4 pixels -> 4 pixel entries of 4 channels (v_perm), 2 ds_write_b128 per task
@@ -179,7 +213,7 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
         }
       }
       u32x2 v[4] = {raw[j][0], raw[j][1], raw[j][2], raw[j][3]};
-      if constexpr (NORM) {
+      if constexpr (NORM && !(UPF_ALLC_ABL & 1)) {
         if (task[j].nv() != 0) {
           const bool from_f2 = __builtin_amdgcn_readfirstlane((tid & ~63) + j * NTHREADS) >= N1;
           const float2* sp = st + (from_f2 ? KQ * 4 : 0) + task[j].kq() * 4;
@@ -308,8 +342,9 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
   // tile order: consecutive workgroups (after the XCD remap) own consecutive tiles; with TPW = 2 a workgroup's two tiles
   // are gridDim.x apart, so that both halves of the grid sweep the images in the same order
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  load_stats(bid / ntiles);
   issue(bid, true);
-  merge_stats(bid / ntiles);
+  merge_stats();
   land();
   __syncthreads();
   if constexpr (TPW == 2) {
@@ -319,7 +354,8 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
     compute(bid);
     __syncthreads();                                                    // every wave is done reading the first tile
     if (live2) {
-      merge_stats(tile2 / ntiles);
+      load_stats(tile2 / ntiles);
+      merge_stats();
       land();
       __syncthreads();
       compute(tile2);
