@@ -78,6 +78,13 @@ long long upf_corr81_norm_workspace_bytes(int B, int C, int H, int W);
 int upf_corr81_norm_forward(const void* f1, const void* f2, void* out,
                             int B, int C, int H, int W, int dtype,
                             long long out_batch_stride, float leaky_slope, void* workspace, void* stream);
+/* The same into channel octets (round 3; the flow estimator's input buffer in the C8 layout of upf_conv_forward_c8):
+ * out8 = the first of 11 octets of a [n][octet][H][W][8] buffer, out8_batch_stride its batch stride in elements.
+ * Octet j < 9: displacements (dy = j-4, dx = -4..+3) in positions 0..7; octet 9 position p: (dy = p-4, dx = +4);
+ * octet 10 position 0: (+4,+4), positions 1..7 zero.  The convolution reading it learns this order through the k-map
+ * of upf_conv_pack_weights_kmap.  Values are bit-identical to upf_corr81_norm_forward's.  W % 8 == 0. */
+int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* out8, long long out8_batch_stride,
+                               int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream);
 /* measurement helper (bench.py): one statistics launch, then nrep launches of the normalising cost volume, each between
  * its own pair of HIP events on `stream` — the kernel that runs inside the inference step */
 int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out,
@@ -297,6 +304,10 @@ int upf_conv_bias_grad(const void* grad_pre, long long g_batch_stride, float* gr
  * rows out_batch_stride elements apart (0 = per_item). */
 int upf_flow_update(const float* a, const void* b, const void* c, void* out, long long out_batch_stride,
                     int out_is_f32, int N, int per_item, int dtype, void* stream);
+/* The same sum of a 2-channel flow a : [N,2,HW] (b, c likewise) written as one octet of a C8 buffer: positions 0, 1 = the two
+ * components, positions 2..7 = 0.  out8 : the octet, out8_batch_stride in elements. */
+int upf_flow_update_c8(const float* a, const void* b, const void* c, void* out8, long long out8_batch_stride,
+                       int N, int HW, int dtype, void* stream);
 
 /* ---- occlusion check  (tools.occ_check_model(obj), utils/tools.py:519-588, 641-677) -------------
  * flow_f, flow_b : [B,2,H,W] fp32 -> occ_fw, occ_bw : [B,1,H,W] fp32 in {0,1}. */

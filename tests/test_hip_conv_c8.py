@@ -144,6 +144,7 @@ def test_whole_net_c8_levels_are_bit_identical_to_nchw():
     net = net.cuda().bfloat16().eval()
     im1, im2 = _weights.make_images(2, 2, 384, 1280)
     assert c8_level_ok(4, 96, 320, torch.bfloat16) and not c8_level_ok(4, 24, 80, torch.bfloat16)
+    net._no_c8_est = True              # (the estimator's octet form has another K order: its own test below)
     with torch.no_grad():
         a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
         net._no_c8 = True
@@ -151,6 +152,78 @@ def test_whole_net_c8_levels_are_bit_identical_to_nchw():
     for k in ('flow_f_out', 'flow_b_out', 'occ_fw', 'occ_bw'):
         assert torch.equal(a[k], b[k]), k
     assert torch.isfinite(a['flow_f_out']).all() and float(a['flow_f_out'].abs().mean()) > 0
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(8, 32, 96, 320), (2, 64, 48, 160), (2, 96, 24, 80), (1, 196, 8, 24)])
+def test_corr81_norm_c8_is_the_nchw_cost_volume_in_octet_order(shape, dt):
+    """upf_corr81_norm_forward_c8 writes the SAME 81 values as upf_corr81_norm_forward (bit for bit), in the octet order of
+    ops.corr81_c8_channel_map, zeros in the 7 padding positions; every tile geometry of the kernel (C = 32 ... 196)."""
+    from upflow_pytorch_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    f1 = (torch.randn(B, C, H, W, generator=g) * 2 + 0.3).to(dt).cuda()
+    f2 = (torch.randn(B, C, H, W, generator=g) * 2 - 0.1).to(dt).cuda()
+    want = ops.corr81_norm_forward_raw(f1, f2, leaky_slope=0.1)
+    buf8 = torch.full((B, 14, H, W, 8), float('nan'), dtype=dt, device='cuda')       # (a slice of a wider buffer)
+    ops.corr81_norm_forward_c8(f1, f2, buf8[:, 2:13], leaky_slope=0.1)
+    got = buf8[:, 2:13].permute(0, 1, 4, 2, 3).reshape(B, 88, H, W)
+    m = ops.corr81_c8_channel_map()
+    assert sorted(c for c in m if c >= 0) == list(range(81)) and len(m) == 88
+    for p, c in enumerate(m):
+        if c >= 0:
+            assert torch.equal(got[:, p], want[:, c]), (p, c)
+        else:
+            assert float(got[:, p].float().abs().max()) == 0.0
+    assert torch.isnan(buf8[:, :2].float()).all() and torch.isnan(buf8[:, 13:].float()).all()      # nothing outside the 11 octets
+
+
+def test_flow_update_c8():
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(4, 2, 24, 40, generator=g).cuda()
+    b = torch.randn(4, 2, 24, 40, generator=g).bfloat16().cuda()
+    c = torch.randn(4, 2, 24, 40, generator=g).bfloat16().cuda()
+    for bb, cc in ((None, None), (b, None), (b, c)):
+        buf8 = torch.full((4, 3, 24, 40, 8), float('nan'), dtype=torch.bfloat16, device='cuda')
+        ops.flow_update_c8(a, bb, cc, buf8[:, 1:2])
+        want = ops.flow_update(a, bb, cc, out=torch.empty(4, 2, 24, 40, dtype=torch.bfloat16, device='cuda'))
+        got = buf8[:, 1].permute(0, 3, 1, 2)
+        assert torch.equal(got[:, :2], want) and float(got[:, 2:].float().abs().max()) == 0.0
+        assert torch.isnan(buf8[:, 0].float()).all() and torch.isnan(buf8[:, 2].float()).all()
+
+
+@pytest.mark.parametrize('dt,size', [(torch.bfloat16, (384, 1280)), (torch.float16, (448, 1024))])
+def test_whole_net_with_the_estimator_in_octets(dt, size):
+    """The flow estimator of the two fine levels in the channel-octet layout (cost volume, 1x1 features and flows written as
+    octets; UPFlow_net._level_c8) is the same arithmetic with another K order inside the matrix-core sums: the whole forward
+    stays within the 16-bit envelope of the NCHW path — compared with the fp32 forward it is as close as the NCHW path is."""
+    import _weights
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    conf = UPFlow_net.config()
+    conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False, 'norm_moments_across_images': False,
+                 'if_sgu_upsample': True, 'warp_mask_mode': 'robust'}, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0))
+    net = net.cuda().eval()
+    im1, im2 = _weights.make_images(2, 4, *size)
+    with torch.no_grad():
+        ref = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        net = net.to(dt)
+        calls = []
+        orig = net._level_c8
+        net._level_c8 = lambda *a, **k: (calls.append(a[0]), orig(*a, **k))[1]
+        a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        net._no_c8_est = True
+        b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    assert len(calls) == 2                                                   # the two fine levels took the octet path
+    for k in ('flow_f_out', 'flow_b_out'):
+        ea = float((a[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())
+        eb = float((b[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())
+        eab = float((a[k].float() - b[k].float()).pow(2).sum(1).sqrt().mean())
+        print('%s %s: EPE vs fp32: octets %.5f px, NCHW %.5f px; octets vs NCHW %.5f px' % (k, dt, ea, eb, eab))
+        assert torch.isfinite(a[k]).all()
+        assert ea <= 1.25 * eb + 1e-4 and eab <= 1.5 * eb + 1e-4
 
 
 def test_conv3x3_stride2_nchw_to_c8():

@@ -19,6 +19,7 @@ runners = []
 for v in variants:
     opts = dict(kv.split('=') for kv in v.split(',') if kv)
     net._no_c8 = bool(int(opts.pop('no_c8', 0)))          # (model switch, not a library option: NCHW at every level)
+    net._no_c8_est = bool(int(opts.pop('no_c8_est', 0)))  # (model switch: the flow estimator of the fine levels in NCHW)
     prev = {k: ops.conv_set_option(k, int(val)) for k, val in opts.items()}
     r = GraphedInference(net, B, H, W, device=dev)
     r.load(im1, im2)

@@ -111,6 +111,12 @@ def main_c8():
             items.append(('est.conv%d' % (i + 1), c8, 83, f, 1, True)); c8 += f
         items.append(('est.conv_last', c8, 83, 2, 1, False))
         items.append(('ctx.conv0', 480, 85, 128, 1, True))
+        if '--pure' in sys.argv:                     # what the estimator would cost if corr81 / features / flows were octets too
+            c8 = 120                                 # 81 + 32 + 2 + 2 = 117 channels -> 15 octets
+            for i, f in enumerate((128, 128, 96, 64, 32)):
+                items.append(('est.conv%d/pure' % (i + 1), c8, 0, f, 1, True)); c8 += f
+            items.append(('est.conv_last/pure', c8, 0, 2, 1, False))
+            items.append(('ctx.conv0/pure', 568, 0, 128, 1, True))
         ch = (128, 128, 128, 96, 64, 32, 2)
         for i, d in enumerate((2, 4, 8, 16, 1)):
             items.append(('ctx.conv%d' % (i + 1), ch[i], 0, ch[i + 1], d, True))

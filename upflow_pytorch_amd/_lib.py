@@ -32,6 +32,8 @@ SIGNATURES = {
     'upf_warp_forward_strided': [_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_warp_forward_c8': [_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_update': [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp],
+    'upf_flow_update_c8': [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp],
+    'upf_corr81_norm_forward_c8': [_vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp],
     'upf_warp_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_forward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_backward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -87,7 +87,12 @@ struct Task {      // two registers per task: NT = 8 tasks + their 64 raw-data r
 // before the matrix work of the first and lands them in LDS afterwards.  Measured on MI355X and NOT used: 31.5 us instead
 // of 23.8 us at [8,32,96,320] (57.6 vs 39.4 at [16,32,112,256]) — the two tiles of a workgroup serialise (load, compute,
 // land, compute) while two rounds of independent workgroups, two resident per CU, overlap each other's phases for free.
-template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, int TPW = 1>
+// OC8 (!RAGGED): the 81 channels leave as 11 channel octets of a C8 buffer [n][octet][H][W][8] (conv_c8.hip), out_bs = its batch
+// stride in elements, `out` = the first of the 11 octets.  Octet j < 9 holds displacements (dy = j - 4, dx = -4 .. +3), octet 9
+// position p holds (dy = p - 4, dx = +4), octet 10 position 0 holds (+4, +4) and zeros: a wave (= one dy) stores ONE whole
+// 16-byte entry per pixel straight from its registers (no transposition patch) + one 2-byte element.  The convolution that
+// reads the buffer gets this order through its k-map (upf_conv_pack_weights_kmap; ops.corr81_c8_channel_map).
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, int TPW = 1, bool OC8 = false>
 __global__ __launch_bounds__(NTHREADS, 5)       // <= 102 VGPRs: two 9-wave workgroups per CU
 void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* __restrict__ out,
                         int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope,
@@ -258,7 +263,7 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
   auto compute = [&](int tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / ntiles;
     const int x0 = tx * G::TW, y0 = ty * G::TH;
-    st16* obase = reinterpret_cast<st16*>(out) + (size_t)n * out_bs + (size_t)(dyi * D) * H * W;
+    st16* obase = reinterpret_cast<st16*>(out) + (size_t)n * out_bs + (OC8 ? (size_t)0 : (size_t)(dyi * D) * H * W);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
@@ -297,7 +302,20 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
       const float t8 = sel(m1, a2[1], a2[0]), t9 = sel(m1, a2[2], a2[1]), t10 = sel(m1, a2[3], a2[2]);
       const float f[9] = {sel(m2, t2, t0), sel(m2, t3, t1), sel(m2, t4, t2), sel(m2, t5, t3), sel(m2, t6, t4),
                           sel(m2, t7, t5), sel(m2, t8, t6), sel(m2, t9, t7), sel(m2, t10, t8)};
-      if constexpr (RAGGED) {
+      if constexpr (OC8) {
+        static_assert(!OC8 || !RAGGED, "octet output needs W % 8 == 0");
+        const int y = y0 + u * G::UR + rsel, x = x0 + pix;
+        if (y < H && x < W) {
+          float v[D];
+#pragma unroll
+          for (int t = 0; t < D; ++t) { v[t] = f[t] * invC; v[t] = (slope != 0.f) ? fmaxf(v[t], v[t] * slope) : v[t]; }
+          const size_t px = (size_t)y * W + x, oct = (size_t)H * W * 8;
+          *reinterpret_cast<uint4*>(obase + dyi * oct + px * 8) = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+          const uint32_t last = pack2<T>(v[8], 0.f);
+          if (dyi < 8) obase[9 * oct + px * 8 + dyi] = (st16)(last & 0xffffu);
+          else *reinterpret_cast<uint4*>(obase + 10 * oct + px * 8) = make_uint4(last & 0xffffu, 0u, 0u, 0u);
+        }
+      } else if constexpr (RAGGED) {
         const int y = y0 + u * G::UR + rsel, x = x0 + pix;
         if (y < H && x < W) {
           st16* o = obase + (size_t)y * W + x;

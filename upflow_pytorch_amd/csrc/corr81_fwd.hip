@@ -127,7 +127,7 @@ static int allc_pick(int B, int C, int H, int W, bool ragged, bool norm, bool ch
   return first;
 }
 
-template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM>
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, bool OC8 = false>
 int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
                     const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   using G = corrx::Geo<UW, NU>;
@@ -136,7 +136,7 @@ int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W
   UPF_REQUIRE(nblocks < (1ll << 31), UPF_EINVAL, "corr81_forward: grid too large");
   const size_t lds = corrx::lds_bytes<UW, NU>((C + 3) / 4, RAGGED, NORM);
   static LdsOptIn opt;
-  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, 1>;
+  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, 1, OC8>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipExtLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(corrx::NTHREADS), lds, stream, ev0, ev1, 0,
                         f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg, (int)nblocks);
@@ -155,6 +155,22 @@ int launch_allc(int v, const T* f1, const T* f2, T* out, int B, int C, int H, in
   }
 #undef UPF_ALLC
   set_error("corr81_forward: internal routing error (variant %d)", v);
+  return UPF_EUNSUPPORTED;
+}
+
+// normalising cost volume into channel octets (upf_corr81_norm_forward_c8): !RAGGED, NORM, OC8
+template <typename T>
+int launch_allc_c8(int v, const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
+                   const float* ws1, const float* ws2, int nseg, hipStream_t stream) {
+#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, false, true, true>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, nullptr, nullptr)
+  switch (v) {
+    case 0: UPF_ALLC(32, 4, 4);
+    case 1: UPF_ALLC(32, 2, 8);
+    case 2: UPF_ALLC(32, 1, 8);
+    case 3: UPF_ALLC(16, 1, 8);
+  }
+#undef UPF_ALLC
+  set_error("corr81_norm_forward_c8: internal routing error (variant %d)", v);
   return UPF_EUNSUPPORTED;
 }
 
@@ -343,6 +359,31 @@ extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out
   else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
   UPF_REQUIRE(rc != 1, UPF_EUNSUPPORTED, "corr81_norm_forward: no kernel variant fits C=%d W=%d (W >= 4 required)", C, W);
   return rc;
+}
+
+extern "C" int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                          int dtype, float leaky_slope, void* workspace, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(f1 && f2 && out8 && workspace, UPF_EINVAL, "corr81_norm_forward_c8: null pointer");
+  UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_norm_forward_c8: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+  UPF_REQUIRE(upf_corr81_norm_supported(C, dtype), UPF_EUNSUPPORTED,
+              "corr81_norm_forward_c8: bf16 / fp16 with C <= 208 only (dtype %d, C %d)", dtype, C);
+  UPF_REQUIRE((size_t)C * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward_c8: batch item >= 2 GiB");
+  UPF_REQUIRE(W % 8 == 0 && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out8, 16) && out8_batch_stride % 8 == 0, UPF_EUNSUPPORTED,
+              "corr81_norm_forward_c8: W %% 8 == 0 and 16-byte aligned operands required (W = %d)", W);
+  UPF_REQUIRE(out8_batch_stride >= (long long)11 * H * W * 8, UPF_EINVAL, "corr81_norm_forward_c8: out8_batch_stride %lld < 11 octets", out8_batch_stride);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const long long N = (long long)B * C;
+  const int nseg = misc::launch_stats2(f1, f2, ws, N, H * W, dtype, s);
+  int rc = check_launch("corr81_norm_forward_c8 (statistics)");
+  if (rc != UPF_OK) return rc;
+  const float* ws1 = ws;
+  const float* ws2 = ws + (size_t)N * nseg * 3;
+  const int v = corr::allc_pick(B, C, H, W, false, true, false);
+  UPF_REQUIRE(v >= 0, UPF_EUNSUPPORTED, "corr81_norm_forward_c8: no kernel variant fits C=%d", C);
+  if (dtype == UPF_BF16) return corr::launch_allc_c8<bf16_t>(v, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s);
+  return corr::launch_allc_c8<f16_t>(v, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s);
 }
 
 // The NORM cost volume — the variant inside the inference step — timed like upf_corr81_forward_timed: one (untimed) statistics

@@ -350,6 +350,29 @@ __global__ void flow_update_kernel(const float* __restrict__ a, const T* __restr
   Elem<TO>::store(out + n * obs + r, v);
 }
 
+// The same sum written as ONE channel-octet entry per pixel of a C8 buffer (conv_c8.hip): the 2 flow components in positions
+// 0, 1 and zeros in 2..7 (a whole 16-byte store: the padding positions of the octet are defined, not left-over memory).
+template <typename T>
+__global__ void flow_update_c8_kernel(const float* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                      uint4* __restrict__ out, long long obs16, int HW, long long total) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;        // (item, pixel)
+  if (i >= total) return;
+  const long long n = i / HW;
+  const int r = (int)(i - n * HW);
+  float v[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long long j = (n * 2 + k) * HW + r;
+    v[k] = a[j];
+    if (b) {
+      float t = Elem<T>::load(b + j);
+      if (c) t = t + Elem<T>::load(c + j);
+      v[k] = v[k] + t;
+    }
+  }
+  out[n * obs16 + r] = make_uint4(pack2<T>(v[0], v[1]), 0u, 0u, 0u);
+}
+
 }  // namespace sgu
 }  // namespace upf
 
@@ -469,4 +492,20 @@ extern "C" int upf_flow_update(const float* a, const void* b, const void* c, voi
   if (dtype == UPF_BF16) { UPF_FU(bf16_t) } else { UPF_FU(f16_t) }
 #undef UPF_FU
   return check_launch("flow_update");
+}
+
+extern "C" int upf_flow_update_c8(const float* a, const void* b, const void* c, void* out8, long long out8_batch_stride, int N, int HW,
+                                  int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(a && out8 && N > 0 && HW > 0, UPF_EINVAL, "flow_update_c8: bad arguments");
+  UPF_REQUIRE(b || !c, UPF_EINVAL, "flow_update_c8: c without b");
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "flow_update_c8: bf16 / fp16 buffers");
+  UPF_REQUIRE(out8_batch_stride % 8 == 0 && out8_batch_stride >= (long long)HW * 8 && aligned_to(out8, 16), UPF_EINVAL,
+              "flow_update_c8: out8 must be a 16-byte aligned octet of a C8 buffer");
+  const long long total = (long long)N * HW;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UPF_BF16) hipLaunchKernelGGL((sgu::flow_update_c8_kernel<bf16_t>), grid, block, 0, st, a, (const bf16_t*)b, (const bf16_t*)c, (uint4*)out8, out8_batch_stride / 8, HW, total);
+  else hipLaunchKernelGGL((sgu::flow_update_c8_kernel<f16_t>), grid, block, 0, st, a, (const f16_t*)b, (const f16_t*)c, (uint4*)out8, out8_batch_stride / 8, HW, total);
+  return check_launch("flow_update_c8");
 }

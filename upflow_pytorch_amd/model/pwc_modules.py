@@ -310,26 +310,39 @@ class _DenseStack(tools.abstract_model):
         """The whole stack can live in a channel-octet buffer: every width a whole number of octets."""
         return self._ch_in % 8 == 0 and all(f % 8 == 0 for f in self._f)
 
-    def forward_in_buffer_c8(self, buf8, out=None):
-        """forward_in_buffer on a channel-octet buffer [B, n_total / 8, H, W, 8] (ops.c8_empty) whose input octets are
-        filled: the same layout in octets, every layer reads an octet suffix by LDS-DMA and writes its octets straight from
-        the accumulators; conv_last writes NCHW planes -> x_out [B, out_channels, H, W]."""
-        if getattr(self, '_packed8', None) is None:
-            nt = self._n_total
-            packed, hi = [], nt - self._ch_in
+    def c8_outputs_ok(self):
+        """The layers' OUTPUT widths are whole octets (the input part may then be any octet-position map, forward_in_buffer_c8)."""
+        return all(f % 8 == 0 for f in self._f)
+
+    def forward_in_buffer_c8(self, buf8, out=None, in_map=None):
+        """forward_in_buffer on a channel-octet buffer (ops.c8_empty) whose input octets are filled: the same layout in
+        octets, every layer reads an octet range by LDS-DMA and writes its octets straight from the accumulators; conv_last
+        writes NCHW planes -> x_out [B, out_channels, H, W].
+        in_map None: the input part is the stack's ch_in channels in order (ch_in % 8 == 0), the buffer has n_total / 8 octets.
+        in_map: for every POSITION of the input octets the input channel it carries, or -1 for a padding position (which must
+        hold finite values: the weights there are zero) — e.g. the flow estimator's [cost volume in the octet order of
+        ops.corr81_c8_channel_map | features | flow, flow, 0 x 6].  Octets after the input part (a tail) are not read."""
+        key = None if in_map is None else tuple(in_map)
+        cache = self.__dict__.setdefault('_packed8', {})
+        if key not in cache:
+            imap = list(range(self._ch_in)) if in_map is None else list(in_map)
+            assert len(imap) % 8 == 0 and sorted(m for m in imap if m >= 0) == list(range(self._ch_in)), 'in_map must place every input channel once'
+            packed, nconv = [], 0
             for name, f in zip(self._NAMES, self._f):
-                packed.append(_PackedConvC8(getattr(self, name), range(nt - hi)))      # input = channels [hi, nt) in this order
-                hi -= f
-            packed.append(_PackedConvC8(self.conv_last, range(nt)))
-            self._packed8 = packed
-        no = self._n_total // 8
-        hi = (self._n_total - self._ch_in) // 8
-        for pc, f in zip(self._packed8[:5], self._f):
+                # layer input = [conv_{k-1} | ... | conv1 | x]: identity on the conv outputs, then the input part's map
+                packed.append(_PackedConvC8(getattr(self, name), list(range(nconv)) + [m + nconv if m >= 0 else -1 for m in imap]))
+                nconv += f
+            packed.append(_PackedConvC8(self.conv_last, list(range(nconv)) + [m + nconv if m >= 0 else -1 for m in imap]))
+            cache[key] = (packed, len(imap) // 8)
+        packed, n_in = cache[key]
+        hi = sum(self._f) // 8
+        no = hi + n_in
+        for pc, f in zip(packed[:5], self._f):
             pc(buf8[:, hi:no], None, buf8[:, hi - f // 8:hi])
             hi -= f // 8
         if out is None:
             out = torch.empty((buf8.shape[0], self.conv_last[0].out_channels) + tuple(buf8.shape[2:4]), dtype=buf8.dtype, device=buf8.device)
-        self._packed8[5](buf8[:, :no], None, out)
+        packed[5](buf8[:, :no], None, out)
         return out
 
     def _train_convs(self):
@@ -412,19 +425,26 @@ class ContextNetwork_v2_(nn.Module):
             x = fast_conv_seq(seq, x, cache)
         return x
 
-    def forward_c8(self, x):
-        """Inference on a large grid (c8_level_ok): the chain in the channel-octet layout — conv0 reads the NCHW estimator
-        buffer and writes octets, conv1..5 read and write octets (LDS-DMA staging), conv6 writes the two NCHW flow planes."""
-        if getattr(self, '_packed8', None) is None:
+    def forward_c8(self, x, in_map=None):
+        """Inference on a large grid (c8_level_ok): the chain in the channel-octet layout — conv0 reads the estimator buffer
+        (NCHW planes; or, with in_map, a channel-octet buffer [B, n_oct, H, W, 8] whose position p carries input channel
+        in_map[p], -1 = padding) and writes octets, conv1..5 read and write octets (LDS-DMA staging), conv6 writes the two
+        NCHW flow planes."""
+        key = None if in_map is None else tuple(in_map)
+        cache = self.__dict__.setdefault('_packed8', {})
+        if key not in cache:
             chans = [s_[0].in_channels for s_ in self.convs]
-            self._packed8 = [_PackedConvC8(self.convs[0], (), range(chans[0]))] + \
-                            [_PackedConvC8(self.convs[i], range(chans[i])) for i in range(1, 7)]
-        B, _, H, W = x.shape
+            first = _PackedConvC8(self.convs[0], (), range(chans[0])) if in_map is None else _PackedConvC8(self.convs[0], list(in_map))
+            cache[key] = [first] + [_PackedConvC8(self.convs[i], range(chans[i])) for i in range(1, 7)]
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
         t = None
-        for i, pc in enumerate(self._packed8):
+        for i, pc in enumerate(cache[key]):
             co = self.convs[i][0].out_channels
             y = ops.c8_empty(B, co, H, W, x.dtype, x.device) if i < 6 else torch.empty((B, co, H, W), dtype=x.dtype, device=x.device)
-            pc(None if i == 0 else t, x if i == 0 else None, y)
+            if i == 0:
+                pc(x if in_map is not None else None, None if in_map is not None else x, y)
+            else:
+                pc(t, None, y)
             t = y
         return t
 

@@ -465,11 +465,20 @@ class UPFlow_net(tools.abstract_model):
         for level in range(nlev):
             Fm, pair = pyramid[level], pairs[level]
             C, H, W = shapes[level]
-            buf, slot = est.alloc_buffer(nb, H, W, dt, dev, tail=2)
             use_sgu = sgu and level > 0
             # large grids: the SGU stack and the context network run in the channel-octet layout (same arithmetic, same
             # summation order: bit-identical outputs; `_no_c8 = True` keeps NCHW everywhere)
             c8 = c8_level_ok(nb, H, W, dt) and not getattr(self, '_no_c8', False)
+            # ... and so does the flow estimator when the cost volume can write octets (`_no_c8_est = True`: estimator in NCHW).
+            # Its K order differs from the NCHW kernel's (81 cost-volume channels in 11 octets, flows padded to an octet), so
+            # this part agrees with the NCHW path to fp32 summation order, not bit for bit.
+            c8_est = (c8 and level > 0 and est.c8_outputs_ok() and not getattr(self, '_no_c8_est', False)
+                      and ops.corr81_norm_supported(pair) and not getattr(self, '_no_fused_norm', False) and nc == 81)
+            if c8_est:
+                flow, flows_entry = self._level_c8(level, Fm, pair, flow, nb, B, C, H, W, dt, dev, cache, use_sgu)
+                flows.append(flows_entry)
+                continue
+            buf, slot = est.alloc_buffer(nb, H, W, dt, dev, tail=2)
             sbuf8 = None
             if use_sgu and c8 and sgi.dense_estimator_mask.c8_ok():
                 em = sgi.dense_estimator_mask
@@ -527,6 +536,40 @@ class UPFlow_net(tools.abstract_model):
                     raise RuntimeError('sgu output_conv / flow size mismatch %s vs %s' % (tuple(G.shape), tuple(flow.shape)))
                 flow_out = sgi.forward_in_buffer(flow, sbuf, sslot, output_level_flow=flow_out, batch_shift=B)[1]
         return flow_out[:B], flow_out[B:], flows[::-1]
+
+    def _level_c8(self, level, Fm, pair, flow, nb, B, C, H, W, dt, dev, cache, use_sgu):
+        """One level of _forward_stacked_fast with EVERY dense stack in the channel-octet layout: the estimator buffer is
+        [conv5 | conv4 | conv3 | conv2 | conv1 | cost volume (11 octets, ops.corr81_c8_channel_map) | features (4) | flow (1) |
+        refined flow (1)] octets; the cost volume, the 1x1 convolution and the flow bookkeeping write their octets directly."""
+        est, sgi = self.flow_estimators, self.sgi_model
+        nconv = sum(est._f) // 8
+        ncorr = ops.CORR81_C8_OCTETS
+        in_map = ops.corr81_c8_channel_map() + list(range(81, 113)) + [113, 114] + [-1] * 6
+        n_est = nconv + len(in_map) // 8
+        buf8 = ops.c8_empty(nb, (n_est + 1) * 8, H, W, dt, dev)
+        o_feat, o_flow = nconv + ncorr, nconv + ncorr + 4
+        pc = cache.get(('c8_1x1', level))
+        if pc is None:
+            pc = cache[('c8_1x1', level)] = _PackedConvC8(self.conv_1x1[level], (), range(C))
+        pc(None, Fm, buf8[:, o_feat:o_feat + 4])
+        flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
+        if use_sgu:
+            em = sgi.dense_estimator_mask
+            sbuf8 = ops.c8_empty(nb, em._n_total, H, W, dt, dev)
+            o0 = (em._n_total - em._ch_in) // 8
+            pc(None, Fm, sbuf8[:, o0:o0 + 4])
+            flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B)[1]
+        ops.warp_into(Fm, flow_up, pair[1], self.warping_layer.mask_mode, B)
+        ops.corr81_norm_forward_c8(pair[0], pair[1], buf8[:, nconv:nconv + ncorr], leaky_slope=0.1)
+        ops.flow_update_c8(flow_up, None, None, buf8[:, o_flow:o_flow + 1])
+        res = est.forward_in_buffer_c8(buf8, in_map=in_map)
+        ops.flow_update_c8(flow_up, res, None, buf8[:, o_flow + 1:o_flow + 2])        # flow_up + res -> context network input
+        # the context network reads [x5 | refined flow] = every octet of the buffer
+        nch = nconv * 8
+        ctx_map = list(range(nch)) + [m + nch if m >= 0 else -1 for m in in_map] + [nch + 115, nch + 116] + [-1] * 6
+        fine = self.context_networks.forward_c8(buf8, in_map=ctx_map)
+        flow = ops.flow_update(flow_up, res, fine)                            # flow_up + (res + fine)
+        return flow, [flow[:B], flow[B:]]
 
     def _level_update(self, Fn, Fwn, A, flow_up, add_to_flow=False):
         """res + fine for all 2B stacked items (model/upflow.py:557-572); add_to_flow: flow_up + (res + fine), the level's

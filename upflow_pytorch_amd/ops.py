@@ -85,6 +85,53 @@ def corr81_norm_forward_raw(f1, f2, out=None, leaky_slope=0.0):
     return out
 
 
+CORR81_C8_OCTETS = 11
+
+
+def corr81_c8_channel_map():
+    """Position -> cost-volume channel of the 11 octets upf_corr81_norm_forward_c8 writes (-1 = a zero position): octet j < 9
+    holds channels 9j .. 9j+7 (dy = j-4, dx = -4..3), octet 9 position p channel 9p+8 (dx = +4), octet 10 position 0 channel 80."""
+    m = []
+    for j in range(9):
+        m += [9 * j + t for t in range(8)]
+    m += [9 * p + 8 for p in range(8)]
+    m += [80] + [-1] * 7
+    return m
+
+
+def corr81_norm_forward_c8(f1, f2, out8, leaky_slope=0.0):
+    """corr81_norm_forward_raw into 11 octets `out8` [B,11,H,W,8] of a channel-octet buffer (order: corr81_c8_channel_map)."""
+    if f1.shape != f2.shape or f1.dim() != 4 or f1.dtype != f2.dtype:
+        raise UpflowHipError('corr81_norm_c8: inputs must be two [B,C,H,W] tensors of one dtype')
+    B, C, H, W = f1.shape
+    dev = _lib.check_gpu(f1, f2)
+    if not out8.is_cuda or tuple(out8.shape) != (B, CORR81_C8_OCTETS, H, W, 8) or not _c8_view_ok(out8) or out8.dtype != f1.dtype:
+        raise UpflowHipError('corr81_norm_c8: out8 must be an octet slice [%d,11,%d,%d,8] of a C8 buffer, got %s' % (B, H, W, tuple(out8.shape)))
+    ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
+    with torch.cuda.device(dev):
+        _lib.call('upf_corr81_norm_forward_c8', _lib.ptr(f1.contiguous()), _lib.ptr(f2.contiguous()), _lib.ptr(out8), out8.stride(0), B, C, H, W,
+                  _lib.dtype_code(f1), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
+    return out8
+
+
+def flow_update_c8(a, b, c, out8):
+    """flow_update for a 2-channel flow into ONE octet `out8` [N,1,H,W,8] of a channel-octet buffer (positions 0, 1; 2..7 = 0)."""
+    a = _f32(a).contiguous()
+    N, two, H, W = a.shape
+    if two != 2 or tuple(out8.shape) != (N, 1, H, W, 8) or not _c8_view_ok(out8) or out8.dtype not in (torch.bfloat16, torch.float16):
+        raise UpflowHipError('flow_update_c8: a [N,2,H,W] and one octet [N,1,H,W,8] of a 16-bit C8 buffer expected')
+    for t in (b, c):
+        if t is not None and (tuple(t.shape) != tuple(a.shape) or not t.is_contiguous() or t.dtype != out8.dtype):
+            raise UpflowHipError('flow_update_c8: b / c must be contiguous tensors of the buffer dtype shaped like a')
+    dev = _lib.check_gpu(a, b, c)
+    if not out8.is_cuda:
+        raise UpflowHipError('flow_update_c8: GPU tensors expected (there is no CPU fallback)')
+    with torch.cuda.device(dev):
+        _lib.call('upf_flow_update_c8', _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(out8), out8.stride(0), N, H * W,
+                  _lib.dtype_code(out8), _lib.stream_ptr(dev))
+    return out8
+
+
 def corr81_forward_timed(f1, f2, out, leaky_slope=0.0, nrep=50):
     """-> (avg_us, min_us) of `nrep` launches, each timed by HIP events recorded around the kernel on
     the current stream (upf_corr81_forward_timed).  Measurement helper for bench.py."""
