@@ -74,9 +74,17 @@ def roofline_probe(B, H, W, dtype, device):
     # the kernel INSIDE the timed step is the variant whose loader normalises the features (upf_corr81_norm_forward: 16-bit
     # inference); the plain variant (training, fp32) is reported beside it
     norm = dtype != torch.float32 and ops.corr81_norm_supported(f1)
-    timed = ops.corr81_norm_forward_timed if norm else ops.corr81_forward_timed
+    # ... and at the levels whose flow estimator runs in the channel-octet layout (this one, at config 2) it stores octets
+    from upflow_pytorch_amd.model.pwc_modules import c8_level_ok
+    c8 = norm and c8_level_ok(B, h, w, dtype)
+    if c8:
+        out8 = ops.c8_empty(B, 88, h, w, dtype, device)
+        timed = lambda f1_, f2_, out_, slope, nrep: ops.corr81_norm_forward_c8_timed(f1_, f2_, out8, slope, nrep=nrep)
+    else:
+        timed = ops.corr81_norm_forward_timed if norm else ops.corr81_forward_timed
     timed(f1, f2, out, 0.1, nrep=20)                                         # warm
     avg_us, min_us = timed(f1, f2, out, 0.1, nrep=200)
+    nchw_norm_us = ops.corr81_norm_forward_timed(f1, f2, out, 0.1, nrep=200)[0] if c8 else None
     plain_us = ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=200)[0] if norm else avg_us
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
     cold = []
@@ -98,12 +106,16 @@ def roofline_probe(B, H, W, dtype, device):
             continue
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))['summary']
-            if pmc['shape'] == [B, C, h, w] and pmc['dtype'] == dn and pmc.get('variant', 'plain') == ('norm' if norm else 'plain'):
+            if pmc['shape'] == [B, C, h, w] and pmc['dtype'] == dn and pmc.get('variant', 'plain') == ('norm_c8' if c8 else 'norm' if norm else 'plain'):
                 traffic = int(pmc['traffic_bytes'])
                 break
         except Exception:
             pass
-    return {'bound': 'hbm', 'kernel': ('corr81_allc_kernel<8x32 tile, NORM: normalisation fused into the loader> (the launch inside the step)' if norm else 'corr81_allc_kernel<8x32 tile>') if dtype != torch.float32 else 'corr81_fwd_kernel', 'shape': [B, C, h, w],
+    kname = 'corr81_fwd_kernel' if dtype == torch.float32 else 'corr81_allc_kernel<8x32 tile>' if not norm else \
+        ('corr81_allc_kernel<8x32 tile, NORM: normalisation fused into the loader, OC8: octet output> (the launch inside the step)' if c8 else
+         'corr81_allc_kernel<8x32 tile, NORM: normalisation fused into the loader> (the launch inside the step)')
+    extra = {'nchw_output_variant_us': round(nchw_norm_us, 2)} if c8 else {}
+    return {'bound': 'hbm', 'kernel': kname, 'shape': [B, C, h, w], **extra,
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2),
             'timing': 'HIP events around each of 200 back-to-back launches (inputs resident in the infinity cache)',

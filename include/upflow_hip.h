@@ -91,6 +91,10 @@ int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out,
                                   int B, int C, int H, int W, int dtype,
                                   long long out_batch_stride, float leaky_slope, void* workspace, void* stream,
                                   int nrep, float* avg_us, float* min_us);
+/* ... and of upf_corr81_norm_forward_c8 (the form the step launches at the levels whose estimator runs on octets) */
+int upf_corr81_norm_forward_c8_timed(const void* f1, const void* f2, void* out8, long long out8_batch_stride,
+                                     int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream,
+                                     int nrep, float* avg_us, float* min_us);
 
 /* Launch heuristics of the 16-bit cost volume, for tuning and for the tests to reach every kernel variant:
  *   "variant"  (-1)  -1 = choose by shape; 0..3 = force tile geometry 8x32 / 4x32 / 2x32 / 4x16 where C fits

@@ -11,12 +11,18 @@ from upflow_pytorch_amd import ops
 
 B, C, H, W = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (4, 32, 96, 320)))
 dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[sys.argv[5] if len(sys.argv) > 5 else 'bf16']
-norm = len(sys.argv) > 6 and sys.argv[6] == 'norm'      # the normalising variant (upf_corr81_norm_forward): the kernel inside the step
-fwd = (lambda: ops.corr81_norm_forward_raw(f1, f2, out=out, leaky_slope=0.1)) if norm else (lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1))
+var = sys.argv[6] if len(sys.argv) > 6 else 'plain'      # norm: the normalising variant (upf_corr81_norm_forward); norm_c8: the same with octet output (the kernel inside the step at the fine levels)
+if var == 'norm_c8':
+    fwd = lambda: ops.corr81_norm_forward_c8(f1, f2, out8, leaky_slope=0.1)
+elif var == 'norm':
+    fwd = lambda: ops.corr81_norm_forward_raw(f1, f2, out=out, leaky_slope=0.1)
+else:
+    fwd = lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)
 g = torch.Generator().manual_seed(2004)
 f1 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
 f2 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
 out = torch.empty(B, 81, H, W, device='cuda', dtype=dt)
+out8 = ops.c8_empty(B, 88, H, W, dt, 'cuda') if dt != torch.float32 and W % 8 == 0 else None
 # evict the 256 MiB infinity cache between launches so FETCH_SIZE reflects HBM, not MALL hits
 junk = torch.empty(320 * 1024 * 1024, dtype=torch.uint8, device='cuda')
 for i in range(20):

@@ -45,7 +45,7 @@ def main():
     write_cold = sum(wk[:nw]) / nw
     fetch_bytes = fetch_cold * 1024 * 2
     write_bytes = write_cold * 1024
-    summ = {'shape': [B, C, H, W], 'dtype': dtype, 'kernel': name, 'variant': 'norm' if name.rstrip().endswith(', true, 1>') else 'plain', 'algorithmic_bytes': alg_r + alg_w, 'algorithmic_read_bytes': alg_r,
+    summ = {'shape': [B, C, H, W], 'dtype': dtype, 'kernel': name, 'variant': 'norm_c8' if name.rstrip().endswith(', true, 1, true>') else 'norm' if (name.rstrip().endswith(', true, 1>') or name.rstrip().endswith(', true, 1, false>')) else 'plain', 'algorithmic_bytes': alg_r + alg_w, 'algorithmic_read_bytes': alg_r,
             'algorithmic_write_bytes': alg_w, 'fetch_bytes_corrected_x2': fetch_bytes, 'write_bytes': write_bytes,
             'traffic_bytes': fetch_bytes + write_bytes, 'traffic_over_algorithmic': (fetch_bytes + write_bytes) / (alg_r + alg_w),
             'calibration_cast_kernel_fetch_KB': fcal[:2], 'calibration_cast_kernel_bytes_read': 4 * B * C * H * W,

@@ -25,6 +25,7 @@ SIGNATURES = {
     'upf_corr81_forward_timed': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
     'upf_corr81_norm_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp],
     'upf_corr81_norm_forward_timed': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
+    'upf_corr81_norm_forward_c8_timed': [_vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
     'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_out_shape': [_i, _i, _i, _i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],

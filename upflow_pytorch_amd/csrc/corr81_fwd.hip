@@ -161,8 +161,8 @@ int launch_allc(int v, const T* f1, const T* f2, T* out, int B, int C, int H, in
 // normalising cost volume into channel octets (upf_corr81_norm_forward_c8): !RAGGED, NORM, OC8
 template <typename T>
 int launch_allc_c8(int v, const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
-                   const float* ws1, const float* ws2, int nseg, hipStream_t stream) {
-#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, false, true, true>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, nullptr, nullptr)
+                   const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, false, true, true>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1)
   switch (v) {
     case 0: UPF_ALLC(32, 4, 4);
     case 1: UPF_ALLC(32, 2, 8);
@@ -388,14 +388,19 @@ extern "C" int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* 
 
 // The NORM cost volume — the variant inside the inference step — timed like upf_corr81_forward_timed: one (untimed) statistics
 // launch, then nrep launches of the cost-volume kernel, each between its own pair of HIP events on the launch stream.
-extern "C" int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
-                                             long long out_batch_stride, float leaky_slope, void* workspace, void* stream, int nrep,
-                                             float* avg_us, float* min_us) {
+static int norm_forward_timed_impl(bool c8, const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
+                                   long long out_batch_stride, float leaky_slope, void* workspace, void* stream, int nrep,
+                                   float* avg_us, float* min_us) {
   using namespace upf;
   UPF_REQUIRE(f1 && f2 && out && workspace && avg_us, UPF_EINVAL, "corr81_norm_forward_timed: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nrep > 0 && nrep <= 1024, UPF_EINVAL, "corr81_norm_forward_timed: bad arguments");
   UPF_REQUIRE(upf_corr81_norm_supported(C, dtype) && (size_t)C * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward_timed: unsupported shape / dtype");
-  if (out_batch_stride == 0) out_batch_stride = (long long)corr::ND * H * W;
+  if (c8) {
+    UPF_REQUIRE(W % 8 == 0 && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out, 16) && out_batch_stride % 8 == 0 &&
+                out_batch_stride >= (long long)11 * H * W * 8, UPF_EUNSUPPORTED, "corr81_norm_forward_c8_timed: octet output needs W %% 8 == 0, aligned operands, 11 octets");
+  } else if (out_batch_stride == 0) out_batch_stride = (long long)corr::ND * H * W;
+  const int vc8 = c8 ? corr::allc_pick(B, C, H, W, false, true, false) : 0;
+  UPF_REQUIRE(vc8 >= 0, UPF_EUNSUPPORTED, "corr81_norm_forward_c8_timed: no kernel variant fits C=%d", C);
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const long long N = (long long)B * C;
@@ -407,7 +412,9 @@ extern "C" int upf_corr81_norm_forward_timed(const void* f1, const void* f2, voi
   hipEvent_t* ev = new hipEvent_t[2 * nrep];
   for (int i = 0; i < 2 * nrep; ++i) (void)hipEventCreate(&ev[i]);
   for (int i = 0; i < nrep && rc == UPF_OK; ++i) {
-    if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
+    if (c8 && dtype == UPF_BF16) rc = corr::launch_allc_c8<bf16_t>(vc8, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
+    else if (c8) rc = corr::launch_allc_c8<f16_t>(vc8, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
+    else if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
     else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
     if (rc == 1) { set_error("corr81_norm_forward_timed: no kernel variant fits C=%d W=%d", C, W); rc = UPF_EUNSUPPORTED; }
   }
@@ -424,6 +431,16 @@ extern "C" int upf_corr81_norm_forward_timed(const void* f1, const void* f2, voi
   delete[] ev;
   if (rc == UPF_OK) { *avg_us = (float)(sum / nrep * 1e3); if (min_us) *min_us = (float)(mn * 1e3); }
   return rc;
+}
+
+extern "C" int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
+                                             long long out_batch_stride, float leaky_slope, void* workspace, void* stream, int nrep,
+                                             float* avg_us, float* min_us) {
+  return norm_forward_timed_impl(false, f1, f2, out, B, C, H, W, dtype, out_batch_stride, leaky_slope, workspace, stream, nrep, avg_us, min_us);
+}
+extern "C" int upf_corr81_norm_forward_c8_timed(const void* f1, const void* f2, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                                int dtype, float leaky_slope, void* workspace, void* stream, int nrep, float* avg_us, float* min_us) {
+  return norm_forward_timed_impl(true, f1, f2, out8, B, C, H, W, dtype, out8_batch_stride, leaky_slope, workspace, stream, nrep, avg_us, min_us);
 }
 
 extern "C" int upf_corr_set_option(const char* name, int value) {

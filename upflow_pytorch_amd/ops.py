@@ -161,6 +161,23 @@ def corr81_norm_forward_timed(f1, f2, out, leaky_slope=0.0, nrep=50):
     return avg.value, mn.value
 
 
+def corr81_norm_forward_c8_timed(f1, f2, out8, leaky_slope=0.0, nrep=50):
+    """corr81_norm_forward_timed for the octet-output form (corr81_norm_forward_c8): the launch inside the inference step at
+    the levels whose flow estimator runs in the channel-octet layout."""
+    import ctypes
+    B, C, H, W = f1.shape
+    dev = _lib.check_gpu(f1, f2)
+    if tuple(out8.shape) != (B, CORR81_C8_OCTETS, H, W, 8) or not _c8_view_ok(out8):
+        raise UpflowHipError('corr81_norm_c8_timed: out8 must be an octet slice [%d,11,%d,%d,8]' % (B, H, W))
+    ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
+    avg, mn = ctypes.c_float(), ctypes.c_float()
+    with torch.cuda.device(dev):
+        _lib.call('upf_corr81_norm_forward_c8_timed', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(out8), out8.stride(0), B, C, H, W,
+                  _lib.dtype_code(f1), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev), int(nrep),
+                  ctypes.byref(avg), ctypes.byref(mn))
+    return avg.value, mn.value
+
+
 def corr81_backward_raw(f1, f2, grad_out):
     B, C, H, W = f1.shape
     grad_out = grad_out.contiguous()
