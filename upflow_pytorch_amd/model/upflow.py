@@ -519,23 +519,35 @@ class UPFlow_net(tools.abstract_model):
             flows.append([flow[:B], flow[B:]])
         flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
         if sgu:
-            H4, W4 = flow.shape[2:]
-            em = sgi.dense_estimator_mask
-            last = sgi.upsample_output_conv[-1][0]
-            if (c8_level_ok(nb, H4, W4, dt) and not getattr(self, '_no_c8', False) and em.c8_ok() and X.shape[3] % 32 == 0
-                    and last.stride[0] == 2 and last.in_channels > 16 and last.out_channels == em._ch_in // 2
-                    and ops.conv3x3_out_hw(X.shape[2] // 2, X.shape[3] // 2, 2) == (H4, W4) and X.shape[2] % 2 == 0):
-                sbuf8 = ops.c8_empty(nb, em._n_total, H4, W4, dt, dev)
-                o0 = (em._n_total - em._ch_in) // 8
-                sgi.output_conv(X, out8=sbuf8[:, o0:o0 + em._ch_in // 16])          # the guidance stem's last layer writes octets
-                flow_out = sgi.forward_in_buffer_c8(flow, sbuf8, output_level_flow=flow_out, batch_shift=B)[1]
+            # (measured and not kept, round 3: this stem on a side stream = a parallel branch of the captured graph, forked before
+            # or after the feature pyramid — 3.075 vs 3.076 ms: the step is not idle-CU bound)
+            guide = self._final_guidance(X, nb, tuple(flow.shape[2:]))
+            if guide[0] == 'c8':
+                flow_out = sgi.forward_in_buffer_c8(flow, guide[1], output_level_flow=flow_out, batch_shift=B)[1]
             else:
-                sbuf, sslot = em.alloc_buffer(nb, H4, W4, dt, dev)
-                G = sgi.output_conv(X, out=sslot[:, :32])
-                if tuple(G.shape[2:]) != (H4, W4):
-                    raise RuntimeError('sgu output_conv / flow size mismatch %s vs %s' % (tuple(G.shape), tuple(flow.shape)))
-                flow_out = sgi.forward_in_buffer(flow, sbuf, sslot, output_level_flow=flow_out, batch_shift=B)[1]
+                flow_out = sgi.forward_in_buffer(flow, guide[1], guide[2], output_level_flow=flow_out, batch_shift=B)[1]
         return flow_out[:B], flow_out[B:], flows[::-1]
+
+    def _final_guidance(self, X, nb, hw4):
+        """The SGU's guidance features of the final up-sampling (model/upflow.py:525-531: sgi_model.output_conv on the frames)
+        written into the input slot of the SGU stack's buffer -> ('c8', sbuf8) or ('nchw', sbuf, sslot)."""
+        sgi = self.sgi_model
+        em = sgi.dense_estimator_mask
+        H4, W4 = hw4
+        dt, dev = X.dtype, X.device
+        last = sgi.upsample_output_conv[-1][0]
+        if (c8_level_ok(nb, H4, W4, dt) and not getattr(self, '_no_c8', False) and em.c8_ok() and X.shape[3] % 32 == 0
+                and last.stride[0] == 2 and last.in_channels > 16 and last.out_channels == em._ch_in // 2
+                and ops.conv3x3_out_hw(X.shape[2] // 2, X.shape[3] // 2, 2) == (H4, W4) and X.shape[2] % 2 == 0):
+            sbuf8 = ops.c8_empty(nb, em._n_total, H4, W4, dt, dev)
+            o0 = (em._n_total - em._ch_in) // 8
+            sgi.output_conv(X, out8=sbuf8[:, o0:o0 + em._ch_in // 16])          # the guidance stem's last layer writes octets
+            return ('c8', sbuf8)
+        sbuf, sslot = em.alloc_buffer(nb, H4, W4, dt, dev)
+        G = sgi.output_conv(X, out=sslot[:, :32])
+        if tuple(G.shape[2:]) != (H4, W4):
+            raise RuntimeError('sgu output_conv / flow size mismatch %s vs %s' % (tuple(G.shape), (H4, W4)))
+        return ('nchw', sbuf, sslot)
 
     def _level_c8(self, level, Fm, pair, flow, nb, B, C, H, W, dt, dev, cache, use_sgu):
         """One level of _forward_stacked_fast with EVERY dense stack in the channel-octet layout: the estimator buffer is
