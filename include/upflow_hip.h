@@ -262,6 +262,10 @@ int upf_conv_c8_set_option(const char* name, int value);   /* "rpw4" (1): Cout <
  *              upf_conv_bias_grad_workspace_bytes). */
 int upf_conv_pack_weights_f32(const float* w /* [Cout,Cin,k,k] fp32 */, void* w_packed, int Cin, int Cout, int kernel_size,
                               int dtype, int dgrad, void* stream);
+/* njobs of the above in one launch (host arrays of the per-layer arguments): a training step re-packs every layer from its
+ * fp32 master weights after the optimiser step */
+int upf_conv_pack_weights_f32_multi(const float* const* w, void* const* w_packed, const int* Cin, const int* Cout, const int* kernel_size,
+                                    const int* dgrad, int njobs, int dtype, void* stream);
 int upf_leaky_backward(const void* grad_y, const void* y, void* grad_pre, long long n, float slope, int dtype, void* stream);
 int upf_conv_wgrad_supported(int Cin, int Cout, int H, int W, int kernel_size, int dilation, int stride, int dtype);
 long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation);

@@ -66,11 +66,12 @@ __global__ void pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp,
 // elsewhere; packed here is w4's data-gradient operand (Cin' = Cout k-columns, Cout' = 4*Cin rows) straight from w.
 __device__ __forceinline__ int s2d_tap(int phase, int a) { return a == 0 ? (phase == 1 ? 0 : -1) : (a == 1 ? (phase == 0 ? 1 : 2) : -1); }
 template <typename T>
-__global__ void pack_weights_f32_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps, int dgrad) {
+__device__ __forceinline__ void pack_weights_f32_body(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps, int dgrad,
+                                                      unsigned bid, unsigned nblocks) {
   const int cinp = dgrad ? Cout : Cin, coutp = dgrad == 2 ? 4 * Cin : (dgrad ? Cin : Cout);   // channel counts of the convolution being packed
   const int cip = pad32(cinp), cop = pad32(coutp), nk = cip / 16;
   const long long total = (long long)ntaps * cop * cip;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = bid * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)nblocks * blockDim.x) {
     const int j = (int)(i & 7), px = (int)((i >> 3) & 31), kg = (int)((i >> 8) & 1);
     const long long b = i >> 9;
     const int tap = (int)(b % ntaps), kstep = (int)((b / ntaps) % nk), slab = (int)(b / ((long long)ntaps * nk));
@@ -86,6 +87,27 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, T* __restri
     }
     Elem<T>::store(wp + i, v);
   }
+}
+template <typename T>
+__global__ void pack_weights_f32_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps, int dgrad) {
+  pack_weights_f32_body<T>(w, wp, Cin, Cout, ntaps, dgrad, blockIdx.x, gridDim.x);
+}
+// Every layer of a training step in ONE launch (upf_conv_pack_weights_f32_multi): the job table travels in the kernel
+// arguments, a workgroup finds its job by its block index (a step packs ~60 layers: 60 launches of 3-5 us otherwise).
+constexpr int PACK_JOBS = 56;
+struct PackJobs {
+  const float* w[PACK_JOBS];
+  void* wp[PACK_JOBS];
+  int Cin[PACK_JOBS], Cout[PACK_JOBS];
+  unsigned char ntaps[PACK_JOBS], dgrad[PACK_JOBS];
+  unsigned blk0[PACK_JOBS + 1];
+  int n;
+};
+template <typename T>
+__global__ void pack_weights_f32_multi_kernel(PackJobs J) {
+  int j = 0;
+  while (j + 1 < J.n && blockIdx.x >= J.blk0[j + 1]) ++j;           // (workgroup-uniform)
+  pack_weights_f32_body<T>(J.w[j], (T*)J.wp[j], J.Cin[j], J.Cout[j], J.ntaps[j], J.dgrad[j], blockIdx.x - J.blk0[j], J.blk0[j + 1] - J.blk0[j]);
 }
 
 // Split-K variant for the COARSE pyramid levels (a handful of pixel tiles on 256 CUs: the kernel above is then a
@@ -415,6 +437,34 @@ extern "C" int upf_conv_pack_weights_f32(const float* w, void* w_packed, int Cin
   else
     hipLaunchKernelGGL((conv::pack_weights_f32_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (f16_t*)w_packed, Cin, Cout, ntaps, dgrad);
   return check_launch("conv_pack_weights_f32");
+}
+
+extern "C" int upf_conv_pack_weights_f32_multi(const float* const* w, void* const* w_packed, const int* Cin, const int* Cout, const int* kernel_size,
+                                               const int* dgrad, int njobs, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(w && w_packed && Cin && Cout && kernel_size && dgrad && njobs > 0, UPF_EINVAL, "conv_pack_weights_f32_multi: bad arguments");
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_pack_weights_f32_multi: packs to bf16 / fp16");
+  for (int j = 0; j < njobs; ++j) {
+    UPF_REQUIRE(w[j] && w_packed[j] && Cin[j] > 0 && Cout[j] > 0, UPF_EINVAL, "conv_pack_weights_f32_multi: job %d: bad arguments", j);
+    UPF_REQUIRE(kernel_size[j] == 3 || kernel_size[j] == 1, UPF_EUNSUPPORTED, "conv_pack_weights_f32_multi: job %d: kernel_size %d (1 or 3)", j, kernel_size[j]);
+    UPF_REQUIRE(dgrad[j] >= 0 && dgrad[j] <= 2 && (dgrad[j] != 2 || kernel_size[j] == 3), UPF_EINVAL, "conv_pack_weights_f32_multi: job %d: dgrad 0 / 1 / 2 (2: 3x3 only)", j);
+  }
+  for (int j0 = 0; j0 < njobs; j0 += conv::PACK_JOBS) {
+    conv::PackJobs J;
+    J.n = njobs - j0 < conv::PACK_JOBS ? njobs - j0 : conv::PACK_JOBS;
+    unsigned nb = 0;
+    for (int j = 0; j < J.n; ++j) {
+      const int q = j0 + j, ntaps = kernel_size[q] * kernel_size[q];
+      J.w[j] = w[q]; J.wp[j] = w_packed[q]; J.Cin[j] = Cin[q]; J.Cout[j] = Cout[q]; J.ntaps[j] = (unsigned char)ntaps; J.dgrad[j] = (unsigned char)dgrad[q];
+      const long long total = (long long)ntaps * conv::pad32(dgrad[q] == 2 ? 4 * Cin[q] : (dgrad[q] ? Cin[q] : Cout[q])) * conv::pad32(dgrad[q] ? Cout[q] : Cin[q]);
+      J.blk0[j] = nb;
+      nb += (unsigned)((total + 255) / 256 > 256 ? 256 : (total + 255) / 256);
+    }
+    J.blk0[J.n] = nb;
+    if (dtype == UPF_BF16) hipLaunchKernelGGL((conv::pack_weights_f32_multi_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, J);
+    else hipLaunchKernelGGL((conv::pack_weights_f32_multi_kernel<f16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, J);
+  }
+  return check_launch("conv_pack_weights_f32_multi");
 }
 
 extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,

@@ -436,12 +436,13 @@ class UPFlow_net(tools.abstract_model):
             else:
                 Fn, Fwn = Fm, Fw
             flow = self._level_update(Fn, Fwn, A, flow_up, add_to_flow=True)
-            flows.append([flow[:B], flow[B:]])
+            flows.append(list(ops.split_batch(flow, B)))
         flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
         if sgu:
             G = self.sgi_model.output_conv(X)
             flow_out = self.sgi_model(flow, G, G, output_level_flow=flow_out, batch_shift=B)[1]
-        return flow_out[:B], flow_out[B:], flows[::-1]
+        f_out, b_out = ops.split_batch(flow_out, B)
+        return f_out, b_out, flows[::-1]
 
     def _forward_stacked_fast(self, X, B):
         """_forward_stacked for bf16/fp16 with the published normalisation flags: same arithmetic, and every

@@ -373,6 +373,39 @@ def flow_sum3(a, b, c):
     return FlowSum3Function.apply(a, b, c)
 
 
+class SplitBatchFunction(Function):
+    """x[:B], x[B:] of a stacked-direction tensor (both flow directions along the batch) as one autograd node: the backward of
+    two plain slices is two zero-filled full-size tensors, two slice copies and an add (5 launches); here it is one
+    concatenation of the two incoming gradients."""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.B = B
+        ctx.meta = (tuple(x.shape), x.dtype, x.device)
+        ctx.set_materialize_grads(False)
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        shape, dtype, dev = ctx.meta
+        g = torch.empty(shape, dtype=dtype, device=dev)
+        for part, gp in ((g[:ctx.B], ga), (g[ctx.B:], gb)):
+            if gp is None:
+                part.zero_()
+            else:
+                part.copy_(gp)
+        return g, None
+
+
+def split_batch(x, B):
+    """-> (x[:B], x[B:]); under autograd one node whose backward is a single concatenation."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return SplitBatchFunction.apply(x, int(B))
+    return x[:B], x[B:]
+
+
 # ------------------------------------------------------------------------------------------------
 # flow up-sampling
 # ------------------------------------------------------------------------------------------------
@@ -428,6 +461,7 @@ class SguBlendFunction(Function):
                       _lib.ptr(inter_flow), _lib.ptr(inter_mask), _lib.ptr(ws), B, h, w, Hf, Wf, _lib.dtype_code(x_out),
                       _lib.stream_ptr(dev))
         ctx.save_for_backward(flow_init, x_out)
+        ctx.set_materialize_grads(False)        # (no zero tensors for the two non-differentiable outputs: two fills per call)
         if want_inter:
             ctx.mark_non_differentiable(inter_flow, inter_mask)
             return flow_up, inter_flow, inter_mask
@@ -435,6 +469,8 @@ class SguBlendFunction(Function):
 
     @staticmethod
     def backward(ctx, g_up, _gi, _gm):
+        if g_up is None:
+            return None, None, None
         flow_init, x_out = ctx.saved_tensors
         B, _, h, w = x_out.shape
         _, _, Hf, Wf = flow_init.shape
@@ -784,10 +820,13 @@ class RobustLossFunction(Function):
         ctx.qe = (float(q), float(eps))
         s_loss, s_occ = sums.unbind(0)                       # (mark and return the SAME view objects: ADVICE r2)
         ctx.mark_non_differentiable(s_occ)
+        ctx.set_materialize_grads(False)                     # (no zero tensor for s_occ's gradient)
         return s_loss, s_occ
 
     @staticmethod
     def backward(ctx, g, _g_occ):
+        if g is None:
+            return None, None, None, None, None
         if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]:
             raise UpflowHipError('robust_loss: the occlusion weights are treated as constants (hard masks); a mask that '
                                  'requires grad would silently get a zero gradient')
@@ -867,6 +906,7 @@ def conv_pack_from_master(weight32, dtype, dgrad=False):
         slot = None
     if slot is not None and key in slot[1]:
         return slot[1][key]
+    _pack_wanted(weight32, dtype, 1 if dgrad else 0)
     packed = _conv_pack_from_master(weight32, dtype, dgrad)
     if slot is None:
         if len(_PACK_CACHE) > 4096:
@@ -880,6 +920,79 @@ def conv_pack_from_master(weight32, dtype, dgrad=False):
 
 def conv_pack_cache_clear():
     _PACK_CACHE.clear()
+
+
+# ---- every layer's operands in one launch ---------------------------------------------------------------------------------
+# A training step re-packs ~60 operands (forward / data-gradient form of every layer) after the optimiser has changed the
+# fp32 master weights: 60 launches of 3-5 us.  The per-layer packers above REMEMBER what was asked of each parameter
+# (_PACK_WANTED); conv_prepack(weights) — called by shared_conv_grads at the start of a forward — then makes all of them for
+# the current parameter versions in ONE launch (upf_conv_pack_weights_f32_multi) and the per-layer calls find them cached.
+_PACK_WANTED = {}
+
+
+def _pack_wanted(weight32, dtype, mode):
+    slot = _PACK_WANTED.get(id(weight32))
+    if slot is None or slot[0]() is not weight32:
+        if len(_PACK_WANTED) > 4096:
+            _PACK_WANTED.clear()
+        slot = _PACK_WANTED[id(weight32)] = (weakref.ref(weight32), set())
+    slot[1].add((dtype, mode))
+
+
+def conv_prepack(weights):
+    """Pack, in one launch, every operand form the per-layer packers have been asked for so far (forward, data gradient,
+    space-to-depth data gradient) of the given fp32 master weights at their CURRENT versions; fills the same caches."""
+    import ctypes
+    jobs = []
+    for w in weights:
+        slot = _PACK_WANTED.get(id(w))
+        if slot is None or slot[0]() is not w or not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
+            continue
+        Cout, Cin, k, _ = w.shape
+        for (dtype, mode) in slot[1]:
+            if mode == 2:
+                hit = _S2D_CACHE.get(id(w))
+                if hit is not None and hit[0] == (w._version, w.data_ptr(), dtype) and hit[1]() is w:
+                    continue
+                nbytes = _lib.lib().upf_conv_packed_bytes(Cout, 4 * Cin, 3)
+            else:
+                cs = _PACK_CACHE.get(id(w))
+                if cs is not None and cs[0]() is w and (w.data_ptr(), w._version, dtype, bool(mode)) in cs[1]:
+                    continue
+                nbytes = _lib.lib().upf_conv_packed_bytes(Cout if mode else Cin, Cin if mode else Cout, k)
+            jobs.append((w, dtype, mode, nbytes))
+    by_dev = {}
+    for j in jobs:
+        by_dev.setdefault((j[0].device, j[1]), []).append(j)
+    for (dev, dtype), js in by_dev.items():
+        if len(js) < 2:
+            continue                                            # (the per-layer packer does a single one just as well)
+        sizes = [(j[3] // 2 + 7) // 8 * 8 for j in js]          # elements, every operand 16-byte aligned
+        pool = torch.empty((sum(sizes),), dtype=dtype, device=dev)
+        outs, o = [], 0
+        for n in sizes:
+            outs.append(pool[o:o + n])
+            o += n
+        n = len(js)
+        wp = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in js])
+        op = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+        ci = (ctypes.c_int * n)(*[j[0].shape[1] for j in js])
+        co = (ctypes.c_int * n)(*[j[0].shape[0] for j in js])
+        ks = (ctypes.c_int * n)(*[j[0].shape[2] for j in js])
+        dg = (ctypes.c_int * n)(*[j[2] for j in js])
+        with torch.cuda.device(dev):
+            _lib.call('upf_conv_pack_weights_f32_multi', wp, op, ci, co, ks, dg, n, _lib.dtype_code(pool), _lib.stream_ptr(dev))
+        for (w, dtype, mode, nbytes), t in zip(js, outs):
+            packed = t[:nbytes // 2]
+            if mode == 2:
+                _S2D_CACHE[id(w)] = ((w._version, w.data_ptr(), dtype), weakref.ref(w), packed)
+            else:
+                cs = _PACK_CACHE.get(id(w))
+                if cs is None or cs[0]() is not w:
+                    cs = _PACK_CACHE[id(w)] = (weakref.ref(w), {})
+                for k_ in [k_ for k_ in cs[1] if k_[1] != w._version or k_[0] != w.data_ptr()]:
+                    del cs[1][k_]
+                cs[1][(w.data_ptr(), w._version, dtype, bool(mode))] = packed
 
 
 def train_caches_clear():
@@ -1035,6 +1148,8 @@ class shared_conv_grads(object):
 
     def __enter__(self):
         if torch.is_grad_enabled():
+            if not getattr(shared_conv_grads, 'no_prepack', False):
+                conv_prepack([c.weight for c in self.convs if c.weight.is_cuda])      # one launch for every layer's operands
             for c in self.convs:
                 if id(c.weight) in _GATES or not c.weight.is_cuda:
                     continue
@@ -1121,6 +1236,7 @@ def _s2d_dgrad_pack(master, dtype):
     slot = _S2D_CACHE.get(id(master))
     if slot is not None and slot[0] == key and slot[1]() is master:
         return slot[2]
+    _pack_wanted(master, dtype, 2)
     Cout, Cin = master.shape[:2]
     w = master.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
