@@ -604,7 +604,7 @@ class UPFlow_net(tools.abstract_model):
             fine = self.context_networks(buf).float()
             return fin(res + fine)
         if torch.is_grad_enabled() and (Fn.requires_grad or Fwn.requires_grad):
-            c = self.leakyRELU(self.correlation(Fn, Fwn))
+            c = self._corr_leaky(Fn, Fwn)
             if est.train_in_buffer_ok([c, A, flow_up]):
                 # training on the matrix cores: the estimator is one autograd node in the inference buffer layout; the
                 # refined flow is appended to its buffer, which the context network reads whole (no concatenations)
@@ -621,12 +621,21 @@ class UPFlow_net(tools.abstract_model):
         fine = self.context_networks(torch.cat([feat, (flow_up + res).to(feat.dtype)], dim=1)).float()
         return fin(res + fine)
 
+    def _corr_leaky(self, f_a, f_b_warp):
+        """LeakyReLU(corr81(f_a, f_b_warp)) under autograd (model/upflow.py:561-563) as ONE node: the kernel applies the
+        activation to its fp32 sums (fp32: the same bits as the two ops; 16-bit: one rounding instead of two), the backward
+        masks the incoming gradient by the sign of the output."""
+        c = self.correlation
+        if (c.pad_size, c.kernel_size, c.max_displacement, c.stride1, c.stride2) == (4, 1, 4, 1, 1) and f_a.is_cuda:
+            return ops.corr81(f_a, f_b_warp, float(self.leakyRELU.negative_slope))
+        return self.leakyRELU(c(f_a, f_b_warp))
+
     def _estimator_input(self, f_a, f_b_warp, feat_1x1, flow):
         """cat[LeakyReLU(corr81(f_a, f_b_warp)), feat_1x1, flow]  (model/upflow.py:557-566).
         Inference: the kernel applies the LeakyReLU and writes the 81 channels straight into the
         115-channel buffer, so the cost volume is never re-read for an activation or a concat."""
         if torch.is_grad_enabled() and (f_a.requires_grad or f_b_warp.requires_grad):
-            c = self.leakyRELU(self.correlation(f_a, f_b_warp))
+            c = self._corr_leaky(f_a, f_b_warp)
             return torch.cat([c, feat_1x1, flow.to(c.dtype)], dim=1)
         B, _, H, W = f_a.shape
         buf = torch.empty((B, self.num_ch_in, H, W), dtype=f_a.dtype, device=f_a.device)

@@ -210,7 +210,7 @@ class Corr81Function(Function):
     def backward(ctx, grad_out):
         if ctx.slope != 0.0:
             f1, f2, out = ctx.saved_tensors
-            grad_out = torch.where(out > 0, grad_out, grad_out * ctx.slope)
+            grad_out = torch.ops.aten.leaky_relu_backward(grad_out.to(out.dtype), out, ctx.slope, True)   # (sign of the output = sign of the input)
         else:
             f1, f2 = ctx.saved_tensors
         g1, g2 = corr81_backward_raw(f1, f2, grad_out.to(f1.dtype))

@@ -4,6 +4,57 @@ import torch
 import torch.nn.functional as F
 
 
+class _GreyFunction(torch.autograd.Function):
+    """0.2989 r + 0.5870 g + 0.1140 b (utils/loss.py:53-55), evaluated left to right like the reference, as one autograd node:
+    the backward is one broadcast multiply instead of the five nodes of the spelled-out expression."""
+
+    @staticmethod
+    def forward(ctx, image):
+        r, g, b = image[:, 0:1], image[:, 1:2], image[:, 2:3]
+        return 0.2989 * r + 0.5870 * g + 0.1140 * b
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy * _grey_weights(gy)
+
+
+_VALID = {}
+_ZEROS = {}
+_GREY_W = {}
+
+
+def _grey_weights(like):
+    """[1,3,1,1] constant on the device (made once, outside any graph capture: a host-to-device copy cannot be captured)."""
+    key = (like.dtype, like.device)
+    w = _GREY_W.get(key)
+    if w is None:
+        w = _GREY_W[key] = torch.tensor([0.2989, 0.5870, 0.1140], dtype=like.dtype, device=like.device).view(1, 3, 1, 1)
+    return w
+
+
+def _census_valid(mask, max_distance):
+    """ones inside, zeros in the max_distance-pixel border (utils/loss.py:58-60): a constant of the shape, built once."""
+    key = (tuple(mask.shape), mask.dtype, mask.device, max_distance)
+    v = _VALID.get(key)
+    if v is None:
+        if len(_VALID) > 64:
+            _VALID.clear()
+        inner = torch.ones(mask.shape[0], mask.shape[1], mask.shape[2] - 2 * max_distance, mask.shape[3] - 2 * max_distance,
+                           dtype=mask.dtype, device=mask.device)
+        v = _VALID[key] = F.pad(inner, [max_distance] * 4)
+    return v
+
+
+def _zeros_like_cached(t):
+    key = (tuple(t.shape), t.dtype, t.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 64:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros_like(t)
+    return z
+
+
 class loss_functions():
 
     @classmethod
@@ -30,12 +81,14 @@ class loss_functions():
         from .. import ops
 
         def grey(image):
-            r, g, b = torch.split(image.float(), 1, 1)
-            return 0.2989 * r + 0.5870 * g + 0.1140 * b
+            return _GreyFunction.apply(image.float())
         dist = ops.census_distance(grey(img1), grey(img1_warp), max_distance).to(img1.dtype)
-        inner = torch.ones(mask.shape[0], mask.shape[1], mask.shape[2] - 2 * max_distance, mask.shape[3] - 2 * max_distance,
-                           dtype=mask.dtype, device=mask.device)
-        valid = F.pad(inner, [max_distance] * 4)
+        valid = _census_valid(mask, max_distance)
+        if (not charbonnier_or_abs_robust) and if_use_occ and dist.is_cuda and dist.dtype == torch.float32:
+            # sum((|d| + 0.01)^q * m) / (sum(m) * 2 + 1e-6), utils/loss.py:28-31, as the one-launch reduction of csrc/loss.hip
+            # (ops.robust_loss_sums with y = 0) instead of nine element-wise / reduction launches each way
+            s, s_m = ops.robust_loss_sums(dist, _zeros_like_cached(dist), mask * valid, q=q, eps=0.01)
+            return s / (s_m * 2 + 1e-6)
         return cls.photo_loss_function(diff=dist, mask=mask * valid, q=q, charbonnier_or_abs_robust=charbonnier_or_abs_robust,
                                        if_use_occ=if_use_occ, averge=averge)
 
