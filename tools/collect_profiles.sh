@@ -26,11 +26,14 @@ tools/train_profile.sh train_bf16 --no-graph > /dev/null 2>&1
 tools/train_profile.sh train_fp32 --dtype fp32 --no-graph > /dev/null 2>&1
 python bench.py --mode train > $P/r03_train_bf16_bench.json 2>/dev/null
 python bench.py --mode train --dtype fp32 > $P/r03_train_fp32_bench.json 2>/dev/null
-# 4. cost volume: rocprof + PMC of the NORMALISING variant (the kernel inside the step) at the 1/4-resolution level of configs 2 and 5
+# 4. cost volume: rocprof + PMC of the normalising, octet-writing variant (the kernel inside the step) at the 1/4-resolution level of configs 2 and 5
 if [ -z "$SKIP_CORR" ]; then
-tools/prof_corr_run.sh 8 32 96 320 bf16 norm_l4_cfg2_stacked_bf16 norm > /dev/null 2>&1
-tools/prof_corr_run.sh 2 32 240 720 bf16 norm_l4_cfg5_stacked_bf16 norm > /dev/null 2>&1
+tools/prof_corr_run.sh 8 32 96 320 bf16 normc8_l4_cfg2_stacked_bf16 norm_c8 > /dev/null 2>&1
+tools/prof_corr_run.sh 2 32 240 720 bf16 normc8_l4_cfg5_stacked_bf16 norm_c8 > /dev/null 2>&1
+rm -rf $R/gpurun_out/prof_normc8_*
 fi
+# 4b. the other inference workloads of BASELINE.json (parity-test cases, not bench lines: recorded for DESIGN §6)
+for wl in config4 config5 kitti_native; do python bench.py --workload $wl --no-cpu-baseline --no-train-probe 2>/dev/null | tail -1 > $P/r03_bench_$wl.json; done
 # 5. every other operator at the level shapes
 python tools/kbench.py > $P/r03_kbench.txt 2>&1
 # 6. every convolution of one config-2 step, per layer (and the C8 variants of the layers the model runs in C8)
