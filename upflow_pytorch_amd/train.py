@@ -146,6 +146,7 @@ class Trainer():
                     warnings.warn('hipGraph capture of the training step failed (%s: %s); continuing with eager steps' % (type(e).__name__, e))
                     self.use_graph = False
                     self.capture_fallback = True
+                    self.capture_error = '%s: %s' % (type(e).__name__, e)
                     self._graph = None
                     self._static = self._static_stats = None
                     torch.cuda.synchronize(torch.device(self.device))
