@@ -85,51 +85,18 @@ def test_trainer_under_rccl_ddp_real_net():
     """Row (e): the REAL UPFlow_net (ctypes autograd Functions, stacked training schedule) wrapped in
     DistributedDataParallel on an `nccl` (= RCCL) process group — world size 1 on this 1-GPU box: the DDP reducer, the
     25 MB bucket with gradient_as_bucket_view and the RCCL all-reduce run for real; with one rank the averaged gradient
-    must equal the plain single-process gradient, and the Trainer's loss all-reduce must return the same terms."""
+    must equal the plain single-process gradient, and the Trainer's loss all-reduce must return the same terms.
+    Runs in its OWN process (tests/_ddp_one_rank.py): a process group leaves RCCL's watchdog / heartbeat threads behind in
+    the process that created it, and those threads poll HIP events — an error for every later hipGraph capture of the pytest
+    process under the default (global) capture mode."""
     import os
-    import socket
-    import torch.distributed as dist
-    from upflow_pytorch_amd import parallel
-    from upflow_pytorch_amd.train import Trainer
-    assert not dist.is_initialized()
-    batch = {k: v.cuda() for k, v in _weights.make_train_batch().items()}
-    plain = Trainer(build(), lr=1e-4, distributed=False)
-    want = plain.step(batch)
-    want_g = {n: p.grad.detach().clone() for n, p in plain.raw_net.named_parameters()}
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    saved = {k: os.environ.get(k) for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    try:
-        dist.init_process_group(backend='nccl', rank=0, world_size=1)
-        tr = Trainer(build(), lr=1e-4, device=torch.device('cuda', 0))
-        assert tr.distributed and type(tr.net).__name__ == 'DistributedDataParallel' and dist.get_backend() == 'nccl'
-        got = tr.step(tr.shard(batch))
-        # DDP + hipGraph: 11 eager warm-up steps, then the captured step (bucket all-reduce included) replays
-        trg = Trainer(build(), lr=1e-4, device=torch.device('cuda', 0), graph=True)
-        for _ in range(trg.graph_warmup + 2):
-            sg = trg.step(batch)
-        assert trg._graph is not None and all(np.isfinite(v) for v in sg.values())
-        assert parallel.max_over_ranks(1.25, torch.device('cuda', 0)) == 1.25
-        for k in want:
-            assert abs(got[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k])), (k, got[k], want[k])
-        gnorm = float(torch.cat([g.flatten() for g in want_g.values()]).norm())
-        worst = 0.0
-        for n, p in tr.raw_net.named_parameters():
-            assert p.grad is not None, n
-            worst = max(worst, float((p.grad - want_g[n]).norm()) / max(float(want_g[n].norm()), 1e-3 * gnorm))
-        print('DDP (1 rank, RCCL) vs plain gradient: worst relative difference %.3g' % worst)
-        assert worst <= 2e-3          # (MIOpen's backward kernels use atomics: not bit-reproducible run to run)
-    finally:
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, '_ddp_one_rank.py')], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-2000:])
+    assert out.returncode == 0, out.stderr[-4000:]
+    assert 'DDP-ONE-RANK-OK' in out.stdout
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'fp32'])

@@ -109,7 +109,8 @@ class Trainer():
         # thread_local: the process group's watchdog thread polls its events while this thread captures; under the
         # default (global) capture mode that hipEventQuery is an error that aborts the process
         try:
-            with torch.cuda.graph(g, capture_error_mode='thread_local' if self.distributed else 'global'):
+            # (also when this trainer is not distributed but the process holds a process group: its threads are there all the same)
+            with torch.cuda.graph(g, capture_error_mode='thread_local' if (self.distributed or (dist.is_available() and dist.is_initialized())) else 'global'):
                 self._static_stats = self._step_body(self._static)
         finally:
             # packed-weight cache entries made during the capture point into graph-pool memory whose packing kernels were
