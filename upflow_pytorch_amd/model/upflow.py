@@ -474,7 +474,9 @@ class UPFlow_net(tools.abstract_model):
             # Its K order differs from the NCHW kernel's (81 cost-volume channels in 11 octets, flows padded to an octet), so
             # this part agrees with the NCHW path to fp32 summation order, not bit for bit.
             c8_est = (c8 and level > 0 and est.c8_outputs_ok() and not getattr(self, '_no_c8_est', False)
-                      and ops.corr81_norm_supported(pair) and not getattr(self, '_no_fused_norm', False) and nc == 81)
+                      and ops.corr81_norm_supported(pair) and not getattr(self, '_no_fused_norm', False) and nc == 81
+                      and est._ch_in == nc + 32 + 2 and self.conv_1x1[level][0].out_channels == 32
+                      and self.context_networks.convs[0][0].in_channels == est._n_total + 2)
             if c8_est:
                 flow, flows_entry = self._level_c8(level, Fm, pair, flow, nb, B, C, H, W, dt, dev, cache, use_sgu)
                 flows.append(flows_entry)
@@ -557,6 +559,7 @@ class UPFlow_net(tools.abstract_model):
         est, sgi = self.flow_estimators, self.sgi_model
         nconv = sum(est._f) // 8
         ncorr = ops.CORR81_C8_OCTETS
+        # input part of the estimator: [cost volume 81 | 1x1 features 32 | flow 2] (model/upflow.py:563-566) as 11 + 4 + 1 octets
         in_map = ops.corr81_c8_channel_map() + list(range(81, 113)) + [113, 114] + [-1] * 6
         n_est = nconv + len(in_map) // 8
         buf8 = ops.c8_empty(nb, (n_est + 1) * 8, H, W, dt, dev)
