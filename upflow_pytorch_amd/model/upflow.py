@@ -523,7 +523,8 @@ class UPFlow_net(tools.abstract_model):
         flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
         if sgu:
             # (measured and not kept, round 3: this stem on a side stream = a parallel branch of the captured graph, forked before
-            # or after the feature pyramid — 3.075 vs 3.076 ms: the step is not idle-CU bound)
+            # or after the feature pyramid — 3.075 vs 3.076 ms; and with eager launches on two real streams 3.13 vs 3.14 ms: the step is
+            # not idle-CU bound)
             guide = self._final_guidance(X, nb, tuple(flow.shape[2:]))
             if guide[0] == 'c8':
                 flow_out = sgi.forward_in_buffer_c8(flow, guide[1], output_level_flow=flow_out, batch_shift=B)[1]
