@@ -285,3 +285,76 @@ def test_space_to_depth_and_stride2_gradients(shape, dtype):
     assert (gx.float() - gx_ref).abs().max() <= 2 * eps * max(1.0, float(gx_ref.abs().max()))
     assert gw.shape == w.shape and (gw - gw_ref).abs().max() <= 2e-4 * max(1.0, float(gw_ref.abs().max())), float((gw - gw_ref).abs().max())
     assert (gb - gpre.sum((0, 2, 3))).abs().max() <= 1e-4 * max(1.0, float(gpre.sum((0, 2, 3)).abs().max()))
+
+
+def test_pack_weights_multi_equals_the_single_packs():
+    """upf_conv_pack_weights_f32_multi (every layer's operands of a training step in one launch) writes bit for bit what
+    upf_conv_pack_weights_f32 writes per layer: forward, data-gradient and space-to-depth data-gradient forms, 3x3 and 1x1,
+    more jobs than one kernel-argument table holds (56)."""
+    import ctypes
+    from upflow_pytorch_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    shapes = [(16, 3, 3), (16, 16, 3), (32, 16, 3), (128, 115, 3), (2, 563, 3), (32, 196, 1), (96, 371, 3), (128, 565, 3), (3, 184, 3), (64, 96, 3)]
+    jobs = []
+    for rep in range(7):                                   # 70 jobs -> two launches
+        for (co, ci, k) in shapes:
+            w = (torch.randn(co, ci, k, k, generator=g) * 0.1).cuda()
+            mode = (rep + co) % 3 if k == 3 else (rep + co) % 2
+            jobs.append((w, mode))
+    singles, outs = [], []
+    for w, mode in jobs:
+        co, ci, k, _ = w.shape
+        n = _lib.lib().upf_conv_packed_bytes(co, 4 * ci, 3) if mode == 2 else _lib.lib().upf_conv_packed_bytes(co if mode else ci, ci if mode else co, k)
+        a = torch.full((n // 2,), float('nan'), dtype=torch.bfloat16, device='cuda')
+        _lib.call('upf_conv_pack_weights_f32', _lib.ptr(w), _lib.ptr(a), ci, co, k, _lib.UPF_BF16, mode, _lib.stream_ptr(w.device))
+        singles.append(a)
+        outs.append(torch.full((n // 2,), float('nan'), dtype=torch.bfloat16, device='cuda'))
+    n = len(jobs)
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in jobs])
+    op = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+    ci = (ctypes.c_int * n)(*[w.shape[1] for w, _ in jobs])
+    co = (ctypes.c_int * n)(*[w.shape[0] for w, _ in jobs])
+    ks = (ctypes.c_int * n)(*[w.shape[2] for w, _ in jobs])
+    dg = (ctypes.c_int * n)(*[m for _, m in jobs])
+    _lib.call('upf_conv_pack_weights_f32_multi', wp, op, ci, co, ks, dg, n, _lib.UPF_BF16, _lib.stream_ptr(torch.device('cuda', 0)))
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(singles, outs)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (i, jobs[i][0].shape, jobs[i][1])
+
+
+def test_conv_prepack_fills_the_caches_the_layers_read():
+    """ops.conv_prepack: after a first step has told the packers which forms each parameter needs, one launch makes all of them
+    for the NEW parameter versions, and conv_train then packs nothing itself (same results as without the prepack)."""
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(12)
+    ws = [(torch.randn(32, 16, 3, 3, generator=g) * 0.1).cuda().requires_grad_(True), (torch.randn(16, 32, 3, 3, generator=g) * 0.1).cuda().requires_grad_(True)]
+    bs = [torch.zeros(32).cuda().requires_grad_(True), torch.zeros(16).cuda().requires_grad_(True)]
+    x = torch.randn(2, 16, 16, 32, generator=g).bfloat16().cuda().requires_grad_(True)
+
+    def step():
+        y = ops.conv_train(ops.conv_train(x, ws[0], bs[0], 1, 0.1, 1), ws[1], bs[1], 1, 0.1, 1)
+        gx, = torch.autograd.grad(y.float().sum(), x)
+        return y.detach().clone(), gx.clone()
+    ops.train_caches_clear()
+    want = step()                                           # registers the wanted forms
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)                                     # an optimiser step: new versions
+    ref = step()
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.0)                                     # bump the versions, same values
+    calls = {'n': 0}
+    real = ops._conv_pack_from_master
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+    ops._conv_pack_from_master = counting
+    try:
+        ops.conv_prepack(ws)
+        got = step()
+    finally:
+        ops._conv_pack_from_master = real
+    assert calls['n'] == 0                                  # every operand came out of the one prepack launch
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and not torch.equal(got[0], want[0])
