@@ -240,3 +240,17 @@ def test_conv3x3_stride2_nchw_to_c8():
     ref = torch.empty(B, Cout, H // 2, W // 2, dtype=torch.bfloat16, device='cuda')
     ops.conv3x3_forward_raw(x, ops.conv3x3_pack(w), b, ref, 1, 0.1, 2)
     assert torch.equal(ops.from_c8(y), ref)            # the same kernel with another epilogue: bit-identical to the NCHW output
+
+
+def test_corr81_norm_c8_timed_helper_runs_the_same_kernel():
+    """bench.py's roofline probe (upf_corr81_norm_forward_c8_timed): positive event durations, and the buffer it leaves equals
+    what upf_corr81_norm_forward_c8 writes."""
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(4)
+    f1 = torch.randn(4, 32, 48, 160, generator=g).bfloat16().cuda()
+    f2 = torch.randn(4, 32, 48, 160, generator=g).bfloat16().cuda()
+    a = ops.c8_empty(4, 88, 48, 160, torch.bfloat16, 'cuda')
+    b = ops.c8_empty(4, 88, 48, 160, torch.bfloat16, 'cuda')
+    avg, mn = ops.corr81_norm_forward_c8_timed(f1, f2, a, 0.1, nrep=5)
+    ops.corr81_norm_forward_c8(f1, f2, b, 0.1)
+    assert 0 < mn <= avg < 1e4 and torch.equal(a.view(torch.int16), b.view(torch.int16))
