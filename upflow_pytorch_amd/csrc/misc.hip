@@ -90,6 +90,38 @@ void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int
   }
 }
 
+// Small planes (the coarse pyramid levels: 24x80 pixels and fewer), 16-bit features: ONE WAVE per row, eight rows per
+// workgroup, no workgroup barrier — the kernel above spends its time there on four __syncthreads of 512 mostly idle threads
+// and runs its 3000 workgroups in two rounds (8.4 us whatever the size; this form: one round).  Same one-sweep pivot
+// arithmetic; the sums are taken in another order, so both users of the statistics (normalize_forward and the fused
+// loader of the cost volume) go through the same dispatch (launch_stats) and keep agreeing bit for bit.
+constexpr int WAVE_ROWS = 8;
+template <typename T, bool VEC>
+__global__ __launch_bounds__(WAVE_ROWS * 64)
+void normalize_stats_wave_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, size_t rows,
+                                 const T* __restrict__ x2, size_t rows1) {
+  constexpr int V = VEC ? VecIO<T>::N : 1;
+  const size_t row = (size_t)blockIdx.x * WAVE_ROWS + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const T* xr = (row < rows1) ? x + row * HW : x2 + (row - rows1) * HW;
+  const float K = Elem<T>::load(xr);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane * V; i < HW; i += 64 * V) {
+    if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
+    } else { const float d = Elem<T>::load(xr + i) - K; s1 += d; s2 += d * d; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (lane == 0) {
+    const float cnt = (float)HW;
+    float* w = ws + row * 3;
+    w[0] = cnt; w[1] = K + s1 / cnt; w[2] = fmaxf(s2 - s1 * (s1 / cnt), 0.f);
+  }
+}
+
 // fp32 (the parity mode): (x - mean) / std with an IEEE division, the reference's arithmetic (model/upflow.py:130-134).
 // 16-bit: (x - mean) * (1/std) — the fused loader of the cost volume (corr81_allc_kernel.hpp, NORM) computes exactly
 // this, so the fused and the two-kernel paths agree bit for bit; the difference to the division (<= 1 ulp of fp32)
@@ -345,6 +377,15 @@ static int normalize_nseg(long long N, int HW) {
   return nseg;
 }
 
+// small planes of 16-bit features: the one-wave-per-row kernel (see normalize_stats_wave_kernel)
+static bool stats_wave_form(int nseg, int HW, int dtype) { return nseg == 1 && HW <= 4096 && dtype != UPF_F32; }
+template <typename T>
+static void launch_stats_wave(const T* x1, const T* x2, float* ws, size_t rows, size_t rows1, int HW, bool vec, hipStream_t stream) {
+  const unsigned grid = (unsigned)((rows + upf::misc::WAVE_ROWS - 1) / upf::misc::WAVE_ROWS);
+  if (vec) hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, true>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1);
+  else hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, false>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1);
+}
+
 // statistics of TWO [N,HW] tensors in one launch -> ws[(2N rows)][nseg][3]; returns nseg (internal.hpp)
 int upf::misc::launch_stats2(const void* x1, const void* x2, float* ws, long long N, int HW, int dtype, hipStream_t stream) {
   const int nseg = normalize_nseg(2 * N, HW);
@@ -352,6 +393,11 @@ int upf::misc::launch_stats2(const void* x1, const void* x2, float* ws, long lon
   const unsigned grid = (unsigned)(2 * N * nseg);
   const int vn = (dtype == UPF_F32) ? 4 : 8;
   const bool vec = (HW % vn == 0) && (seglen % vn == 0) && aligned_to(x1, 16) && aligned_to(x2, 16);
+  if (stats_wave_form(nseg, HW, dtype)) {
+    if (dtype == UPF_BF16) launch_stats_wave<bf16_t>((const bf16_t*)x1, (const bf16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream);
+    else launch_stats_wave<f16_t>((const f16_t*)x1, (const f16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream);
+    return nseg;
+  }
   UPF_DISPATCH(dtype, T,
                if (vec) hipLaunchKernelGGL((misc::normalize_stats_kernel<T, true>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N);
                else hipLaunchKernelGGL((misc::normalize_stats_kernel<T, false>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N));
@@ -375,7 +421,8 @@ extern "C" int upf_normalize_forward(const void* x, void* y, float* mean, float*
   const int vn = (dtype == UPF_F32) ? 4 : 8;
   const bool vec = (HW % vn == 0) && (seglen % vn == 0) && aligned_to(x, 16) && aligned_to(y, 16);
 #define UPF_NORM_LAUNCH(VEC)                                                                                                   \
-  hipLaunchKernelGGL((misc::normalize_stats_kernel<T, VEC>), dim3(grid), dim3(misc::NT), 0, (hipStream_t)stream, (const T*)x,  \
+  if (stats_wave_form(nseg, HW, dtype)) launch_stats_wave<T>((const T*)x, (const T*)nullptr, (float*)workspace, (size_t)N, (size_t)N, HW, VEC, (hipStream_t)stream); \
+  else hipLaunchKernelGGL((misc::normalize_stats_kernel<T, VEC>), dim3(grid), dim3(misc::NT), 0, (hipStream_t)stream, (const T*)x,  \
                      (float*)workspace, HW, nseg, seglen);                                                                     \
   hipLaunchKernelGGL((misc::normalize_apply_kernel<T, VEC>), dim3(grid), dim3(misc::NT), 0, (hipStream_t)stream, (const T*)x,  \
                      (T*)y, (const float*)workspace, mean, rstd, HW, nseg, seglen)

@@ -498,7 +498,8 @@ class UPFlow_net(tools.abstract_model):
                 slot[:, nc:nc + 32].copy_(A)
             else:
                 fast_conv_seq(self.conv_1x1[level], Fm, cache, out=slot[:, nc:nc + 32])
-            flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
+            # (level 0: the initial zero flow already has the coarsest size — the resize is the identity: no launch)
+            flow_up = flow if (level == 0 and tuple(flow.shape[2:]) == (H, W)) else upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
             if level == 0:                                                    # no warp at the coarsest level (:539-541)
                 pair[1, :B].copy_(Fm[B:])
                 pair[1, B:].copy_(Fm[:B])
