@@ -247,6 +247,17 @@ int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, int n8_oct, c
                         int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
                         int dtype, void* stream);
 int upf_conv_c8_set_option(const char* name, int value);   /* "rpw4" (1): Cout <= 32 on large grids: 16-row tiles */
+/* Layers with Cout <= 16 (the 2- / 3-channel heads of the dense stacks, 176->8, 160->16; model/pwc_modules.py:262-263,
+ * model/upflow.py:36-41) on the 16-output-channel matrix instruction: half the matrix work of a 32-channel block that would be
+ * mostly padding.  3x3, dilation 1, stride 1, input = C8 octets only (k-map as in upf_conv_pack_weights_kmap, K % 32 == 0);
+ * the same products as upf_conv_forward_c8, summed 32 input channels per instruction instead of 16 (fp32 sums may differ in
+ * the last bit). */
+long long upf_conv_packed_bytes_k16(int K, int Cout);
+int upf_conv_pack_weights_kmap16(const void* w /* [Cout,Cin,3,3] */, void* w_packed, int Cin, int Cout,
+                                 const int* kmap /* device, [K] */, int K, int dtype, void* stream);
+int upf_conv_forward_c8_narrow(const void* x8, long long x8_batch_stride, int n8_oct, const void* w_packed16, const float* bias,
+                               void* y, long long y_batch_stride, int y_is_c8, int B, int Cout, int H, int W, float leaky_slope,
+                               int dtype, void* stream);
 
 /* ---- the same convolutions under autograd: training on the matrix cores  (model/pwc_modules.py:250-286, :396-412) ----
  * forward      upf_conv_forward on weights packed straight from the fp32 master copy: upf_conv_pack_weights_f32(dgrad=0)

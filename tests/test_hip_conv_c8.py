@@ -145,10 +145,14 @@ def test_whole_net_c8_levels_are_bit_identical_to_nchw():
     im1, im2 = _weights.make_images(2, 2, 384, 1280)
     assert c8_level_ok(4, 96, 320, torch.bfloat16) and not c8_level_ok(4, 24, 80, torch.bfloat16)
     net._no_c8_est = True              # (the estimator's octet form has another K order: its own test below)
+    from upflow_pytorch_amd.model import pwc_modules
+    monkey_narrow = pwc_modules._NO_NARROW[0]
+    pwc_modules._NO_NARROW[0] = True   # (so has the 16-channel instruction of the <= 16-channel layers: test_conv_c8_narrow_layers)
     with torch.no_grad():
         a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
         net._no_c8 = True
         b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    pwc_modules._NO_NARROW[0] = monkey_narrow
     for k in ('flow_f_out', 'flow_b_out', 'occ_fw', 'occ_bw'):
         assert torch.equal(a[k], b[k]), k
     assert torch.isfinite(a['flow_f_out']).all() and float(a['flow_f_out'].abs().mean()) > 0
@@ -254,3 +258,36 @@ def test_corr81_norm_c8_timed_helper_runs_the_same_kernel():
     avg, mn = ops.corr81_norm_forward_c8_timed(f1, f2, a, 0.1, nrep=5)
     ops.corr81_norm_forward_c8(f1, f2, b, 0.1)
     assert 0 < mn <= avg < 1e4 and torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(8, 184, 3, 96, 320, False), (8, 176, 8, 96, 320, True), (2, 160, 16, 48, 160, True), (8, 568, 2, 96, 320, False),
+                                  (2, 32, 2, 24, 40, False), (1, 64, 12, 20, 24, True), (2, 40, 16, 8, 32, True), (2, 72, 5, 33, 48, False)])
+def test_conv_c8_narrow_layers(case, dt):
+    """upf_conv_forward_c8_narrow (Cout <= 16 on the 16-output-channel matrix instruction) vs F.conv2d on the same rounded operands
+    and vs the 32-channel kernel (same products; fp32 sums grouped 32 instead of 16 input channels per instruction): octet
+    inputs with padding positions, NCHW and octet outputs, 16- and 8-row tiles, heights that are not whole tiles."""
+    from upflow_pytorch_amd import ops
+    B, Cin, Cout, H, W, y_c8 = case
+    g = torch.Generator().manual_seed(Cin * 17 + Cout)
+    n_oct = (Cin + 7) // 8
+    x = torch.randn(B, Cin, H, W, generator=g).to(dt).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(dt).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    x8 = ops.to_c8(x)
+    if n_oct * 8 != Cin:
+        x8[..., Cin - (n_oct - 1) * 8:][:, -1] = 3.0                        # finite junk in the padding positions of the last octet
+    cmap = list(range(Cin)) + [-1] * (n_oct * 8 - Cin)
+    want = F.leaky_relu(F.conv2d(x.float(), w.float(), b, padding=1), 0.1)
+    ya = ops.c8_empty(B, Cout, H, W, dt, 'cuda') if y_c8 else torch.empty(B, Cout, H, W, dtype=dt, device='cuda')
+    yb = torch.empty_like(ya)
+    ops.conv_c8_forward_narrow_raw(x8, ops.conv_c8_pack16(w, cmap), b, ya, 0.1)
+    ops.conv_c8_forward_raw(x8, None, ops.conv_c8_pack(w, cmap), b, yb, 1, 0.1)
+    got = (ops.from_c8(ya, Cout) if y_c8 else ya).float()
+    ref = (ops.from_c8(yb, Cout) if y_c8 else yb).float()
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert (got - want).abs().max() <= eps * float(want.abs().max()) + 1e-3
+    assert (got - ref).abs().max() <= 2 * eps * float(want.abs().max())      # at most one rounding step (of the largest binade) apart
+    assert float((got != ref).float().mean()) < 0.02                         # ... and that rarely
+    if y_c8 and Cout % 8:
+        assert float(ya[:, -1, :, :, Cout % 8:].float().abs().max()) == 0.0  # padding channels of the last output octet: exact zeros

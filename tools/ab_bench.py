@@ -20,6 +20,10 @@ for v in variants:
     opts = dict(kv.split('=') for kv in v.split(',') if kv)
     net._no_c8 = bool(int(opts.pop('no_c8', 0)))          # (model switch, not a library option: NCHW at every level)
     net._no_c8_est = bool(int(opts.pop('no_c8_est', 0)))  # (model switch: the flow estimator of the fine levels in NCHW)
+    from upflow_pytorch_amd.model import pwc_modules
+    pwc_modules._NO_NARROW[0] = bool(int(opts.pop('no_narrow', 0)))   # (Cout <= 16 octet layers on the 32-channel kernel)
+    for m in net.modules():
+        m.__dict__.pop('_packed8', None)                  # (packed operands are cached per module: rebuild for this variant)
     prev = {k: ops.conv_set_option(k, int(val)) for k, val in opts.items()}
     r = GraphedInference(net, B, H, W, device=dev)
     r.load(im1, im2)

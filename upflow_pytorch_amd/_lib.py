@@ -48,6 +48,8 @@ SIGNATURES = {
     'upf_conv_pack_weights_f32_multi': [_c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _i, _vp],
     'upf_conv_pack_weights_kmap': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp],
     'upf_conv_forward_c8': [_vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    'upf_conv_pack_weights_kmap16': [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    'upf_conv_forward_c8_narrow': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_leaky_backward': [_vp, _vp, _vp, _ll, _f, _i, _vp],
     'upf_conv_wgrad': [_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_bias_grad': [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -130,6 +132,8 @@ def lib():
         L.upf_conv_packed_bytes_k.restype = _ll
         L.upf_conv_c8_k.argtypes = [_i, _i]
         L.upf_conv_c8_k.restype = _i
+        L.upf_conv_packed_bytes_k16.argtypes = [_i, _i]
+        L.upf_conv_packed_bytes_k16.restype = _ll
         L.upf_version.restype = _c.c_char_p
         L.upf_last_error.restype = _c.c_char_p
         _lib = L

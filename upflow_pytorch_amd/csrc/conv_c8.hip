@@ -34,6 +34,23 @@ __global__ void pack_weights_kmap_kernel(const T* __restrict__ w, T* __restrict_
   }
 }
 
+// N16 operand order (conv_kernel<..., N16>): [16-channel output block][32-channel chunk][tap][lane = co % 16 + 16 * k-octet][8 k]
+template <typename T>
+__global__ void pack_weights_kmap16_kernel(const T* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int ntaps, const int* __restrict__ kmap, int K) {
+  const int nblk = (Cout + 15) / 16, nch = K / 32;
+  const long long total = (long long)nblk * nch * ntaps * 512;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long long b = i >> 9;                      // (block * nch + chunk) * ntaps + tap
+    const int tap = (int)(b % ntaps), chunk = (int)((b / ntaps) % nch), blk = (int)(b / ((long long)ntaps * nch));
+    const int co = blk * 16 + (lane & 15), kk = chunk * 32 + (lane >> 4) * 8 + j;
+    const int ci = kmap[kk];
+    T v; v.v = 0;
+    if (ci >= 0 && ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ntaps + tap];
+    wp[i] = v;
+  }
+}
+
 struct ArgsC8 {
   const void* x8; long long x8bs; int n8oct;       // C8 slice of the input (XL >= 1)
   const void* x2; long long x2bs; int C2;          // NCHW part of the input (XL == 0 or 2)
@@ -41,7 +58,7 @@ struct ArgsC8 {
   int B, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
 };
 
-template <typename T, int MTW, int RPW, int S, int NOCTS, int D, int XL, bool YC8>
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, int XL, bool YC8, bool N16 = false>
 int launch_one_c8(const ArgsC8& a, int slabs) {
   constexpr int TH = (4 / MTW) * RPW;
   constexpr bool PH = (D >= 2 && S == 1);
@@ -52,10 +69,10 @@ int launch_one_c8(const ArgsC8& a, int slabs) {
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int tiles_x = cdiv(Wo, TW), tiles_y = PH ? cdiv(Ho, D * TH) * D : cdiv(Ho, TH);
   size_t lds = (XL >= 1) ? (size_t)2 * EBP * 16 : (size_t)EB * 16;
-  if (!YC8 && lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;
+  if (!YC8 && !N16 && lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward_c8: tile does not fit LDS (dilation %d)", a.d);
   static LdsOptIn opt;
-  auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, false, false, XL, YC8>;
+  auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, false, false, XL, YC8, N16>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x2, a.x2bs,
                      (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.C2, a.Cout, a.H, a.W, Ho, Wo, g_ablate, tiles_x, tiles_y, a.slope,
@@ -64,6 +81,7 @@ int launch_one_c8(const ArgsC8& a, int slabs) {
 }
 
 inline int g_c8_rpw4 = 1;      // Cout <= 32 layers on large grids: 16-row tiles (1) or 8-row tiles (0)
+inline int g_c8_narrow_tall = 0;
 
 // (MTW, tile rows) by Cout and grid like launch() of conv3x3.hip; stride 1; the instantiated subset:
 //   dilation 1 (and 1x1 with an NCHW input): any input layout, both output layouts (NCHW in -> NCHW out is conv3x3.hip's);
@@ -166,6 +184,7 @@ extern "C" int upf_conv_c8_set_option(const char* name, int value) {
   using namespace upf::conv;
   int* slot = nullptr;
   if (name && !strcmp(name, "rpw4")) slot = &g_c8_rpw4;
+  else if (name && !strcmp(name, "narrow_tall")) slot = &g_c8_narrow_tall;
   if (!slot) return INT32_MIN;
   const int prev = *slot;
   *slot = value;
@@ -195,4 +214,49 @@ extern "C" int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, in
   conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, x2, x2_batch_stride, C2, w_packed, bias, y, y_batch_stride,
                  B, Cout, H, W, kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};
   return dtype == UPF_BF16 ? conv::dispatch_c8<bf16_t>(a, y_is_c8 != 0) : conv::dispatch_c8<f16_t>(a, y_is_c8 != 0);
+}
+
+// ---- layers with at most 16 output channels on the 16-channel matrix instruction (conv_kernel<..., N16>) -------------------------
+extern "C" long long upf_conv_packed_bytes_k16(int K, int Cout) {
+  return (long long)((Cout + 15) / 16) * (upf::conv::pad32(K) / 32) * 9 * 1024;
+}
+
+extern "C" int upf_conv_pack_weights_kmap16(const void* w, void* w_packed, int Cin, int Cout, const int* kmap, int K, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(w && w_packed && kmap && Cin > 0 && Cout > 0 && K > 0 && K % 32 == 0, UPF_EINVAL, "conv_pack_weights_kmap16: bad arguments (K %% 32 == 0)");
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_pack_weights_kmap16: bf16 / fp16 only");
+  const long long total = (long long)((Cout + 15) / 16) * (K / 32) * 9 * 512;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == UPF_BF16)
+    hipLaunchKernelGGL((conv::pack_weights_kmap16_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)w_packed, Cin, Cout, 9, kmap, K);
+  else
+    hipLaunchKernelGGL((conv::pack_weights_kmap16_kernel<f16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)w, (f16_t*)w_packed, Cin, Cout, 9, kmap, K);
+  return check_launch("conv_pack_weights_kmap16");
+}
+
+extern "C" int upf_conv_forward_c8_narrow(const void* x8, long long x8_batch_stride, int n8_oct, const void* w_packed16, const float* bias,
+                                          void* y, long long y_batch_stride, int y_is_c8, int B, int Cout, int H, int W, float leaky_slope,
+                                          int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x8 && n8_oct > 0 && w_packed16 && bias && y, UPF_EINVAL, "conv_forward_c8_narrow: null pointer");
+  UPF_REQUIRE(B > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_forward_c8_narrow: bad shape B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_c8_narrow: bf16 / fp16 only");
+  UPF_REQUIRE(W % 8 == 0, UPF_EUNSUPPORTED, "conv_forward_c8_narrow: W = %d is not a multiple of 8", W);
+  UPF_REQUIRE(aligned_to(x8, 16) && x8_batch_stride % 8 == 0, UPF_EINVAL, "conv_forward_c8_narrow: the C8 input must be 16-byte aligned");
+  UPF_REQUIRE(!y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8_narrow: the C8 output must be 16-byte aligned");
+  UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31), UPF_EINVAL, "conv_forward_c8_narrow: input too large for one buffer descriptor");
+  UPF_REQUIRE((long long)(y_is_c8 ? (Cout + 7) / 8 * 8 : Cout) * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward_c8_narrow: output too large for one buffer descriptor");
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward_c8_narrow: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, nullptr, 0, 0, w_packed16, bias, y, y_batch_stride, B, Cout, H, W, 1, 1, 9,
+                 leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};
+  const int blocks16 = (Cout + 15) / 16;
+  // 8-row tiles: with 32-channel chunks a 16-row tile's two LDS buffers (87 KB) leave ONE workgroup per CU (measured: no faster
+  // than the 32-channel kernel); `narrow_tall` = 1 selects them for experiments
+  const bool tall = conv::g_c8_narrow_tall && (long long)B * cdiv(W, conv::TW) * cdiv(H, 16) >= conv::g_rpw4_min;
+#define UPF_N16(T)                                                                                                   \
+  if (y_is_c8) return tall ? conv::launch_one_c8<T, 1, 4, 1, 4, 1, 1, true, true>(a, blocks16) : conv::launch_one_c8<T, 1, 2, 1, 4, 1, 1, true, true>(a, blocks16);   \
+  return tall ? conv::launch_one_c8<T, 1, 4, 1, 4, 1, 1, false, true>(a, blocks16) : conv::launch_one_c8<T, 1, 2, 1, 4, 1, 1, false, true>(a, blocks16);
+  if (dtype == UPF_BF16) { UPF_N16(bf16_t) }
+  UPF_N16(f16_t)
+#undef UPF_N16
 }

@@ -18,6 +18,7 @@ __host__ __device__ constexpr int xw(int S, int marg) { return S * TW + 2 * marg
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
@@ -30,6 +31,21 @@ template <> struct Mma32<bf16_t> {
 template <> struct Mma32<f16_t> {
   static __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// 16 output channels x 16 pixels x 32 input channels per instruction (the narrow layers, N16): A = weights [16 co][32 k]
+// (lane = co + 16 * k-octet), B = x [32 k][16 px] (lane = px + 16 * k-octet: one LDS entry of 8 channels), D: lane holds
+// channels 4 * (lane / 16) + i, i = 0..3, of pixel lane % 16
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+  static __device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<f16_t> {
+  static __device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
 };
 
@@ -194,12 +210,17 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
 //     kernels hold 2.1 GHz and the interleaved form IS 10 % faster.  The wide layers are POWER-bound at ~1.1 PFLOP/s on
 //     random bf16 data; a better schedule buys nothing there, and the narrow layers (Cout <= 32) did not move either
 //     (their ~2.8 TB/s is set by the 96-byte row segments of a 32-pixel tile: two cache lines each).
-template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false>
+// N16 (round 3; C8 input, 3x3, dilation 1, stride 1, MTW = 1, 32-channel chunks): layers with at most 16 output channels (the
+// 563->2 / 184->3 heads, 176->8, 160->16) on `v_mfma_f32_16x16x32` instead of 32x32x16 — a 16-channel output block, so half the
+// matrix work of the 32-channel block that is mostly padding for them (ablation, 568->2 at 96x320: matrix phase alone 58 us,
+// staging alone 45 us, together 73 us).  blockIdx.y = the 16-channel block; weights packed by pack_weights_kmap16_kernel.
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false, bool N16 = false>
 __global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
 void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                  T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
                  int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct) {
   static_assert(XL == 0 || (D >= 0 && !GEN && !ONE), "C8 input: compile-time dilation, aligned rows");
+  static_assert(!N16 || (XL == 1 && MTW == 1 && NOCTS == 4 && D == 1 && S == 1 && RPW >= 2), "N16: C8 input, 3x3, dilation 1, stride 1");
   constexpr int ntaps = (D == 0) ? 1 : 9;
   constexpr int marg = margin_of(D);
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
@@ -238,16 +259,27 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   // 0x80000000, channel planes >= Cin fall off the end -> the hardware returns the zero padding
   const uint32_t plane = (uint32_t)HW * 2u;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
-  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)(N16 ? (Cout + 15) / 16 * 16 : pad32(Cout)) * (uint32_t)cip * 2u, 0x00020000);
 
   // accumulators start at the bias (channels >= Cout read 0 through the descriptor)
   __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, (uint32_t)Cout * 4u, 0x00020000);
-  f32x16 acc[RPW];
+  f32x16 acc[N16 ? 1 : RPW];
+  f32x4 acc16[N16 ? RPW : 1][2];                     // N16: [tile row][pixel half], channels 4 * (lane / 16) + i of pixel lane % 16 (+ 16)
+  const int p16 = lane & 15, ko = lane >> 4;         // N16 operand lane: pixel of its half / k-octet (= output channel quad)
+  if constexpr (N16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 16 + 4 * ko + i) * 4u, 0, 0));
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) { acc16[r][0][i] = bv; acc16[r][1][i] = bv; }
+    }
+  } else {
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
 #pragma unroll
     for (int r = 0; r < RPW; ++r) acc[r][e] = bv;
+  }
   }
 
   // x staging tasks: (octet, row, 8-pixel group) -> 8 loads (8 channel rows), 32 perms, 8 LDS entries
@@ -282,24 +314,62 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   // this lane's A operands (row px of the weight tile, k-octet kg of each k-step) for every tap of a chunk
   uint4 wa[ntaps][KS];
   auto wload = [&](int cc, int tap, int ks) {
-    const uint32_t off = (cc < nchunks && !(abl & 8)) ? (uint32_t)(((slab * nksteps + cc * KS + ks) * ntaps + tap) * 1024 + lane * 16) : 0x80000000u;
+    // (N16: one 1 KB operand per 32-channel chunk and tap, [16-channel block][chunk][tap][lane]; ks is 0)
+    const uint32_t idx = N16 ? (uint32_t)((slab * nchunks + cc) * ntaps + tap) : (uint32_t)((slab * nksteps + cc * KS + ks) * ntaps + tap);
+    const uint32_t off = (cc < nchunks && !(abl & 8)) ? idx * 1024u + (uint32_t)lane * 16u : 0x80000000u;
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
   };
+  constexpr int KSW = N16 ? 1 : KS;                  // weight operands per tap and chunk
 #pragma unroll
   for (int tap = 0; tap < ntaps; ++tap)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wa[tap][ks] = wload(0, tap, ks);
+    for (int ks = 0; ks < KSW; ++ks) wa[tap][ks] = wload(0, tap, ks);
 
   constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * DV) * 3 < 9 * RPW);
   const int colx[3] = {swz(marg + px - (D > 0 ? D : 0)), swz(marg + px), swz(marg + px + (D > 0 ? D : 0))};   // REUSE windows
 
   // ---- the matrix phase of chunk cc on the tile image at xb (also fetches the weights of chunk cc + 1)
+  // (N16, measured and not kept: the four waves of a workgroup multiply by the SAME weights, and their 4 x 9 KB of operand loads
+  // per chunk are more L2 traffic than the 22 KB of x — 1.2 GB against 0.28 GB of input for 568->2.  Passing the operands through
+  // LDS once per workgroup needs 18 KB more LDS: one workgroup per CU instead of two, 66 -> 109 us.)
   auto matrix_phase = [&](const uint4* __restrict__ xb, int cc) {
     // matrix phase at raised wave priority: the CU's other workgroup is usually in its staging phase, and the arbiter then
     // serves the MFMA stream first (A/B on one box, three runs each: 1165 -> 1173 frame-pairs/s)
     __builtin_amdgcn_s_setprio(2);
 
     if (abl & 1) {
+    } else if constexpr (N16) {
+      // staged row sr feeds output rows sr - ky; per row three windows (kx) for each 16-pixel half, each used by up to three MFMAs
+      constexpr int NR = RPW + 2;
+      const int c16[2][3] = {{swz(marg + p16 - 1), swz(marg + p16), swz(marg + p16 + 1)}, {swz(marg + p16 + 15), swz(marg + p16 + 16), swz(marg + p16 + 17)}};
+      uint4 bq[2][6];
+      auto bload = [&](int sr, uint4 (&b)[6]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) b[h * 3 + kx] = xb[(ko * rows + RPW * rg + sr) * XWP + c16[h][kx]];
+      };
+      bload(0, bq[0]);
+#pragma unroll
+      for (int sr = 0; sr < NR; ++sr) {
+        if (sr + 1 < NR) bload(sr + 1, bq[(sr + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+              if (sr - ky >= 0 && sr - ky < RPW)
+                acc16[sr - ky][h] = Mma16<T>::mma(wa[ky * 3 + kx][0], bq[sr & 1][h * 3 + kx], acc16[sr - ky][h]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+          if (sr == ky + RPW - 1) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) wa[ky * 3 + kx][0] = wload(cc + 1, ky * 3 + kx, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else if constexpr (REUSE) {
       // staged row sr of this wave's strip feeds output rows r = sr - ky*DV.  The three windows (kx) of row sr+1 are
       // read from LDS while the (up to 9*KS) MFMAs of row sr run: left to itself hipcc issues each ds_read right
@@ -430,6 +500,40 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 
   // ---- epilogue (bias is already in the accumulators)
   const int gy0 = __builtin_amdgcn_readfirstlane(y0 + RPW * rg * RS);
+  if constexpr (N16) {
+    // lane: channels slab*16 + 4*ko + i of pixels x0 + p16 (+ 16).  YC8: the quad is half an octet entry -> one 8-byte store;
+    // NCHW (the 2- / 3-channel heads): one 2-byte store per channel, channels >= Cout fall off the descriptor.
+    const uint32_t plane16 = (uint32_t)(Ho * Wo) * 16u, plane2 = (uint32_t)(Ho * Wo) * 2u;
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * ybs, 0, YC8 ? (uint32_t)((Cout + 7) / 8) * plane16 : (uint32_t)Cout * plane2, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int gy = gy0 + r;                        // uniform
+      if (gy < Ho) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int gx = x0 + p16 + 16 * h;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { v[i] = acc16[r][h][i]; v[i] = fmaxf(v[i], v[i] * slope); }
+          if constexpr (YC8) {
+            const uint32_t off = (gx < Wo) ? (uint32_t)(slab * 2 + (ko >> 1)) * plane16 + (uint32_t)(gy * Wo + gx) * 16u + (uint32_t)(ko & 1) * 8u : 0x80000000u;
+            u32x2 o;
+            o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b64(o, yr, off, 0, 0);
+          } else {
+            const uint32_t off = (gx < Wo) ? (uint32_t)(slab * 16 + 4 * ko) * plane2 + (uint32_t)(gy * Wo + gx) * 2u : 0x80000000u;
+            const uint32_t p01 = pack2<T>(v[0], v[1]), p23 = pack2<T>(v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)p01, yr, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(p01 >> 16), yr, off + plane2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)p23, yr, off + 2u * plane2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(p23 >> 16), yr, off + 3u * plane2, 0, 0);
+          }
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (!N16) {
   if constexpr (YC8) {
     // y as octets [c/8][Ho][Wo][8]: register e of this lane is channel (e&3) + 8*(e>>2) + 4*kg of the wave's 32-block, so
     // registers 4g..4g+3 are bytes [8*kg, 8*kg + 8) of the entry (octet g, pixel): one 8-byte store; the two half-waves
@@ -474,6 +578,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
         epilogue_store<T, GEN>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * Wo) * 2u, slope);
     }
   }
+  }  // !N16
 }
 
 // launch heuristics and experiment switches (upf_conv_set_option)

@@ -178,6 +178,9 @@ class _PackedConv3x3(object):
                                        self.conv.kernel_size[0])
 
 
+_NO_NARROW = [False]        # experiment switch (tools/ab_bench.py "no_narrow=1"): Cout <= 16 layers on the 32-channel kernel
+
+
 class _PackedConvC8(object):
     """_PackedConv3x3 for the channel-octet entry (ops.conv_c8_forward_raw): weights packed through a channel map — for every
     channel position of the layer's C8 input slice and for every plane of its NCHW tail the input channel of the Conv2d it
@@ -187,6 +190,9 @@ class _PackedConvC8(object):
         self.conv = seq[0]
         self.slope = 0.1 if any(isinstance(m, nn.LeakyReLU) for m in seq) else 0.0
         self.maps = (tuple(c8_channels), tuple(tail_channels))
+        # layers with <= 16 output channels on octets only: the 16-channel matrix instruction (ops.conv_c8_forward_narrow_raw)
+        self.narrow = (not _NO_NARROW[0]) and ops.conv_c8_narrow_ok(self.conv.out_channels, self.conv.kernel_size[0], self.conv.dilation[0],
+                                                                    self.conv.stride[0], len(self.maps[1]) > 0) and len(self.maps[0]) > 0
         self.key = None
         self.packed = None
         self.bias = None
@@ -195,7 +201,7 @@ class _PackedConvC8(object):
         w, b = self.conv.weight, self.conv.bias
         key = (w._version, w.dtype, w.device, w.data_ptr(), b._version, b.data_ptr())
         if key != self.key:
-            self.packed = ops.conv_c8_pack(w, self.maps[0], self.maps[1])
+            self.packed = ops.conv_c8_pack16(w, self.maps[0]) if self.narrow else ops.conv_c8_pack(w, self.maps[0], self.maps[1])
             self.bias = self.conv.bias.detach().float().contiguous()
             self.key = key
         return self.packed, self.bias
@@ -205,6 +211,8 @@ class _PackedConvC8(object):
 
     def __call__(self, x8, x2, y):
         packed, bias = self.get()
+        if self.narrow:
+            return ops.conv_c8_forward_narrow_raw(x8, packed, bias, y, self.slope)
         return ops.conv_c8_forward_raw(x8, x2, packed, bias, y, self.conv.dilation[0], self.slope, self.conv.kernel_size[0], self.conv.stride[0])
 
 

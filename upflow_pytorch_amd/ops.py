@@ -661,6 +661,51 @@ def conv_c8_pack(weight, c8_channels=(), tail_channels=()):
     return packed
 
 
+def conv_c8_narrow_ok(Cout, kernel_size, dilation, stride, has_tail):
+    """Layers upf_conv_forward_c8_narrow takes (the 16-output-channel matrix instruction): Cout <= 16, 3x3, dilation 1, stride 1,
+    octet input only."""
+    return Cout <= 16 and kernel_size == 3 and dilation == 1 and stride == 1 and not has_tail
+
+
+def conv_c8_pack16(weight, c8_channels):
+    """conv_c8_pack for upf_conv_forward_c8_narrow (Cout <= 16): the k-map padded to whole 32-channel chunks."""
+    w = weight.detach().contiguous()
+    Cout, Cin, kh, kw = w.shape
+    c8_channels = list(c8_channels)
+    if kh != 3 or kw != 3 or len(c8_channels) % 8 or not c8_channels:
+        raise UpflowHipError('conv_c8_pack16: 3x3 kernels, a C8 slice of whole octets')
+    K = (len(c8_channels) + 31) // 32 * 32
+    kmap = c8_channels + [-1] * (K - len(c8_channels))
+    dev = _lib.check_gpu(w)
+    kmap_t = torch.tensor(kmap, dtype=torch.int32, device=w.device)
+    packed = torch.empty((_lib.lib().upf_conv_packed_bytes_k16(K, Cout) // 2,), dtype=w.dtype, device=w.device)
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_pack_weights_kmap16', _lib.ptr(w), _lib.ptr(packed), Cin, Cout, _lib.ptr(kmap_t), K,
+                  _lib.dtype_code(w), _lib.stream_ptr(dev))
+    return packed
+
+
+def conv_c8_forward_narrow_raw(x8, packed16, bias32, y, leaky_slope=0.0):
+    """conv_c8_forward_raw for a layer with Cout <= 16 packed by conv_c8_pack16 (3x3, dilation 1, stride 1, octet input)."""
+    B, n, H, W, _ = x8.shape
+    Cout = bias32.shape[0]
+    y_is_c8 = y.dim() == 5
+    if not _c8_view_ok(x8):
+        raise UpflowHipError('conv_c8_narrow: x8 must be an octet slice of a contiguous C8 buffer')
+    if y_is_c8:
+        if not _c8_view_ok(y) or tuple(y.shape) != (B, (Cout + 7) // 8, H, W, 8):
+            raise UpflowHipError('conv_c8_narrow: C8 output must be [%d,%d,%d,%d,8], got %s' % (B, (Cout + 7) // 8, H, W, tuple(y.shape)))
+    elif tuple(y.shape) != (B, Cout, H, W) or y.stride()[1:] != (H * W, W, 1):
+        raise UpflowHipError('conv_c8_narrow: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, H, W))
+    dev = x8.device
+    if not (x8.is_cuda and y.is_cuda) or x8.dtype != y.dtype:
+        raise UpflowHipError('conv_c8_narrow: GPU tensors of one dtype expected (there is no CPU fallback)')
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_forward_c8_narrow', _lib.ptr(x8), x8.stride(0), n, _lib.ptr(packed16), _lib.ptr(bias32), _lib.ptr(y), y.stride(0),
+                  int(y_is_c8), B, Cout, H, W, float(leaky_slope), _lib.dtype_code(x8), _lib.stream_ptr(dev))
+    return y
+
+
 def _c8_view_ok(t):
     B, n, H, W, e = t.shape
     return e == 8 and t.stride()[1:] == (H * W * 8, W * 8, 8, 1)
