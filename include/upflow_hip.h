@@ -120,6 +120,17 @@ int upf_correlation_forward(const void* in1, const void* in2, void* out,
                             int B, int C, int H, int W, int dtype,
                             int pad_size, int kernel_size, int max_displacement,
                             int stride1, int stride2, int corr_type_multiply, void* stream);
+/* Gradients of upf_correlation_forward (correlation_cuda.backward with the full argument list, correlation_cuda.cc:89-167 ->
+ * correlation_cuda_kernel.cu:116-300): the tuned kernels for (4,1,4,1,1); a plain one-thread-per-element kernel for any
+ * (pad, md, stride2) with kernel_size 1 and stride1 1 — the parameter sets for which the reference's backward kernels are the
+ * gradient of its forward (their block -> pixel map and (ymin, ymax) windows, :129-141, :222-256, are not for stride1 > 1 or
+ * kernel_size > 1); UPF_EUNSUPPORTED otherwise.  grad_out [B,(2*(md/s2)+1)^2,outH,outW], g1 / g2 [B,C,H,W], all of `dtype`.
+ * upf_correlation_forward itself returns UPF_EUNSUPPORTED where the reference reads outside its padded buffers
+ * (kernel_size > 1 with md - (md/s2)*s2 < (k-1)/2: correlation_cuda_kernel.cu:62, :87-91). */
+int upf_correlation_backward(const void* in1, const void* in2, const void* grad_out, void* g1, void* g2,
+                             int B, int C, int H, int W, int dtype,
+                             int pad_size, int kernel_size, int max_displacement,
+                             int stride1, int stride2, int corr_type_multiply, void* stream);
 /* output geometry of upf_correlation_forward */
 int upf_correlation_out_shape(int H, int W, int pad_size, int kernel_size, int max_displacement,
                               int stride1, int stride2, int* out_channels, int* out_h, int* out_w);

@@ -18,6 +18,7 @@ Their published algorithms are restated explicitly in `oracle/ops.py` (no call t
 interpolate), anchored on the reference's call sites `model/pwc_modules.py:74,79,101,200,205`,
 `utils/tools.py:1257,1261,1304`, `utils/pytorch_correlation.py:30-31,38`.
 """
-from .ops import (corr81, corr81_unfold, corr81_backward, correlation_general, warp, warp_backward,
+from .ops import (corr81, corr81_unfold, corr81_backward, correlation_general, correlation_well_defined, correlation_forward_literal,
+                  correlation_backward_supported, correlation_general_backward, correlation_backward_literal, warp, warp_backward,
                   flow_upsample, sgu_blend, normalize_pair, occ_check, census_distance, epe,
                   boundary_warp, robust_loss_sums, smooth_edge1)  # noqa: F401

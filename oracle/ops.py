@@ -75,13 +75,28 @@ def corr81_backward(f1, f2, grad_out):
     return g1 / C, g2p[:, :, R:R + H, R:R + W] / C
 
 
+def correlation_well_defined(pad_size, kernel_size, max_displacement, stride1, stride2):
+    """Parameter sets for which `correlation_forward<T>` (correlation_cuda_kernel.cu:41-114) only reads INSIDE its padded
+    buffers.  The kernel centres output pixel (by, bx) at padded row y1 = by*stride1 + max_displacement (:62) and reads rows
+    y1 + j and y1 + tj*stride2 + j for |j| <= kernel_rad, |tj| <= max_displacement/stride2 (:87-91): the smallest row index is
+    max_displacement - (max_displacement/stride2)*stride2 - kernel_rad, negative whenever kernel_size > 1 and stride2 divides
+    max_displacement closely enough — there the reference reads whatever precedes the buffer (undefined behaviour), so no
+    output of it can be restated.  The largest index stays inside by construction of the output size (correlation_cuda.cc:24-34)."""
+    kr = (kernel_size - 1) // 2
+    return max_displacement - (max_displacement // stride2) * stride2 - kr >= 0
+
+
 def correlation_general(f1, f2, pad_size, kernel_size, max_displacement, stride1, stride2):
     """General-parameter cost volume, restating correlation_cuda_kernel.cu:41-114 and the shape math
     of correlation_cuda.cc:19-34: padded inputs, kernel radius kr=(k-1)/2, displacement radius
     dr=md/stride2, output (2dr+1)^2 channels of size ceil((H+2p-2(kr+md))/s1).
-    Unpinned beyond the (4,1,4,1,1) case (the reference's Python fallback asserts pad==md, s=1).
+    PINNED (round 4) on `correlation_forward_literal` below — a scalar, thread-by-thread emulation of the CUDA kernel's own
+    index arithmetic — and on hand-computed vectors (tests/test_oracle_golden.py); at (4,1,4,1,1) it is corr81, which is pinned
+    on the reference's Python fallback.  Raises outside `correlation_well_defined`.
     """
     import math
+    if not correlation_well_defined(pad_size, kernel_size, max_displacement, stride1, stride2):
+        raise ValueError('correlation: the reference reads outside its padded buffer for these parameters (undefined)')
     B, C, H, W = f1.shape
     kr = (kernel_size - 1) // 2
     br = kr + max_displacement
@@ -103,9 +118,165 @@ def correlation_general(f1, f2, pad_size, kernel_size, max_displacement, stride1
                 for i in range(-kr, kr + 1):
                     a = p1[:, :, (ys + j)][:, :, :, (xs + i)]
                     b = p2[:, :, (ys + tj * stride2 + j)][:, :, :, (xs + ti * stride2 + i)]
-                    acc += (a * b).sum(1)
+                    acc = acc + (a * b).sum(1)
             out[:, (tj + dr) * ds + (ti + dr)] = acc / nelems
     return out
+
+
+def _cdiv_trunc(a, b):
+    """C integer division (truncation toward zero), as the CUDA kernels compute their index bounds."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b > 0) else -q
+
+
+def _channels_first(x, pad_size):
+    """channels_first<T> (correlation_cuda_kernel.cu:15-39): NCHW -> zero-padded NHWC, as a flat list-like numpy buffer."""
+    import numpy as np
+    B, C, H, W = x.shape
+    r = np.zeros((B, H + 2 * pad_size, W + 2 * pad_size, C), dtype=np.float64)
+    r[:, pad_size:pad_size + H, pad_size:pad_size + W, :] = x.permute(0, 2, 3, 1).double().numpy()
+    return r.reshape(-1)
+
+
+def correlation_forward_literal(f1, f2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """`correlation_forward<T>` emulated block by block, thread by thread, with the kernel's OWN flat index arithmetic
+    (correlation_cuda_kernel.cu:41-114: pdimyxc / pdimxc / pdimc strides :66-68, indx1 / indx2 :88-89, the 32 per-thread partial
+    sums and their serial reduction :81-104, tc and tindx :105-107, division by nelems :108) on the padded NHWC buffers that
+    channels_first<T> builds (:15-39), launched over (batch, outputHeight, outputWidth) blocks of 32 threads as
+    correlation_forward_cuda_kernel does (:302-393), output geometry from correlation_cuda.cc:24-34.  Pure python scalar loops in
+    float64 — small cases only; asserts that no index leaves the buffer (the reference would read foreign memory there)."""
+    import math
+    import numpy as np
+    THREADS = 32
+    B, C, H, W = f1.shape
+    kernel_rad = (kernel_size - 1) // 2
+    border = kernel_rad + max_displacement
+    pH, pW = H + 2 * pad_size, W + 2 * pad_size
+    oH = int(math.ceil(float(pH - 2 * border) / float(stride1)))
+    oW = int(math.ceil(float(pW - 2 * border) / float(stride1)))
+    displacement_rad = max_displacement // stride2
+    displacement_size = 2 * displacement_rad + 1
+    nOut = displacement_size * displacement_size
+    r1, r2 = _channels_first(f1, pad_size), _channels_first(f2, pad_size)
+    pdimyxc, pdimxc, pdimc = pH * pW * C, pW * C, C
+    tdimcyx, tdimyx, tdimx = nOut * oH * oW, oH * oW, oW
+    nelems = float(kernel_size * kernel_size * pdimc)
+    out = np.zeros(B * nOut * oH * oW, dtype=np.float64)
+    for n in range(B):
+        for by in range(oH):
+            for bx in range(oW):
+                y1, x1 = by * stride1 + max_displacement, bx * stride1 + max_displacement
+                for tj in range(-displacement_rad, displacement_rad + 1):
+                    for ti in range(-displacement_rad, displacement_rad + 1):
+                        prod_sum = [0.0] * THREADS
+                        x2, y2 = x1 + ti * stride2, y1 + tj * stride2
+                        for c in range(THREADS):
+                            for j in range(-kernel_rad, kernel_rad + 1):
+                                for i in range(-kernel_rad, kernel_rad + 1):
+                                    for ch in range(c, pdimc, THREADS):
+                                        assert 0 <= y1 + j < pH and 0 <= x1 + i < pW and 0 <= y2 + j < pH and 0 <= x2 + i < pW, 'read outside the padded buffer'
+                                        indx1 = n * pdimyxc + (y1 + j) * pdimxc + (x1 + i) * pdimc + ch
+                                        indx2 = n * pdimyxc + (y2 + j) * pdimxc + (x2 + i) * pdimc + ch
+                                        prod_sum[c] += r1[indx1] * r2[indx2]
+                        reduce_sum = 0.0
+                        for index in range(THREADS):
+                            reduce_sum += prod_sum[index]
+                        tc = (tj + displacement_rad) * displacement_size + (ti + displacement_rad)
+                        out[n * tdimcyx + tc * tdimyx + by * tdimx + bx] = reduce_sum / nelems
+    return torch.from_numpy(out.reshape(B, nOut, oH, oW)).to(f1.dtype)
+
+
+def correlation_backward_supported(pad_size, kernel_size, max_displacement, stride1, stride2):
+    """Where the reference's backward kernels ARE the gradient of its forward: kernel_size 1 and stride1 1.  Their blocks sit at
+    padded pixel y = blockIdx.x * stride1 + pad_size over an inputHeight x inputWidth grid (correlation_cuda_kernel.cu:129-130,
+    :222-223, launch :475-520): with stride1 > 1 most input pixels are never visited and rows past the image are, and with
+    kernel_size > 1 the (ymin, ymax) window of :137-141 attributes the whole patch sum to the centre tap — neither is the
+    derivative of :86-94.  Nothing in the model uses such parameters (model/upflow.py:335)."""
+    return kernel_size == 1 and stride1 == 1 and correlation_well_defined(pad_size, kernel_size, max_displacement, stride1, stride2)
+
+
+def correlation_general_backward(f1, f2, grad_out, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """(gradInput1, gradInput2) of correlation_general by autograd — the definition the HIP kernel is held to where
+    correlation_backward_supported; tests check that it equals the literal emulation of the reference's kernels below."""
+    a = f1.detach().clone().requires_grad_(True)
+    b = f2.detach().clone().requires_grad_(True)
+    out = correlation_general(a, b, pad_size, kernel_size, max_displacement, stride1, stride2)
+    return torch.autograd.grad(out, (a, b), grad_out)
+
+
+def correlation_backward_literal(f1, f2, grad_out, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """`correlation_backward_input1<T>` / `_input2<T>` (correlation_cuda_kernel.cu:116-207, :209-300) emulated block by block
+    with their own index arithmetic: block (y, x, c) per item over the inputHeight x inputWidth x channels grid (:475-520),
+    y = blockIdx.x * stride1 + pad_size (:129), the truncating integer divisions of the (xmin .. ymax) windows (:137-141, :252-256),
+    the early-outs (:143-151, :258-266), the clamps (:153-157), the 32 per-thread partial sums over output channels (:181-196) and
+    their serial reduction (:199-205).  Reads outside the padded buffer are asserted to carry no weight (an in-bounds gradOutput
+    window never meets them) and taken as zero.  float64 scalar loops, small cases only."""
+    import numpy as np
+    THREADS = 32
+    B, C, H, W = f1.shape
+    nOut, oH, oW = grad_out.shape[1:]
+    kernel_rad = (kernel_size - 1) // 2
+    displacement_rad = max_displacement // stride2
+    displacement_size = 2 * displacement_rad + 1
+    assert nOut == displacement_size * displacement_size
+    pH, pW = H + 2 * pad_size, W + 2 * pad_size
+    r1, r2 = _channels_first(f1, pad_size), _channels_first(f2, pad_size)
+    go = grad_out.double().numpy().reshape(-1)
+    pdimyxc, pdimxc, pdimc = pH * pW * C, pW * C, C
+    tdimcyx, tdimyx, tdimx = nOut * oH * oW, oH * oW, oW
+    nelems = float(kernel_size * kernel_size * C)
+    g1 = np.zeros((B, C, H, W), dtype=np.float64)
+    g2 = np.zeros((B, C, H, W), dtype=np.float64)
+
+    def rd(buf, n, yy, xx, c):
+        if 0 <= yy < pH and 0 <= xx < pW:
+            return buf[n * pdimyxc + yy * pdimxc + xx * pdimc + c], True
+        return 0.0, False
+
+    for n in range(B):
+        for by in range(H):
+            for bx in range(W):
+                y, x = by * stride1 + pad_size, bx * stride1 + pad_size
+                if y - pad_size >= H or x - pad_size >= W:
+                    continue                                   # (stride1 > 1: the reference writes past the image here)
+                for c in range(C):
+                    # ---- input1 (:116-207)
+                    xmin = _cdiv_trunc(x - kernel_rad - max_displacement, stride1)
+                    ymin = _cdiv_trunc(y - kernel_rad - max_displacement, stride1)
+                    xmax = _cdiv_trunc(x + kernel_rad - max_displacement, stride1)
+                    ymax = _cdiv_trunc(y + kernel_rad - max_displacement, stride1)
+                    if not (xmax < 0 or ymax < 0 or xmin >= oW or ymin >= oH or xmin > xmax or ymin > ymax):
+                        xmin, xmax, ymin, ymax = max(0, xmin), min(oW - 1, xmax), max(0, ymin), min(oH - 1, ymax)
+                        prod_sum = [0.0] * THREADS
+                        for t in range(THREADS):
+                            for tc in range(t, nOut, THREADS):
+                                i2 = (tc % displacement_size - displacement_rad) * stride2
+                                j2 = (tc // displacement_size - displacement_rad) * stride2
+                                val2, inside = rd(r2, n, y + j2, x + i2, c)
+                                for j in range(ymin, ymax + 1):
+                                    for i in range(xmin, xmax + 1):
+                                        w = go[n * tdimcyx + tc * tdimyx + j * tdimx + i]
+                                        prod_sum[t] += w * val2
+                        g1[n, c, y - pad_size, x - pad_size] = sum(prod_sum) / nelems
+                    # ---- input2 (:209-300)
+                    prod_sum = [0.0] * THREADS
+                    for t in range(THREADS):
+                        for tc in range(t, nOut, THREADS):
+                            i2 = (tc % displacement_size - displacement_rad) * stride2
+                            j2 = (tc // displacement_size - displacement_rad) * stride2
+                            xmin = _cdiv_trunc(x - kernel_rad - max_displacement - i2, stride1)
+                            ymin = _cdiv_trunc(y - kernel_rad - max_displacement - j2, stride1)
+                            xmax = _cdiv_trunc(x + kernel_rad - max_displacement - i2, stride1)
+                            ymax = _cdiv_trunc(y + kernel_rad - max_displacement - j2, stride1)
+                            if xmax < 0 or ymax < 0 or xmin >= oW or ymin >= oH or xmin > xmax or ymin > ymax:
+                                continue
+                            xmin, xmax, ymin, ymax = max(0, xmin), min(oW - 1, xmax), max(0, ymin), min(oH - 1, ymax)
+                            val1, inside = rd(r1, n, y - j2, x - i2, c)
+                            for j in range(ymin, ymax + 1):
+                                for i in range(xmin, xmax + 1):
+                                    prod_sum[t] += go[n * tdimcyx + tc * tdimyx + j * tdimx + i] * val1
+                    g2[n, c, y - pad_size, x - pad_size] = sum(prod_sum) / nelems
+    return torch.from_numpy(g1).to(f1.dtype), torch.from_numpy(g2).to(f1.dtype)
 
 
 # ------------------------------------------------------------------------------------------------

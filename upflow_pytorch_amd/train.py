@@ -42,7 +42,16 @@ class Loss_manager():
 class Trainer():
     """net: a module with the UPFlow_net dict contract (input_dict -> output_dict with loss terms)."""
 
-    def __init__(self, net, lr=1e-4, weight_decay=1e-4, scheduler_gamma=1.0, device=None, distributed=None, graph=False):
+    def __init__(self, net, lr=1e-4, weight_decay=1e-4, scheduler_gamma=1.0, device=None, distributed=None, graph=False,
+                 batch_check='collective'):
+        """batch_check (graph mode under DDP only): what happens when a rank is handed a batch that differs from the captured one
+        (a last partial batch): 'collective' (default) — every step the ranks all-reduce one mismatch bit and, if ANY rank
+        mismatches, ALL ranks take that step eagerly (same collective sequence everywhere: DDP's bucket all-reduce + the
+        logging all-reduce); 'raise' — no per-step exchange, a mismatching rank raises ValueError.  A single process always
+        decides locally (eager step + a warning)."""
+        if batch_check not in ('collective', 'raise'):
+            raise ValueError("batch_check must be 'collective' or 'raise', got %r" % (batch_check,))
+        self.batch_check = batch_check
         self.device = device
         self.distributed = dist.is_initialized() if distributed is None else distributed
         self.world = dist.get_world_size() if self.distributed else 1
@@ -64,6 +73,9 @@ class Trainer():
         # (the reducer finalises its buckets), then fwd + bwd (incl. the bucket's RCCL all-reduce) + Adam captured.
         self.use_graph = bool(graph) and (device is not None) and torch.device(device).type == 'cuda'
         self.capture_fallback = False        # True once a capture failed and the trainer went back to eager steps
+        self.capture_error = None            # 'ExceptionType: message' of that failure
+        self._graph_keepalive = None         # pre-capture tensors whose addresses the captured graph reads (see _capture)
+        self._mismatch_flag = None
         # graph mode: the learning rate is a DEVICE TENSOR — capturable Adam then reads it inside the captured step and the
         # scheduler updates it in place; a python float would be baked into the graph at capture time and every later
         # scheduler.step() silently ignored
@@ -105,6 +117,8 @@ class Trainer():
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         self.optimizer.zero_grad(set_to_none=True)
         from . import ops
+        from .utils import loss as loss_mod
+        mark = ops.train_caches_mark()
         g = torch.cuda.CUDAGraph()
         # thread_local: the process group's watchdog thread polls its events while this thread captures; under the
         # default (global) capture mode that hipEventQuery is an error that aborts the process
@@ -113,10 +127,12 @@ class Trainer():
             with torch.cuda.graph(g, capture_error_mode='thread_local' if (self.distributed or (dist.is_available() and dist.is_initialized())) else 'global'):
                 self._static_stats = self._step_body(self._static)
         finally:
-            # packed-weight cache entries made during the capture point into graph-pool memory whose packing kernels were
-            # only RECORDED: an eager step that found them would multiply by garbage.  The captured step itself
-            # re-runs its packing kernels at every replay, so it does not need them.
-            ops.train_caches_clear()
+            # packed-weight cache entries made DURING the capture point into graph-pool memory whose packing kernels were
+            # only RECORDED: an eager step that found them would multiply by garbage -> dropped.  Entries that
+            # existed BEFORE it and were cache hits inside it (the zero-bias operand of the data-gradient convolutions, packs
+            # of frozen parameters) and the loss module's constants have their eager-pool addresses baked into the graph:
+            # they stay cached AND are pinned here for the graph's lifetime (dropping them was a use-after-free).
+            self._graph_keepalive = ops.train_caches_after_capture(mark) + loss_mod.cached_constants()
         self._graph = g
         torch.cuda.synchronize(dev)
 
@@ -124,9 +140,10 @@ class Trainer():
         """One optimisation step on this rank's shard; returns the loss terms averaged over ranks
         (sync_stats=False: the device tensor of the terms, no host synchronisation)."""
         self.net.train()
-        if self.use_graph and self._graph is not None and not self._matches_static(batch):
+        if self.use_graph and self._graph is not None and not self._replay_agreed(batch):
             import warnings
-            warnings.warn('batch differs from the captured one (keys / shapes / non-tensor values): this step runs eagerly')
+            warnings.warn('batch differs from the captured one (keys / shapes / non-tensor values)%s: this step runs eagerly'
+                          % (' on at least one rank' if self.distributed else ''))
             self.optimizer.zero_grad(set_to_none=True)
             stats = self._step_body(batch)
         elif self.use_graph and self._graph is not None:
@@ -154,6 +171,26 @@ class Trainer():
         if not sync_stats:
             return stats
         return {k: float(v) for k, v in zip(self._names, stats.cpu())}
+
+    def _replay_agreed(self, batch):
+        """True: replay the captured step; False: this step runs eagerly.  A single process decides by its own batch.  Under DDP
+        the decision must be the SAME on every rank — a rank that stepped eagerly (DDP's bucket all-reduce issued from python)
+        while the others replay their graphs (the same all-reduce inside the graph, then the logging all-reduce) would pair
+        mismatched collectives or hang: the ranks exchange one bit (MAX) per step, or, with
+        batch_check='raise', a mismatching rank raises instead."""
+        ok = self._matches_static(batch)
+        if not self.distributed or self.world == 1:
+            return ok
+        if self.batch_check == 'raise':
+            if not ok:
+                raise ValueError('rank %d: batch differs from the captured one (keys / shapes / non-tensor values) — under DDP with '
+                                 "batch_check='raise' every rank must feed the captured shapes (drop or pad the last partial batch)" % self.rank)
+            return True
+        if self._mismatch_flag is None:
+            self._mismatch_flag = torch.zeros(1, dtype=torch.int32, device=self.device if self.device is not None else 'cpu')
+        self._mismatch_flag.fill_(0 if ok else 1)
+        dist.all_reduce(self._mismatch_flag, op=dist.ReduceOp.MAX)
+        return int(self._mismatch_flag.item()) == 0
 
     def _matches_static(self, batch):
         """The captured step replays on the tensors it was captured with: same keys, same shapes / dtypes, same non-tensor

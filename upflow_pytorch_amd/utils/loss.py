@@ -32,13 +32,19 @@ def _grey_weights(like):
     return w
 
 
+def cached_constants():
+    """Every constant tensor of this module's caches: a trainer that captured a hipGraph keeps them alive (their addresses are
+    baked into the graph; the caches evict when they grow past 64 shapes — ADVICE r3)."""
+    return list(_GREY_W.values()) + list(_VALID.values()) + list(_ZEROS.values())
+
+
 def _census_valid(mask, max_distance):
     """ones inside, zeros in the max_distance-pixel border (utils/loss.py:58-60): a constant of the shape, built once."""
     key = (tuple(mask.shape), mask.dtype, mask.device, max_distance)
     v = _VALID.get(key)
     if v is None:
         if len(_VALID) > 64:
-            _VALID.clear()
+            _VALID.clear()       # (a captured trainer holds its own references: cached_constants(), train.Trainer._capture)
         inner = torch.ones(mask.shape[0], mask.shape[1], mask.shape[2] - 2 * max_distance, mask.shape[3] - 2 * max_distance,
                            dtype=mask.dtype, device=mask.device)
         v = _VALID[key] = F.pad(inner, [max_distance] * 4)
@@ -50,7 +56,7 @@ def _zeros_like_cached(t):
     z = _ZEROS.get(key)
     if z is None:
         if len(_ZEROS) > 64:
-            _ZEROS.clear()
+            _ZEROS.clear()       # (see _census_valid)
         z = _ZEROS[key] = torch.zeros_like(t)
     return z
 
