@@ -114,7 +114,9 @@ def roofline_probe(B, H, W, dtype, device):
     kname = 'corr81_fwd_kernel' if dtype == torch.float32 else 'corr81_allc_kernel<8x32 tile>' if not norm else \
         ('corr81_allc_kernel<8x32 tile, NORM: normalisation fused into the loader, OC8: octet output> (the launch inside the step)' if c8 else
          'corr81_allc_kernel<8x32 tile, NORM: normalisation fused into the loader> (the launch inside the step)')
-    extra = {'nchw_output_variant_us': round(nchw_norm_us, 2)} if c8 else {}
+    # (octet output: the kernel STORES 88 positions per pixel — the 7 zero positions of the 11th octet — while `achieved` prices
+    # the 81 algorithmic channels; stored / algorithmic bytes = (2C + 88) / (2C + 81))
+    extra = {'nchw_output_variant_us': round(nchw_norm_us, 2), 'stored_over_algorithmic_bytes': round((2 * C + 88) / (2 * C + 81), 4)} if c8 else {}
     return {'bound': 'hbm', 'kernel': kname, 'shape': [B, C, h, w], **extra,
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2),
@@ -153,6 +155,50 @@ def conv_roofline_probe(B, H, W, dtype, device):
     return {'bound': 'mfma', 'kernel': 'conv_kernel<MTW=4> (context network layer 1, 565->128, 3x3)', 'shape': [N, Cin, h, w],
             'achieved': round(achieved, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(achieved / 2500.0, 4), 'traffic': None,
             'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
+
+
+def conv_flop_per_step(net, B, H, W):
+    """Algorithmic flop (2 * k*k * Cin * Cout * output pixels) of every convolution one inference step runs, from the module
+    shapes and the schedule of UPFlow_net._forward_stacked (both directions stacked: 2B items): six pyramid stages, the 1x1
+    projections / flow estimator / context network at the five decoder levels, the SGU estimator at levels 1-4 and at the final
+    up-sampling, the SGU guidance stem on the frames."""
+    nb = 2 * B
+
+    def seq_flop(seq, h, w):
+        c = seq[0]
+        s = c.stride[0]
+        ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+        return 2.0 * c.kernel_size[0] * c.kernel_size[1] * c.in_channels * c.out_channels * ho * wo * nb, ho, wo
+    total, parts = 0.0, {}
+
+    def add(name, f):
+        nonlocal total
+        total += f
+        parts[name] = parts.get(name, 0.0) + f
+    h, w = H, W
+    sizes = []
+    for stage in net.feature_pyramid_extractor.convs:
+        for seq in stage:
+            f, h, w = seq_flop(seq, h, w)
+            add('pyramid', f)
+        sizes.append((h, w))
+    levels = sizes[::-1][:net.output_level + 1]                      # coarsest first
+    for lvl, (h, w) in enumerate(levels):
+        add('conv_1x1', seq_flop(net.conv_1x1[lvl], h, w)[0])
+        for name in ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv_last'):
+            add('estimator', seq_flop(getattr(net.flow_estimators, name), h, w)[0])
+        for seq in net.context_networks.convs:
+            add('context', seq_flop(seq, h, w)[0])
+    if net.sgi_model is not None:
+        em = net.sgi_model.dense_estimator_mask
+        for (h, w) in levels[1:] + [levels[-1]]:
+            for name in ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv_last'):
+                add('sgu_estimator', seq_flop(getattr(em, name), h, w)[0])
+        h, w = H, W
+        for seq in net.sgi_model.upsample_output_conv:
+            f, h, w = seq_flop(seq, h, w)
+            add('sgu_stem', f)
+    return total, parts
 
 
 def _median(v):
@@ -318,7 +364,7 @@ def train_probe(device, steps=30):
         ms = (time.perf_counter() - t0) / steps * 1e3
         loss = float(stats.cpu()[tr._names.index('loss')]) if 'loss' in tr._names else None
         return {'workload': 'config3: unsupervised training step, 256x832 crops, batch 4, bf16 activations / fp32 master weights, '
-                            'forward + losses + backward + Adam(amsgrad) in one hipGraph', 'ms_per_step': round(ms, 3),
+                            'forward + losses + backward + Adam(amsgrad) in one hipGraph', 'dtype': 'bf16', 'ms_per_step': round(ms, 3),
                 'frame_pairs_per_s': round(4e3 / ms, 2), 'steps': steps, 'hip_graph': tr.use_graph, 'capture_fallback': tr.capture_fallback, 'final_loss': loss}
     except Exception as e:                                   # (an extra: it must never take the headline line down)
         return {'error': '%s: %s' % (type(e).__name__, e)}
@@ -367,6 +413,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train-probe', action='store_true', help='skip the config-3 training step reported as `train_step`')
+    ap.add_argument('--no-literal-split', action='store_true',
+                    help="skip `literal_split` (the same step with the north star's literal split, feature pyramid through PyTorch-ROCm, timed beside the headline)")
     ap.add_argument('--torch-pyramid', action='store_true',
                     help="the north star's literal split: feature-pyramid convolutions through PyTorch-ROCm (MIOpen)")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train', 'launch-check'],
@@ -445,6 +493,35 @@ def main():
         conv_rf = conv_roofline_probe(B, H, W, dtype, device)
         if conv_rf is not None:
             line['roofline_conv'] = conv_rf
+        if dtype != torch.float32:
+            # the whole step against the matrix-core peak: every convolution's algorithmic flop / the
+            # step time bench.py reports — the efficiency of the STEP, not of its best layer (`roofline_conv`)
+            flop, parts = conv_flop_per_step(net, B, H, W)
+            tf = flop / (elapsed / args.steps) / 1e12
+            line['roofline_step'] = {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
+                                     'algorithmic_gflop_per_step': round(flop / 1e9, 1),
+                                     'gflop_by_stack': {k: round(v / 1e9, 1) for k, v in parts.items()},
+                                     'note': 'sum of 2*k*k*Cin*Cout*pixels over the convolutions of one step / ms_per_step; includes the memory-bound operators\' time'}
+        if world == 1 and not args.no_literal_split and not args.torch_pyramid and dtype != torch.float32 and not args.no_graph:
+            # north_star's letter ("the feature-pyramid convolutions stay PyTorch-ROCm"): the same workload with the pyramid
+            # through MIOpen, timed in this run beside the headline (which runs the pyramid on the hand-written kernel too)
+            try:
+                net_ls = build_net(dtype, device, hip_pyramid_convs=False)
+                r2 = GraphedInference(net_ls, B, H, W, device=device)
+                r2.load(im1, im2)
+                for _ in range(10):
+                    r2.replay()
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    r2.replay()
+                torch.cuda.synchronize(device)
+                ms = (time.perf_counter() - t1) / 20 * 1e3
+                line['literal_split'] = {'pyramid_convs': 'PyTorch-ROCm (MIOpen)', 'value': round(B * 1e3 / ms, 2), 'unit': 'frame-pairs/s',
+                                         'ms_per_step': round(ms, 3), 'steps': 20}
+                del r2, net_ls
+            except Exception as e:                            # (an extra: it must never take the headline line down)
+                line['literal_split'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if world == 1 and not args.no_train_probe and args.workload == 'config2':

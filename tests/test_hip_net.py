@@ -256,8 +256,12 @@ def test_fp32_path_vs_reference_at_realistic_motion(name, H, W, cids):
     assert (out['occ_fw'].cpu() != occ).float().mean() <= 2e-3
 
 
-# measured on MI355X (printed by the test): the benchmarked path vs the REFERENCE at 15.6 px mean motion
-BENCH_PATH_VS_REFERENCE_PX = {torch.bfloat16: 0.5, torch.float16: 0.08}
+# measured on MI355X (printed by the test): the benchmarked path vs the REFERENCE at 15.6 px mean motion —
+# bf16 0.179 px fwd / 0.164 bwd (1.15 % of the mean flow magnitude, p99 0.55 px), fp16 0.028 / 0.029 px (0.18 %); where it comes from:
+# profiles/r04_precision_localise.txt (spread over the network: the feature pyramid's weights and activations carry most of it).
+# Bounds = 1.4x the measurement.
+BENCH_PATH_VS_REFERENCE_PX = {torch.bfloat16: 0.25, torch.float16: 0.04}
+BENCH_PATH_VS_REFERENCE_FRAC = {torch.bfloat16: 0.016, torch.float16: 0.0026}
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
@@ -287,7 +291,7 @@ def test_bench_path_vs_reference_at_realistic_motion(dtype):
     print('bench path %s 384x1280 B=4 graphed vs REFERENCE: EPE fwd %.4f px (p99 %.3f) bwd %.4f px = %.3f %% of mean |flow| %.2f px; occlusion-mask mismatches %.3f %%'
           % (dtype, e, p99, eb, 100 * e / meta['mean_flow_px'], meta['mean_flow_px'], 100 * occ_mis))
     assert e <= BENCH_PATH_VS_REFERENCE_PX[dtype] and eb <= BENCH_PATH_VS_REFERENCE_PX[dtype]
-    assert e <= 0.035 * meta['mean_flow_px']
+    assert e <= BENCH_PATH_VS_REFERENCE_FRAC[dtype] * meta['mean_flow_px']
 
 
 # measured on MI355X (printed by the tests): 16-bit all-HIP path vs the fp32 forward of the same network, robust mask,

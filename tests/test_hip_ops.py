@@ -331,9 +331,11 @@ def test_scatter_gradients_surface_overflow_and_nan(hip):
     assert 3 <= int(nf.sum()) <= 12                               # each bad output pixel reaches <= 4 source pixels of its channel
     assert not nf[0, 0, :3].any() and nf[0, 0, 4:7, 6:9].any() and nf[0, 1, 1:4, 2:5].any() and nf[0, 2, 8:11, 8:11].any()
     assert torch.equal(gx1[~nf], gx0[~nf])                        # bit for bit elsewhere (integer accumulation)
-    assert not torch.isfinite(gf1[0, :, 5, 7]).all() and not torch.isfinite(gf1[0, :, 2, 3]).all()
-    ok = torch.isfinite(gf1)
-    assert int((~ok).sum()) <= 6 and torch.equal(gf1[ok], gf0[ok])
+    # (the flow gradient of a pixel is a plain fp32 sum in this launch form: NaN / inf propagate, 1e30 stays a huge finite number)
+    assert not torch.isfinite(gf1[0, :, 5, 7]).any() and not torch.isfinite(gf1[0, :, 9, 9]).any() and float(gf1[0, :, 2, 3].abs().max()) > 1e20
+    ok = torch.ones_like(gf1, dtype=torch.bool)
+    ok[0, :, 5, 7] = ok[0, :, 9, 9] = ok[0, :, 2, 3] = False
+    assert torch.equal(gf1[ok], gf0[ok])
     # an honest sum beyond +-2^18 is flagged too instead of wrapping around silently
     big = torch.full_like(go, 3.0e4)
     gx2, = torch.autograd.grad(hip.warp(x, torch.zeros_like(flow), 'robust'), x, big)
