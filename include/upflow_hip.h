@@ -236,6 +236,24 @@ int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_pack
                      int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
 
+/* ---- the same convolutions for the fp32 PARITY mode: split-precision products on the fp16 matrix cores  (round 4;
+ * csrc/conv_x3.hip).  The reference's convolutions are fp32 (model/pwc_modules.py:122-142, :250-286, :396-412,
+ * model/upflow.py:24-60; cuDNN there, MIOpen here until round 4).  x, y, bias and w are fp32; both operands are split into two
+ * fp16 halves (a = fp16(a) + fp16(a - fp16(a)), 22-23 bits) on the way into the kernel and every product is formed as
+ * a_hi*b_hi + a_lo*b_hi + a_hi*b_lo (nprod = 3; + a_lo*b_lo with nprod = 4) with fp32 accumulation in the MFMA: fp32-class
+ * results (~1e-6 relative per layer) at about a third of the 16-bit rate.  Range: |x|, |w| < 65504.
+ * 3x3 with dilation 1..16 at stride 1, 3x3 at stride 2, 1x1; any H, W >= 1 (element-wise bounds at ragged / unaligned rows);
+ * x / y are channel slices of contiguous NCHW fp32 buffers (batch strides in elements).  w_packed: upf_conv_x3_packed_bytes
+ * bytes, filled by upf_conv_x3_pack_weights from w [Cout,Cin,k,k] fp32. */
+long long upf_conv_x3_packed_bytes(int Cin, int Cout, int kernel_size);
+int upf_conv_x3_pack_weights(const float* w, void* w_packed, int Cin, int Cout, int kernel_size, void* stream);
+int upf_conv_x3_forward(const float* x, long long x_batch_stride, const void* w_packed, const float* bias, float* y,
+                        long long y_batch_stride, int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation,
+                        int stride, float leaky_slope, int nprod, void* stream);
+/* writes 2^-6 to out_device[0] if v_mfma_f32_32x32x16_f16 multiplies fp16 SUBNORMAL inputs un-flushed (what the low halves of
+ * small operands rely on), 0 if it flushes them */
+int upf_mfma_f16_denorm_probe(float* out_device, void* stream);
+
 /* ---- the same convolutions with operands in the channel-octet layout  (round 3; csrc/conv_c8.hip) -----------------------
  * "C8": [n][ceil(C/8)][H][W][8] — the 8 channels of a pixel are one 16-byte entry, which is one entry of the kernel's LDS
  * tile image and one k-octet of an MFMA operand.  Between the convolutions of a dense stack (model/pwc_modules.py:279-286,

@@ -70,7 +70,8 @@ def test_conv3x3_rejects_unsupported():
     x = torch.zeros(1, 8, 8, 6, dtype=torch.bfloat16, device='cuda')        # rows shorter than one 8-pixel group
     assert not ops.conv3x3_supported(x, 8, 1)
     x = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda')
-    assert not ops.conv3x3_supported(x.float(), 8, 1)
+    assert ops.conv3x3_supported(x.float(), 8, 1)                              # (fp32: the split-precision kernel, round 4)
+    assert ops.conv3x3_supported(torch.zeros(1, 8, 8, 6, device='cuda'), 8, 1)   # ... which takes any size
     assert not ops.conv3x3_supported(x, 8, 17) and not ops.conv3x3_supported(x, 8, 2, 2)
     w = ops.conv3x3_pack(torch.zeros(8, 8, 3, 3, dtype=torch.bfloat16, device='cuda'))
     with pytest.raises(RuntimeError):

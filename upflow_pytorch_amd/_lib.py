@@ -45,6 +45,9 @@ SIGNATURES = {
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_conv_pack_weights': [_vp, _vp, _i, _i, _i, _i, _vp],
     'upf_conv_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    'upf_conv_x3_pack_weights': [_vp, _vp, _i, _i, _i, _vp],
+    'upf_conv_x3_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    'upf_mfma_f16_denorm_probe': [_vp, _vp],
     'upf_conv_pack_weights_f32': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_conv_pack_weights_f32_multi': [_c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _i, _vp],
     'upf_conv_pack_weights_kmap': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp],
@@ -125,6 +128,8 @@ def lib():
         L.upf_loss_partials.restype = _i
         L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]
         L.upf_conv_packed_bytes.restype = _ll
+        L.upf_conv_x3_packed_bytes.argtypes = [_i, _i, _i]
+        L.upf_conv_x3_packed_bytes.restype = _ll
         L.upf_conv_set_option.argtypes = [_c.c_char_p, _i]
         L.upf_conv_set_option.restype = _i
         L.upf_conv_c8_set_option.argtypes = [_c.c_char_p, _i]

@@ -1,0 +1,301 @@
+// Split-precision convolution for the fp32 PARITY mode — gfx950 (round 4).
+//
+// The reference's estimator / context / pyramid convolutions are fp32 (/root/reference/model/pwc_modules.py:122-142, :250-286,
+// :396-412; model/upflow.py:24-60), and the <= 1e-4 px end-point-error bar of BASELINE.json is only reachable with fp32-class
+// products.  gfx950 has no reduced-precision fast path for fp32 MFMA inputs (no xf32; v_mfma_f32_32x32x2_f32 runs at the
+// VALU rate, 1/16 of the 16-bit matrix rate), so until now the parity mode ran every convolution through PyTorch-ROCm (MIOpen).
+// This kernel keeps fp32 tensors in HBM and multiplies on the fp16 matrix cores with BOTH operands split in two halves,
+//     a = a_hi + a_lo,  a_hi = fp16(a),  a_lo = fp16(a - a_hi)          (22-23 significant bits together)
+//     a * b ~= a_hi*b_hi + a_lo*b_hi + a_hi*b_lo   (+ a_lo*b_lo with NPROD = 4)      fp32 accumulation inside the MFMA,
+// i.e. three (four) v_mfma_f32_32x32x16_f16 per 16-bit-path MFMA: relative error of a product <= ~2^-21 (2^-22 for the
+// dropped a_lo*b_lo and each truncation), against 2^-24 for an fp32 product — the sums of a few thousand such products that a
+// layer forms land within ~1e-6 relative of the fp32 convolution, measured per layer in tests/test_hip_conv_x3.py and as whole-net
+// EPE vs the reference in tests/test_hip_net.py.  Range: fp16's — |x|, |w| < 65504 (inf beyond; frames are O(1), activations of
+// this network O(10)); fp16 subnormal halves are multiplied un-flushed (default denormal mode, checked by upf_mfma_f16_denorm_probe).
+//
+// Structure (the NCHW kernel of conv_kernel.hpp, reduced to what the parity mode needs): a workgroup (4 waves) owns an
+// 8 x 32 pixel tile of one image and MTW * 32 output channels; per chunk of 16 input channels the fp32 tile + halo is loaded
+// (two 16-byte loads per 8 pixels of a channel row, or element-wise with bounds at ragged / unaligned edges: ANY H, W >= 1),
+// split on the way in, transposed in registers (stage_store) into TWO LDS tile images (hi, lo) of 16-byte [8 channels x 1 pixel]
+// entries; the taps read shifted windows of them.  Weights: packed once per layer as fp16 hi / lo operand blocks in MFMA lane
+// order, kept in registers per chunk.  Dilation 1..16 by ROW PHASE (a tile's rows are d image rows apart: 2 halo rows whatever d
+// is), stride 2, 1x1.  x / y are channel slices of contiguous NCHW fp32 buffers (the concat-free dense-stack buffers work in fp32
+// too); the epilogue adds nothing (the accumulators start at the bias), applies LeakyReLU and stores fp32.
+#include "conv_kernel.hpp"
+
+namespace upf {
+namespace convx3 {
+using namespace upf::conv;
+
+constexpr int TH = 8;                    // tile rows
+constexpr int NOCT = 2;                  // channel octets per chunk (16 input channels)
+
+__host__ __device__ constexpr int pad16(int v) { return (v + 15) / 16 * 16; }
+
+// 8 consecutive fp32 pixels of one channel row -> 4 dwords of fp16 hi halves, 4 dwords of fp16 lo halves
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    const uint32_t h = pack2<f16_t>(v[2 * pp], v[2 * pp + 1]);
+    const float r0 = v[2 * pp] - f16_bits_to_f32(h & 0xffffu), r1 = v[2 * pp + 1] - f16_bits_to_f32(h >> 16);
+    hi[pp] = h;
+    lo[pp] = pack2<f16_t>(r0, r1);
+  }
+}
+
+// w [Cout, Cin, k, k] fp32 -> [slab = co/32][k-step = ci/16][tap][half: hi, lo][kg = (ci/8)%2][px = co%32][ci%8] fp16:
+// the 1 KB block of one (slab, k-step, tap, half) is the A operand of one v_mfma_f32_32x32x16_f16 in lane order.
+__global__ void pack_x3_kernel(const float* __restrict__ w, f16_t* __restrict__ wp, int Cin, int Cout, int ntaps) {
+  const int cip = pad16(Cin), cop = pad32(Cout), nk = cip / 16;
+  const long long total = (long long)ntaps * cop * cip * 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), px = (int)((i >> 3) & 31), kg = (int)((i >> 8) & 1), hl = (int)((i >> 9) & 1);
+    const long long b = i >> 10;                     // (slab * nk + kstep) * ntaps + tap
+    const int tap = (int)(b % ntaps), kstep = (int)((b / ntaps) % nk), slab = (int)(b / ((long long)ntaps * nk));
+    const int co = slab * 32 + px, ci = kstep * 16 + kg * 8 + j;
+    float v = 0.f;
+    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ntaps + tap];
+    const uint16_t h = f32_to_f16_bits(v);
+    wp[i].v = hl ? f32_to_f16_bits(v - f16_bits_to_f32(h)) : h;
+  }
+}
+
+// MTW: 32-channel output blocks per workgroup (1 or 2);  S: stride;  MARG: staged halo columns (>= the dilation, whole 8-pixel
+// groups);  K1: 1x1 kernel;  NPROD: products per (a, b) pair, 3 or 4.
+template <int MTW, int S, int MARG, bool K1, int NPROD>
+__global__ __launch_bounds__(NTHREADS, 2)
+void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __restrict__ wp, const float* __restrict__ bias,
+                    float* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d,
+                    int tiles_x, int tiles_y, float slope, int aligned) {
+  constexpr int ntaps = K1 ? 1 : 9;
+  constexpr int RG = 4 / MTW, RPW = TH / RG;         // MTW = 2: two row groups of 4 rows;  MTW = 1: four of 2
+  constexpr int XW = S * TW + 2 * MARG, XWP = XW + XW / 16;
+  constexpr int ROWS = K1 ? TH : S * (TH - 1) + 3;   // staged rows (row phase: 2 halo rows whatever the dilation)
+  constexpr int IMG = NOCT * ROWS * XWP;             // entries of one tile image
+  constexpr int ngroups = XW / 8, ntasks = NOCT * ROWS * ngroups;
+  extern __shared__ __attribute__((aligned(16))) uint4 xs[];
+  uint4* xhi = xs;
+  uint4* xlo = xs + IMG;
+
+  const int RS = (S == 1 && !K1) ? d : 1;            // image rows between consecutive tile rows
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int x0 = tx * TW, y0 = (ty / RS) * (RS * TH) + ty % RS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 31, kg = lane >> 5;
+  const int cb = wave % MTW, rg = wave / MTW;
+  const int slab = blockIdx.y * MTW + cb;
+  const int cip = pad16(Cin), nchunks = cip / 16;
+  const int HW = H * W;
+  const float* xn = x + (size_t)n * xbs;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (uint32_t)Cin * (uint32_t)HW * 4u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 4u, 0x00020000);
+  __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, (uint32_t)Cout * 4u, 0x00020000);
+
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r][e] = bv;
+  }
+
+  uint4 wh[ntaps], wl[ntaps];
+  const int colx[3] = {swz(MARG + S * px - (K1 ? 0 : d)), swz(MARG + S * px), swz(MARG + S * px + (K1 ? 0 : d))};
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    // this chunk's weight operands (L2-resident; their latency hides under the staging below)
+#pragma unroll
+    for (int tap = 0; tap < ntaps; ++tap) {
+      const uint32_t off = (uint32_t)(((slab * nchunks + cc) * ntaps + tap) * 2) * 1024u + (uint32_t)lane * 16u;
+      wh[tap] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+      wl[tap] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off + 1024u, 0, 0));
+    }
+    __syncthreads();                                 // the previous chunk is fully consumed
+    // ---- stage channels [16 cc, 16 cc + 16): load fp32, split, transpose into the two tile images
+    for (int t = tid; t < ntasks; t += NTHREADS) {
+      const int oct = t / (ROWS * ngroups), rem = t - oct * (ROWS * ngroups), r = rem / ngroups, g = rem - r * ngroups;
+      const int gy = K1 ? y0 + r : (S == 1 ? y0 + (r - 1) * RS : 2 * y0 - 1 + r), gx = S * x0 - MARG + 8 * g;
+      const bool row_ok = gy >= 0 && gy < H;
+      const int c0 = cc * 16 + oct * 8;
+      const long long e0 = (long long)c0 * HW + (long long)gy * W + gx;            // element index of (channel c0, gy, gx)
+      u32x4 hi[8], lo[8];
+      if (aligned && row_ok && gx >= 0 && gx + 8 <= W) {
+        const uint32_t off = (uint32_t)(e0 * 4);
+        f32x4 v0[8], v1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                // (channels >= Cin fall off the descriptor: zeros)
+          v0[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off + (uint32_t)(k * HW) * 4u, 0, 0));
+          v1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off + (uint32_t)(k * HW) * 4u + 16u, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
+          split8(v, hi[k], lo[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const bool ok = row_ok && gx + q >= 0 && gx + q < W;
+            const uint32_t off = ok ? (uint32_t)((e0 + (long long)k * HW + q) * 4) : 0x80000000u;
+            v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+          }
+          split8(v, hi[k], lo[k]);
+        }
+      }
+      const int enc = ((oct * ROWS + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);
+      stage_store<false>(xhi, enc, 0, hi);
+      stage_store<false>(xlo, enc, 0, lo);
+    }
+    __syncthreads();
+
+    // ---- matrix phase: lane (px, kg) reads entry (octet kg, row, column) of both images
+    auto mm = [&](int tap, const uint4& bh, const uint4& bl, f32x16& a) {
+      a = Mma32<f16_t>::mma(wl[tap], bh, a);
+      a = Mma32<f16_t>::mma(wh[tap], bl, a);
+      if constexpr (NPROD == 4) a = Mma32<f16_t>::mma(wl[tap], bl, a);
+      a = Mma32<f16_t>::mma(wh[tap], bh, a);
+    };
+    if constexpr (K1) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int e = (kg * ROWS + RPW * rg + r) * XWP + colx[1];
+        mm(0, xhi[e], xlo[e], acc[r]);
+      }
+    } else if constexpr (S == 1) {
+      // staged row sr of this wave's strip feeds output rows r = sr - ky: each window is read once and used by up to three taps
+#pragma unroll
+      for (int sr = 0; sr < RPW + 2; ++sr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int e = (kg * ROWS + RPW * rg + sr) * XWP + colx[kx];
+          const uint4 bh = xhi[e], bl = xlo[e];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+            if (sr - ky >= 0 && sr - ky < RPW) mm(ky * 3 + kx, bh, bl, acc[sr - ky]);
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - 3 * ky;
+          const int e = (kg * ROWS + 2 * (RPW * rg + r) + ky) * XWP + colx[kx];
+          mm(tap, xhi[e], xlo[e], acc[r]);
+        }
+    }
+  }
+
+  // ---- epilogue: LeakyReLU, fp32 stores (lane = pixel column; register e = channel (e&3) + 8*(e>>2) + 4*kg of the block)
+  const uint32_t plane = (uint32_t)(Ho * Wo) * 4u;
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * ybs, 0, (uint32_t)Cout * plane, 0x00020000);
+  const int gx = x0 + px;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int gy = y0 + (RPW * rg + r) * RS;         // uniform
+    if (gy < Ho) {
+      const uint32_t base = (gx < Wo) ? (uint32_t)(gy * Wo + gx) * 4u : 0x80000000u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[r][e];
+        v = fmaxf(v, v * slope);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, base + (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * plane, 0, 0);
+      }
+    }
+  }
+}
+
+struct Args {
+  const float* x; long long xbs; const void* wp; const float* bias; float* y; long long ybs;
+  int B, Cin, Cout, H, W, d, stride, k; float slope; int nprod; hipStream_t stream;
+};
+
+template <int MTW, int S, int MARG, bool K1, int NPROD>
+int launch_one(const Args& a) {
+  const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const int rs = (S == 1 && !K1) ? a.d : 1;
+  const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, rs * TH) * rs;
+  constexpr int XW = S * TW + 2 * MARG, XWP = XW + XW / 16;
+  constexpr int ROWS = K1 ? TH : S * (TH - 1) + 3;
+  const size_t lds = (size_t)2 * NOCT * ROWS * XWP * 16;
+  const bool aligned = a.W % 4 == 0 && aligned_to(a.x, 16) && a.xbs % 4 == 0;
+  static LdsOptIn opt;
+  auto kern = &conv_x3_kernel<MTW, S, MARG, K1, NPROD>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  const int slabs = cdiv(cdiv(a.Cout, 32), MTW);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, a.x, a.xbs, (const f16_t*)a.wp, a.bias,
+                     a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, K1 ? 1 : a.d, tiles_x, tiles_y, a.slope, (int)aligned);
+  return check_launch("conv_x3_forward");
+}
+
+template <int MTW, int NPROD>
+int launch_shape(const Args& a) {
+  if (a.k == 1) return launch_one<MTW, 1, 0, true, NPROD>(a);
+  if (a.stride == 2) return launch_one<MTW, 2, 8, false, NPROD>(a);
+  if (a.d <= 8) return launch_one<MTW, 1, 8, false, NPROD>(a);
+  return launch_one<MTW, 1, 16, false, NPROD>(a);
+}
+
+// probe: does v_mfma_f32_32x32x16_f16 multiply fp16 SUBNORMAL inputs un-flushed?  A = subnormal 2^-20 in every (row, k),
+// B = 2^10 in every (k, col): every output = 16 * 2^-20 * 2^10 = 2^-6 if the inputs are kept, 0 if they are flushed.
+__global__ void mfma_f16_denorm_probe_kernel(float* out) {
+  const uint32_t sub = 0x00100010u;                  // two fp16 subnormals 2^-20 (bit 4 of the mantissa: 2^-24 * 16)
+  const uint32_t big = 0x64006400u;                  // two fp16 1024.0
+  uint4 a = {sub, sub, sub, sub}, b = {big, big, big, big};
+  f32x16 c;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = 0.f;
+  c = Mma32<f16_t>::mma(a, b, c);
+  if (threadIdx.x == 0) out[0] = c[0];
+}
+
+}  // namespace convx3
+}  // namespace upf
+
+extern "C" long long upf_conv_x3_packed_bytes(int Cin, int Cout, int kernel_size) {
+  return (long long)kernel_size * kernel_size * upf::conv::pad32(Cout) * upf::convx3::pad16(Cin) * 2 * 2;
+}
+
+extern "C" int upf_conv_x3_pack_weights(const float* w, void* w_packed, int Cin, int Cout, int kernel_size, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(w && w_packed && Cin > 0 && Cout > 0, UPF_EINVAL, "conv_x3_pack_weights: bad arguments");
+  UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_x3_pack_weights: kernel_size %d (1 or 3)", kernel_size);
+  const int ntaps = kernel_size * kernel_size;
+  const long long total = (long long)ntaps * conv::pad32(Cout) * convx3::pad16(Cin) * 2;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(convx3::pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (f16_t*)w_packed, Cin, Cout, ntaps);
+  return check_launch("conv_x3_pack_weights");
+}
+
+extern "C" int upf_conv_x3_forward(const float* x, long long x_batch_stride, const void* w_packed, const float* bias, float* y,
+                                   long long y_batch_stride, int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation,
+                                   int stride, float leaky_slope, int nprod, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv_x3_forward: null pointer");
+  UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_x3_forward: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
+  UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_x3_forward: kernel_size %d (1 or 3)", kernel_size);
+  UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_x3_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
+  UPF_REQUIRE(stride == 1 || (stride == 2 && dilation == 1 && kernel_size == 3), UPF_EUNSUPPORTED, "conv_x3_forward: stride %d (1, or 2 for a 3x3 with dilation 1)", stride);
+  UPF_REQUIRE(nprod == 3 || nprod == 4, UPF_EINVAL, "conv_x3_forward: nprod %d (3 or 4 products per operand pair)", nprod);
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_x3_forward: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  UPF_REQUIRE((long long)Cin * H * W * 4 < (1ll << 31) && (long long)Cout * Ho * Wo * 4 < (1ll << 31), UPF_EINVAL,
+              "conv_x3_forward: image too large for one buffer descriptor");
+  convx3::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, kernel_size,
+                 leaky_slope == 0.f ? 1.f : leaky_slope, nprod, (hipStream_t)stream};
+  // 64-channel workgroups where there are enough tiles to fill the chip with them; 32-channel ones for narrow layers and small grids
+  const long long tiles = (long long)B * cdiv(Wo, conv::TW) * cdiv(Ho, convx3::TH);
+  const bool two = Cout > 32 && tiles * cdiv(cdiv(Cout, 32), 2) >= 256;
+  if (nprod == 3) return two ? convx3::launch_shape<2, 3>(a) : convx3::launch_shape<1, 3>(a);
+  return two ? convx3::launch_shape<2, 4>(a) : convx3::launch_shape<1, 4>(a);
+}
+
+extern "C" int upf_mfma_f16_denorm_probe(float* out_device, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(out_device, UPF_EINVAL, "mfma_f16_denorm_probe: null pointer");
+  hipLaunchKernelGGL(convx3::mfma_f16_denorm_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_device);
+  return check_launch("mfma_f16_denorm_probe");
+}

@@ -267,10 +267,35 @@ def train_conv_seq(seq, x):
     return seq(x.float()).to(x.dtype)
 
 
+# fp32 inference (the parity mode): 'hip_x3' / 'hip_x4' = the split-precision matrix-core kernel (csrc/conv_x3.hip, 3 / 4 fp16
+# products per operand pair), 'miopen' = PyTorch-ROCm.  Set by UPFlow_net for the duration of a forward (config `fp32_conv`).
+FP32_CONV = ['hip_x3']
+
+
+class fp32_conv_mode(object):
+    def __init__(self, mode):
+        if mode not in ('hip_x3', 'hip_x4', 'miopen'):
+            raise ValueError("fp32_conv must be 'hip_x3', 'hip_x4' or 'miopen', got %r" % (mode,))
+        self.mode = mode
+
+    def __enter__(self):
+        self.saved = (FP32_CONV[0], ops.CONV_X3_NPROD[0])
+        FP32_CONV[0] = self.mode
+        ops.CONV_X3_NPROD[0] = 4 if self.mode == 'hip_x4' else 3
+
+    def __exit__(self, *exc):
+        FP32_CONV[0], ops.CONV_X3_NPROD[0] = self.saved
+
+
 def _fast_conv_ok(t):
-    """Inference in bf16/fp16 on the GPU (rows of at least 8 pixels): the hand-written MFMA convolution and
-    the copy-free concat buffer apply; otherwise the same arithmetic runs through MIOpen + torch.cat."""
-    return (not torch.is_grad_enabled()) and t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.shape[3] >= 8
+    """Inference on the GPU in bf16/fp16 (rows of at least 8 pixels) or — unless fp32_conv = 'miopen' — in fp32 (any size): the
+    hand-written MFMA convolutions and the copy-free concat buffer apply; otherwise the same arithmetic runs through MIOpen +
+    torch.cat."""
+    if torch.is_grad_enabled() or not t.is_cuda:
+        return False
+    if t.dtype == torch.float32:
+        return FP32_CONV[0] != 'miopen'
+    return t.dtype in (torch.bfloat16, torch.float16) and t.shape[3] >= 8
 
 
 class _DenseStack(tools.abstract_model):

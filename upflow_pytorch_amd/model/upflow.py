@@ -229,6 +229,7 @@ class UPFlow_net(tools.abstract_model):
             self.warp_mask_mode = 'literal'
             self.hip_pyramid_convs = True
             self.train_conv_dtype = 'fp32'          # 'bf16' / 'fp16': decoder convolutions under autograd on the matrix cores
+            self.fp32_conv = 'hip_x3'               # fp32 inference: 'hip_x3' / 'hip_x4' split-precision MFMA kernel, 'miopen' PyTorch-ROCm
 
         def __call__(self, ):
             return UPFlow_net(self)
@@ -354,6 +355,11 @@ class UPFlow_net(tools.abstract_model):
     def forward_2_frame_v3(self, x1_raw, x2_raw, if_loss=False):
         """Coarse-to-fine bidirectional decode, model/upflow.py:494-533."""
         cdt = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype      # compute dtype of the convs
+        from .pwc_modules import fp32_conv_mode
+        with fp32_conv_mode(getattr(self.conf, 'fp32_conv', 'hip_x3')):
+            return self._forward_2_frame_v3(x1_raw, x2_raw, if_loss, cdt)
+
+    def _forward_2_frame_v3(self, x1_raw, x2_raw, if_loss, cdt):
         if not torch.is_grad_enabled() or getattr(self, 'stacked_training', True):
             # (training too: every operator on this path is per-item and differentiable — both directions as one
             # batch halve the launch count and double every convolution's batch; `stacked_training = False` restores
@@ -405,7 +411,7 @@ class UPFlow_net(tools.abstract_model):
         normalisation, cost volume, estimator, context network — halving the launch count and doubling every
         grid, which is what the coarse levels need on a 256-CU chip."""
 
-        if (_fast_conv_ok(X) and self.conf.if_norm_before_cost_volume and not self.conf.norm_moments_across_channels
+        if (_fast_conv_ok(X) and X.dtype != torch.float32 and self.conf.if_norm_before_cost_volume and not self.conf.norm_moments_across_channels
                 and not self.conf.norm_moments_across_images and not getattr(self, '_no_fast_stacked', False)
                 and self.feature_pyramid_extractor.out_shapes(X.shape[2], X.shape[3])[-1][2] >= 8):   # every level takes the conv kernel
             return self._forward_stacked_fast(X, B)

@@ -587,13 +587,23 @@ def occ_check(flow_f, flow_b, alpha1=0.1, alpha2=0.5):
 # ------------------------------------------------------------------------------------------------
 # 3x3 convolution on the matrix cores (inference, bf16 / fp16)
 # ------------------------------------------------------------------------------------------------
+# fp32 tensors (the parity mode) take the split-precision kernel (csrc/conv_x3.hip): this many fp16 products per operand pair
+CONV_X3_NPROD = [3]
+
+
 def conv3x3_pack(weight):
-    """[Cout,Cin,k,k] (k = 3 or 1) bf16/fp16 -> the kernel's packed layout (done once per layer)."""
+    """[Cout,Cin,k,k] (k = 3 or 1) -> the kernel's packed layout (done once per layer).  bf16 / fp16 weights: the 16-bit operand
+    of upf_conv_forward; fp32 weights: fp16 hi / lo operand pairs for upf_conv_x3_forward."""
     w = weight.detach().contiguous()
     Cout, Cin, kh, kw = w.shape
     if kh != kw or kh not in (1, 3):
         raise UpflowHipError('conv pack: 3x3 or 1x1 kernels only')
     dev = _lib.check_gpu(w)
+    if w.dtype == torch.float32:
+        packed = torch.empty((_lib.lib().upf_conv_x3_packed_bytes(Cin, Cout, kh) // 2,), dtype=torch.float16, device=w.device)
+        with torch.cuda.device(dev):
+            _lib.call('upf_conv_x3_pack_weights', _lib.ptr(w), _lib.ptr(packed), Cin, Cout, kh, _lib.stream_ptr(dev))
+        return packed
     nbytes = _lib.lib().upf_conv_packed_bytes(Cin, Cout, kh)
     packed = torch.empty((nbytes // 2,), dtype=w.dtype, device=w.device)
     with torch.cuda.device(dev):
@@ -602,10 +612,19 @@ def conv3x3_pack(weight):
 
 
 def conv3x3_supported(x_view, Cout, dilation, stride=1, kernel_size=3):
-    """Shapes the matrix-core kernel takes; everything else stays with MIOpen."""
-    return (x_view.is_cuda and x_view.dtype in (torch.bfloat16, torch.float16) and kernel_size in (1, 3)
+    """Shapes the matrix-core kernels take (16-bit: rows of >= 8 pixels; fp32, split precision: any size); everything else
+    stays with MIOpen."""
+    return (x_view.is_cuda and x_view.dtype in (torch.bfloat16, torch.float16, torch.float32) and kernel_size in (1, 3)
             and 1 <= dilation <= 16 and (stride == 1 or (stride == 2 and dilation == 1 and kernel_size == 3))
-            and x_view.shape[3] >= 8)
+            and (x_view.shape[3] >= 8 or x_view.dtype == torch.float32))
+
+
+def mfma_f16_denorm_probe(device):
+    """True if the fp16 matrix instruction multiplies subnormal inputs un-flushed (the low halves of small fp32 operands)."""
+    out = torch.zeros(1, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.call('upf_mfma_f16_denorm_probe', _lib.ptr(out), _lib.stream_ptr(device))
+    return float(out.item()) == 2.0 ** -6
 
 
 def conv_set_option(name, value):
@@ -631,6 +650,14 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
     if x_view.stride()[1:] != (H * W, W, 1) or y_view.stride()[1:] != (Ho * Wo, Wo, 1):
         raise UpflowHipError('conv: operands must be channel slices of contiguous NCHW buffers')
     dev = x_view.device
+    if x_view.dtype == torch.float32:
+        if y_view.dtype != torch.float32 or packed.dtype != torch.float16:
+            raise UpflowHipError('conv (fp32, split precision): fp32 output and weights packed from fp32 expected')
+        with torch.cuda.device(dev):
+            _lib.call('upf_conv_x3_forward', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(packed), _lib.ptr(bias32),
+                      _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
+                      float(leaky_slope), int(CONV_X3_NPROD[0]), _lib.stream_ptr(dev))
+        return y_view
     with torch.cuda.device(dev):
         _lib.call('upf_conv_forward', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(packed), _lib.ptr(bias32),
                   _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
