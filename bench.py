@@ -43,11 +43,11 @@ FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': Fal
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_net(dtype, device, hip_pyramid_convs=True):
+def build_net(dtype, device, hip_pyramid_convs=True, fp32_conv='hip_x3'):
     from upflow_pytorch_amd import synthetic as _weights
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     conf = UPFlow_net.config()
-    conf.update(dict(FLAGS, hip_pyramid_convs=hip_pyramid_convs), verbose=False)
+    conf.update(dict(FLAGS, hip_pyramid_convs=hip_pyramid_convs, fp32_conv=fp32_conv), verbose=False)
     torch.manual_seed(0)
     net = conf()
     net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))      # random-init weights of the architecture
@@ -417,6 +417,8 @@ def main():
                     help="skip `literal_split` (the same step with the north star's literal split, feature pyramid through PyTorch-ROCm, timed beside the headline)")
     ap.add_argument('--torch-pyramid', action='store_true',
                     help="the north star's literal split: feature-pyramid convolutions through PyTorch-ROCm (MIOpen)")
+    ap.add_argument('--fp32-conv', default='hip_x3', choices=['hip_x3', 'hip_x3s', 'miopen'],
+                    help='--dtype fp32 (the parity mode): split-precision MFMA kernel (hip_x3s: low-order products in their own accumulators), or PyTorch-ROCm')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train', 'launch-check'],
                     help='train = BASELINE config 3: unsupervised step (fwd+loss+bwd+Adam), 256x832 crops, batch 4 per GPU, DDP')
     ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'],
@@ -440,7 +442,7 @@ def main():
     dname = args.dtype or dname
     dtype = DT[dname]
     from upflow_pytorch_amd import synthetic as _weights
-    net = build_net(dtype, device, hip_pyramid_convs=not args.torch_pyramid)
+    net = build_net(dtype, device, hip_pyramid_convs=not args.torch_pyramid, fp32_conv=args.fp32_conv)
     im1, im2 = _weights.make_images(2 + rank, B, H, W)                      # every rank its own image pairs (the path shards by pair)
     im1, im2 = im1.to(device), im2.to(device)                               # inputs resident in HBM
 
@@ -487,7 +489,8 @@ def main():
                        'global_batch': world * B, 'parallelism': 'replicas x%d (image pairs sharded, no collective)' % world,
                        'ranks': world, 'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
                        'hip_graph': not args.no_graph, 'capture_fallback': False,
-                       'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or dtype == torch.float32 else 'HIP (MFMA kernel)'},
+                       'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or (dtype == torch.float32 and args.fp32_conv == 'miopen') else 'HIP (MFMA kernel)',
+                       'fp32_conv': args.fp32_conv if dtype == torch.float32 else None},
             'roofline': roofline_probe(B, H, W, dtype, device),
         }
         conv_rf = conv_roofline_probe(B, H, W, dtype, device)

@@ -240,8 +240,10 @@ int upf_conv_set_option(const char* name, int value);
  * csrc/conv_x3.hip).  The reference's convolutions are fp32 (model/pwc_modules.py:122-142, :250-286, :396-412,
  * model/upflow.py:24-60; cuDNN there, MIOpen here until round 4).  x, y, bias and w are fp32; both operands are split into two
  * fp16 halves (a = fp16(a) + fp16(a - fp16(a)), 22-23 bits) on the way into the kernel and every product is formed as
- * a_hi*b_hi + a_lo*b_hi + a_hi*b_lo (nprod = 3; + a_lo*b_lo with nprod = 4) with fp32 accumulation in the MFMA: fp32-class
- * results (~1e-6 relative per layer) at about a third of the 16-bit rate.  Range: |x|, |w| < 65504.
+ * a_hi*b_hi + a_lo*b_hi + a_hi*b_lo (nprod = 3; nprod = 11: the low-order products accumulate in their own registers and
+ * join the sum once, a third of the rounding chain) with fp32 accumulation in the MFMA: fp32-class results at about a third of
+ * the 16-bit rate.  The weights are scaled by a per-layer power of two (computed on the device at pack time, stored in the packed
+ * operand's 1 KB header) so that their low halves are normal fp16 numbers.  Range: |x| < 65504.
  * 3x3 with dilation 1..16 at stride 1, 3x3 at stride 2, 1x1; any H, W >= 1 (element-wise bounds at ragged / unaligned rows);
  * x / y are channel slices of contiguous NCHW fp32 buffers (batch strides in elements).  w_packed: upf_conv_x3_packed_bytes
  * bytes, filled by upf_conv_x3_pack_weights from w [Cout,Cin,k,k] fp32. */

@@ -43,10 +43,42 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
   }
 }
 
-// w [Cout, Cin, k, k] fp32 -> [slab = co/32][k-step = ci/16][tap][half: hi, lo][kg = (ci/8)%2][px = co%32][ci%8] fp16:
+// Packed operand = a 1 KB header {|w|max bits, scale 2^s, 2^-s, 0...} + the blocks
+//   [slab = co/32][k-step = ci/16][tap][half: hi, lo][kg = (ci/8)%2][px = co%32][ci%8]   of fp16(w * 2^s) halves:
 // the 1 KB block of one (slab, k-step, tap, half) is the A operand of one v_mfma_f32_32x32x16_f16 in lane order.
+// The per-layer POWER-OF-TWO scale 2^s puts max|w| into [2^13, 2^14): MSRA-sized weights (~0.02) would otherwise have low halves
+// of ~2^-17, deep inside fp16's subnormal range (spacing 2^-24): hi + lo then represents w to only ~2^-20 relative, and that —
+// not the dropped lo*lo product, not the accumulation chain — was the whole error of the first form of this kernel (per-layer rms
+// 8.7e-7 vs fp64, reproduced on the CPU with exact accumulation).  Scaled, the low halves are normal numbers with their own 11
+// bits.  The kernel starts its accumulators at bias * 2^s and multiplies the result by 2^-s in the epilogue: both exact.
+constexpr int HDR_F16 = 512;                          // header size in fp16 elements (1 KB)
+__global__ void x3_hdr_zero_kernel(uint32_t* hdr) { if (threadIdx.x < 256) hdr[threadIdx.x] = 0u; }
+__global__ void x3_absmax_kernel(const float* __restrict__ w, long long n, uint32_t* hdr) {
+  float m = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float a = fabsf(w[i]);
+    m = (a == a && a > m) ? a : m;                    // (NaN weights do not define the scale)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(hdr, __float_as_uint(m));           // non-negative floats order like their bit patterns
+}
+__device__ __forceinline__ float x3_scale_of(uint32_t absmax_bits) {
+  const float m = __uint_as_float(absmax_bits);
+  if (!(m > 0.f) || m > 3.0e38f) return 1.f;
+  int e = (int)((absmax_bits >> 23) & 0xffu) - 127;   // floor(log2(m)) for normal m (a subnormal maximum: e = -127, clamped below)
+  int sft = 13 - e;
+  sft = sft > 100 ? 100 : (sft < -100 ? -100 : sft);
+  return __uint_as_float((uint32_t)(127 + sft) << 23);
+}
 __global__ void pack_x3_kernel(const float* __restrict__ w, f16_t* __restrict__ wp, int Cin, int Cout, int ntaps) {
   const int cip = pad16(Cin), cop = pad32(Cout), nk = cip / 16;
+  const float sc = x3_scale_of(reinterpret_cast<const uint32_t*>(wp)[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    reinterpret_cast<float*>(wp)[1] = sc;
+    reinterpret_cast<float*>(wp)[2] = 1.0f / sc;
+  }
+  f16_t* blocks = wp + HDR_F16;
   const long long total = (long long)ntaps * cop * cip * 2;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int j = (int)(i & 7), px = (int)((i >> 3) & 31), kg = (int)((i >> 8) & 1), hl = (int)((i >> 9) & 1);
@@ -54,16 +86,22 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, f16_t* __restrict__ 
     const int tap = (int)(b % ntaps), kstep = (int)((b / ntaps) % nk), slab = (int)(b / ((long long)ntaps * nk));
     const int co = slab * 32 + px, ci = kstep * 16 + kg * 8 + j;
     float v = 0.f;
-    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ntaps + tap];
+    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ntaps + tap] * sc;
     const uint16_t h = f32_to_f16_bits(v);
-    wp[i].v = hl ? f32_to_f16_bits(v - f16_bits_to_f32(h)) : h;
+    blocks[i].v = hl ? f32_to_f16_bits(v - f16_bits_to_f32(h)) : h;
   }
 }
 
 // MTW: 32-channel output blocks per workgroup (1 or 2);  S: stride;  MARG: staged halo columns (>= the dilation, whole 8-pixel
 // groups);  K1: 1x1 kernel;  NPROD: products per (a, b) pair, 3 or 4.
-template <int MTW, int S, int MARG, bool K1, int NPROD>
-__global__ __launch_bounds__(NTHREADS, 2)
+// SPLITACC: the low-order products (a_lo*b_hi, a_hi*b_lo, a_lo*b_lo: 2^-11 of the result) accumulate in their OWN registers and
+// join the main sum once, in the epilogue.  Every MFMA rounds its fp32 accumulator once; a 565-channel 3x3 layer chains
+// 36 chunks x 9 taps x 3 products = 972 of them, and the random walk of those roundings (~sqrt(972) * 2^-25 ~ 1e-6 relative),
+// not the operand split (~2^-23), is the kernel's error.  With the low-order terms out of the chain it is a third as long, and
+// the roundings of the low-order chain are 2^-11 smaller.  Costs RPW * 16 more accumulator registers: the 64-channel
+// workgroups then run one per CU (accumulators in AGPRs).
+template <int MTW, int S, int MARG, bool K1, int NPROD, bool SPLITACC>
+__global__ __launch_bounds__(NTHREADS, (SPLITACC && MTW == 2) ? 1 : 2)
 void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __restrict__ wp, const float* __restrict__ bias,
                     float* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d,
                     int tiles_x, int tiles_y, float slope, int aligned) {
@@ -89,15 +127,18 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
   const int HW = H * W;
   const float* xn = x + (size_t)n * xbs;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (uint32_t)Cin * (uint32_t)HW * 4u, 0x00020000);
-  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 4u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(wp + HDR_F16), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 4u, 0x00020000);
+  const float wsc = reinterpret_cast<const float*>(wp)[1], winv = reinterpret_cast<const float*>(wp)[2];   // the layer's weight scale 2^s, 2^-s
   __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, (uint32_t)Cout * 4u, 0x00020000);
 
-  f32x16 acc[RPW];
+  f32x16 acc[RPW], accs[SPLITACC ? RPW : 1];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
+    const float bv = wsc * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
 #pragma unroll
     for (int r = 0; r < RPW; ++r) acc[r][e] = bv;
+#pragma unroll
+    for (int r = 0; r < (SPLITACC ? RPW : 1); ++r) accs[r][e] = 0.f;
   }
 
   uint4 wh[ntaps], wl[ntaps];
@@ -153,17 +194,18 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
     __syncthreads();
 
     // ---- matrix phase: lane (px, kg) reads entry (octet kg, row, column) of both images
-    auto mm = [&](int tap, const uint4& bh, const uint4& bl, f32x16& a) {
-      a = Mma32<f16_t>::mma(wl[tap], bh, a);
-      a = Mma32<f16_t>::mma(wh[tap], bl, a);
-      if constexpr (NPROD == 4) a = Mma32<f16_t>::mma(wl[tap], bl, a);
-      a = Mma32<f16_t>::mma(wh[tap], bh, a);
+    auto mm = [&](int tap, const uint4& bh, const uint4& bl, int r) {
+      f32x16& lo = SPLITACC ? accs[SPLITACC ? r : 0] : acc[r];
+      lo = Mma32<f16_t>::mma(wl[tap], bh, lo);
+      lo = Mma32<f16_t>::mma(wh[tap], bl, lo);
+      if constexpr (NPROD == 4) lo = Mma32<f16_t>::mma(wl[tap], bl, lo);
+      acc[r] = Mma32<f16_t>::mma(wh[tap], bh, acc[r]);
     };
     if constexpr (K1) {
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const int e = (kg * ROWS + RPW * rg + r) * XWP + colx[1];
-        mm(0, xhi[e], xlo[e], acc[r]);
+        mm(0, xhi[e], xlo[e], r);
       }
     } else if constexpr (S == 1) {
       // staged row sr of this wave's strip feeds output rows r = sr - ky: each window is read once and used by up to three taps
@@ -175,7 +217,7 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
           const uint4 bh = xhi[e], bl = xlo[e];
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
-            if (sr - ky >= 0 && sr - ky < RPW) mm(ky * 3 + kx, bh, bl, acc[sr - ky]);
+            if (sr - ky >= 0 && sr - ky < RPW) mm(ky * 3 + kx, bh, bl, sr - ky);
         }
     } else {
 #pragma unroll
@@ -184,7 +226,7 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
         for (int tap = 0; tap < 9; ++tap) {
           const int ky = tap / 3, kx = tap - 3 * ky;
           const int e = (kg * ROWS + 2 * (RPW * rg + r) + ky) * XWP + colx[kx];
-          mm(tap, xhi[e], xlo[e], acc[r]);
+          mm(tap, xhi[e], xlo[e], r);
         }
     }
   }
@@ -201,6 +243,8 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         float v = acc[r][e];
+        if constexpr (SPLITACC) v += accs[r][e];
+        v *= winv;
         v = fmaxf(v, v * slope);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, base + (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * plane, 0, 0);
       }
@@ -213,7 +257,7 @@ struct Args {
   int B, Cin, Cout, H, W, d, stride, k; float slope; int nprod; hipStream_t stream;
 };
 
-template <int MTW, int S, int MARG, bool K1, int NPROD>
+template <int MTW, int S, int MARG, bool K1, int NPROD, bool SPLITACC>
 int launch_one(const Args& a) {
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int rs = (S == 1 && !K1) ? a.d : 1;
@@ -223,7 +267,7 @@ int launch_one(const Args& a) {
   const size_t lds = (size_t)2 * NOCT * ROWS * XWP * 16;
   const bool aligned = a.W % 4 == 0 && aligned_to(a.x, 16) && a.xbs % 4 == 0;
   static LdsOptIn opt;
-  auto kern = &conv_x3_kernel<MTW, S, MARG, K1, NPROD>;
+  auto kern = &conv_x3_kernel<MTW, S, MARG, K1, NPROD, SPLITACC>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   const int slabs = cdiv(cdiv(a.Cout, 32), MTW);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, a.x, a.xbs, (const f16_t*)a.wp, a.bias,
@@ -231,12 +275,18 @@ int launch_one(const Args& a) {
   return check_launch("conv_x3_forward");
 }
 
-template <int MTW, int NPROD>
+template <int MTW, int NPROD, bool SPLITACC>
 int launch_shape(const Args& a) {
-  if (a.k == 1) return launch_one<MTW, 1, 0, true, NPROD>(a);
-  if (a.stride == 2) return launch_one<MTW, 2, 8, false, NPROD>(a);
-  if (a.d <= 8) return launch_one<MTW, 1, 8, false, NPROD>(a);
-  return launch_one<MTW, 1, 16, false, NPROD>(a);
+  if (a.k == 1) return launch_one<MTW, 1, 0, true, NPROD, SPLITACC>(a);
+  if (a.stride == 2) return launch_one<MTW, 2, 8, false, NPROD, SPLITACC>(a);
+  if (a.d <= 8) return launch_one<MTW, 1, 8, false, NPROD, SPLITACC>(a);
+  return launch_one<MTW, 1, 16, false, NPROD, SPLITACC>(a);
+}
+template <int MTW>
+int launch_mode(const Args& a) {
+  // (NPROD = 4, the a_lo*b_lo product, was measured and changes nothing: per layer 2.41e-6 -> 2.41e-6 max, whole net 7.1e-5 ->
+  // 6.9e-5 px for 8 % more time — profiles/r04_fp32_conv_modes.txt; not instantiated)
+  return a.nprod == 3 ? launch_shape<MTW, 3, false>(a) : launch_shape<MTW, 3, true>(a);
 }
 
 // probe: does v_mfma_f32_32x32x16_f16 multiply fp16 SUBNORMAL inputs un-flushed?  A = subnormal 2^-20 in every (row, k),
@@ -256,7 +306,7 @@ __global__ void mfma_f16_denorm_probe_kernel(float* out) {
 }  // namespace upf
 
 extern "C" long long upf_conv_x3_packed_bytes(int Cin, int Cout, int kernel_size) {
-  return (long long)kernel_size * kernel_size * upf::conv::pad32(Cout) * upf::convx3::pad16(Cin) * 2 * 2;
+  return (long long)upf::convx3::HDR_F16 * 2 + (long long)kernel_size * kernel_size * upf::conv::pad32(Cout) * upf::convx3::pad16(Cin) * 2 * 2;
 }
 
 extern "C" int upf_conv_x3_pack_weights(const float* w, void* w_packed, int Cin, int Cout, int kernel_size, void* stream) {
@@ -266,6 +316,9 @@ extern "C" int upf_conv_x3_pack_weights(const float* w, void* w_packed, int Cin,
   const int ntaps = kernel_size * kernel_size;
   const long long total = (long long)ntaps * conv::pad32(Cout) * convx3::pad16(Cin) * 2;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  const long long nw = (long long)Cout * Cin * ntaps;
+  hipLaunchKernelGGL(convx3::x3_hdr_zero_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (uint32_t*)w_packed);
+  hipLaunchKernelGGL(convx3::x3_absmax_kernel, dim3((unsigned)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, nw, (uint32_t*)w_packed);
   hipLaunchKernelGGL(convx3::pack_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (f16_t*)w_packed, Cin, Cout, ntaps);
   return check_launch("conv_x3_pack_weights");
 }
@@ -279,7 +332,8 @@ extern "C" int upf_conv_x3_forward(const float* x, long long x_batch_stride, con
   UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_x3_forward: kernel_size %d (1 or 3)", kernel_size);
   UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_x3_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
   UPF_REQUIRE(stride == 1 || (stride == 2 && dilation == 1 && kernel_size == 3), UPF_EUNSUPPORTED, "conv_x3_forward: stride %d (1, or 2 for a 3x3 with dilation 1)", stride);
-  UPF_REQUIRE(nprod == 3 || nprod == 4, UPF_EINVAL, "conv_x3_forward: nprod %d (3 or 4 products per operand pair)", nprod);
+  UPF_REQUIRE(nprod == 3 || nprod == 11, UPF_EINVAL,
+              "conv_x3_forward: nprod %d (3 products per operand pair; 11 = 3 + 8: the low-order products in their own accumulators)", nprod);
   UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_x3_forward: leaky_slope %g not in [0,1]", (double)leaky_slope);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   UPF_REQUIRE((long long)Cin * H * W * 4 < (1ll << 31) && (long long)Cout * Ho * Wo * 4 < (1ll << 31), UPF_EINVAL,
@@ -289,8 +343,7 @@ extern "C" int upf_conv_x3_forward(const float* x, long long x_batch_stride, con
   // 64-channel workgroups where there are enough tiles to fill the chip with them; 32-channel ones for narrow layers and small grids
   const long long tiles = (long long)B * cdiv(Wo, conv::TW) * cdiv(Ho, convx3::TH);
   const bool two = Cout > 32 && tiles * cdiv(cdiv(Cout, 32), 2) >= 256;
-  if (nprod == 3) return two ? convx3::launch_shape<2, 3>(a) : convx3::launch_shape<1, 3>(a);
-  return two ? convx3::launch_shape<2, 4>(a) : convx3::launch_shape<1, 4>(a);
+  return two ? convx3::launch_mode<2>(a) : convx3::launch_mode<1>(a);
 }
 
 extern "C" int upf_mfma_f16_denorm_probe(float* out_device, void* stream) {

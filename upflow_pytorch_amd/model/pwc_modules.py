@@ -267,21 +267,22 @@ def train_conv_seq(seq, x):
     return seq(x.float()).to(x.dtype)
 
 
-# fp32 inference (the parity mode): 'hip_x3' / 'hip_x4' = the split-precision matrix-core kernel (csrc/conv_x3.hip, 3 / 4 fp16
-# products per operand pair), 'miopen' = PyTorch-ROCm.  Set by UPFlow_net for the duration of a forward (config `fp32_conv`).
+# fp32 inference (the parity mode): 'hip_x3' = the split-precision matrix-core kernel (csrc/conv_x3.hip, 3 fp16 products per
+# operand pair; 'hip_x3s': with the low-order products in their own accumulators), 'miopen' = PyTorch-ROCm.  Set by UPFlow_net for the duration of a forward (config `fp32_conv`).
 FP32_CONV = ['hip_x3']
+FP32_CONV_NPROD = {'hip_x3': 3, 'hip_x3s': 11}
 
 
 class fp32_conv_mode(object):
     def __init__(self, mode):
-        if mode not in ('hip_x3', 'hip_x4', 'miopen'):
-            raise ValueError("fp32_conv must be 'hip_x3', 'hip_x4' or 'miopen', got %r" % (mode,))
+        if mode != 'miopen' and mode not in FP32_CONV_NPROD:
+            raise ValueError("fp32_conv must be one of %s or 'miopen', got %r" % (sorted(FP32_CONV_NPROD), mode))
         self.mode = mode
 
     def __enter__(self):
         self.saved = (FP32_CONV[0], ops.CONV_X3_NPROD[0])
         FP32_CONV[0] = self.mode
-        ops.CONV_X3_NPROD[0] = 4 if self.mode == 'hip_x4' else 3
+        ops.CONV_X3_NPROD[0] = FP32_CONV_NPROD.get(self.mode, ops.CONV_X3_NPROD[0])
 
     def __exit__(self, *exc):
         FP32_CONV[0], ops.CONV_X3_NPROD[0] = self.saved

@@ -229,7 +229,7 @@ class UPFlow_net(tools.abstract_model):
             self.warp_mask_mode = 'literal'
             self.hip_pyramid_convs = True
             self.train_conv_dtype = 'fp32'          # 'bf16' / 'fp16': decoder convolutions under autograd on the matrix cores
-            self.fp32_conv = 'hip_x3'               # fp32 inference: 'hip_x3' / 'hip_x4' split-precision MFMA kernel, 'miopen' PyTorch-ROCm
+            self.fp32_conv = 'hip_x3'               # fp32 inference: 'hip_x3' / 'hip_x3s' split-precision MFMA kernel, 'miopen' PyTorch-ROCm
 
         def __call__(self, ):
             return UPFlow_net(self)
