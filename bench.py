@@ -411,6 +411,9 @@ def main():
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
+    ap.add_argument('--streams', type=int, default=3,
+                    help='steps in flight (inference): the captured step is replayed round-robin on this many HIP streams, each with its own '
+                         'batch buffers (runtime.PipelinedInference); 1 = one step at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train-probe', action='store_true', help='skip the config-3 training step reported as `train_step`')
     ap.add_argument('--no-literal-split', action='store_true',
@@ -450,6 +453,20 @@ def main():
         def step():
             with torch.no_grad():
                 return net({'im1': im1, 'im2': im2, 'if_loss': False})
+    elif args.streams > 1:
+        # throughput mode: `streams` independent steps in flight (each the full forward on its own batch of B pairs, its own
+        # static buffers), the coarse pyramid levels of one under the fine levels of another — runtime.PipelinedInference
+        from upflow_pytorch_amd.runtime import GraphedInference, PipelinedInference
+        pipe = PipelinedInference(net, B, H, W, streams=args.streams, device=device)
+        for slot in range(args.streams):
+            a, b = _weights.make_images(2 + rank + 100 * slot, B, H, W)          # every slot its own image pairs
+            pipe.load(slot, a.to(device), b.to(device))
+        pipe.synchronize()
+        last = [0]
+
+        def step():
+            last[0] = pipe.replay()
+            return pipe.runners[last[0]].out
     else:
         from upflow_pytorch_amd.runtime import GraphedInference
         runner = GraphedInference(net, B, H, W, device=device)
@@ -476,6 +493,23 @@ def main():
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
     assert torch.isfinite(out['flow_f_out']).all()
+    pipelined = (not args.no_graph) and args.streams > 1
+    single = None
+    if pipelined:
+        for r_ in pipe.runners:                                  # every slot's outputs, not only the last step's
+            assert torch.isfinite(r_.out['flow_f_out']).all() and torch.isfinite(r_.out['flow_b_out']).all()
+        # the same K steps with ONE step in flight (the latency-bound schedule every earlier round reported), for continuity
+        r0 = pipe.runners[0]
+        for _ in range(args.warmup):
+            r0.replay()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            r0.replay()
+        barrier()
+        el1 = parallel.max_over_ranks(time.perf_counter() - t1, device)
+        single = {'value': round(world * B * args.steps / el1, 3), 'unit': 'frame-pairs/s', 'ms_per_step': round(el1 / args.steps * 1e3, 3),
+                  'note': 'one step in flight: the per-step latency; the headline keeps %d independent steps in flight on %d HIP streams' % (args.streams, args.streams)}
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -489,6 +523,7 @@ def main():
                        'global_batch': world * B, 'parallelism': 'replicas x%d (image pairs sharded, no collective)' % world,
                        'ranks': world, 'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
                        'hip_graph': not args.no_graph, 'capture_fallback': False,
+                       'steps_in_flight': args.streams if pipelined else 1,
                        'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or (dtype == torch.float32 and args.fp32_conv == 'miopen') else 'HIP (MFMA kernel)',
                        'fp32_conv': args.fp32_conv if dtype == torch.float32 else None},
             'roofline': roofline_probe(B, H, W, dtype, device),
@@ -525,6 +560,8 @@ def main():
                 del r2, net_ls
             except Exception as e:                            # (an extra: it must never take the headline line down)
                 line['literal_split'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if single is not None:
+            line['one_step_in_flight'] = single
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if world == 1 and not args.no_train_probe and args.workload == 'config2':

@@ -267,31 +267,65 @@ BENCH_PATH_VS_REFERENCE_FRAC = {torch.bfloat16: 0.016, torch.float16: 0.0026}
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_bench_path_vs_reference_at_realistic_motion(dtype):
     """EXACTLY what bench.py times — 384x1280, batch 4, 16-bit, every convolution on the hand-written kernels, octet
-    estimator, one hipGraph replay through GraphedInference — against the REFERENCE's fp32 output at realistic motion
+    estimator, hipGraph replays with two steps in flight (PipelinedInference) — against the REFERENCE's fp32 output at realistic motion
     (tests/golden/net_384x1280_hs1_robust.npz: two distinct pairs, mean |flow| 15.6 px; batch = [p0, p1, p1, p0]).  The
     reference has no 16-bit path, so this is a measured distance with a bound, reported in px and as a
     fraction of the mean flow magnitude; items that hold the same pair must agree bit for bit."""
-    from upflow_pytorch_amd.runtime import GraphedInference
+    from upflow_pytorch_amd.runtime import PipelinedInference
     im1, im2, g, occ, meta = _hs1_case('net_384x1280_hs1_robust', 384, 1280, (2, 12))
-    idx = [0, 1, 1, 0]
-    im1, im2 = im1[idx].contiguous(), im2[idx].contiguous()
     net = build('robust', dtype, head_scale=1.0)
-    runner = GraphedInference(net, 4, 384, 1280, device=im1.device)
-    runner.load(im1, im2)
-    out = runner.replay()
-    f = out['flow_f_out'].float().cpu()
-    assert torch.isfinite(f).all()
-    assert torch.equal(f[0], f[3]) and torch.equal(f[1], f[2])
-    gf = g['flow_f_out'][idx]
-    e = oracle.epe(f, gf)
-    per = (f - gf).pow(2).sum(1).sqrt()
-    p99 = float(per.flatten()[::7].quantile(0.99))
-    eb = oracle.epe(out['flow_b_out'].float()[:, :, ::4, ::4].cpu(), g['flow_b_out'][idx])
-    occ_mis = float((out['occ_fw'].float().cpu() != occ[idx]).float().mean())
-    print('bench path %s 384x1280 B=4 graphed vs REFERENCE: EPE fwd %.4f px (p99 %.3f) bwd %.4f px = %.3f %% of mean |flow| %.2f px; occlusion-mask mismatches %.3f %%'
-          % (dtype, e, p99, eb, 100 * e / meta['mean_flow_px'], meta['mean_flow_px'], 100 * occ_mis))
-    assert e <= BENCH_PATH_VS_REFERENCE_PX[dtype] and eb <= BENCH_PATH_VS_REFERENCE_PX[dtype]
-    assert e <= BENCH_PATH_VS_REFERENCE_FRAC[dtype] * meta['mean_flow_px']
+    # bench.py keeps two steps in flight on two HIP streams (runtime.PipelinedInference): slot 0 runs [p0, p1, p1, p0], slot 1
+    # [p1, p0, p0, p1], several rounds, concurrently
+    pipe = PipelinedInference(net, 4, 384, 1280, streams=2, device=im1.device)
+    idxs = ([0, 1, 1, 0], [1, 0, 0, 1])
+    for slot, idx in enumerate(idxs):
+        pipe.load(slot, im1[idx].contiguous(), im2[idx].contiguous())
+    for _ in range(3):
+        for slot in range(2):
+            pipe.replay(slot)
+    worst = 0.0
+    for slot, idx in enumerate(idxs):
+        out = pipe.result(slot)
+        f = out['flow_f_out'].float().cpu()
+        assert torch.isfinite(f).all()
+        assert torch.equal(f[0], f[3]) and torch.equal(f[1], f[2])
+        gf = g['flow_f_out'][idx]
+        e = oracle.epe(f, gf)
+        per = (f - gf).pow(2).sum(1).sqrt()
+        p99 = float(per.flatten()[::7].quantile(0.99))
+        eb = oracle.epe(out['flow_b_out'].float()[:, :, ::4, ::4].cpu(), g['flow_b_out'][idx])
+        occ_mis = float((out['occ_fw'].float().cpu() != occ[idx]).float().mean())
+        print('bench path %s 384x1280 B=4 graphed, 2 steps in flight, slot %d vs REFERENCE: EPE fwd %.4f px (p99 %.3f) bwd %.4f px = %.3f %% of mean |flow| %.2f px; occlusion-mask mismatches %.3f %%'
+              % (dtype, slot, e, p99, eb, 100 * e / meta['mean_flow_px'], meta['mean_flow_px'], 100 * occ_mis))
+        assert e <= BENCH_PATH_VS_REFERENCE_PX[dtype] and eb <= BENCH_PATH_VS_REFERENCE_PX[dtype]
+        assert e <= BENCH_PATH_VS_REFERENCE_FRAC[dtype] * meta['mean_flow_px']
+        worst = max(worst, e)
+    # the two slots hold the same pairs in another order: concurrent execution must not change a bit
+    a, b = pipe.result(0)['flow_f_out'], pipe.result(1)['flow_f_out']
+    assert torch.equal(a[0], b[1]) and torch.equal(a[1], b[0])
+
+
+def test_pipelined_inference_equals_one_step_at_a_time():
+    """runtime.PipelinedInference (what bench.py times): three slots on three streams, each with its own batch, replayed
+    interleaved — every slot's outputs are bit-identical to the same batch run alone through GraphedInference."""
+    from upflow_pytorch_amd.runtime import GraphedInference, PipelinedInference
+    net = build('robust', torch.bfloat16)
+    dev = torch.device('cuda', 0)
+    batches = [tuple(t.cuda() for t in _weights.make_smooth_images(40 + i, 2, 128, 256)) for i in range(3)]
+    ref = []
+    single = GraphedInference(net, 2, 128, 256, device=dev)
+    for a, b in batches:
+        o = single(a, b)
+        ref.append({k: v.clone() for k, v in o.items()})
+    pipe = PipelinedInference(net, 2, 128, 256, streams=3, device=dev)
+    tickets = [pipe.submit(a, b) for a, b in batches]
+    for _ in range(4):                                       # more rounds, no new inputs: same results
+        for t in tickets:
+            pipe.replay(t)
+    for t, want in zip(tickets, ref):
+        got = pipe.result(t)
+        for k in ('flow_f_out', 'flow_b_out', 'occ_fw', 'occ_bw'):
+            assert torch.equal(got[k], want[k]), k
 
 
 # measured on MI355X (printed by the tests): 16-bit all-HIP path vs the fp32 forward of the same network, robust mask,

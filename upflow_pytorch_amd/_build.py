@@ -27,6 +27,12 @@ SOURCES = [
     ('loss.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+# No packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) anywhere in the library: on MI355X they were
+# observed to return wrong results while a wave of a v_mfma_f32_16x16x32 kernel shares the SIMD — i.e. as soon as two of this
+# library's kernels run concurrently on two HIP streams (runtime.PipelinedInference; csrc/corr81_allc_kernel.hpp has the record,
+# tools/corr_race3.py the reproducer).  The feature is switched off for the device pass (the host pass prints "not a recognized
+# feature for this target (ignoring feature)", which is filtered below); the arithmetic is the same, in scalar fp32 instructions.
+NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
 def hipcc():
@@ -57,12 +63,17 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([cc] + COMMON + extra + ['-c', s, '-o', o])
+            jobs.append([cc] + COMMON + NO_PACKED_FP32 + extra + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:
             print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        err = '\n'.join(l for l in r.stderr.splitlines() if 'is not a recognized feature for this target' not in l)
+        if err.strip():
+            sys.stderr.write(err + '\n')
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
     if jobs:                                           # independent translation units: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:

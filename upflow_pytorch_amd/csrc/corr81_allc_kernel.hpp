@@ -227,6 +227,12 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
             const float2 ms = sp[k];
             // (x - mean) * rstd in separately rounded fp32 steps, then ONE rounding to the storage type (pack2), exactly
             // like normalize_apply_kernel
+            // NOTE (round 4): hipcc's SLP vectoriser used to turn these four sub / mul pairs into v_pk_add_f32 / v_pk_mul_f32 (bf16
+            // only: the fp16 conversions keep the lanes apart).  On MI355X those packed-fp32 VALU instructions return WRONG results
+            // now and then while a wave of a v_mfma_f32_16x16x32 kernel (the narrow convolution) shares the SIMD: alone on the GPU
+            // this kernel is bit-reproducible, beside the narrow convolution on a second stream 29 of 30 launches differed (whole
+            // tiles, |diff| up to 0.3), and with the same arithmetic in scalar fp32 instructions 0 of 30 (tools/corr_race3.py).
+            // The whole library is therefore built without the packed-fp32 target feature (upflow_pytorch_amd/_build.py).
             v[k].x = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].x), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].x), ms.x), ms.y));
             v[k].y = pack2<T>(__fmul_rn(__fsub_rn(Mma<T>::lo(v[k].y), ms.x), ms.y), __fmul_rn(__fsub_rn(Mma<T>::hi(v[k].y), ms.x), ms.y));
           }

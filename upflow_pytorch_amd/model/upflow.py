@@ -82,7 +82,7 @@ class network_tools():
             _, x_out = self.dense_estimator_mask.forward_in_buffer(buf)
             return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)   # (flow_init, flow_up, None, None)
 
-        def forward_in_buffer_c8(self, flow_init, buf8, output_level_flow=None, batch_shift=0):
+        def forward_in_buffer_c8(self, flow_init, buf8, output_level_flow=None, batch_shift=0, tap=None):
             """forward_in_buffer with the estimator's buffer in the channel-octet layout (pwc_modules.c8_level_ok): feature_1 is
             already in its octets (written there by the 1x1 convolution); the other frame's features are warped from those
             octets into the second half, the stack runs on octets, x_out comes back as NCHW planes for the blend."""
@@ -91,6 +91,8 @@ class network_tools():
             half = est._ch_in // 16
             ops.warp_c8_into(buf8[:, o0:o0 + half], flow_init, buf8[:, o0 + half:o0 + 2 * half], self.warping_layer.mask_mode, batch_shift)
             x_out = est.forward_in_buffer_c8(buf8)
+            if tap is not None:
+                tap('sgu_x_out', x_out)
             return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)
 
         def output_conv(self, x, out=None, out8=None):
@@ -450,6 +452,13 @@ class UPFlow_net(tools.abstract_model):
         f_out, b_out = ops.split_batch(flow_out, B)
         return f_out, b_out, flows[::-1]
 
+    def _tap(self, name, t):
+        """Debug tap (tools/pipe_debug3.py): with `net._taps = []` every named intermediate BUFFER of the fast schedule is kept
+        (a reference, no copy, no launch) so that two runs can be compared tensor by tensor."""
+        taps = getattr(self, '_taps', None)
+        if taps is not None:
+            taps.append((name, t))
+
     def _forward_stacked_fast(self, X, B):
         """_forward_stacked for bf16/fp16 with the published normalisation flags: same arithmetic, and every
         intermediate is produced IN the buffer its consumer reads — the pyramid's convs write the per-level
@@ -467,6 +476,9 @@ class UPFlow_net(tools.abstract_model):
         pairs = [torch.empty((2, nb) + shp, dtype=dt, device=dev) for shp in shapes[:nlev]]
         outs = ([p[0] for p in pairs] + [None] * (len(shapes) - nlev))[::-1]   # stage order: finest first
         pyramid = fpe(X, outs=outs)
+        self._tap('X', X)
+        for i_, p_ in enumerate(pyramid):
+            self._tap('pyramid%d' % i_, p_)
         flow = torch.zeros((nb, 2) + shapes[0][1:], dtype=torch.float32, device=dev)
         flows = []
         for level in range(nlev):
@@ -486,10 +498,11 @@ class UPFlow_net(tools.abstract_model):
             if c8_est:
                 flow, flows_entry = self._level_c8(level, Fm, pair, flow, nb, B, C, H, W, dt, dev, cache, use_sgu)
                 flows.append(flows_entry)
+                self._tap('L%d.flow' % level, flow)
                 continue
             buf, slot = est.alloc_buffer(nb, H, W, dt, dev, tail=2)
             sbuf8 = None
-            if use_sgu and c8 and sgi.dense_estimator_mask.c8_ok():
+            if use_sgu and c8 and sgi.dense_estimator_mask.c8_ok() and not getattr(self, '_no_c8_sgu', False):
                 em = sgi.dense_estimator_mask
                 sbuf8 = ops.c8_empty(nb, em._n_total, H, W, dt, dev)
                 o0 = (em._n_total - em._ch_in) // 8
@@ -524,10 +537,17 @@ class UPFlow_net(tools.abstract_model):
             ops.flow_update(flow_up, out=slot[:, nc + 32:])
             _, res = est.forward_in_buffer(buf)
             ops.flow_update(flow_up, res, out=buf[:, est._n_total:])          # flow_up + res -> context network input
-            fine = self.context_networks.forward_c8(buf) if c8 else self.context_networks(buf)
+            fine = self.context_networks.forward_c8(buf) if (c8 and not getattr(self, '_no_c8_ctx', False)) else self.context_networks(buf)
             flow = ops.flow_update(flow_up, res, fine)                        # flow_up + (res + fine)
             flows.append([flow[:B], flow[B:]])
+            self._tap('L%d.pair' % level, pair)
+            self._tap('L%d.buf' % level, buf)
+            self._tap('L%d.flow_up' % level, flow_up)
+            self._tap('L%d.res' % level, res)
+            self._tap('L%d.fine' % level, fine)
+            self._tap('L%d.flow' % level, flow)
         flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
+        self._tap('final.flow_bilinear', flow_out)
         if sgu:
             # (measured and not kept, round 3: this stem on a side stream = a parallel branch of the captured graph, forked before
             # or after the feature pyramid — 3.075 vs 3.076 ms; and with eager launches on two real streams 3.13 vs 3.14 ms: the step is
@@ -547,7 +567,7 @@ class UPFlow_net(tools.abstract_model):
         H4, W4 = hw4
         dt, dev = X.dtype, X.device
         last = sgi.upsample_output_conv[-1][0]
-        if (c8_level_ok(nb, H4, W4, dt) and not getattr(self, '_no_c8', False) and em.c8_ok() and X.shape[3] % 32 == 0
+        if (c8_level_ok(nb, H4, W4, dt) and not getattr(self, '_no_c8', False) and not getattr(self, '_no_c8_sgu', False) and em.c8_ok() and X.shape[3] % 32 == 0
                 and last.stride[0] == 2 and last.in_channels > 16 and last.out_channels == em._ch_in // 2
                 and ops.conv3x3_out_hw(X.shape[2] // 2, X.shape[3] // 2, 2) == (H4, W4) and X.shape[2] % 2 == 0):
             sbuf8 = ops.c8_empty(nb, em._n_total, H4, W4, dt, dev)
@@ -577,12 +597,15 @@ class UPFlow_net(tools.abstract_model):
             pc = cache[('c8_1x1', level)] = _PackedConvC8(self.conv_1x1[level], (), range(C))
         pc(None, Fm, buf8[:, o_feat:o_feat + 4])
         flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
+        self._tap('L%d.flow_bilinear' % level, flow_up)
         if use_sgu:
             em = sgi.dense_estimator_mask
             sbuf8 = ops.c8_empty(nb, em._n_total, H, W, dt, dev)
             o0 = (em._n_total - em._ch_in) // 8
             pc(None, Fm, sbuf8[:, o0:o0 + 4])
-            flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B)[1]
+            flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B, tap=lambda n_, t_: self._tap('L%d.%s' % (level, n_), t_))[1]
+            self._tap('L%d.sbuf8' % level, sbuf8)
+            self._tap('L%d.flow_sgu' % level, flow_up)
         ops.warp_into(Fm, flow_up, pair[1], self.warping_layer.mask_mode, B)
         ops.corr81_norm_forward_c8(pair[0], pair[1], buf8[:, nconv:nconv + ncorr], leaky_slope=0.1)
         ops.flow_update_c8(flow_up, None, None, buf8[:, o_flow:o_flow + 1])
@@ -593,6 +616,10 @@ class UPFlow_net(tools.abstract_model):
         ctx_map = list(range(nch)) + [m + nch if m >= 0 else -1 for m in in_map] + [nch + 115, nch + 116] + [-1] * 6
         fine = self.context_networks.forward_c8(buf8, in_map=ctx_map)
         flow = ops.flow_update(flow_up, res, fine)                            # flow_up + (res + fine)
+        self._tap('L%d.pair' % level, pair)
+        self._tap('L%d.buf8' % level, buf8)
+        self._tap('L%d.res' % level, res)
+        self._tap('L%d.fine' % level, fine)
         return flow, [flow[:B], flow[B:]]
 
     def _level_update(self, Fn, Fwn, A, flow_up, add_to_flow=False):
