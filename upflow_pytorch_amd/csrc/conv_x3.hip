@@ -43,6 +43,32 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
   }
 }
 
+// 4 consecutive fp32 pixels of one channel row -> 2 dwords of fp16 hi halves, 2 dwords of fp16 lo halves
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const uint32_t h = pack2<f16_t>(v[2 * pp], v[2 * pp + 1]);
+    hi[pp] = h;
+    lo[pp] = pack2<f16_t>(v[2 * pp] - f16_bits_to_f32(h & 0xffffu), v[2 * pp + 1] - f16_bits_to_f32(h >> 16));
+  }
+}
+// 8 channel rows x 4 pixels (half of an 8-pixel group: pixels 4*half .. 4*half+3) -> 4 LDS entries of 8 channels x 1 pixel,
+// at the rotated slots of stage_store (conv_kernel.hpp): entry of pixel q of the group = dst[(q + rot) & 7]
+__device__ __forceinline__ void stage_store_half(uint4* tile, int enc, int half, const u32x2 (&ch)[8]) {
+  uint4* dst = tile + (enc >> 3);
+  const int rot = enc & 7;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    uint4 e0, e1;
+    e0.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1][pp], ch[0][pp], 0x07060302u);
+    e0.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3][pp], ch[2][pp], 0x07060302u);
+    e0.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x05040100u); e1.z = __builtin_amdgcn_perm(ch[5][pp], ch[4][pp], 0x07060302u);
+    e0.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x05040100u); e1.w = __builtin_amdgcn_perm(ch[7][pp], ch[6][pp], 0x07060302u);
+    dst[(4 * half + 2 * pp + rot) & 7] = e0;
+    dst[(4 * half + 2 * pp + 1 + rot) & 7] = e1;
+  }
+}
+
 // Packed operand = a 1 KB header {|w|max bits, scale 2^s, 2^-s, 0...} + the blocks
 //   [slab = co/32][k-step = ci/16][tap][half: hi, lo][kg = (ci/8)%2][px = co%32][ci%8]   of fp16(w * 2^s) halves:
 // the 1 KB block of one (slab, k-step, tap, half) is the A operand of one v_mfma_f32_32x32x16_f16 in lane order.
@@ -110,7 +136,6 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
   constexpr int XW = S * TW + 2 * MARG, XWP = XW + XW / 16;
   constexpr int ROWS = K1 ? TH : S * (TH - 1) + 3;   // staged rows (row phase: 2 halo rows whatever the dilation)
   constexpr int IMG = NOCT * ROWS * XWP;             // entries of one tile image
-  constexpr int ngroups = XW / 8, ntasks = NOCT * ROWS * ngroups;
   extern __shared__ __attribute__((aligned(16))) uint4 xs[];
   uint4* xhi = xs;
   uint4* xlo = xs + IMG;
@@ -144,6 +169,54 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
   uint4 wh[ntaps], wl[ntaps];
   const int colx[3] = {swz(MARG + S * px - (K1 ? 0 : d)), swz(MARG + S * px), swz(MARG + S * px + (K1 ? 0 : d))};
 
+  // ---- staging tasks: (octet, staged row, 4-pixel half of an 8-pixel group) -> 8 channel rows x 4 fp32 pixels (eight 16-byte
+  // loads, or element-wise with bounds at ragged / unaligned places), split into fp16 hi / lo halves, transposed into 4 entries
+  // of each tile image.  240 tasks per chunk at stride 1: one per thread, whose loads for chunk c + 1 are issued BEFORE the matrix
+  // phase of chunk c (HBM latency under the MFMAs) and land in LDS after it.
+  constexpr int nhalves = XW / 4, ntasks = NOCT * ROWS * nhalves;
+  auto task_geom = [&](int t, long long& e0, int& enc, int& half, int& mode) {
+    const int oct = t / (ROWS * nhalves), rem = t - oct * (ROWS * nhalves), r = rem / nhalves, hq = rem - r * nhalves;
+    const int g = hq >> 1;
+    half = hq & 1;
+    const int gy = K1 ? y0 + r : (S == 1 ? y0 + (r - 1) * RS : 2 * y0 - 1 + r), gx = S * x0 - MARG + 4 * hq;
+    const bool row_ok = gy >= 0 && gy < H;
+    e0 = (long long)(oct * 8) * HW + (long long)gy * W + gx;              // element index of (channel 8*oct of chunk 0, gy, gx)
+    enc = ((oct * ROWS + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);
+    // mode 0: nothing inside the image (zeros);  1: four aligned pixels inside -> 16-byte loads;  2: element-wise with bounds
+    mode = (t >= ntasks || !row_ok || gx + 4 <= 0 || gx >= W) ? 0 : ((aligned && gx >= 0 && gx + 4 <= W) ? 1 : 2);
+    if (mode == 2) e0 = (long long)(oct * 8) * HW + (long long)gy * W;    // (row start: the columns are checked one by one)
+  };
+  auto task_load = [&](long long e0, int mode, int cc, int gx, f32x4 (&v)[8]) {
+    const long long base = e0 + (long long)cc * 16 * HW;
+    if (mode == 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)                                          // (channels >= Cin fall off the descriptor: zeros)
+        v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (uint32_t)((base + (long long)k * HW) * 4), 0, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = mode == 2 && gx + q >= 0 && gx + q < W;
+          const uint32_t off = ok ? (uint32_t)((base + (long long)k * HW + gx + q) * 4) : 0x80000000u;
+          v[k][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+        }
+    }
+  };
+  auto task_store = [&](int enc, int half, const f32x4 (&v)[8]) {
+    u32x2 hi[8], lo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split4(v[k], hi[k], lo[k]);
+    stage_store_half(xhi, enc, half, hi);
+    stage_store_half(xlo, enc, half, lo);
+  };
+  // this thread's first task: geometry once, data prefetched a chunk ahead
+  long long pe0; int penc, phalf, pmode;
+  task_geom(tid, pe0, penc, phalf, pmode);
+  const int pgx = S * x0 - MARG + 4 * ((tid % (ROWS * nhalves)) % nhalves);
+  f32x4 pre[8];
+  task_load(pe0, pmode, 0, pgx, pre);
+
   for (int cc = 0; cc < nchunks; ++cc) {
     // this chunk's weight operands (L2-resident; their latency hides under the staging below)
 #pragma unroll
@@ -153,45 +226,17 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
       wl[tap] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off + 1024u, 0, 0));
     }
     __syncthreads();                                 // the previous chunk is fully consumed
-    // ---- stage channels [16 cc, 16 cc + 16): load fp32, split, transpose into the two tile images
-    for (int t = tid; t < ntasks; t += NTHREADS) {
-      const int oct = t / (ROWS * ngroups), rem = t - oct * (ROWS * ngroups), r = rem / ngroups, g = rem - r * ngroups;
-      const int gy = K1 ? y0 + r : (S == 1 ? y0 + (r - 1) * RS : 2 * y0 - 1 + r), gx = S * x0 - MARG + 8 * g;
-      const bool row_ok = gy >= 0 && gy < H;
-      const int c0 = cc * 16 + oct * 8;
-      const long long e0 = (long long)c0 * HW + (long long)gy * W + gx;            // element index of (channel c0, gy, gx)
-      u32x4 hi[8], lo[8];
-      if (aligned && row_ok && gx >= 0 && gx + 8 <= W) {
-        const uint32_t off = (uint32_t)(e0 * 4);
-        f32x4 v0[8], v1[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {                // (channels >= Cin fall off the descriptor: zeros)
-          v0[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off + (uint32_t)(k * HW) * 4u, 0, 0));
-          v1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off + (uint32_t)(k * HW) * 4u + 16u, 0, 0));
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
-          split8(v, hi[k], lo[k]);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const bool ok = row_ok && gx + q >= 0 && gx + q < W;
-            const uint32_t off = ok ? (uint32_t)((e0 + (long long)k * HW + q) * 4) : 0x80000000u;
-            v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
-          }
-          split8(v, hi[k], lo[k]);
-        }
-      }
-      const int enc = ((oct * ROWS + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);
-      stage_store<false>(xhi, enc, 0, hi);
-      stage_store<false>(xlo, enc, 0, lo);
+    // ---- stage channels [16 cc, 16 cc + 16)
+    if (tid < ntasks) task_store(penc, phalf, pre);
+    for (int t = tid + NTHREADS; t < ntasks; t += NTHREADS) {
+      long long e0; int enc, half, mode;
+      task_geom(t, e0, enc, half, mode);
+      f32x4 v[8];
+      task_load(e0, mode, cc, S * x0 - MARG + 4 * ((t % (ROWS * nhalves)) % nhalves), v);
+      task_store(enc, half, v);
     }
     __syncthreads();
+    if (cc + 1 < nchunks) task_load(pe0, pmode, cc + 1, pgx, pre);
 
     // ---- matrix phase: lane (px, kg) reads entry (octet kg, row, column) of both images
     auto mm = [&](int tap, const uint4& bh, const uint4& bl, int r) {
