@@ -411,7 +411,7 @@ def main():
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
-    ap.add_argument('--streams', type=int, default=3,
+    ap.add_argument('--streams', type=int, default=4,
                     help='steps in flight (inference): the captured step is replayed round-robin on this many HIP streams, each with its own '
                          'batch buffers (runtime.PipelinedInference); 1 = one step at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
