@@ -38,7 +38,11 @@ class GraphedInference:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
+        # a live process group (bench.py --gpus N, DDP serving) has a watchdog thread that polls its events while this thread
+        # captures: under the default (global) capture mode that hipEventQuery aborts the capture (train.Trainer does the same)
+        import torch.distributed as dist
+        mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode=mode):
             self.out = self._forward()
         self.graph = g
 
