@@ -22,7 +22,7 @@ float run(const bf16_t* f1, const bf16_t* f2, bf16_t* out, const float* ws, int 
   for (auto& e : ev) (void)hipEventCreate(&e);
   for (int i = 0; i < nrep; ++i)
     hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(corrx::NTHREADS), lds, 0, ev[2 * i], ev[2 * i + 1], 0,
-                          f1, f2, out, C, H, W, tiles_x, tiles_y, (long long)81 * H * W, 0.1f, ws, ws + (size_t)B * C * nseg * 3, nseg, nblocks);
+                          f1, f2, out, C, H, W, tiles_x, tiles_y, (long long)81 * H * W, 0.1f, ws, ws + (size_t)B * C * 2, nseg, nblocks);   // (round 4: final (mean, 1/std) pairs)
   (void)hipDeviceSynchronize();
   std::vector<float> t(nrep);
   for (int i = 0; i < nrep; ++i) (void)hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]);
@@ -36,14 +36,14 @@ int main() {
   const size_t n_in = (size_t)B * C * H * W, n_out = (size_t)B * 81 * H * W;
   bf16_t *f1, *f2, *out; float* ws;
   (void)hipMalloc(&f1, n_in * 2); (void)hipMalloc(&f2, n_in * 2); (void)hipMalloc(&out, n_out * 2);
-  (void)hipMalloc(&ws, (size_t)2 * B * C * nseg * 3 * 4);
+  (void)hipMalloc(&ws, (size_t)2 * B * C * 2 * 4);
   std::vector<uint16_t> h(n_in);
   for (auto& v : h) v = (uint16_t)(0x3f00 + (rand() & 0xff));
   (void)hipMemcpy(f1, h.data(), n_in * 2, hipMemcpyHostToDevice);
   for (auto& v : h) v = (uint16_t)(0x3f00 + (rand() & 0xff));
   (void)hipMemcpy(f2, h.data(), n_in * 2, hipMemcpyHostToDevice);
-  std::vector<float> hw((size_t)2 * B * C * nseg * 3);
-  for (size_t i = 0; i < hw.size(); i += 3) { hw[i] = (float)(H * W / nseg); hw[i + 1] = 0.6f + 0.001f * (i % 7); hw[i + 2] = 300.f + (i % 11); }
+  std::vector<float> hw((size_t)2 * B * C * 2);
+  for (size_t i = 0; i < hw.size(); i += 2) { hw[i] = 0.6f + 0.001f * (i % 7); hw[i + 1] = 1.0f / (1.0f + 0.01f * (i % 11)); }
   (void)hipMemcpy(ws, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
   run<false>(f1, f2, out, ws, B, C, H, W, nseg, 20); run<true>(f1, f2, out, ws, B, C, H, W, nseg, 20);
   for (int rep = 0; rep < 3; ++rep) {

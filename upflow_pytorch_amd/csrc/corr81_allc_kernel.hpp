@@ -17,15 +17,21 @@
 //     straddles the row end is masked; results leave as per-pixel 2-byte stores) — so every level of every
 //     configuration (W = 20, 45, 90, 13, 26, 311 ...) takes the matrix-core path, none falls back to the VALU kernel.
 //   * NORM: network_tools.normalize_features (model/upflow.py:94-137, inference flags) fused into the loader — the
-//     statistics kernel leaves per-row (count, mean, M2) partials, the workgroup merges the rows it needs (Chan), and
-//     every element is normalised and re-rounded to 16 bits on its way into LDS: bit-identical to
-//     normalize_apply + corr81, without the write + read of both normalised feature maps and without that launch.
+//     statistics launch leaves the FINAL (mean, 1/std) pair of every (item, channel) row (round 4: rounds 2-3 left per-row
+//     (count, mean, M2) partials that every workgroup merged itself: partial loads, two IEEE divisions + a square root + a
+//     reciprocal per row, an LDS hand-off and a workgroup barrier in front of the loader), and every element is normalised
+//     and re-rounded to 16 bits on its way into LDS: bit-identical to normalize_apply + corr81, without the write + read of
+//     both normalised feature maps and without that launch.  With <= 4 staging tasks per thread (the 8x32 and 4x32 tiles) a
+//     task's four (mean, 1/std) pairs travel with its feature loads into registers (two 16-byte loads): no LDS, no barrier.
 #pragma once
 #include "common.hpp"
 #include "norm_merge.hpp"
 
+#ifndef UPF_ALLC_STREG
+#define UPF_ALLC_STREG 0   // 1: a task's (mean, 1/std) pairs travel with its feature loads into registers (measured SLOWER: see the header)
+#endif
 #ifndef UPF_ALLC_ABL
-#define UPF_ALLC_ABL 0     // tools/corr_norm_ablate.hip: 1 no normalisation arithmetic, 2 no merge arithmetic, 4 no statistics loads, 8 no barrier after the merge
+#define UPF_ALLC_ABL 0     // tools/corr_norm_ablate.hip: 1 no normalisation arithmetic, 4 no statistics loads, 8 no barrier behind the LDS copy of the statistics (8-task variants)
 #endif
 
 namespace upf {
@@ -44,7 +50,7 @@ template <int UW, int NU> struct Geo {
 
 template <int UW, int NU>
 __host__ __device__ constexpr size_t lds_bytes(int KQ, bool ragged, bool norm) {
-  return (size_t)KQ * Geo<UW, NU>::E * 8 + (ragged ? 0 : NWAVES * PATCH_BYTES) + (norm ? (size_t)2 * KQ * 4 * 8 : 0);
+  return (size_t)KQ * Geo<UW, NU>::E * 8 + (ragged ? 0 : NWAVES * PATCH_BYTES) + (norm ? (size_t)2 * KQ * 4 * 8 : 0);   // (norm: the LDS copy of the statistics, used by the 8-task variants)
 }
 template <int UW, int NU>
 __host__ __device__ constexpr int ntasks(int KQ) {       // f1 tasks padded to a whole number of waves, then the f2 tasks
@@ -82,7 +88,7 @@ struct Task {      // two registers per task: NT = 8 tasks + their 64 raw-data r
 };
 
 // out: [B,81,H,W] (batch stride out_bs).  !RAGGED requires W % 8 == 0 and 16-byte aligned pointers / strides.
-// ws1 / ws2 (NORM): (count, mean, M2) partials of normalize_stats, [B*C][nseg][3] for f1 / f2.
+// ws1 / ws2 (NORM): the final (mean, 1/std) pairs of the rows of f1 / f2, float2 [B*C] each (misc::launch_stats2); nseg unused.
 // TPW (tiles per workgroup; the product instantiates 1): with 2 the workgroup issues the global loads of a SECOND tile
 // before the matrix work of the first and lands them in LDS afterwards.  Measured on MI355X and NOT used: 31.5 us instead
 // of 23.8 us at [8,32,96,320] (57.6 vs 39.4 at [16,32,112,256]) — the two tiles of a workgroup serialise (load, compute,
@@ -112,6 +118,8 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
 
   Task task[NT];
   u32x2 raw[NT][4];
+  constexpr bool STREG = NORM && NT <= 4 && (UPF_ALLC_STREG != 0);   // statistics in registers, per task (else: staged through LDS once)
+  f32x4 sreg[STREG ? NT : 1][2];                        // (mean, 1/std) of the task's 4 channels
   // ---- staging: every load of a tile is issued before anything is consumed
   auto issue = [&](int tile, bool live) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / ntiles;
@@ -119,6 +127,9 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
     const size_t item = (size_t)n * C * H * W;
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1 + item), 0, live ? item_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f2 + item), 0, live ? item_bytes : 0u, 0x00020000);
+    // (NORM) the item's (mean, 1/std) pairs: channels >= C fall off the descriptor -> (0, 0): (x - 0) * 0 keeps the zero padding
+    const __amdgpu_buffer_rsrc_t q1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws1 + (NORM ? (size_t)n * C * 2 : 0)), 0, (live && NORM) ? (uint32_t)C * 8u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t q2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws2 + (NORM ? (size_t)n * C * 2 : 0)), 0, (live && NORM) ? (uint32_t)C * 8u : 0u, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int t = tid + j * NTHREADS;
@@ -156,48 +167,30 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
       const __amdgpu_buffer_rsrc_t rs = from_f2 ? r2 : r1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) raw[j][k] = __builtin_amdgcn_raw_buffer_load_b64(rs, s.voff + k * plane, 0, 0);
+      if constexpr (STREG) {
+        const uint32_t so = (lds_at >= 0 && !(UPF_ALLC_ABL & 4)) ? (uint32_t)kq * 32u : 0x80000000u;
+        const __amdgpu_buffer_rsrc_t qs = from_f2 ? q2 : q1;
+        sreg[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qs, so, 0, 0));
+        sreg[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qs, so + 16u, 0, 0));
+      }
     }
   };
-  // ---- NORM: merge the (count, mean, M2) partials of the 2 x C rows of item n -> (mean, rstd) in LDS
-  // Two steps around issue(): the partials are LOADED first (older than the feature loads, so the wait for them does not
-  // wait for the features: vmcnt retires in order) and MERGED — two IEEE divisions per segment, a square root and a
-  // reciprocal — while the feature loads are in flight.  (Round 2 loaded them after issue(): the merge then started only
-  // when every feature load had landed, ~2 us of a 28 us launch.)
-  constexpr int PRE = 4;                                  // segments held in registers; further ones (rare: one huge plane) are read in the merge
-  float pw[PRE * 3];
-  const float* wrow = nullptr;
+  // ---- NORM, 8-task variants: the 2 x C final (mean, 1/std) pairs of item n -> LDS (one 8-byte load per thread, issued BEFORE the
+  // feature loads: vmcnt retires in order, so the wait for it does not wait for the features), one barrier
+  float2 pst = make_float2(0.f, 0.f);
   auto load_stats = [&](int n) {
-    if constexpr (NORM) {
+    if constexpr (NORM && !STREG) {
       const int c4 = KQ * 4;
-      wrow = nullptr;
+      pst = make_float2(0.f, 0.f);                   // channels >= C: (x - 0) * 0 keeps the zero padding of the quad
       if (tid < 2 * c4) {
         const int sel = tid >= c4, c = tid - sel * c4;
-        if (c < C && !(UPF_ALLC_ABL & 4)) {
-          wrow = (sel ? ws2 : ws1) + ((size_t)n * C + c) * nseg * 3;
-#pragma unroll
-          for (int k = 0; k < PRE; ++k)
-            if (k < nseg) { pw[3 * k] = wrow[3 * k]; pw[3 * k + 1] = wrow[3 * k + 1]; pw[3 * k + 2] = wrow[3 * k + 2]; }
-        }
+        if (c < C && !(UPF_ALLC_ABL & 4)) pst = *reinterpret_cast<const float2*>((sel ? ws2 : ws1) + ((size_t)n * C + c) * 2);
       }
     }
   };
   auto merge_stats = [&]() {
-    if constexpr (NORM) {
-      const int c4 = KQ * 4;
-      if (tid < 2 * c4) {
-        float2 ms = make_float2(0.f, 0.f);             // channels >= C: (x - 0) * 0 keeps the zero padding of the quad
-        if ((UPF_ALLC_ABL & 2) && wrow) ms = make_float2(pw[1], pw[2]);
-        else if (wrow) {
-          MergeState s = {pw[0], pw[1], pw[2]};
-#pragma unroll
-          for (int k = 1; k < PRE; ++k)
-            if (k < nseg) norm_merge_add(s, pw[3 * k], pw[3 * k + 1], pw[3 * k + 2]);
-          for (int k = PRE; k < nseg; ++k) norm_merge_add(s, wrow[3 * k], wrow[3 * k + 1], wrow[3 * k + 2]);
-          const RowStats r = norm_merge_finish(s, H * W);
-          ms = make_float2(r.mean, r.rstd);
-        }
-        st[tid] = ms;
-      }
+    if constexpr (NORM && !STREG) {
+      if (tid < 2 * KQ * 4) st[tid] = pst;
       if (!(UPF_ALLC_ABL & 8)) __syncthreads();
     }
   };
@@ -224,7 +217,9 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
           const float2* sp = st + (from_f2 ? KQ * 4 : 0) + task[j].kq() * 4;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float2 ms = sp[k];
+            float2 ms;
+            if constexpr (STREG) ms = make_float2(sreg[j][k >> 1][2 * (k & 1)], sreg[j][k >> 1][2 * (k & 1) + 1]);
+            else ms = sp[k];
             // (x - mean) * rstd in separately rounded fp32 steps, then ONE rounding to the storage type (pack2), exactly
             // like normalize_apply_kernel
             // NOTE (round 4): hipcc's SLP vectoriser used to turn these four sub / mul pairs into v_pk_add_f32 / v_pk_mul_f32 (bf16

@@ -344,7 +344,8 @@ extern "C" int upf_corr81_norm_supported(int C, int dtype) {
 }
 
 extern "C" long long upf_corr81_norm_workspace_bytes(int B, int C, int H, int W) {
-  return (long long)2 * B * C * upf::misc::stats2_nseg((long long)B * C, H * W) * 3 * sizeof(float);
+  const long long part = ((long long)2 * B * C * upf::misc::stats2_nseg((long long)B * C, H * W) * 3 + 3) / 4 * 4;   // floats, rounded to 16 bytes
+  return part * (long long)sizeof(float) + (long long)2 * B * C * (long long)sizeof(float2);
 }
 
 extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
@@ -360,11 +361,12 @@ extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const long long N = (long long)B * C;
-  const int nseg = misc::launch_stats2(f1, f2, ws, N, H * W, dtype, s);
+  float2* fin = reinterpret_cast<float2*>(ws + ((size_t)2 * N * misc::stats2_nseg(N, H * W) * 3 + 3) / 4 * 4);    // final (mean, 1/std) pairs behind the partials (16-byte aligned)
+  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s);
   int rc = check_launch("corr81_norm_forward (statistics)");
   if (rc != UPF_OK) return rc;
-  const float* ws1 = ws;
-  const float* ws2 = ws + (size_t)N * nseg * 3;
+  const float* ws1 = reinterpret_cast<const float*>(fin);            // what the cost volume reads: final pairs of f1's rows ...
+  const float* ws2 = reinterpret_cast<const float*>(fin + N);        // ... and of f2's
   if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
   else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
   UPF_REQUIRE(rc != 1, UPF_EUNSUPPORTED, "corr81_norm_forward: no kernel variant fits C=%d W=%d (W >= 4 required)", C, W);
@@ -385,11 +387,12 @@ extern "C" int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* 
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const long long N = (long long)B * C;
-  const int nseg = misc::launch_stats2(f1, f2, ws, N, H * W, dtype, s);
+  float2* fin = reinterpret_cast<float2*>(ws + ((size_t)2 * N * misc::stats2_nseg(N, H * W) * 3 + 3) / 4 * 4);    // final (mean, 1/std) pairs behind the partials (16-byte aligned)
+  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s);
   int rc = check_launch("corr81_norm_forward_c8 (statistics)");
   if (rc != UPF_OK) return rc;
-  const float* ws1 = ws;
-  const float* ws2 = ws + (size_t)N * nseg * 3;
+  const float* ws1 = reinterpret_cast<const float*>(fin);            // what the cost volume reads: final pairs of f1's rows ...
+  const float* ws2 = reinterpret_cast<const float*>(fin + N);        // ... and of f2's
   const int v = corr::allc_pick(B, C, H, W, false, true, false);
   UPF_REQUIRE(v >= 0, UPF_EUNSUPPORTED, "corr81_norm_forward_c8: no kernel variant fits C=%d", C);
   if (dtype == UPF_BF16) return corr::launch_allc_c8<bf16_t>(v, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s);
@@ -414,11 +417,12 @@ static int norm_forward_timed_impl(bool c8, const void* f1, const void* f2, void
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const long long N = (long long)B * C;
-  const int nseg = misc::launch_stats2(f1, f2, ws, N, H * W, dtype, s);
+  float2* fin = reinterpret_cast<float2*>(ws + ((size_t)2 * N * misc::stats2_nseg(N, H * W) * 3 + 3) / 4 * 4);    // final (mean, 1/std) pairs behind the partials (16-byte aligned)
+  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s);
   int rc = check_launch("corr81_norm_forward_timed (statistics)");
   if (rc != UPF_OK) return rc;
-  const float* ws1 = ws;
-  const float* ws2 = ws + (size_t)N * nseg * 3;
+  const float* ws1 = reinterpret_cast<const float*>(fin);            // what the cost volume reads: final pairs of f1's rows ...
+  const float* ws2 = reinterpret_cast<const float*>(fin + N);        // ... and of f2's
   hipEvent_t* ev = new hipEvent_t[2 * nrep];
   for (int i = 0; i < 2 * nrep; ++i) (void)hipEventCreate(&ev[i]);
   for (int i = 0; i < nrep && rc == UPF_OK; ++i) {

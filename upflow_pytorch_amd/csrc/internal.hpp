@@ -4,8 +4,9 @@
 
 namespace upf {
 namespace misc {
-// (count, mean, M2) partials of the rows of two [N,HW] tensors in ONE launch: ws[2N][nseg][3]; returns nseg.
-int launch_stats2(const void* x1, const void* x2, float* ws, long long N, int HW, int dtype, hipStream_t stream);
+// (count, mean, M2) partials of the rows of two [N,HW] tensors in ONE launch: ws[2N][nseg][3], and their final (mean, 1/std)
+// pairs fin[2N] (nullable); returns nseg.
+int launch_stats2(const void* x1, const void* x2, float* ws, float2* fin, long long N, int HW, int dtype, hipStream_t stream);
 int stats2_nseg(long long N, int HW);
 }  // namespace misc
 }  // namespace upf

@@ -42,7 +42,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 template <typename T, bool VEC>
 __global__ __launch_bounds__(NT)
 void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, int nseg, int seglen,
-                            const T* __restrict__ x2 = nullptr, size_t rows1 = ~(size_t)0) {
+                            const T* __restrict__ x2 = nullptr, size_t rows1 = ~(size_t)0, float2* __restrict__ fin = nullptr) {
   __shared__ float sh[NT / 64];
   constexpr int V = VEC ? VecIO<T>::N : 1;
   const size_t row = blockIdx.x / nseg;
@@ -87,7 +87,20 @@ void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int
   if (threadIdx.x == 0) {
     float* w = ws + ((size_t)row * nseg + seg) * 3;
     w[0] = cnt; w[1] = mean; w[2] = m2;
+    if (fin && nseg == 1) {                          // a one-segment row: its final (mean, 1/std), the same arithmetic as the merge
+      const MergeState st = {cnt, mean, m2};
+      const RowStats r = norm_merge_finish(st, HW);
+      fin[row] = make_float2(r.mean, r.rstd);
+    }
   }
+}
+
+// rows with several segments: merge the partials in fixed order (norm_merge_full, what normalize_apply_kernel does per thread)
+__global__ void stats_finalize_kernel(const float* __restrict__ ws, float2* __restrict__ fin, long long rows, int nseg, int HW) {
+  const long long row = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const RowStats r = norm_merge_full(ws + (size_t)row * nseg * 3, nseg, HW);
+  fin[row] = make_float2(r.mean, r.rstd);
 }
 
 // Small planes (the coarse pyramid levels: 24x80 pixels and fewer), 16-bit features: ONE WAVE per row, eight rows per
@@ -99,7 +112,7 @@ constexpr int WAVE_ROWS = 8;
 template <typename T, bool VEC>
 __global__ __launch_bounds__(WAVE_ROWS * 64)
 void normalize_stats_wave_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, size_t rows,
-                                 const T* __restrict__ x2, size_t rows1) {
+                                 const T* __restrict__ x2, size_t rows1, float2* __restrict__ fin = nullptr) {
   constexpr int V = VEC ? VecIO<T>::N : 1;
   const size_t row = (size_t)blockIdx.x * WAVE_ROWS + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -118,7 +131,13 @@ void normalize_stats_wave_kernel(const T* __restrict__ x, float* __restrict__ ws
   if (lane == 0) {
     const float cnt = (float)HW;
     float* w = ws + row * 3;
-    w[0] = cnt; w[1] = K + s1 / cnt; w[2] = fmaxf(s2 - s1 * (s1 / cnt), 0.f);
+    const float mean = K + s1 / cnt, m2 = fmaxf(s2 - s1 * (s1 / cnt), 0.f);
+    w[0] = cnt; w[1] = mean; w[2] = m2;
+    if (fin) {
+      const MergeState st = {cnt, mean, m2};
+      const RowStats r = norm_merge_finish(st, HW);
+      fin[row] = make_float2(r.mean, r.rstd);
+    }
   }
 }
 
@@ -370,37 +389,42 @@ extern "C" int upf_space_to_depth2(const void* src, void* dst, int B, int C, int
   return check_launch("space_to_depth2");
 }
 
-// segments per row: enough workgroups for ~4 per CU, at least 2048 elements per segment
+// segments per row: enough workgroups for ~2 per CU (round 4: 512, was 1024 — a one-segment row gets its final statistics from
+// the statistics kernel itself, no merge launch), at least 2048 elements per segment
 static int normalize_nseg(long long N, int HW) {
   int nseg = 1;
-  while (N * nseg < 1024 && HW / (nseg * 2) >= 2048) nseg *= 2;
+  while (N * nseg < 512 && HW / (nseg * 2) >= 2048) nseg *= 2;
   return nseg;
 }
 
 // small planes of 16-bit features: the one-wave-per-row kernel (see normalize_stats_wave_kernel)
 static bool stats_wave_form(int nseg, int HW, int dtype) { return nseg == 1 && HW <= 4096 && dtype != UPF_F32; }
 template <typename T>
-static void launch_stats_wave(const T* x1, const T* x2, float* ws, size_t rows, size_t rows1, int HW, bool vec, hipStream_t stream) {
+static void launch_stats_wave(const T* x1, const T* x2, float* ws, size_t rows, size_t rows1, int HW, bool vec, hipStream_t stream, float2* fin = nullptr) {
   const unsigned grid = (unsigned)((rows + upf::misc::WAVE_ROWS - 1) / upf::misc::WAVE_ROWS);
-  if (vec) hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, true>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1);
-  else hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, false>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1);
+  if (vec) hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, true>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1, fin);
+  else hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, false>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1, fin);
 }
 
-// statistics of TWO [N,HW] tensors in one launch -> ws[(2N rows)][nseg][3]; returns nseg (internal.hpp)
-int upf::misc::launch_stats2(const void* x1, const void* x2, float* ws, long long N, int HW, int dtype, hipStream_t stream) {
+// statistics of TWO [N,HW] tensors in one launch -> ws[(2N rows)][nseg][3] partials and fin[2N] final (mean, 1/std) pairs (the
+// statistics kernel writes them itself where a row is one segment; a small second launch merges the partials otherwise);
+// returns nseg (internal.hpp)
+int upf::misc::launch_stats2(const void* x1, const void* x2, float* ws, float2* fin, long long N, int HW, int dtype, hipStream_t stream) {
   const int nseg = normalize_nseg(2 * N, HW);
   const int seglen = cdiv(HW, nseg);
   const unsigned grid = (unsigned)(2 * N * nseg);
   const int vn = (dtype == UPF_F32) ? 4 : 8;
   const bool vec = (HW % vn == 0) && (seglen % vn == 0) && aligned_to(x1, 16) && aligned_to(x2, 16);
   if (stats_wave_form(nseg, HW, dtype)) {
-    if (dtype == UPF_BF16) launch_stats_wave<bf16_t>((const bf16_t*)x1, (const bf16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream);
-    else launch_stats_wave<f16_t>((const f16_t*)x1, (const f16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream);
+    if (dtype == UPF_BF16) launch_stats_wave<bf16_t>((const bf16_t*)x1, (const bf16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream, fin);
+    else launch_stats_wave<f16_t>((const f16_t*)x1, (const f16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream, fin);
     return nseg;
   }
   UPF_DISPATCH(dtype, T,
-               if (vec) hipLaunchKernelGGL((misc::normalize_stats_kernel<T, true>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N);
-               else hipLaunchKernelGGL((misc::normalize_stats_kernel<T, false>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N));
+               if (vec) hipLaunchKernelGGL((misc::normalize_stats_kernel<T, true>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N, fin);
+               else hipLaunchKernelGGL((misc::normalize_stats_kernel<T, false>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N, fin));
+  if (fin && nseg > 1)
+    hipLaunchKernelGGL(misc::stats_finalize_kernel, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, stream, (const float*)ws, fin, 2 * N, nseg, HW);
   return nseg;
 }
 int upf::misc::stats2_nseg(long long N, int HW) { return normalize_nseg(2 * N, HW); }
