@@ -318,7 +318,10 @@ def test_pipelined_inference_equals_one_step_at_a_time():
         o = single(a, b)
         ref.append({k: v.clone() for k, v in o.items()})
     pipe = PipelinedInference(net, 2, 128, 256, streams=3, device=dev)
-    tickets = [pipe.submit(a, b) for a, b in batches]
+    # inputs handed over as TEMPORARIES of a host-to-device copy on the caller's stream (`x.cpu().cuda()`): load() must wait for
+    # the caller's stream and keep the temporary alive until its own copy has read it (a first form did neither: slot 0 ran on
+    # whatever the recycled block held)
+    tickets = [pipe.submit(a.cpu().cuda(), b.cpu().cuda()) for a, b in batches]
     for _ in range(4):                                       # more rounds, no new inputs: same results
         for t in tickets:
             pipe.replay(t)

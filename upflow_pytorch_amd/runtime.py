@@ -90,9 +90,17 @@ class PipelinedInference:
         torch.cuda.synchronize(self.device)
 
     def load(self, slot, im1, im2):
-        """Copy a batch into slot's static inputs (on the slot's stream: ordered before its next replay)."""
-        with torch.cuda.stream(self.streams[slot]):
+        """Copy a batch into slot's static inputs on the slot's stream (ordered before its next replay).  The copy waits for
+        the caller's current stream — the producer of im1 / im2, e.g. a host-to-device transfer that is still in flight — and
+        the sources are recorded on the slot's stream, so that a temporary (`x.to(device)`) is not recycled by the allocator
+        before the copy has read it."""
+        st = self.streams[slot]
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
             self.runners[slot].load(im1, im2)
+        for t in (im1, im2):
+            if t.is_cuda:
+                t.record_stream(st)
 
     def replay(self, slot=None):
         """Replay one step on the next (or the given) slot without touching its inputs; returns the slot."""
@@ -108,7 +116,6 @@ class PipelinedInference:
 
     def submit(self, im1, im2):
         slot = self._next
-        self.streams[slot].wait_stream(torch.cuda.current_stream(self.device))     # the caller's tensors are ready
         self.load(slot, im1, im2)
         return self.replay()
 
