@@ -326,7 +326,18 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     for (int ks = 0; ks < KSW; ++ks) wa[tap][ks] = wload(0, tap, ks);
 
   constexpr bool REUSE = (S == 1 && D >= 1 && (RPW + 2 * DV) * 3 < 9 * RPW);
-  const int colx[3] = {swz(marg + px - (D > 0 ? D : 0)), swz(marg + px), swz(marg + px + (D > 0 ? D : 0))};   // REUSE windows
+  // Round 4: with a pure C8 input (XL == 1) the tile image is filled by LDS-DMA — contiguous 1 KB pieces, conflict-free whatever
+  // the layout — so its rows are stored LINEARLY (position = column): a read window of 16 consecutive columns is then 256
+  // contiguous bytes = 16 different bank quads from ANY start.  The slot rotation of swz() exists for the register-staged
+  // (NCHW) writes; it costs the shifted read windows a 2-way conflict per 16-lane pass (tools/lds_b128_probe.hip: the 50 % of
+  // LDS-active cycles that SQ_LDS_BANK_CONFLICT reports for every variant are real).  The odd row pitch (XWP = 51 / 85 entries)
+  // keeps rows apart.  UPF_C8_LINEAR=0 restores the rotated image for A/B runs.
+#ifndef UPF_C8_LINEAR
+#define UPF_C8_LINEAR 1
+#endif
+  constexpr bool LIN = (XL == 1) && (UPF_C8_LINEAR != 0);
+  auto pos_of = [](int col) { return LIN ? col : swz(col); };
+  const int colx[3] = {pos_of(marg + px - (D > 0 ? D : 0)), pos_of(marg + px), pos_of(marg + px + (D > 0 ? D : 0))};   // REUSE windows
 
   // ---- the matrix phase of chunk cc on the tile image at xb (also fetches the weights of chunk cc + 1)
   // (N16, measured and not kept: the four waves of a workgroup multiply by the SAME weights, and their 4 x 9 KB of operand loads
@@ -341,7 +352,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     } else if constexpr (N16) {
       // staged row sr feeds output rows sr - ky; per row three windows (kx) for each 16-pixel half, each used by up to three MFMAs
       constexpr int NR = RPW + 2;
-      const int c16[2][3] = {{swz(marg + p16 - 1), swz(marg + p16), swz(marg + p16 + 1)}, {swz(marg + p16 + 15), swz(marg + p16 + 16), swz(marg + p16 + 17)}};
+      const int c16[2][3] = {{pos_of(marg + p16 - 1), pos_of(marg + p16), pos_of(marg + p16 + 1)}, {pos_of(marg + p16 + 15), pos_of(marg + p16 + 16), pos_of(marg + p16 + 17)}};
       uint4 bq[2][6];
       auto bload = [&](int sr, uint4 (&b)[6]) {
 #pragma unroll
@@ -412,7 +423,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
       for (int tap = 0; tap < ntaps; ++tap) {
         const int ky = (ntaps == 1) ? 1 : tap / 3, kx = (ntaps == 1) ? 1 : tap - 3 * (tap / 3);
         // shifted window: output pixel (row, px) reads staged entry (S*row + ky*d, marg + S*px + (kx-1)*d)
-        const int col = swz(marg + S * px + (kx - 1) * d);
+        const int col = pos_of(marg + S * px + (kx - 1) * d);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -441,7 +452,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     for (int j = 0; j < NSL; ++j) {
       const int p = (j * 4 + wave_u) * 64 + lane;
       const int oct = p / (rowsC * XWP), rem = p - oct * (rowsC * XWP), r = rem / XWP, pos = rem - r * XWP;
-      const int grp = pos & ~7, col = grp | ((pos - (grp >> 4)) & 7);   // inverse of swz
+      const int grp = pos & ~7, col = LIN ? pos : (grp | ((pos - (grp >> 4)) & 7));   // inverse of the position map
       const int gy = PH ? y0 + (r - 1) * RS : S * y0 - DV + r, gx = S * x0 - marg + col;
       const bool in = p < EB && pos < XW && col >= marg - DH && col < marg + S * TW + DH && gy >= 0 && gy < H && gx >= 0 && gx < W && !(abl & 2);
       voff8[j] = in ? (uint32_t)((oct * HW + gy * W + gx) * 16) : 0x80000000u;
