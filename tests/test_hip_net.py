@@ -256,6 +256,20 @@ def test_fp32_path_vs_reference_at_realistic_motion(name, H, W, cids):
     assert (out['occ_fw'].cpu() != occ).float().mean() <= 2e-3
 
 
+@pytest.mark.parametrize('mode', ['hip_x3', 'hip_x3s', 'miopen'])
+def test_fp32_conv_back_ends_all_meet_the_bar(mode):
+    """config `fp32_conv`: the split-precision matrix-core kernel (default), its separate-accumulator variant and PyTorch-ROCm —
+    each against the REFERENCE at 10.6 px mean motion (256x256, full-scale heads): <= 1e-4 px."""
+    im1, im2, g, occ, meta = _hs1_case('net_256x256_hs1_robust', 256, 256, (1,))
+    net = build('robust', head_scale=1.0)
+    net.conf.fp32_conv = mode
+    with torch.no_grad():
+        out = net({'im1': im1, 'im2': im2, 'if_loss': False})
+    e = oracle.epe(out['flow_f_out'].cpu(), g['flow_f_out'])
+    print('fp32_conv=%s: EPE vs reference %.3g px' % (mode, e))
+    assert e <= 1e-4
+
+
 # measured on MI355X (printed by the test; DESIGN.md section 2): the benchmarked path vs the REFERENCE at 15.6 px mean motion —
 # bf16 0.179 px fwd / 0.164 bwd (1.15 % of the mean flow magnitude, p99 0.55 px), fp16 0.028 / 0.029 px (0.18 %); where it comes from:
 # profiles/r04_precision_localise.txt (spread over the network: the feature pyramid's weights and activations carry most of it).

@@ -381,7 +381,8 @@ extern "C" int upf_conv_x3_forward(const float* x, long long x_batch_stride, con
               "conv_x3_forward: nprod %d (3 products per operand pair; 11 = 3 + 8: the low-order products in their own accumulators)", nprod);
   UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_x3_forward: leaky_slope %g not in [0,1]", (double)leaky_slope);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  UPF_REQUIRE((long long)Cin * H * W * 4 < (1ll << 31) && (long long)Cout * Ho * Wo * 4 < (1ll << 31), UPF_EINVAL,
+  UPF_REQUIRE((long long)Cin * H * W * 4 < (1ll << 31) && (long long)Cout * Ho * Wo * 4 < (1ll << 31) &&
+                  (long long)upf::convx3::pad16(Cin) * H * W * 4 < (1ll << 32), UPF_EINVAL,      // (the padding channels' offsets must not wrap)
               "conv_x3_forward: image too large for one buffer descriptor");
   convx3::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, dilation, stride, kernel_size,
                  leaky_slope == 0.f ? 1.f : leaky_slope, nprod, (hipStream_t)stream};
