@@ -12,7 +12,7 @@ import csv, glob
 f = glob.glob('$R/gpurun_out/prof_bench/*/*kernel_stats.csv')[0]
 rows = list(csv.DictReader(open(f)))
 out = open('$P/r04_bench_default_rocprof_stats.txt', 'w')
-out.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline   (MI355X; config 2, hipGraph replay with 3 steps in flight on 3 HIP streams, 10 warm-up + 50 timed steps + 50 steps one at a time,\n# then the roofline probes: 220 + 30 launches of the cost volume at [8,32,96,320], 55 of the 565->128 convolution)\n')
+out.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline   (MI355X; config 2, hipGraph replay with 4 steps in flight on 4 HIP streams, 10 warm-up + 50 timed steps + 50 steps one at a time,\n# then the roofline probes: 220 + 30 launches of the cost volume at [8,32,96,320], 55 of the 565->128 convolution)\n')
 out.write('# bench line of this run: ' + [l for l in open('$R/gpurun_out/prof_bench/bench.log').read().split('\\n') if l.startswith('{')][-1] + '\\n')
 out.write('%-150s %8s %14s %12s %8s\\n' % ('kernel', 'calls', 'total_ns', 'avg_ns', 'pct'))
 for r in rows[:45]:
@@ -22,6 +22,10 @@ PY
 rm -rf $R/gpurun_out/prof_eager; mkdir -p $R/gpurun_out/prof_eager
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_eager -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-probe --no-graph > $R/gpurun_out/prof_eager/bench.log 2>&1)
 (echo "# rocprofv3 --kernel-trace --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-probe --no-graph   (tools/steady_profile.py on the trace)"; python tools/steady_profile.py $(ls $R/gpurun_out/prof_eager/*/*kernel_trace.csv | head -1)) > $P/r04_bench_config2_eager_kernel_stats.txt
+# 2b. the same for the fp32 parity mode (split-precision convolutions)
+rm -rf $R/gpurun_out/prof_eager32; mkdir -p $R/gpurun_out/prof_eager32
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_eager32 -- python $R/bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-train-probe --no-graph > $R/gpurun_out/prof_eager32/bench.log 2>&1)
+(echo "# rocprofv3 --kernel-trace --output-format csv -- python bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-train-probe --no-graph   (tools/steady_profile.py on the trace)"; python tools/steady_profile.py $(ls $R/gpurun_out/prof_eager32/*/*kernel_trace.csv | head -1)) > $P/r04_bench_config2_fp32_eager_kernel_stats.txt
 # 3. training steps
 tools/train_profile.sh train_bf16 --no-graph > /dev/null 2>&1
 tools/train_profile.sh train_fp32 --dtype fp32 --no-graph > /dev/null 2>&1
@@ -45,6 +49,6 @@ python tools/kbench.py > $P/r04_kbench.txt 2>&1
 python tools/conv_layers.py > $P/r04_conv_layers.txt 2>&1
 python tools/conv_layers.py --c8 > $P/r04_conv_layers_c8.txt 2>&1
 # the raw traces are hundreds of MB: only the summaries travel back (gpurun merges <= 64 MiB)
-rm -rf $R/gpurun_out/prof_bench/*/ $R/gpurun_out/prof_eager/*/ $R/gpurun_out/prof_train_bf16/trace $R/gpurun_out/prof_train_fp32/trace
+rm -rf $R/gpurun_out/prof_bench/*/ $R/gpurun_out/prof_eager/*/ $R/gpurun_out/prof_eager32/*/ $R/gpurun_out/prof_train_bf16/trace $R/gpurun_out/prof_train_fp32/trace
 du -sh $R/gpurun_out
 ls -la $P
