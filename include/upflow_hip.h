@@ -252,6 +252,11 @@ int upf_conv_x3_pack_weights(const float* w, void* w_packed, int Cin, int Cout, 
 int upf_conv_x3_forward(const float* x, long long x_batch_stride, const void* w_packed, const float* bias, float* y,
                         long long y_batch_stride, int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation,
                         int stride, float leaky_slope, int nprod, void* stream);
+/* launch heuristics of upf_conv_x3_forward, for tuning and for the tests to reach both kernels: "sk_max_tiles" (96) — the split-K
+ * kernel (2 x 32-pixel tiles, the four waves of a workgroup split the input channels; stride 1, >= 64 input channels, 3 products)
+ * is chosen where the batch has at most this many 8 x 32-pixel tiles (0: never; 1 << 30: wherever eligible).
+ * Returns the previous value, INT32_MIN for an unknown name. */
+int upf_conv_x3_set_option(const char* name, int value);
 /* writes 2^-6 to out_device[0] if v_mfma_f32_32x32x16_f16 multiplies fp16 SUBNORMAL inputs un-flushed (what the low halves of
  * small operands rely on), 0 if it flushes them */
 int upf_mfma_f16_denorm_probe(float* out_device, void* stream);

@@ -23,7 +23,7 @@ CASES = [  # B, Cin, Cout, H, W, k, dilation, stride
     (2, 32, 32, 24, 40, 1, 1, 1), (1, 196, 32, 6, 20, 1, 1, 1), (1, 128, 32, 12, 26, 1, 1, 1), (1, 16, 32, 7, 13, 1, 1, 1), (1, 64, 200, 3, 5, 1, 1, 1)]
 
 
-def _run(x, w, b, d, s, k, slope, nprod, off=5):
+def _run(x, w, b, d, s, k, slope, nprod, off=5, launch=None):
     from upflow_pytorch_amd import ops
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -36,10 +36,13 @@ def _run(x, w, b, d, s, k, slope, nprod, off=5):
     packed = ops.conv3x3_pack(w)
     prev = ops.CONV_X3_NPROD[0]
     ops.CONV_X3_NPROD[0] = nprod
+    prev_sk = ops.conv_x3_set_option('sk_max_tiles', {'tiled': 0, 'splitk': 1 << 30}[launch]) if launch else None
     try:
         ops.conv3x3_forward_raw(xv, packed, b, ybuf[:, 2:2 + Cout], dilation=d, leaky_slope=slope, stride=s, kernel_size=k)
     finally:
         ops.CONV_X3_NPROD[0] = prev
+        if launch:
+            ops.conv_x3_set_option('sk_max_tiles', prev_sk)
     assert bool((ybuf[:, :2] == 7).all()) and bool((ybuf[:, 2 + Cout:] == 7).all()), 'wrote outside its channel slice'
     return ybuf[:, 2:2 + Cout].clone()
 
@@ -51,29 +54,32 @@ def test_fp16_matrix_instruction_keeps_subnormal_inputs():
 
 
 @pytest.mark.parametrize('case', CASES)
-@pytest.mark.parametrize('nprod', [3, 11])
-def test_conv_x3_is_fp32_class(case, nprod):
+@pytest.mark.parametrize('nprod,launch', [(3, 'tiled'), (3, 'splitk'), (11, 'tiled')])
+def test_conv_x3_is_fp32_class(case, nprod, launch):
+    """`launch`: the 8 x 32-tile kernel everywhere / the split-K kernel wherever it is eligible (stride 1, >= 64 input channels)."""
     B, Cin, Cout, H, W, k, d, s = case
+    if launch == 'splitk' and (s != 1 or (Cin + 15) // 16 < 4):
+        pytest.skip('not eligible for the split-K kernel: same launch as "tiled"')
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, H, W, generator=g).cuda()
     w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5).cuda()
     b = torch.randn(Cout, generator=g).cuda()
     pad = d * (k - 1) // 2
     want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=pad, dilation=d, stride=s), 0.1)
-    got = _run(x, w, b, d, s, k, 0.1, nprod)
+    got = _run(x, w, b, d, s, k, 0.1, nprod, launch=launch)
     assert got.shape == want.shape and got.dtype == torch.float32
     scale = float(want.abs().max())
     err = float((got.double() - want).abs().max()) / scale
     ref32 = F.leaky_relu(F.conv2d(x, w, b, padding=pad, dilation=d, stride=s), 0.1)
     err32 = float((ref32.double() - want).abs().max()) / scale
     rms = float((got.double() - want).pow(2).mean().sqrt()) / float(want.pow(2).mean().sqrt())
-    print('x%d %s: max err %.2e of max |y| (torch fp32: %.2e), rms %.2e' % (nprod, case, err, err32, rms))
+    print('x%d %s %s: max err %.2e of max |y| (torch fp32: %.2e), rms %.2e' % (nprod, launch, case, err, err32, rms))
     # measured on MI355X (all cases): nprod 3: max <= 2.4e-6, rms <= 8.7e-7; nprod 11: max <= 1.5e-6, rms <= 5.4e-7; torch's own fp32
     # convolution (MIOpen) on the same operands: max <= 1.2e-6, rms <= 7.2e-7
     assert err <= (3.0e-6 if nprod == 3 else 2.0e-6), (err, err32)
     assert rms <= (1.1e-6 if nprod == 3 else 7e-7)
     # no activation
-    got0 = _run(x, w, b, d, s, k, 0.0, nprod)
+    got0 = _run(x, w, b, d, s, k, 0.0, nprod, launch=launch)
     want0 = F.conv2d(x.double(), w.double(), b.double(), padding=pad, dilation=d, stride=s)
     assert float((got0.double() - want0).abs().max()) / float(want0.abs().max()) <= 3.0e-6
 
@@ -99,16 +105,17 @@ def test_conv_x3_operand_magnitudes(mag):
         assert err <= 2e-6
 
 
-def test_conv_x3_is_deterministic_and_alignment_independent():
-    """Same bits whatever the alignment path (16-byte loads / element-wise loads) and from run to run."""
+@pytest.mark.parametrize('launch', ['tiled', 'splitk'])
+def test_conv_x3_is_deterministic_and_alignment_independent(launch):
+    """Same bits whatever the alignment path (16-byte loads / element-wise loads) and from run to run, in both kernels."""
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(2, 40, 12, 24, generator=g).cuda()
-    w = (torch.randn(64, 40, 3, 3, generator=g) * 0.05).cuda()
+    x = torch.randn(2, 72, 12, 24, generator=g).cuda()
+    w = (torch.randn(64, 72, 3, 3, generator=g) * 0.05).cuda()
     b = torch.zeros(64).cuda()
-    a0 = _run(x, w, b, 1, 1, 3, 0.1, 3, off=4)                    # 4*12*24*4 bytes in: aligned
-    a1 = _run(x, w, b, 1, 1, 3, 0.1, 3, off=4)
-    u = _run(x[:, :, :, :23].contiguous(), w, b, 1, 1, 3, 0.1, 3, off=5)        # W = 23: element-wise loads
-    a23 = _run(torch.cat([x[:, :, :, :23], torch.zeros(2, 40, 12, 1, device='cuda')], 3), w, b, 1, 1, 3, 0.1, 3, off=4)
+    a0 = _run(x, w, b, 1, 1, 3, 0.1, 3, off=4, launch=launch)     # 4*12*24*4 bytes in: aligned
+    a1 = _run(x, w, b, 1, 1, 3, 0.1, 3, off=4, launch=launch)
+    u = _run(x[:, :, :, :23].contiguous(), w, b, 1, 1, 3, 0.1, 3, off=5, launch=launch)        # W = 23: element-wise loads
+    a23 = _run(torch.cat([x[:, :, :, :23], torch.zeros(2, 72, 12, 1, device='cuda')], 3), w, b, 1, 1, 3, 0.1, 3, off=4, launch=launch)
     assert torch.equal(a0, a1)
     assert torch.equal(u[:, :, :, :22], a23[:, :, :, :22])       # (column 22 sees the zero column either way)
     assert torch.equal(u[:, :, :, 22], a23[:, :, :, 22])

@@ -143,9 +143,42 @@ def main_c8():
     json.dump(rows, open('gpurun_out/conv_layers_c8.json', 'w'), indent=1)
 
 
+def main_fp32():
+    """The same layer list through the split-precision kernel of the parity mode (csrc/conv_x3.hip), beside the bf16 kernel:
+    effective TFLOP/s = the layer's algorithmic flop / time (the kernel issues three matrix products per operand pair)."""
+    B = 8
+    levels = [(96, 320), (48, 160), (24, 80), (12, 40), (6, 20)]
+    items = [('stem',) + l for l in stem_layers(384, 1280)]
+    for (H, W) in levels:
+        items += [('%dx%d' % (H, W),) + l for l in layers(H, W)]
+    sums = {}
+    for (lvl, name, Cin, Cout, k, d, s, H, W) in items:
+        t, tf, gb = bench_layer(B, Cin, Cout, k, d, s, H, W, dt=torch.float32)
+        t16, tf16, _ = bench_layer(B, Cin, Cout, k, d, s, H, W)
+        a = sums.setdefault(lvl, [0.0, 0.0]); a[0] += t; a[1] += t16
+        extra = ''
+        if '--sweep' in sys.argv:                    # the two kernels forced (tiled 8x32 / split-K 2x32), to set "sk_max_tiles"
+            alt = {}
+            for nm, v in (('tiled', 0), ('splitk', 1 << 30)):
+                prev = ops.conv_x3_set_option('sk_max_tiles', v)
+                try:
+                    alt[nm] = bench_layer(B, Cin, Cout, k, d, s, H, W, dt=torch.float32)[0]
+                finally:
+                    ops.conv_x3_set_option('sk_max_tiles', prev)
+            wgs = B * ((W + 31) // 32) * ((H + 7) // 8) * ((Cout + 31) // 32)
+            extra = '  | tiled %.1f splitk %.1f (8x32-tile workgroups %d)' % (alt['tiled'], alt['splitk'], wgs)
+        print('%-8s %-14s %3d->%3d k%d d%-2d s%d %4dx%-4d  x3 %8.1f us %7.1f TF/s eff. (x3 issued: %4.1f%% of 2.5 PF) %7.0f GB/s | bf16 %7.1f us  x%.2f%s' %
+              (lvl, name, Cin, Cout, k, d, s, H, W, t, tf, 3 * tf / 25.0, 2 * gb, t16, t / t16, extra), flush=True)
+    for lvl, (a, b) in sums.items():
+        print('sum %-8s x3 %8.1f us   bf16 %8.1f us   x%.2f' % (lvl, a, b, a / b))
+    print('sum all x3 %8.1f us   bf16 %8.1f us' % (sum(a for a, _ in sums.values()), sum(b for _, b in sums.values())))
+
+
 def main():
     if '--c8' in sys.argv:
         return main_c8()
+    if '--fp32' in sys.argv:
+        return main_fp32()
     sweep = '--sweep' in sys.argv
     B = 8
     levels = [(96, 320), (48, 160), (24, 80), (12, 40), (6, 20)]

@@ -134,6 +134,8 @@ def lib():
         L.upf_conv_set_option.restype = _i
         L.upf_conv_c8_set_option.argtypes = [_c.c_char_p, _i]
         L.upf_conv_c8_set_option.restype = _i
+        L.upf_conv_x3_set_option.argtypes = [_c.c_char_p, _i]
+        L.upf_conv_x3_set_option.restype = _i
         L.upf_conv_packed_bytes_k.argtypes = [_i, _i, _i]
         L.upf_conv_packed_bytes_k.restype = _ll
         L.upf_conv_c8_k.argtypes = [_i, _i]

@@ -21,13 +21,23 @@
 // order, kept in registers per chunk.  Dilation 1..16 by ROW PHASE (a tile's rows are d image rows apart: 2 halo rows whatever d
 // is), stride 2, 1x1.  x / y are channel slices of contiguous NCHW fp32 buffers (the concat-free dense-stack buffers work in fp32
 // too); the epilogue adds nothing (the accumulators start at the bias), applies LeakyReLU and stores fp32.
+#include <cstring>
+#include <cstdint>
 #include "conv_kernel.hpp"
+
+// Ablation switches for tools/x3_ablate.hip (always 0 in the library): 1 = no matrix phase, 2 = no split / transposition / LDS
+// stores (the loaded values are only kept alive), 4 = no global loads of the tile, 8 = the matrix phase multiplies registers
+// (no LDS reads).
+#ifndef UPF_X3_ABL
+#define UPF_X3_ABL 0
+#endif
 
 namespace upf {
 namespace convx3 {
 using namespace upf::conv;
 
 constexpr int TH = 8;                    // tile rows
+static int g_sk_max_tiles = 96;          // split-K kernel where the image has at most this many 8 x 32 tiles (upf_conv_x3_set_option)
 constexpr int NOCT = 2;                  // channel octets per chunk (16 input channels)
 
 __host__ __device__ constexpr int pad16(int v) { return (v + 15) / 16 * 16; }
@@ -126,11 +136,16 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, f16_t* __restrict__ 
 // not the operand split (~2^-23), is the kernel's error.  With the low-order terms out of the chain it is a third as long, and
 // the roundings of the low-order chain are 2^-11 smaller.  Costs RPW * 16 more accumulator registers: the 64-channel
 // workgroups then run one per CU (accumulators in AGPRs).
+// (Measured and not kept, round 4: TWO chunks of staging data in flight per thread in the 32-channel workgroups — the layers with
+//  Cout <= 32 did not move (531 -> 32 at 96x320: 286.5 -> 286.8 us).  tools/x3_ablate.hip says why: with the matrix phase removed the
+//  same launch still takes 204 us — 1.04 GB of tile + halo at the ~5 TB/s the memory system delivers to this access pattern — and
+//  with the loads removed 212 us; the two overlap to 287-350 us.  These layers are bandwidth bound like their bf16 twins (101 us
+//  for half the bytes), not latency bound.)
 template <int MTW, int S, int MARG, bool K1, int NPROD, bool SPLITACC>
 __global__ __launch_bounds__(NTHREADS, (SPLITACC && MTW == 2) ? 1 : 2)
 void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __restrict__ wp, const float* __restrict__ bias,
                     float* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d,
-                    int tiles_x, int tiles_y, float slope, int aligned) {
+                    int tiles_x, int tiles_y, int nslabs, float slope, int aligned) {
   constexpr int ntaps = K1 ? 1 : 9;
   constexpr int RG = 4 / MTW, RPW = TH / RG;         // MTW = 2: two row groups of 4 rows;  MTW = 1: four of 2
   constexpr int XW = S * TW + 2 * MARG, XWP = XW + XW / 16;
@@ -141,13 +156,17 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
   uint4* xlo = xs + IMG;
 
   const int RS = (S == 1 && !K1) ? d : 1;            // image rows between consecutive tile rows
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  // the workgroups of ONE pixel tile (its Cout / (32 MTW) channel slabs) are consecutive block indices: they run at the same time on
+  // the same XCD, so the tile is fetched into that XCD's L2 once (as gridDim.y they ran a whole grid apart and each fetched it
+  // from beyond L2: 565 -> 128 moved 2 x 555 MB that way)
+  const int bid0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = bid0 / nslabs, slab_w = bid0 - bid * nslabs;
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
   const int x0 = tx * TW, y0 = (ty / RS) * (RS * TH) + ty % RS;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 31, kg = lane >> 5;
   const int cb = wave % MTW, rg = wave / MTW;
-  const int slab = blockIdx.y * MTW + cb;
+  const int slab = slab_w * MTW + cb;
   const int cip = pad16(Cin), nchunks = cip / 16;
   const int HW = H * W;
   const float* xn = x + (size_t)n * xbs;
@@ -188,6 +207,11 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
   };
   auto task_load = [&](long long e0, int mode, int cc, int gx, f32x4 (&v)[8]) {
     const long long base = e0 + (long long)cc * 16 * HW;
+    if constexpr ((UPF_X3_ABL & 4) != 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = f32x4{slope, slope * (float)k, slope + (float)cc, slope};
+      return;
+    }
     if (mode == 1) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)                                          // (channels >= Cin fall off the descriptor: zeros)
@@ -204,6 +228,11 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
     }
   };
   auto task_store = [&](int enc, int half, const f32x4 (&v)[8]) {
+    if constexpr ((UPF_X3_ABL & 2) != 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(v[k]));
+      return;
+    }
     u32x2 hi[8], lo[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) split4(v[k], hi[k], lo[k]);
@@ -239,7 +268,9 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
     if (cc + 1 < nchunks) task_load(pe0, pmode, cc + 1, pgx, pre);
 
     // ---- matrix phase: lane (px, kg) reads entry (octet kg, row, column) of both images
-    auto mm = [&](int tap, const uint4& bh, const uint4& bl, int r) {
+    if constexpr ((UPF_X3_ABL & 1) != 0) continue;
+    auto mm = [&](int tap, const uint4& bh_, const uint4& bl_, int r) {
+      const uint4 bh = (UPF_X3_ABL & 8) ? wh[(tap + 1) % ntaps] : bh_, bl = (UPF_X3_ABL & 8) ? wl[(tap + 1) % ntaps] : bl_;
       f32x16& lo = SPLITACC ? accs[SPLITACC ? r : 0] : acc[r];
       lo = Mma32<f16_t>::mma(wl[tap], bh, lo);
       lo = Mma32<f16_t>::mma(wh[tap], bl, lo);
@@ -297,6 +328,173 @@ void conv_x3_kernel(const float* __restrict__ x, long long xbs, const f16_t* __r
   }
 }
 
+
+// Split-K variant for the COARSE pyramid levels and other small grids (6x20 .. 24x80 pixels: the kernel above is then a serial
+// chain of Cin/16 chunks of ~2.5 us on a few dozen workgroups — 531 -> 32 at 6x20 took 84 us for 3 us of matrix work).  As in
+// conv3x3.hip's conv_sk_kernel: a workgroup owns a 2 x 32 pixel tile (rows d apart: row phase) and 32 output channels, its four
+// waves take the 16-channel chunks w, w + 4, ..., each staging into its OWN pair of LDS images (no workgroup barrier inside the
+// loop; the LDS operations of one wave execute in order), both staging tasks of a lane prefetched a chunk ahead, the weight
+// operands of a kernel row reloaded for the wave's next chunk right after their last use; the four partial tiles are summed
+// through LDS in wave order (deterministic) and leave through the same scale / LeakyReLU epilogue.
+template <int MARG, bool K1>
+__global__ __launch_bounds__(NTHREADS, 2)
+void conv_x3_sk_kernel(const float* __restrict__ x, long long xbs, const f16_t* __restrict__ wp, const float* __restrict__ bias,
+                       float* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int d,
+                       int tiles_x, int tiles_y, int nslabs, float slope, int aligned) {
+  constexpr int ntaps = K1 ? 1 : 9;
+  constexpr int RPW = 2;
+  constexpr int XW = TW + 2 * MARG, XWP = XW + XW / 16;
+  constexpr int ROWS = K1 ? RPW : RPW + 2;
+  constexpr int IMG = NOCT * ROWS * XWP;             // entries of one image of one wave
+  constexpr int nhalves = XW / 4, ntasks = NOCT * ROWS * nhalves, NT = (ntasks + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) uint4 xs[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint4* xhi = xs + wave * 2 * IMG;
+  uint4* xlo = xhi + IMG;
+
+  const int RS = K1 ? 1 : d;
+  const int bid0 = xcd_remap(blockIdx.x, gridDim.x);                  // (slabs of one tile = consecutive blocks, as above)
+  const int bid = bid0 / nslabs, slab = bid0 - bid * nslabs;
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int x0 = tx * TW, y0 = (ty / RS) * (RS * RPW) + ty % RS;
+  const int px = lane & 31, kg = lane >> 5;
+  const int cip = pad16(Cin), nchunks = cip / 16;
+  const int HW = H * W;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * (uint32_t)HW * 4u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(wp + HDR_F16), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 4u, 0x00020000);
+  const float wsc = reinterpret_cast<const float*>(wp)[1], winv = reinterpret_cast<const float*>(wp)[2];
+  // wave 0's partial tile starts at bias * 2^s (the other waves, and channels >= Cout, read 0 through the descriptor)
+  __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, wave == 0 ? (uint32_t)Cout * 4u : 0u, 0x00020000);
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float bv = wsc * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 4u, 0, 0));
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r][e] = bv;
+  }
+
+  // this lane's staging tasks (octet, staged row, 4-pixel half-group), the same for every chunk
+  long long te0[NT]; int tenc[NT], thalf[NT], tmode[NT], tgx[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int t = lane + 64 * i;
+    const int oct = t / (ROWS * nhalves), rem = t - oct * (ROWS * nhalves), r = rem / nhalves, hq = rem - r * nhalves;
+    const int g = hq >> 1;
+    const int gy = K1 ? y0 + r * RS : y0 + (r - 1) * RS, gx = x0 - MARG + 4 * hq;
+    thalf[i] = hq & 1;
+    tgx[i] = gx;
+    tenc[i] = ((oct * ROWS + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);
+    tmode[i] = (t >= ntasks || gy < 0 || gy >= H || gx + 4 <= 0 || gx >= W) ? 0 : ((aligned && gx >= 0 && gx + 4 <= W) ? 1 : 2);
+    te0[i] = (long long)(oct * 8) * HW + (long long)gy * W + (tmode[i] == 1 ? gx : 0);
+  }
+  auto task_load = [&](int i, int cc, f32x4 (&v)[8]) {
+    const long long base = te0[i] + (long long)cc * 16 * HW;
+    if (tmode[i] == 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (uint32_t)((base + (long long)k * HW) * 4), 0, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = tmode[i] == 2 && tgx[i] + q >= 0 && tgx[i] + q < W;
+          const uint32_t off = ok ? (uint32_t)((base + (long long)k * HW + tgx[i] + q) * 4) : 0x80000000u;
+          v[k][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+        }
+    }
+  };
+  auto task_store = [&](int i, const f32x4 (&v)[8]) {
+    u32x2 hi[8], lo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split4(v[k], hi[k], lo[k]);
+    stage_store_half(xhi, tenc[i], thalf[i], hi);
+    stage_store_half(xlo, tenc[i], thalf[i], lo);
+  };
+  f32x4 pre[NT][8];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    if (wave < nchunks) task_load(i, wave, pre[i]);
+
+  uint4 wh[ntaps], wl[ntaps];
+  auto wload = [&](int cc, int tap) {
+    const uint32_t off = (cc < nchunks) ? (uint32_t)(((slab * nchunks + cc) * ntaps + tap) * 2) * 1024u + (uint32_t)lane * 16u : 0x80000000u;
+    wh[tap] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+    wl[tap] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, off + 1024u, 0, 0));
+  };
+#pragma unroll
+  for (int tap = 0; tap < ntaps; ++tap) wload(wave, tap);
+  const int colx[3] = {swz(MARG + px - (K1 ? 0 : d)), swz(MARG + px), swz(MARG + px + (K1 ? 0 : d))};
+
+  for (int cc = wave; cc < nchunks; cc += 4) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      if (lane + 64 * i < ntasks) task_store(i, pre[i]);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      if (cc + 4 < nchunks) task_load(i, cc + 4, pre[i]);
+    auto mm = [&](int tap, const uint4& bh, const uint4& bl, int r) {
+      acc[r] = Mma32<f16_t>::mma(wl[tap], bh, acc[r]);
+      acc[r] = Mma32<f16_t>::mma(wh[tap], bl, acc[r]);
+      acc[r] = Mma32<f16_t>::mma(wh[tap], bh, acc[r]);
+    };
+    if constexpr (K1) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int e = (kg * ROWS + r) * XWP + colx[1];
+        mm(0, xhi[e], xlo[e], r);
+      }
+      wload(cc + 4, 0);
+    } else {
+#pragma unroll
+      for (int sr = 0; sr < RPW + 2; ++sr) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int e = (kg * ROWS + sr) * XWP + colx[kx];
+          const uint4 bh = xhi[e], bl = xlo[e];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+            if (sr - ky >= 0 && sr - ky < RPW) mm(ky * 3 + kx, bh, bl, sr - ky);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+          if (sr == ky + RPW - 1) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) wload(cc + 4, ky * 3 + kx);
+          }
+      }
+    }
+  }
+
+  // ---- sum the four partial tiles in wave order: part[((w * 2 + r) * 16 + e) * 64 + lane]
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(xs);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[((wave * 2 + r) * 16 + e) * 64 + lane] = acc[r][e];
+  __syncthreads();
+  // wave w finishes output row r = w / 2, accumulator registers [8 * (w % 2), 8 * (w % 2) + 8)
+  const int r = wave >> 1, ebase = 8 * (wave & 1);
+  const int Ho = H, Wo = W;
+  const uint32_t plane = (uint32_t)(Ho * Wo) * 4u;
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * ybs, 0, (uint32_t)Cout * plane, 0x00020000);
+  const int gx = x0 + px, gy = y0 + r * RS;
+  if (gy < Ho) {
+    const uint32_t base = (gx < Wo) ? (uint32_t)(gy * Wo + gx) * 4u : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = ebase + j;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += part[((w * 2 + r) * 16 + e) * 64 + lane];
+      v *= winv;
+      v = fmaxf(v, v * slope);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, base + (uint32_t)(slab * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * plane, 0, 0);
+    }
+  }
+}
+
 struct Args {
   const float* x; long long xbs; const void* wp; const float* bias; float* y; long long ybs;
   int B, Cin, Cout, H, W, d, stride, k; float slope; int nprod; hipStream_t stream;
@@ -315,9 +513,32 @@ int launch_one(const Args& a) {
   auto kern = &conv_x3_kernel<MTW, S, MARG, K1, NPROD, SPLITACC>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   const int slabs = cdiv(cdiv(a.Cout, 32), MTW);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, a.x, a.xbs, (const f16_t*)a.wp, a.bias,
-                     a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, K1 ? 1 : a.d, tiles_x, tiles_y, a.slope, (int)aligned);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y * slabs)), dim3(NTHREADS), lds, a.stream, a.x, a.xbs, (const f16_t*)a.wp, a.bias,
+                     a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, K1 ? 1 : a.d, tiles_x, tiles_y, slabs, a.slope, (int)aligned);
   return check_launch("conv_x3_forward");
+}
+
+template <int MARG, bool K1>
+int launch_sk_one(const Args& a) {
+  const int rs = K1 ? 1 : a.d;
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, rs * 2) * rs;
+  constexpr int XW = TW + 2 * MARG, XWP = XW + XW / 16;
+  constexpr int ROWS = K1 ? 2 : 4;
+  size_t lds = (size_t)4 * 2 * NOCT * ROWS * XWP * 16;
+  if (lds < 4 * 2 * 16 * 64 * 4) lds = 4 * 2 * 16 * 64 * 4;      // (the partial-sum exchange reuses the region)
+  const bool aligned = a.W % 4 == 0 && aligned_to(a.x, 16) && a.xbs % 4 == 0;
+  static LdsOptIn opt;
+  auto kern = &conv_x3_sk_kernel<MARG, K1>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  const int slabs = cdiv(a.Cout, 32);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y * slabs)), dim3(NTHREADS), lds, a.stream, a.x, a.xbs, (const f16_t*)a.wp,
+                     a.bias, a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, K1 ? 1 : a.d, tiles_x, tiles_y, slabs, a.slope, (int)aligned);
+  return check_launch("conv_x3_forward");
+}
+int launch_sk(const Args& a) {
+  if (a.k == 1) return launch_sk_one<0, true>(a);
+  if (a.d <= 8) return launch_sk_one<8, false>(a);
+  return launch_sk_one<16, false>(a);
 }
 
 template <int MTW, int NPROD, bool SPLITACC>
@@ -388,8 +609,23 @@ extern "C" int upf_conv_x3_forward(const float* x, long long x_batch_stride, con
                  leaky_slope == 0.f ? 1.f : leaky_slope, nprod, (hipStream_t)stream};
   // 64-channel workgroups where there are enough tiles to fill the chip with them; 32-channel ones for narrow layers and small grids
   const long long tiles = (long long)B * cdiv(Wo, conv::TW) * cdiv(Ho, convx3::TH);
+  // small grids (the coarse pyramid levels): the input channels split across the four waves of 2-row tiles
+  // (measured per layer, tools/conv_layers.py --fp32 --sweep: faster at 6x20 .. 24x80 x 8 items whatever Cout, slower from 48x160 on —
+  // except the dilation-16 layer there, whose 8-row row-phase tiles waste 5/8 of a 48-row image)
+  if (nprod == 3 && stride == 1 && convx3::pad16(Cin) / 16 >= 4 &&
+      (tiles <= convx3::g_sk_max_tiles || (dilation == 16 && kernel_size == 3 && H < 64 && tiles <= 5ll * convx3::g_sk_max_tiles)))
+    return convx3::launch_sk(a);
   const bool two = Cout > 32 && tiles * cdiv(cdiv(Cout, 32), 2) >= 256;
   return two ? convx3::launch_mode<2>(a) : convx3::launch_mode<1>(a);
+}
+
+extern "C" int upf_conv_x3_set_option(const char* name, int value) {
+  int* slot = nullptr;
+  if (name && !strcmp(name, "sk_max_tiles")) slot = &upf::convx3::g_sk_max_tiles;
+  if (!slot) return INT32_MIN;
+  const int prev = *slot;
+  *slot = value;
+  return prev;
 }
 
 extern "C" int upf_mfma_f16_denorm_probe(float* out_device, void* stream) {

@@ -813,6 +813,14 @@ def conv_c8_set_option(name, value):
     return prev
 
 
+def conv_x3_set_option(name, value):
+    """Launch heuristics of the split-precision convolution (include/upflow_hip.h: upf_conv_x3_set_option); returns the previous value."""
+    prev = _lib.lib().upf_conv_x3_set_option(name.encode(), int(value))
+    if prev == -2 ** 31:
+        raise UpflowHipError('unknown split-precision convolution option %r' % name)
+    return prev
+
+
 # ------------------------------------------------------------------------------------------------
 # soft census distance (photometric loss, utils/loss.py:50-91)
 # ------------------------------------------------------------------------------------------------
