@@ -160,6 +160,18 @@ __device__ __forceinline__ void fix_add(unsigned long long* p, float v) {
   if (fabsf(s) < FIX_MAX_CONTRIB) atomicAdd(p, (unsigned long long)__float2ll_rn(s));      // (NaN fails the comparison)
   else atomicExch(p, (unsigned long long)FIX_POISON);
 }
+// The same in two steps, for kernels that merge the contributions of neighbouring lanes to ONE address before the atomic (integer
+// sums: the accumulator ends up with exactly the bits two fix_add calls would leave): fix_q = the fixed-point value, or FIX_BIG for
+// what fix_add would poison;  fix_emit adds a + b (either may be 0) or poisons.
+constexpr long long FIX_BIG = (long long)0x8000000000000000ull;
+__device__ __forceinline__ long long fix_q(float v) {
+  const float s = v * FIX_SCALE;
+  return (fabsf(s) < FIX_MAX_CONTRIB) ? __float2ll_rn(s) : FIX_BIG;
+}
+__device__ __forceinline__ void fix_emit(unsigned long long* p, long long a, long long b) {
+  if (a != FIX_BIG && b != FIX_BIG) atomicAdd(p, (unsigned long long)(a + b));
+  else atomicExch(p, (unsigned long long)FIX_POISON);
+}
 __device__ __forceinline__ float fix_get(unsigned long long v) {
   const long long q = (long long)v;
   return (q >= FIX_BAND || q <= -FIX_BAND) ? __builtin_nanf("") : (float)((double)q * (double)FIX_INV);

@@ -145,6 +145,9 @@ void warp_fwd_narrow_kernel(const T* __restrict__ x, long long xbs, const float*
   }
 }
 
+#ifndef UPF_WARP_MERGE
+#define UPF_WARP_MERGE 1                                 // (0: one atomic per tap — tools/warp_bwd_ab.py compares the two builds bit for bit)
+#endif
 // Backward: one thread per OUTPUT pixel, loops over its channel slice and scatters into the source image:
 //   gx[tap] += w_tap * gy            gflow += gy * d(sample)/d(pos)
 // A scatter because the inverse map (which output pixels sample a given source pixel) is unbounded for arbitrary flows.
@@ -152,14 +155,24 @@ void warp_fwd_narrow_kernel(const T* __restrict__ x, long long xbs, const float*
 // integer atomics) — integer addition is associative, so the sum does not depend on the order in which the workgroups
 // arrive, unlike the fp32 atomicAdd of the first version.  Quantum 2^-44 = 5.7e-14 (below fp32 resolution for every
 // gradient >= 1e-6, absolute error 5.7e-14 below that), range +-2^19; a second launch converts to the output type.
+//
+// Round 4: HALF the atomics.  With a smooth flow the lanes of a wave (consecutive pixels of a row) sample consecutive source
+// pixels: the right-hand taps of pixel j are the left-hand taps of pixel j + 1.  Each lane passes the fixed-point values of its
+// two right-hand contributions up to the next lane (two 64-bit lane shifts per channel), which adds them to its own left-hand
+// ones where the ADDRESSES agree (checked per lane pair, once per pixel; anything else — row ends, a flow discontinuity, taps
+// outside the image — keeps its own atomic).  The merge is an integer addition of the values the two atomics would have added,
+// so the accumulators, and with them every output bit, are unchanged (tests/test_hip_ops.py::test_warp_*); the kernel was bound
+// by the L2's atomic rate (13.6 M 64-bit atomics = 50 us at the 1/4 level of config 3).
 template <typename T>
 __global__ __launch_bounds__(THREADS)
 void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, const T* __restrict__ gy,
                      unsigned long long* __restrict__ gx64, unsigned long long* __restrict__ gf64, float* __restrict__ gflow,
                      int C, int H, int W, int cpt, int mask_mode, int shift, SampleGeom sg) {
   const int HW = H * W;
-  const int p = blockIdx.x * THREADS + threadIdx.x;
-  if (p >= HW) return;
+  const int p_raw = blockIdx.x * THREADS + threadIdx.x;
+  const bool inside = p_raw < HW;
+  const int p = inside ? p_raw : HW - 1;               // (no early exits: every lane takes part in the lane shifts)
+  const int lane = threadIdx.x & 63;
   const int n = blockIdx.z;
   const int ns = (n + shift) % (int)gridDim.z;
   const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
@@ -168,13 +181,18 @@ void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, co
   const float fy = flow[((size_t)n * 2 + 1) * HW + p];
   const Taps t = make_taps(j, i, fx, fy, H, W, sg);
   float* gf = gflow + (size_t)n * 2 * HW + p;
-  if (!taps_valid(t, mask_mode, j, i, fx, fy, H, W)) {   // mask is a constant factor: zero grads
-    if (gridDim.y == 1) { gf[0] = 0.f; gf[HW] = 0.f; }
-    return;
-  }
+  const bool valid = inside && taps_valid(t, mask_mode, j, i, fx, fy, H, W);   // the mask is a constant factor: zero gradients
+  if (inside && !valid && gridDim.y == 1) { gf[0] = 0.f; gf[HW] = 0.f; }
   const int xa = min(max(t.x0, 0), W - 1), xb1 = min(max(t.x0 + 1, 0), W - 1);
   const int ya = min(max(t.y0, 0), H - 1), yb1 = min(max(t.y0 + 1, 0), H - 1);
   const int o0 = ya * W + xa, o1 = ya * W + xb1, o2 = yb1 * W + xa, o3 = yb1 * W + xb1;
+  const bool in0 = valid && t.in[0], in1 = valid && t.in[1], in2 = valid && t.in[2], in3 = valid && t.in[3];
+  // my right-hand taps join the next lane's left-hand ones (m1, m3); the previous lane's join mine (p1, p3)
+  const int o0n = __shfl_down(o0, 1), o2n = __shfl_down(o2, 1);
+  const int in0n = __shfl_down((int)in0, 1), in2n = __shfl_down((int)in2, 1);
+  const bool m1 = UPF_WARP_MERGE && lane < 63 && in1 && in0n && o1 == o0n;
+  const bool m3 = UPF_WARP_MERGE && lane < 63 && in3 && in2n && o3 == o2n;
+  const bool p1 = __shfl_up((int)m1, 1) && lane > 0, p3 = __shfl_up((int)m3, 1) && lane > 0;
   // d w / d ix, d w / d iy  for nw, ne, sw, se
   const float ax = (float)(t.x0 + 1) - t.ix, bx = t.ix - (float)t.x0;
   const float ay = (float)(t.y0 + 1) - t.iy, by = t.iy - (float)t.y0;
@@ -182,13 +200,20 @@ void warp_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow, co
   const T* gb = gy + ((size_t)n * C + c_begin) * HW + p;
   unsigned long long* gxb = gx64 + ((size_t)ns * C + c_begin) * HW;
   float gix = 0.f, giy = 0.f;
-  for (int c = c_begin; c < c_end; ++c, xb += HW, gb += HW, gxb += HW) {
-    const float g = Elem<T>::load(gb);
-    if (t.in[0]) { const float v = Elem<T>::load(xb + o0); fix_add(gxb + o0, t.w[0] * g); gix -= v * ay * g; giy -= v * ax * g; }
-    if (t.in[1]) { const float v = Elem<T>::load(xb + o1); fix_add(gxb + o1, t.w[1] * g); gix += v * ay * g; giy -= v * bx * g; }
-    if (t.in[2]) { const float v = Elem<T>::load(xb + o2); fix_add(gxb + o2, t.w[2] * g); gix -= v * by * g; giy += v * ax * g; }
-    if (t.in[3]) { const float v = Elem<T>::load(xb + o3); fix_add(gxb + o3, t.w[3] * g); gix += v * by * g; giy += v * bx * g; }
+  for (int c = c_begin; c < c_end; ++c, xb += HW, gb += HW, gxb += HW) {      // (uniform bounds)
+    const float g = valid ? Elem<T>::load(gb) : 0.f;
+    long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (in0) { const float v = Elem<T>::load(xb + o0); q0 = fix_q(t.w[0] * g); gix -= v * ay * g; giy -= v * ax * g; }
+    if (in1) { const float v = Elem<T>::load(xb + o1); q1 = fix_q(t.w[1] * g); gix += v * ay * g; giy -= v * bx * g; }
+    if (in2) { const float v = Elem<T>::load(xb + o2); q2 = fix_q(t.w[2] * g); gix -= v * by * g; giy += v * ax * g; }
+    if (in3) { const float v = Elem<T>::load(xb + o3); q3 = fix_q(t.w[3] * g); gix += v * by * g; giy += v * bx * g; }
+    const long long r1 = __shfl_up(q1, 1), r3 = __shfl_up(q3, 1);
+    if (in0) fix_emit(gxb + o0, q0, p1 ? r1 : 0ll);
+    if (in1 && !m1) fix_emit(gxb + o1, q1, 0ll);
+    if (in2) fix_emit(gxb + o2, q2, p3 ? r3 : 0ll);
+    if (in3 && !m3) fix_emit(gxb + o3, q3, 0ll);
   }
+  if (!valid) return;
   // chain rule through un-normalise ((W-1)/2) and the python-side normalise (2/max(W-1,1))
   const float mx = ((float)(W - 1) * 0.5f) * (2.0f / (float)max(W - 1, 1));
   const float my = ((float)(H - 1) * 0.5f) * (2.0f / (float)max(H - 1, 1));
