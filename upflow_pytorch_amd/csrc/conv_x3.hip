@@ -128,7 +128,7 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, f16_t* __restrict__ 
   }
 }
 
-// MTW: 32-channel output blocks per workgroup (1 or 2);  S: stride;  MARG: staged halo columns (>= the dilation, whole 8-pixel
+// MTW: 32-channel output blocks per workgroup (1 or 2);  S: stride;  MARG: staged halo columns (>= the dilation, whole 4-pixel
 // groups);  K1: 1x1 kernel;  NPROD: products per (a, b) pair, 3 or 4.
 // SPLITACC: the low-order products (a_lo*b_hi, a_hi*b_lo, a_lo*b_lo: 2^-11 of the result) accumulate in their OWN registers and
 // join the main sum once, in the epilogue.  Every MFMA rounds its fp32 accumulator once; a 565-channel 3x3 layer chains
@@ -537,6 +537,7 @@ int launch_sk_one(const Args& a) {
 }
 int launch_sk(const Args& a) {
   if (a.k == 1) return launch_sk_one<0, true>(a);
+  if (a.d <= 4) return launch_sk_one<4, false>(a);
   if (a.d <= 8) return launch_sk_one<8, false>(a);
   return launch_sk_one<16, false>(a);
 }
@@ -545,6 +546,7 @@ template <int MTW, int NPROD, bool SPLITACC>
 int launch_shape(const Args& a) {
   if (a.k == 1) return launch_one<MTW, 1, 0, true, NPROD, SPLITACC>(a);
   if (a.stride == 2) return launch_one<MTW, 2, 8, false, NPROD, SPLITACC>(a);
+  if (a.d <= 4) return launch_one<MTW, 1, 4, false, NPROD, SPLITACC>(a);      // (staging works in 4-pixel units: a 4-column halo is enough)
   if (a.d <= 8) return launch_one<MTW, 1, 8, false, NPROD, SPLITACC>(a);
   return launch_one<MTW, 1, 16, false, NPROD, SPLITACC>(a);
 }
