@@ -389,3 +389,34 @@ def test_full_size_baseline_configs(cfg):
     e = max(errs)
     print('%s %dx%d %s B=%d vs fp32 forward: EPE %.3g px (mean |flow| %.3g px)' % (cfg, H, W, dtype, B, e, mag))
     assert e <= ENVELOPE_PX[dtype]
+
+
+def test_graphed_inference_refuses_to_replay_after_a_weight_change_and_recaptures():
+    """The captured graph reads the PACKED weight copies made at capture time: after load_state_dict (or any parameter update) a
+    replay raises instead of reading freed / stale operands; recapture() picks the new weights up, and the tensors the old graph
+    read stay alive meanwhile (runtime.GraphedInference._keepalive)."""
+    from upflow_pytorch_amd.runtime import GraphedInference, PipelinedInference
+    net = build('robust', dtype=torch.bfloat16)
+    im1, im2 = _weights.make_smooth_images(3, 2, 64, 128)
+    im1, im2 = im1.cuda(), im2.cuda()
+    run = GraphedInference(net, 2, 64, 128)
+    a = run(im1, im2)['flow_f_out'].clone()
+    sd = {k: (v * 1.5 if k.endswith('weight') else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match='recapture'):
+        run.replay()
+    run.recapture()
+    b = run(im1, im2)['flow_f_out'].clone()
+    with torch.no_grad():
+        want = net({'im1': im1, 'im2': im2, 'if_loss': False})['flow_f_out']
+    assert not torch.equal(a, b) and torch.equal(b, want)
+    pipe = PipelinedInference(net, 2, 64, 128, streams=2)
+    pipe.result(pipe.submit(im1, im2))
+    net.load_state_dict({k: (v * 0.5 if k.endswith('weight') else v) for k, v in net.state_dict().items()})
+    with pytest.raises(RuntimeError, match='recapture'):
+        pipe.submit(im1, im2)
+    pipe.recapture()
+    c = pipe.result(pipe.submit(im1, im2))['flow_f_out']
+    with torch.no_grad():
+        want = net({'im1': im1, 'im2': im2, 'if_loss': False})['flow_f_out']
+    assert torch.equal(c, want)

@@ -178,6 +178,27 @@ class _PackedConv3x3(object):
                                        self.conv.kernel_size[0])
 
 
+def packed_convs(net):
+    """Every packed-weight holder (_PackedConv3x3 / _PackedConvC8) the modules of `net` have created so far: the per-module
+    caches `_fast_cache`, `_packed` (dense stacks) and `_packed8` (their channel-octet forms)."""
+    out = []
+    for m in net.modules():
+        d = m.__dict__
+        out += list(d.get('_fast_cache', {}).values())
+        out += list(d.get('_packed', None) or [])
+        for v in d.get('_packed8', {}).values():
+            out += list(v[0]) if isinstance(v, tuple) else list(v)
+    return [pc for pc in out if hasattr(pc, 'invalidate')]
+
+
+def packed_operands(net):
+    """The device tensors behind packed_convs(net) — what a captured graph of net's forward reads besides the parameters."""
+    ts = []
+    for pc in packed_convs(net):
+        ts += [t for t in (getattr(pc, 'packed', None), getattr(pc, 'bias', None)) if torch.is_tensor(t)]
+    return ts
+
+
 _NO_NARROW = [False]        # experiment switch (tools/ab_bench.py "no_narrow=1"): Cout <= 16 layers on the 32-channel kernel
 
 

@@ -16,8 +16,9 @@ class GraphedInference:
         out = runner(im1, im2)          # dict of tensors owned by the runner (valid until next call)
     """
 
-    def __init__(self, net, B, H, W, in_dtype=torch.float32, device=None, warmup=3):
+    def __init__(self, net, B, H, W, in_dtype=torch.float32, device=None, warmup=3, check_weights=True):
         self.net = net
+        self.check_weights = check_weights
         p = next(net.parameters())
         self.device = device if device is not None else p.device
         self.im1 = torch.zeros(B, 3, H, W, dtype=in_dtype, device=self.device)
@@ -45,12 +46,31 @@ class GraphedInference:
         with torch.no_grad(), torch.cuda.graph(g, capture_error_mode=mode):
             self.out = self._forward()
         self.graph = g
+        # The graph has the addresses of the PACKED weight operands baked in (allocated by the warm-up forwards, outside the graph's
+        # pool).  They are re-packed — and the old tensors freed — when a parameter changes (load_state_dict, an optimizer step):
+        # hold them, so that a replay after that reads stale weights rather than recycled memory, and refuse such a replay.
+        from .model.pwc_modules import packed_operands
+        self._keepalive = packed_operands(self.net)
+        self._params = list(self.net.parameters())
+        self._weights_key = self._weights_snapshot()
+
+    def _weights_snapshot(self):             # (~10 us for the 80 parameters)
+        ps = self._params
+        return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr())
+
+    def recapture(self, warmup=1):
+        """Capture again (after the weights changed); the static inputs keep their contents, `out` is a new dict."""
+        self.graph = None
+        self._capture(warmup)
 
     def load(self, im1, im2):
         self.im1.copy_(im1, non_blocking=True)
         self.im2.copy_(im2, non_blocking=True)
 
     def replay(self):
+        if self.check_weights and self._weights_snapshot() != self._weights_key:
+            raise RuntimeError('GraphedInference: the network\'s parameters changed after the capture (the graph reads the packed copies '
+                               'made then) — call recapture()')
         self.graph.replay()
         return self.out
 
@@ -77,13 +97,14 @@ class PipelinedInference:
         out = pipe.result(t)             # waits for that step only; tensors are owned by the pipe until its slot is reused
     """
 
-    def __init__(self, net, B, H, W, streams=2, in_dtype=torch.float32, device=None, warmup=3):
+    def __init__(self, net, B, H, W, streams=2, in_dtype=torch.float32, device=None, warmup=3, check_weights=True):
         p = next(net.parameters())
         self.device = device if device is not None else p.device
         self.n = int(streams)
         if self.n < 1:
             raise ValueError('streams must be >= 1')
-        self.runners = [GraphedInference(net, B, H, W, in_dtype=in_dtype, device=self.device, warmup=warmup if i == 0 else 1) for i in range(self.n)]
+        self.runners = [GraphedInference(net, B, H, W, in_dtype=in_dtype, device=self.device, warmup=warmup if i == 0 else 1, check_weights=check_weights)
+                        for i in range(self.n)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self.events = [None] * self.n
         self._next = 0
@@ -127,3 +148,11 @@ class PipelinedInference:
     def synchronize(self):
         for s in self.streams:
             s.synchronize()
+
+    def recapture(self, warmup=1):
+        """Capture every slot again (after the weights changed): waits for the steps in flight first."""
+        self.synchronize()
+        for r in self.runners:
+            r.recapture(warmup)
+        self.events = [None] * self.n
+        torch.cuda.synchronize(self.device)

@@ -75,9 +75,9 @@ class tools():
         def invalidate_packed(self):
             """Drop every packed-weight copy the 16-bit convolution path keeps (model/pwc_modules.py:_PackedConv3x3).
             Needed only after in-place parameter edits that bypass autograd's version counter (`p.data.copy_()`, EMA)."""
-            for m in self.modules():
-                for pc in list(m.__dict__.get('_fast_cache', {}).values()) + list(m.__dict__.get('_packed', None) or []):
-                    pc.invalidate()
+            from ..model.pwc_modules import packed_convs
+            for pc in packed_convs(self):                # (incl. the channel-octet forms, `_packed8`)
+                pc.invalidate()
 
         def load_state_dict(self, *args, **kwargs):
             r = super().load_state_dict(*args, **kwargs)
