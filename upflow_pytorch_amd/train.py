@@ -43,8 +43,11 @@ class Trainer():
     """net: a module with the UPFlow_net dict contract (input_dict -> output_dict with loss terms)."""
 
     def __init__(self, net, lr=1e-4, weight_decay=1e-4, scheduler_gamma=1.0, device=None, distributed=None, graph=False,
-                 batch_check='collective'):
-        """batch_check (graph mode under DDP only): what happens when a rank is handed a batch that differs from the captured one
+                 batch_check='collective', fused_adam=None):
+        """fused_adam: the optimizer step as ONE multi-tensor kernel (torch.optim.Adam(fused=True): the same update formulas —
+        Adam + amsgrad + L2 weight decay, scripts/simple_train.py:119-130 — in one pass over the 80 parameters instead of the
+        15 `foreach` launches, 0.23 ms of a 11.8 ms step); default: on a GPU.
+        batch_check (graph mode under DDP only): what happens when a rank is handed a batch that differs from the captured one
         (a last partial batch): 'collective' (default) — every step the ranks all-reduce one mismatch bit and, if ANY rank
         mismatches, ALL ranks take that step eagerly (same collective sequence everywhere: DDP's bucket all-reduce + the
         logging all-reduce); 'raise' — no per-step exchange, a mismatching rank raises ValueError.  A single process always
@@ -80,8 +83,10 @@ class Trainer():
         # scheduler updates it in place; a python float would be baked into the graph at capture time and every later
         # scheduler.step() silently ignored
         lr_arg = torch.tensor(float(lr), dtype=torch.float32, device=device) if self.use_graph else lr
+        on_gpu = device is not None and torch.device(device).type == 'cuda'
+        self.fused_adam = on_gpu if fused_adam is None else bool(fused_adam)
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr_arg, amsgrad=True,
-                                          weight_decay=weight_decay, capturable=self.use_graph)
+                                          weight_decay=weight_decay, capturable=self.use_graph, fused=self.fused_adam)
         self.graph_warmup = 11 if self.distributed else 3
         self._graph = None
         self._static = None
@@ -105,6 +110,12 @@ class Trainer():
         loss, parts = self.loss_manager.compute_loss(out)
         loss.backward()                      # DDP overlaps the gradient all-reduce with the rest of backward
         self.optimizer.step()
+        if self.optimizer.defaults.get('fused'):
+            # torch._fused_adam_ updates the parameters WITHOUT advancing their autograd version counters, which is what the packed
+            # 16-bit weight copies of the convolution path are keyed on (ops.conv_pack_from_master, pwc_modules._PackedConv3x3):
+            # the next forward — and, at capture time, the captured step — would keep multiplying by the weights of the step before
+            # (found by test_config3_full_size_step_graphed_equals_eager_and_bf16_tracks_fp32: loss 11.94 instead of 22.35 at step 1)
+            torch.autograd.graph.increment_version([p for g in self.optimizer.param_groups for p in g['params']])
         self._names = ['loss'] + sorted(parts)
         stats = torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
         if self.distributed:                 # loss terms averaged over ranks (one 5-float all-reduce, for logging)
@@ -132,7 +143,10 @@ class Trainer():
             # existed BEFORE it and were cache hits inside it (the zero-bias operand of the data-gradient convolutions, packs
             # of frozen parameters) and the loss module's constants have their eager-pool addresses baked into the graph:
             # they stay cached AND are pinned here for the graph's lifetime (dropping them was a use-after-free).
-            self._graph_keepalive = ops.train_caches_after_capture(mark) + loss_mod.cached_constants()
+            # (+ the packed operands of the inference-style holders, pwc_modules._PackedConv*: forwards under no_grad inside the step
+            #  read them, and a holder re-packs — frees — its tensor when its parameter's version moves; round 4)
+            from .model.pwc_modules import packed_operands
+            self._graph_keepalive = ops.train_caches_after_capture(mark) + loss_mod.cached_constants() + packed_operands(self.raw_net)
         self._graph = g
         torch.cuda.synchronize(dev)
 

@@ -95,6 +95,13 @@ class loss_functions():
             # (ops.robust_loss_sums with y = 0) instead of nine element-wise / reduction launches each way
             s, s_m = ops.robust_loss_sums(dist, _zeros_like_cached(dist), mask * valid, q=q, eps=0.01)
             return s / (s_m * 2 + 1e-6)
+        if (not charbonnier_or_abs_robust) and (not if_use_occ) and dist.is_cuda and dist.dtype == torch.float32:
+            # mean((|d| + 0.01)^q), utils/loss.py:32-33 — the same one-launch deterministic reduction without a mask.  (Round 4: ATen's
+            # multi-block `mean()` zeroes its semaphores with a memset node, the node class that was seen mis-ordered inside
+            # replayed hipGraphs on this ROCm (api.hip: zero_fill_u64_kernel): inside a captured training step whose allocation
+            # pattern had shifted it returned 9.8e3 for inputs whose mean is 2.0 — tools/frozen_graph_probe.py.)
+            s, _ = ops.robust_loss_sums(dist, _zeros_like_cached(dist), None, q=q, eps=0.01)
+            return s / dist.numel() if averge else s
         return cls.photo_loss_function(diff=dist, mask=mask * valid, q=q, charbonnier_or_abs_robust=charbonnier_or_abs_robust,
                                        if_use_occ=if_use_occ, averge=averge)
 
