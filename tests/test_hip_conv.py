@@ -110,3 +110,33 @@ def test_conv1x1(case, conv_mode):
     y = torch.empty(B, Cout, H, W, dtype=torch.bfloat16, device='cuda')
     ops.conv3x3_forward_raw(x, ops.conv3x3_pack(w), b, y, dilation=1, leaky_slope=0.1, stride=1, kernel_size=1)
     assert (y.float() - want).abs().max() <= 2.0 ** -8 * float(want.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [  # Cin, Cout, H, W, k, dilation, stride, LeakyReLU
+    (196, 196, 2, 4, 3, 1, 1, True), (128, 196, 3, 7, 3, 1, 2, True), (565, 128, 1, 2, 3, 1, 1, True), (128, 96, 2, 5, 3, 8, 1, True),
+    (96, 64, 4, 6, 3, 16, 1, True), (196, 32, 2, 4, 1, 1, 1, False), (563, 2, 1, 1, 3, 1, 1, False), (35, 7, 3, 3, 3, 2, 1, True)])
+def test_rows_shorter_than_8_pixels_leave_miopen_too(case, dtype):
+    """pwc_modules.fast_conv_seq on 16-bit tensors whose rows are shorter than the 16-bit kernel's 8-pixel tile (the coarsest levels
+    of small inputs): the same contraction through the split-precision kernel on fp32 copies (_PackedConv3x3.__call__) — equal to
+    F.conv2d on the same rounded operands up to the final rounding to 16 bits, written into a channel slice, and bit-reproducible
+    (MIOpen's fp16 kernels, which these levels used until round 4, are not: tools/pipe_stress_small.py)."""
+    from upflow_pytorch_amd.model import pwc_modules as pm
+    Cin, Cout, H, W, k, d, s, relu = case
+    torch.manual_seed(sum(case))
+    seq = pm.conv(Cin, Cout, kernel_size=k, stride=s, dilation=d, isReLU=relu).cuda().to(dtype)
+    x = torch.randn(2, Cin, H, W, device='cuda').to(dtype)
+    ho, wo = (H - 1) // s + 1, (W - 1) // s + 1
+    buf = torch.full((2, Cout + 5, ho, wo), 3.0, device='cuda', dtype=dtype)
+    cache = {}
+    with torch.no_grad():
+        y = pm.fast_conv_seq(seq, x, cache, out=buf[:, 2:2 + Cout])
+        y2 = pm.fast_conv_seq(seq, x, cache).clone()
+        want = F.conv2d(x.float(), seq[0].weight.float(), seq[0].bias.float(), stride=s, padding=d * (k - 1) // 2, dilation=d)
+        if relu:
+            want = F.leaky_relu(want, 0.1)
+    assert len(cache) == 1 and next(iter(cache.values())).packed32 is not None          # (the hand-written path ran, not nn.Conv2d)
+    assert bool((buf[:, :2] == 3).all()) and bool((buf[:, 2 + Cout:] == 3).all())
+    assert torch.equal(y, y2)
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    assert float((y.float() - want).abs().max()) <= ulp * float(want.abs().max()) + 1e-6

@@ -159,23 +159,49 @@ class _PackedConv3x3(object):
         self.key = None
         self.packed = None
         self.bias = None
+        self.key32 = None
+        self.packed32 = None
+
+    def _key(self):
+        w, b = self.conv.weight, self.conv.bias
+        return (w._version, w.dtype, w.device, w.data_ptr(), b._version, b.data_ptr())
 
     def get(self):
-        w, b = self.conv.weight, self.conv.bias
-        key = (w._version, w.dtype, w.device, w.data_ptr(), b._version, b.data_ptr())
+        key = self._key()
         if key != self.key:
-            self.packed = ops.conv3x3_pack(w)
+            self.packed = ops.conv3x3_pack(self.conv.weight)
             self.bias = self.conv.bias.detach().float().contiguous()
             self.key = key
         return self.packed, self.bias
 
+    def get32(self):
+        """The split-precision operand (csrc/conv_x3.hip) of the fp32 UPCAST of 16-bit weights, for rows shorter than 8 pixels."""
+        key = self._key()
+        if key != self.key32:
+            self.packed32 = ops.conv3x3_pack(self.conv.weight.detach().float())
+            self.bias = self.conv.bias.detach().float().contiguous()
+            self.key32 = key
+        return self.packed32, self.bias
+
     def invalidate(self):
         self.key = None
+        self.key32 = None
 
     def __call__(self, x_view, y_view):
+        c = self.conv
+        if x_view.dtype != torch.float32 and x_view.shape[3] < 8:
+            # rows shorter than 8 pixels (the coarsest levels of small inputs) are below the 16-bit kernel's tile: the same
+            # contraction — exact products of the 16-bit operands, fp32 accumulation, one rounding to 16 bits — through the
+            # split-precision kernel on fp32 copies.  (Until round 4 these levels went through MIOpen, whose fp16 kernels are not
+            # reproducible from run to run: tools/pipe_stress_small.py, 466 of 720 outputs differing at 2 x 128 x 256.)
+            packed, bias = self.get32()
+            ho, wo = ops.conv3x3_out_hw(x_view.shape[2], x_view.shape[3], c.stride[0])
+            yf = torch.empty((x_view.shape[0], c.out_channels, ho, wo), dtype=torch.float32, device=x_view.device)
+            ops.conv3x3_forward_raw(x_view.float(), packed, bias, yf, c.dilation[0], self.slope, c.stride[0], c.kernel_size[0])
+            y_view.copy_(yf)
+            return y_view
         packed, bias = self.get()
-        return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, self.conv.dilation[0], self.slope, self.conv.stride[0],
-                                       self.conv.kernel_size[0])
+        return ops.conv3x3_forward_raw(x_view, packed, bias, y_view, c.dilation[0], self.slope, c.stride[0], c.kernel_size[0])
 
 
 def packed_convs(net):
@@ -195,7 +221,7 @@ def packed_operands(net):
     """The device tensors behind packed_convs(net) — what a captured graph of net's forward reads besides the parameters."""
     ts = []
     for pc in packed_convs(net):
-        ts += [t for t in (getattr(pc, 'packed', None), getattr(pc, 'bias', None)) if torch.is_tensor(t)]
+        ts += [t for t in (getattr(pc, 'packed', None), getattr(pc, 'packed32', None), getattr(pc, 'bias', None)) if torch.is_tensor(t)]
     return ts
 
 
@@ -251,8 +277,9 @@ def fast_conv_seq(seq, x, cache, out=None, allow_hip=True):
     k = c.kernel_size[0]
     if (allow_hip and _fast_conv_ok(x) and c.kernel_size in ((3, 3), (1, 1)) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
             and c.padding == (((k - 1) * c.dilation[0]) // 2,) * 2
-            and ops.conv3x3_supported(x, c.out_channels, c.dilation[0], c.stride[0], k)):
-        pc = cache.get(id(seq))
+            and (ops.conv3x3_supported(x, c.out_channels, c.dilation[0], c.stride[0], k)
+                 or (x.shape[3] < 8 and 1 <= c.dilation[0] <= 16 and (c.stride[0] == 1 or (c.stride[0] == 2 and c.dilation[0] == 1 and k == 3))))):
+        pc = cache.get(id(seq))           # (16-bit rows shorter than 8 pixels: _PackedConv3x3 takes the split-precision kernel)
         if pc is None:
             pc = cache[id(seq)] = _PackedConv3x3(seq)
         ho, wo = ops.conv3x3_out_hw(x.shape[2], x.shape[3], c.stride[0])
@@ -310,14 +337,14 @@ class fp32_conv_mode(object):
 
 
 def _fast_conv_ok(t):
-    """Inference on the GPU in bf16/fp16 (rows of at least 8 pixels) or — unless fp32_conv = 'miopen' — in fp32 (any size): the
-    hand-written MFMA convolutions and the copy-free concat buffer apply; otherwise the same arithmetic runs through MIOpen +
-    torch.cat."""
+    """Inference on the GPU in bf16 / fp16 or — unless fp32_conv = 'miopen' — in fp32, any size: the hand-written MFMA convolutions
+    and the copy-free concat buffer apply (16-bit rows shorter than 8 pixels through the split-precision kernel:
+    _PackedConv3x3.__call__); otherwise the same arithmetic runs through MIOpen + torch.cat."""
     if torch.is_grad_enabled() or not t.is_cuda:
         return False
     if t.dtype == torch.float32:
         return FP32_CONV[0] != 'miopen'
-    return t.dtype in (torch.bfloat16, torch.float16) and t.shape[3] >= 8
+    return t.dtype in (torch.bfloat16, torch.float16)
 
 
 class _DenseStack(tools.abstract_model):
