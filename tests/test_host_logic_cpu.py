@@ -135,3 +135,28 @@ def test_training_caches_after_a_capture_keep_what_the_graph_read():
         for c, s_ in zip((ops._PACK_CACHE, ops._S2D_CACHE, ops._STACK_PACK_CACHE, ops._ZERO_BIAS), saved):
             c.clear()
             c.update(s_)
+
+
+def test_fused_optimizer_steps_advance_parameter_versions():
+    """The packed-weight caches are keyed on the parameters' version counters, which torch's fused optimizers do not advance:
+    importing upflow_pytorch_amd.ops installs a global post-step hook that does (ops._advance_versions_after_fused_step)."""
+    import torch
+    from upflow_pytorch_amd import ops
+
+    class FakeFused:                      # (a fused optimizer needs a GPU; the hook only looks at defaults / param_groups)
+        def __init__(self, ps, fused):
+            self.defaults = {'fused': fused}
+            self.param_groups = [{'params': ps}]
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(2)]
+    v = [p._version for p in ps]
+    ops._advance_versions_after_fused_step(FakeFused(ps, False), (), {})
+    assert [p._version for p in ps] == v
+    ops._advance_versions_after_fused_step(FakeFused(ps, True), (), {})
+    assert [p._version for p in ps] == [x + 1 for x in v]
+    assert ops._FUSED_HOOK is not None    # registered with torch.optim
+    opt = torch.optim.SGD(ps, lr=0.1)     # an ordinary optimizer advances them itself and is left alone by the hook
+    for p in ps:
+        p.grad = torch.ones(3)
+    v = [p._version for p in ps]
+    opt.step()
+    assert [p._version for p in ps] == [x + 1 for x in v]

@@ -1033,6 +1033,23 @@ def conv_pack_cache_clear():
     _PACK_CACHE.clear()
 
 
+# The packed 16-bit weight copies (here and in model/pwc_modules._PackedConv*) and runtime.GraphedInference's staleness check are
+# keyed on the parameters' autograd VERSION counters.  torch's FUSED optimizers (torch.optim.Adam(fused=True), ...) update the
+# parameters in one multi-tensor kernel WITHOUT advancing them: a training loop that uses one would keep multiplying by the weights
+# of its first step (round 4, found by the Trainer's own tests).  Whoever imports this module gets a global optimizer post-step hook
+# that advances the versions of a fused optimizer's parameters — no kernel, a few microseconds of host time per step.
+def _advance_versions_after_fused_step(optimizer, args, kwargs):
+    if optimizer.defaults.get('fused'):
+        torch.autograd.graph.increment_version([p for g in optimizer.param_groups for p in g['params']])
+
+
+try:
+    import torch.optim.optimizer as _torch_optimizer
+    _FUSED_HOOK = _torch_optimizer.register_optimizer_step_post_hook(_advance_versions_after_fused_step)
+except (ImportError, AttributeError):          # (an older torch: Trainer advances the versions itself)
+    _FUSED_HOOK = None
+
+
 # ---- every layer's operands in one launch ---------------------------------------------------------------------------------
 # A training step re-packs ~60 operands (forward / data-gradient form of every layer) after the optimiser has changed the
 # fp32 master weights: 60 launches of 3-5 us.  The per-layer packers above REMEMBER what was asked of each parameter

@@ -110,11 +110,13 @@ class Trainer():
         loss, parts = self.loss_manager.compute_loss(out)
         loss.backward()                      # DDP overlaps the gradient all-reduce with the rest of backward
         self.optimizer.step()
-        if self.optimizer.defaults.get('fused'):
+        from . import ops
+        if self.optimizer.defaults.get('fused') and ops._FUSED_HOOK is None:
             # torch._fused_adam_ updates the parameters WITHOUT advancing their autograd version counters, which is what the packed
             # 16-bit weight copies of the convolution path are keyed on (ops.conv_pack_from_master, pwc_modules._PackedConv3x3):
             # the next forward — and, at capture time, the captured step — would keep multiplying by the weights of the step before
-            # (found by test_config3_full_size_step_graphed_equals_eager_and_bf16_tracks_fp32: loss 11.94 instead of 22.35 at step 1)
+            # (found by test_config3_full_size_step_graphed_equals_eager_and_bf16_tracks_fp32: loss 11.94 instead of 22.35 at step 1).
+            # Normally ops' global optimizer post-step hook has done this already (any training loop, not only this class).
             torch.autograd.graph.increment_version([p for g in self.optimizer.param_groups for p in g['params']])
         self._names = ['loss'] + sorted(parts)
         stats = torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
