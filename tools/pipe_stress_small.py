@@ -9,7 +9,7 @@ import test_hip_net as T
 from upflow_pytorch_amd.runtime import GraphedInference, PipelinedInference
 dev = torch.device('cuda', 0)
 shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ.get("SHAPES", "2x128x256,2x64x128,4x192x640").split(",")]
-for dt in (torch.bfloat16, torch.float16):
+for dt in [getattr(torch, n) for n in os.environ.get('DTYPES', 'bfloat16,float16').split(',')]:
     net = T.build('robust', dt)
     for (B, H, W) in shapes:
         batches = [tuple(t.cuda() for t in _weights.make_smooth_images(40 + i, B, H, W)) for i in range(3)]
