@@ -1,3 +1,4 @@
+"""Packed-fp32 bisect (round 4): the fused-normalisation cost volume beside conv kernels on a second stream — which neighbour kernel makes its output change?"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,3 +1,4 @@
+"""Packed-fp32 fault REPRODUCER (round 4; cited by _build.py): the cost volume beside the 16x16x32-MFMA narrow convolution on two streams, launch by launch bit comparison with an idle-GPU reference."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

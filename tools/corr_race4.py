@@ -1,3 +1,4 @@
+"""Packed-fp32 bisect (round 4): the same pair of kernels as corr_race3.py under the cost-volume kernel's ablation switches (UPF_ALLC_ABL builds), to find the instruction class involved."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,3 +1,4 @@
+# rocprofv3 kernel trace of a few eager (ungraphed) config-2 forwards -> per-kernel table of one steady-state forward (tools/steady_profile.py)
 R=$(pwd); export TMPDIR=/tmp
 P=$R/gpurun_out/profiles; mkdir -p $P
 rm -rf $R/gpurun_out/prof_eager; mkdir -p $R/gpurun_out/prof_eager

@@ -1,3 +1,4 @@
+"""Training gradients of the HIP path vs the reference's recorded ones (golden train_128x192): per-parameter cosine similarity and relative norm, for tuning the tolerances of tests/test_hip_train.py."""
 import sys, os
 sys.path.insert(0, 'tests')
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""Summarise a rocprofv3 --pmc run of tools/lds_b128_probe.hip: SQ_LDS_BANK_CONFLICT / SQ_LDS_ACTIVE per probe kernel (profiles/r04_lds_b128_conflict_probe.txt)."""
 import csv, glob, sys, collections
 d = sys.argv[1]
 f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]

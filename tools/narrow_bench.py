@@ -1,3 +1,4 @@
+"""The Cout <= 16 octet layers on the 16-channel MFMA kernel (upf_conv_forward_c8_narrow) vs the 32-channel kernel, per layer at the config-2 level shapes."""
 import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
 import torch

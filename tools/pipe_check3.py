@@ -1,3 +1,4 @@
+"""PipelinedInference debug (round 4): eager vs one graph vs three slots, sequential and concurrent replays, per input — separates input-loading faults from concurrency faults."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,3 +1,4 @@
+"""PipelinedInference debug (round 4): three runners with the model's debug taps (net._taps) — the FIRST intermediate buffer that differs between concurrent runners (led to the cost volume)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,3 +1,4 @@
+"""PipelinedInference debug (round 4): which model switches (_no_c8, _no_c8_est, _no_c8_sgu, fused normalisation off, narrow kernel off) make concurrent replays reproducible again."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

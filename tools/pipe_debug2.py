@@ -1,3 +1,4 @@
+"""PipelinedInference debug (round 4): as pipe_debug.py, the switches one at a time with mismatch counts per output."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
