@@ -125,14 +125,24 @@ def roofline_probe(B, H, W, dtype, device):
             'plain_variant_us': round(plain_us, 2), 'plain_variant_frac': round(alg_bytes / (plain_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def conv_roofline_probe(B, H, W, dtype, device):
+def conv_roofline_probe(B, H, W, dtype, device, fp32_conv='hip_x3'):
     """The kernel a step spends most of its time in: the matrix-core convolution, measured on its largest launch —
     the context network's first layer (565 -> 128 channels, 3x3) at the 1/4-resolution level, both flow directions
     stacked (2B items).  MFMA-bound: algorithmic flop 2*9*Cin*Cout*N*H*W over the average of `nrep` back-to-back
     launches between two HIP events on the launch stream, against the dense bf16/fp16 MFMA peak (2.5 PFLOP/s)."""
     from upflow_pytorch_amd import ops
-    if dtype == torch.float32:
-        return None                                                          # fp32 convolutions are MIOpen's (parity mode)
+    from upflow_pytorch_amd.model import pwc_modules
+    x3 = dtype == torch.float32
+    if x3 and fp32_conv == 'miopen':
+        return None                                                          # (PyTorch-ROCm's convolutions: not this build's kernel)
+    if x3:
+        with pwc_modules.fp32_conv_mode(fp32_conv):                          # (sets the kernel's product mode: hip_x3 / hip_x3s)
+            return _conv_roofline_probe(B, H, W, dtype, device, True)
+    return _conv_roofline_probe(B, H, W, dtype, device, False)
+
+
+def _conv_roofline_probe(B, H, W, dtype, device, x3):
+    from upflow_pytorch_amd import ops
     N, Cin, Cout, h, w = 2 * B, 565, 128, (H + 3) // 4, (W + 3) // 4
     g = torch.Generator(device='cpu').manual_seed(2005)
     x = torch.randn(N, Cin, h, w, generator=g).to(device).to(dtype)
@@ -152,6 +162,12 @@ def conv_roofline_probe(B, H, W, dtype, device):
     avg_us = e0.elapsed_time(e1) * 1e3 / nrep
     flop = 2.0 * 9 * Cin * Cout * N * h * w
     achieved = flop / (avg_us * 1e-6) / 1e12
+    if x3:
+        # the split-precision kernel issues THREE fp16 matrix products per operand pair: `achieved` / `frac` price the ALGORITHMIC flop
+        # (what the layer computes) against the dense fp16 peak; `issued_frac` = 3x that, the share of the matrix pipe it occupies
+        return {'bound': 'mfma', 'kernel': 'conv_x3_kernel<MTW=2> (split precision, fp16 hi/lo x 3; context network layer 1, 565->128, 3x3)',
+                'shape': [N, Cin, h, w], 'achieved': round(achieved, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(achieved / 2500.0, 4),
+                'issued_frac': round(3 * achieved / 2500.0, 4), 'traffic': None, 'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
     return {'bound': 'mfma', 'kernel': 'conv_kernel<MTW=4> (context network layer 1, 565->128, 3x3)', 'shape': [N, Cin, h, w],
             'achieved': round(achieved, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(achieved / 2500.0, 4), 'traffic': None,
             'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
@@ -528,12 +544,13 @@ def main():
                        'fp32_conv': args.fp32_conv if dtype == torch.float32 else None},
             'roofline': roofline_probe(B, H, W, dtype, device),
         }
-        conv_rf = conv_roofline_probe(B, H, W, dtype, device)
+        conv_rf = conv_roofline_probe(B, H, W, dtype, device, args.fp32_conv)
         if conv_rf is not None:
             line['roofline_conv'] = conv_rf
-        if dtype != torch.float32:
+        if dtype != torch.float32 or args.fp32_conv != 'miopen':
             # the whole step against the matrix-core peak: every convolution's algorithmic flop / the
-            # step time bench.py reports — the efficiency of the STEP, not of its best layer (`roofline_conv`)
+            # step time bench.py reports — the efficiency of the STEP, not of its best layer (`roofline_conv`); in the fp32 parity
+            # mode the split-precision kernel spends three matrix products per operand pair, so its ceiling is a third of the peak
             flop, parts = conv_flop_per_step(net, B, H, W)
             tf = flop / (elapsed / args.steps) / 1e12
             line['roofline_step'] = {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
