@@ -343,6 +343,7 @@ def train_main(args, rank, world, device):
                                    '256x832 crops of 288x864 frames, batch 4 per GPU', 'global_batch': world * B,
                        'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world, 'hip_graph': tr.use_graph,
                        'capture_fallback': tr.capture_fallback,      # True: the hipGraph capture failed and the steps ran eagerly
+                       'optimizer': 'torch.optim.Adam(amsgrad, weight_decay 1e-4, %s)' % ('fused: one multi-tensor kernel' if tr.fused_adam else 'foreach'),
                        'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
                        'gradient_allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 4),
                        'gradient_bytes': 4 * sum(p.numel() for p in tr.raw_net.parameters() if p.requires_grad)},
