@@ -5,9 +5,9 @@ for f in sorted(glob.glob(sys.argv[1] + '/*_counter_collection.csv')):
     rows = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(list)
     for r in rows:
-        if 'conv_kernel' in r['Kernel_Name']:
+        if 'conv_kernel' in r['Kernel_Name'] or 'conv_x3' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
-    kt = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(f.replace('counter_collection', 'kernel_trace'))) if 'conv_kernel' in r['Kernel_Name']]
+    kt = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(f.replace('counter_collection', 'kernel_trace'))) if 'conv_kernel' in r['Kernel_Name'] or 'conv_x3' in r['Kernel_Name']]
     m = {k: sum(v[-3:]) / len(v[-3:]) for k, v in agg.items()}
     if 'SQ_WAVE_CYCLES' not in m:
         continue
