@@ -574,8 +574,24 @@ def main():
                 torch.cuda.synchronize(device)
                 ms = (time.perf_counter() - t1) / 20 * 1e3
                 line['literal_split'] = {'pyramid_convs': 'PyTorch-ROCm (MIOpen)', 'value': round(B * 1e3 / ms, 2), 'unit': 'frame-pairs/s',
-                                         'ms_per_step': round(ms, 3), 'steps': 20}
-                del r2, net_ls
+                                         'ms_per_step': round(ms, 3), 'steps': 20, 'steps_in_flight': 1}
+                del r2
+                if args.streams > 1:                          # ... and with as many steps in flight as the headline
+                    p2 = PipelinedInference(net_ls, B, H, W, streams=args.streams, device=device)
+                    for s_ in range(args.streams):
+                        p2.load(s_, im1, im2)
+                    for _ in range(3 * args.streams):
+                        p2.replay()
+                    p2.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(40):
+                        p2.replay()
+                    p2.synchronize()
+                    ms = (time.perf_counter() - t1) / 40 * 1e3
+                    line['literal_split']['pipelined'] = {'value': round(B * 1e3 / ms, 2), 'ms_per_step': round(ms, 3), 'steps': 40,
+                                                          'steps_in_flight': args.streams}
+                    del p2
+                del net_ls
             except Exception as e:                            # (an extra: it must never take the headline line down)
                 line['literal_split'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if single is not None:
