@@ -420,3 +420,16 @@ def test_graphed_inference_refuses_to_replay_after_a_weight_change_and_recapture
     with torch.no_grad():
         want = net({'im1': im1, 'im2': im2, 'if_loss': False})['flow_f_out']
     assert torch.equal(c, want)
+
+
+def test_pipelined_map_yields_every_batch_in_order():
+    """PipelinedInference.map over 7 batches on 3 streams == the same batches one at a time (bit for bit), in order."""
+    from upflow_pytorch_amd.runtime import GraphedInference, PipelinedInference
+    net = build('robust', torch.float16)
+    batches = [tuple(t.cuda() for t in _weights.make_smooth_images(60 + i, 2, 64, 128)) for i in range(7)]
+    single = GraphedInference(net, 2, 64, 128)
+    want = [single(a, b)['flow_f_out'].clone() for a, b in batches]
+    pipe = PipelinedInference(net, 2, 64, 128, streams=3)
+    got = [out['flow_f_out'].clone() for out in pipe.map(iter(batches))]
+    assert len(got) == 7 and all(torch.equal(g, w) for g, w in zip(got, want))
+    assert [o['flow_f_out'].shape for o in pipe.map([])] == []

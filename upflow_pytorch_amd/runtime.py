@@ -95,6 +95,7 @@ class PipelinedInference:
         pipe = PipelinedInference(net, B, H, W, streams=2)
         t = pipe.submit(im1, im2)        # enqueue on the next stream (returns a ticket); inputs are copied on that stream
         out = pipe.result(t)             # waits for that step only; tensors are owned by the pipe until its slot is reused
+        for out in pipe.map(loader):     # or: a whole iterable of (im1, im2) with `streams` steps in flight, outputs in order
     """
 
     def __init__(self, net, B, H, W, streams=2, in_dtype=torch.float32, device=None, warmup=3, check_weights=True):
@@ -148,6 +149,19 @@ class PipelinedInference:
     def synchronize(self):
         for s in self.streams:
             s.synchronize()
+
+    def map(self, batches):
+        """`for out in pipe.map(pairs)`: runs every (im1, im2) of the iterable with `streams` steps in flight and yields the output
+        dicts IN ORDER.  A yielded dict is the slot's static output: it is overwritten when the generator is advanced past
+        the next `streams - 1` items, so consume (or copy) it before asking for more."""
+        from collections import deque
+        pending = deque()
+        for im1, im2 in batches:
+            if len(pending) == self.n:
+                yield self.result(pending.popleft())      # (the slot this submit is about to reuse)
+            pending.append(self.submit(im1, im2))
+        while pending:
+            yield self.result(pending.popleft())
 
     def recapture(self, warmup=1):
         """Capture every slot again (after the weights changed): waits for the steps in flight first."""
