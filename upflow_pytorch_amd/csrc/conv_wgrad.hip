@@ -496,8 +496,37 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
         const uint4* row = xw + s2 * G::XB + HALO / 8 + 2 * ks + kg;
         Row r;
         r.p2 = r.n2 = make_uint4(0, 0, 0, 0);
-        r.p1 = row[-1]; r.c = row[0]; r.n1 = row[1];
-        if constexpr (D == 16) { r.p2 = row[-2]; r.n2 = row[2]; }
+        r.c = row[0];
+        if constexpr (D == 16) {
+          r.p1 = r.n1 = make_uint4(0, 0, 0, 0);                        // (window<+-16> = the blocks two before / after)
+          r.p2 = row[-2]; r.n2 = row[2];
+        } else {
+          // The two half-waves (kg = 0 / 1) work on neighbouring blocks b and b + 1, so the centre block of one IS the side block
+          // of the other: each half reads its centre and its OUTER side block only (two ds_read_b128 instead of three: the
+          // consumers are LDS-issue bound) and the halves exchange the dwords of their centres that the shifted windows use
+          // through v_permlane32_swap (a'.hi = b.lo, b'.lo = a.hi: tools/permlane_probe.hip).
+          const uint4 side = row[kg ? 1 : -1];
+          r.p1 = r.n1 = side;
+          auto swp = [](uint32_t a, uint32_t b, uint32_t& a_out, uint32_t& b_out) {
+            const auto q = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+            a_out = q[0]; b_out = q[1];
+          };
+          uint32_t fa, fb;                                             // fa: for kg = 1 the other half's centre dword; fb: for kg = 0
+          if constexpr (DD == 1 || DD == 2) {
+            swp(r.c.x, r.c.w, fa, fb);
+            if (kg) r.p1.w = fa; else r.n1.x = fb;
+          } else if constexpr (DD == 4) {
+            swp(r.c.x, r.c.z, fa, fb);
+            if (kg) r.p1.z = fa; else r.n1.x = fb;
+            swp(r.c.y, r.c.w, fa, fb);
+            if (kg) r.p1.w = fa; else r.n1.y = fb;
+          } else {                                                     // DD == 8: whole blocks
+            swp(r.c.x, r.c.x, fa, fb); if (kg) r.p1.x = fa; else r.n1.x = fb;
+            swp(r.c.y, r.c.y, fa, fb); if (kg) r.p1.y = fa; else r.n1.y = fb;
+            swp(r.c.z, r.c.z, fa, fb); if (kg) r.p1.z = fa; else r.n1.z = fb;
+            swp(r.c.w, r.c.w, fa, fb); if (kg) r.p1.w = fa; else r.n1.w = fb;
+          }
+        }
         return r;
       };
       uint4 a[2][TR];
