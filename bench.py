@@ -427,6 +427,7 @@ def main():
     ap.add_argument('--ramp-seconds', type=float, default=0.5, help='untimed replay before the warm-up steps (clock ramp)')
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
+    ap.add_argument('--batch', type=int, default=None, help='frame pairs per step and GPU (default: the workload\'s)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--streams', type=int, default=4,
                     help='steps in flight (inference): the captured step is replayed round-robin on this many HIP streams, each with its own '
@@ -459,6 +460,7 @@ def main():
     if args.mode == 'train':
         return train_main(args, rank, world, device)
     B, H, W, dname = WORKLOADS[args.workload]
+    B = args.batch or B
     dname = args.dtype or dname
     dtype = DT[dname]
     from upflow_pytorch_amd import synthetic as _weights

@@ -54,3 +54,21 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(d, f)
+
+
+def test_correlation_cuda_importable_by_its_own_name():
+    """`import correlation_cuda` — the literal import of the reference's model/correlation_package/correlation.py:4 — resolves to
+    the top-level shim (repo root on sys.path), with the two pybind entry points (correlation_cuda.cc:169-172) and their 11 / 13
+    positional arguments; install_correlation_cuda() registers the same functions under that name without touching sys.path."""
+    import importlib
+    import inspect
+    import sys
+    sys.modules.pop('correlation_cuda', None)
+    mod = importlib.import_module('correlation_cuda')
+    assert len(inspect.signature(mod.forward).parameters) == 11 and len(inspect.signature(mod.backward).parameters) == 13
+    import upflow_pytorch_amd
+    from upflow_pytorch_amd import correlation_cuda as impl
+    assert mod.forward is impl.forward and mod.backward is impl.backward
+    sys.modules.pop('correlation_cuda', None)
+    assert upflow_pytorch_amd.install_correlation_cuda() is impl and sys.modules['correlation_cuda'] is impl
+    sys.modules.pop('correlation_cuda', None)

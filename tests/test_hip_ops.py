@@ -633,6 +633,27 @@ def test_legacy_correlation_cuda_ffi_golden(i):
         correlation_cuda.forward(g['f1'], g['f2'], r1, r2, out, 4, 1, 4, 1, 1, 1)          # CPU tensors: no fallback
 
 
+def test_reference_correlation_function_body_runs_on_the_top_level_module():
+    """The body of the reference's CorrelationFunction.forward / backward (model/correlation_package/correlation.py:17-44: empty
+    `input1.new()` tensors, `with torch.cuda.device_of(input1)`, the 11 / 13 positional arguments) executed against the module
+    that `import correlation_cuda` — the reference's own line 4 — resolves to."""
+    import importlib
+    import sys
+    sys.modules.pop('correlation_cuda', None)
+    correlation_cuda = importlib.import_module('correlation_cuda')
+    g = load_golden('corr_1')
+    input1, input2 = dev(g['f1']), dev(g['f2'])
+    with torch.cuda.device_of(input1):
+        rbot1, rbot2, output = input1.new(), input2.new(), input1.new()
+        correlation_cuda.forward(input1, input2, rbot1, rbot2, output, 4, 1, 4, 1, 1, 1)
+    assert (output.cpu() - g['out']).abs().max() <= 2e-6
+    grad_output = dev(g['grad_out'])
+    with torch.cuda.device_of(input1):
+        rbot1, rbot2, grad_input1, grad_input2 = input1.new(), input2.new(), input1.new(), input2.new()
+        correlation_cuda.backward(input1, input2, rbot1, rbot2, grad_output, grad_input1, grad_input2, 4, 1, 4, 1, 1, 1)
+    assert (grad_input1.cpu() - g['g1']).abs().max() <= 2e-6 and (grad_input2.cpu() - g['g2']).abs().max() <= 2e-6
+
+
 def test_operator_on_second_device_after_first():
     """LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is per device: an operator used on cuda:1 after cuda:0
     must work.  Skipped on 1-GPU boxes."""

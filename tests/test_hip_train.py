@@ -517,3 +517,37 @@ def test_captured_graph_survives_cache_clears_allocator_churn_and_an_eager_step(
         torch.cuda.empty_cache()
     assert ends[0][0] == ends[1][0], (ends[0][0][-1], ends[1][0][-1])
     assert torch.equal(ends[0][1], ends[1][1])
+
+
+def test_validation_between_replayed_steps_sees_the_current_weights():
+    """ADVICE r4 (medium).  A REPLAYED training step changes the parameters on the device without running any host code, so
+    nothing advanced their autograd version counters — and a validation forward (net.eval() under no_grad) between training
+    steps goes through pwc_modules._PackedConv*, whose packed weight copies are keyed on those counters: eval, replay, eval
+    multiplied by the weights of the FIRST eval.  Trainer.step advances the versions after every replay now.  Protocol: graph-
+    train, eval, replay 5 more steps, eval again — the second eval must equal an eval after invalidate_packed() bit for bit,
+    differ from the first, and GraphedInference.check_weights must notice the change too."""
+    from upflow_pytorch_amd.train import Trainer
+    from upflow_pytorch_amd.runtime import GraphedInference
+    net = build()
+    tr = Trainer(net, lr=1e-3, device=torch.device('cuda', 0), distributed=False, graph=True)
+    batch = {k: v.cuda() for k, v in _weights.make_train_batch().items()}
+    for _ in range(tr.graph_warmup + 1):
+        tr.step(batch)
+    assert tr._graph is not None
+    im1, im2 = batch['im1'], batch['im2']
+
+    def validate():
+        tr.raw_net.eval()
+        with torch.no_grad():        # (fp32 inference: every convolution through _PackedConv3x3 -> the split-precision kernel)
+            return tr.raw_net({'im1': im1, 'im2': im2, 'if_loss': False})['flow_f_out'].clone()
+    first = validate()
+    runner = GraphedInference(tr.raw_net.eval(), im1.shape[0], im1.shape[2], im1.shape[3], device=im1.device)
+    for _ in range(5):
+        tr.step(batch)                                   # replays
+    second = validate()
+    tr.raw_net.invalidate_packed()
+    fresh = validate()
+    assert torch.equal(second, fresh), 'a validation forward after replayed steps used stale packed weights'
+    assert not torch.equal(first, second), 'five optimizer steps at lr 1e-3 must move the validation output'
+    with pytest.raises(RuntimeError):
+        runner.replay()                                  # the captured inference graph reads the packed copies made before

@@ -139,24 +139,33 @@ def test_training_caches_after_a_capture_keep_what_the_graph_read():
 
 def test_fused_optimizer_steps_advance_parameter_versions():
     """The packed-weight caches are keyed on the parameters' version counters, which torch's fused optimizers do not advance:
-    importing upflow_pytorch_amd.ops installs a global post-step hook that does (ops._advance_versions_after_fused_step)."""
+    ops.register_version_hook(optimizer) installs a post-step hook ON THAT OPTIMIZER (train.Trainer does it for its own) that
+    does; optimizers of unrelated models are not touched (round 4 registered a process-global hook at import)."""
     import torch
+    import torch.optim.optimizer as topt
     from upflow_pytorch_amd import ops
-
-    class FakeFused:                      # (a fused optimizer needs a GPU; the hook only looks at defaults / param_groups)
-        def __init__(self, ps, fused):
-            self.defaults = {'fused': fused}
-            self.param_groups = [{'params': ps}]
+    assert not hasattr(ops, '_FUSED_HOOK')                    # nothing global any more
     ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(2)]
-    v = [p._version for p in ps]
-    ops._advance_versions_after_fused_step(FakeFused(ps, False), (), {})
-    assert [p._version for p in ps] == v
-    ops._advance_versions_after_fused_step(FakeFused(ps, True), (), {})
-    assert [p._version for p in ps] == [x + 1 for x in v]
-    assert ops._FUSED_HOOK is not None    # registered with torch.optim
-    opt = torch.optim.SGD(ps, lr=0.1)     # an ordinary optimizer advances them itself and is left alone by the hook
     for p in ps:
         p.grad = torch.ones(3)
+    # an ordinary optimizer advances the versions itself: no hook is installed for it
+    opt = torch.optim.SGD(ps, lr=0.1)
+    assert ops.register_version_hook(opt) is None
     v = [p._version for p in ps]
     opt.step()
     assert [p._version for p in ps] == [x + 1 for x in v]
+    # a "fused" optimizer (a real one needs a GPU; the hook only reads defaults / param_groups): one bump per step, idempotent
+    opt2 = torch.optim.SGD(ps, lr=0.0)
+    opt2.defaults['fused'] = True
+    h = ops.register_version_hook(opt2)
+    assert h is not None and ops.register_version_hook(opt2) is h
+    v = [p._version for p in ps]
+    opt2.step()
+    assert [p._version for p in ps] == [x + 2 for x in v]     # SGD's own in-place update + the hook's bump
+    # ... and a third optimizer over other parameters is left alone
+    qs = [torch.nn.Parameter(torch.zeros(2))]
+    qs[0].grad = torch.ones(2)
+    opt3 = torch.optim.SGD(qs, lr=0.1)
+    v3 = qs[0]._version
+    opt3.step()
+    assert qs[0]._version == v3 + 1

@@ -11,3 +11,12 @@ The package computes on the GPU only; importing it needs neither a GPU nor the b
 calling an operator needs both.
 """
 __version__ = '0.1.0'
+
+
+def install_correlation_cuda():
+    """Make `import correlation_cuda` (model/correlation_package/correlation.py:4 of the reference) resolve to this package's
+    implementation of the legacy FFI without touching sys.path; returns the module.  A module of that name that is already
+    imported (the reference's own CUDA build) is left alone."""
+    import sys
+    from . import correlation_cuda as mod
+    return sys.modules.setdefault('correlation_cuda', mod)

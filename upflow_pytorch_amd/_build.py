@@ -49,6 +49,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags_tag(extra):
+    """Hash of everything on an object's command line besides its source: an object built with other flags (e.g. before
+    NO_PACKED_FP32 existed — a CORRECTNESS flag) is stale whatever its time stamp says."""
+    import hashlib
+    return hashlib.sha256(' '.join(COMMON + NO_PACKED_FP32 + list(extra)).encode()).hexdigest()[:16]
+
+
+def _flags_stale(obj, extra):
+    try:
+        return open(obj + '.flags').read().strip() != _flags_tag(extra)
+    except OSError:
+        return True
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libupflow_hip.so next to this file."""
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.hpp')]
@@ -62,10 +76,13 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([cc] + COMMON + NO_PACKED_FP32 + extra + ['-c', s, '-o', o])
+        if force or _stale(o, [s] + headers) or _flags_stale(o, extra):
+            jobs.append(([cc] + COMMON + NO_PACKED_FP32 + extra + ['-c', s, '-o', o], o, extra))
 
-    def run(cmd):
+    def run(job):
+        cmd, obj, extra = job
+        if os.path.exists(obj + '.flags'):
+            os.remove(obj + '.flags')
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -74,6 +91,8 @@ def build(force=False, verbose=False):
             sys.stderr.write(err + '\n')
         if r.returncode:
             raise subprocess.CalledProcessError(r.returncode, cmd)
+        with open(obj + '.flags', 'w') as f:
+            f.write(_flags_tag(extra) + '\n')
     if jobs:                                           # independent translation units: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:

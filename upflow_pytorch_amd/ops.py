@@ -1036,18 +1036,24 @@ def conv_pack_cache_clear():
 # The packed 16-bit weight copies (here and in model/pwc_modules._PackedConv*) and runtime.GraphedInference's staleness check are
 # keyed on the parameters' autograd VERSION counters.  torch's FUSED optimizers (torch.optim.Adam(fused=True), ...) update the
 # parameters in one multi-tensor kernel WITHOUT advancing them: a training loop that uses one would keep multiplying by the weights
-# of its first step (round 4, found by the Trainer's own tests).  Whoever imports this module gets a global optimizer post-step hook
-# that advances the versions of a fused optimizer's parameters — no kernel, a few microseconds of host time per step.
-def _advance_versions_after_fused_step(optimizer, args, kwargs):
-    if optimizer.defaults.get('fused'):
-        torch.autograd.graph.increment_version([p for g in optimizer.param_groups for p in g['params']])
+# of its first step (round 4, found by the Trainer's own tests).  register_version_hook(optimizer) installs a post-step hook ON THAT
+# OPTIMIZER that advances the versions of its parameters — no kernel, a few microseconds of host time per step.  train.Trainer
+# registers it for its own optimizer; a custom loop around a fused optimizer must call it once.  (Round 4 installed a process-global
+# hook at import time, which also touched the optimizers of unrelated models: ADVICE r4.)
+def _advance_versions_after_step(optimizer, args, kwargs):
+    torch.autograd.graph.increment_version([p for g in optimizer.param_groups for p in g['params']])
 
 
-try:
-    import torch.optim.optimizer as _torch_optimizer
-    _FUSED_HOOK = _torch_optimizer.register_optimizer_step_post_hook(_advance_versions_after_fused_step)
-except (ImportError, AttributeError):          # (an older torch: Trainer advances the versions itself)
-    _FUSED_HOOK = None
+def register_version_hook(optimizer):
+    """Advance the autograd version counters of `optimizer`'s parameters after each of its steps if it is a fused optimizer
+    (see above); idempotent; returns the hook handle (None: not fused, nothing to do)."""
+    if not optimizer.defaults.get('fused'):
+        return None
+    handle = getattr(optimizer, '_upf_version_hook', None)
+    if handle is None:
+        handle = optimizer.register_step_post_hook(_advance_versions_after_step)
+        optimizer._upf_version_hook = handle
+    return handle
 
 
 # ---- every layer's operands in one launch ---------------------------------------------------------------------------------
@@ -1135,8 +1141,15 @@ def _train_cache_tensors():
 
 
 def train_caches_mark():
-    """Snapshot taken right BEFORE a hipGraph capture of a training step: the identities of the cached tensors that exist."""
-    return set(id(t) for t in _train_cache_tensors())
+    """Snapshot taken right BEFORE a hipGraph capture of a training step: the cached tensors that exist — the OBJECTS, held for as
+    long as the mark lives (round 4 kept their id()s only: the per-layer packers delete old-version entries during the capture,
+    CPython readily hands a freed object's id to a new one, and a pack made inside the capture could then pass for a
+    pre-existing one — ADVICE r4)."""
+    return {id(t): t for t in _train_cache_tensors()}
+
+
+def _marked(mark, t):
+    return mark.get(id(t)) is t
 
 
 def train_caches_after_capture(mark):
@@ -1150,15 +1163,15 @@ def train_caches_after_capture(mark):
         caches, and the full list of pre-capture tensors is RETURNED so that the trainer keeps them alive as long as its graph
         (whatever another trainer or a cache eviction does to the dictionaries later).
     The zero-bias buffers are never dropped."""
-    keep = [t for t in _train_cache_tensors() if id(t) in mark]
+    keep = list(mark.values())
     for wid in list(_PACK_CACHE):
         ref, d = _PACK_CACHE[wid]
-        for k in [k for k, t in d.items() if id(t) not in mark]:
+        for k in [k for k, t in d.items() if not _marked(mark, t)]:
             del d[k]
         if not d:
             del _PACK_CACHE[wid]
     for cache in (_S2D_CACHE, _STACK_PACK_CACHE):
-        for k in [k for k, v in cache.items() if id(v[2]) not in mark]:
+        for k in [k for k, v in cache.items() if not _marked(mark, v[2])]:
             del cache[k]
     return keep
 

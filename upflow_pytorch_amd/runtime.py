@@ -129,7 +129,11 @@ class PipelinedInference:
         if slot is None:
             slot = self._next
             self._next = (self._next + 1) % self.n
-        with torch.cuda.stream(self.streams[slot]):
+        st = self.streams[slot]
+        # whoever consumed the slot's previous outputs (or wrote its inputs) did so on the caller's current stream: the new replay
+        # overwrites those buffers, so it is ordered behind that work — as load() does for the inputs
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
             self.runners[slot].replay()
             ev = torch.cuda.Event()
             ev.record(self.streams[slot])
@@ -152,8 +156,10 @@ class PipelinedInference:
 
     def map(self, batches):
         """`for out in pipe.map(pairs)`: runs every (im1, im2) of the iterable with `streams` steps in flight and yields the output
-        dicts IN ORDER.  A yielded dict is the slot's static output: it is overwritten when the generator is advanced past
-        the next `streams - 1` items, so consume (or copy) it before asking for more."""
+        dicts IN ORDER.  A yielded dict is the slot's STATIC output: advancing the generator re-submits into that very slot (the
+        oldest pending step's slot is the next one to be reused), so a yielded dict is valid only until the generator is advanced
+        ONCE — consume it, or clone what you keep, before asking for the next item (`list(pipe.map(...))` would hold overwritten
+        tensors)."""
         from collections import deque
         pending = deque()
         for im1, im2 in batches:

@@ -87,6 +87,12 @@ class Trainer():
         self.fused_adam = on_gpu if fused_adam is None else bool(fused_adam)
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr_arg, amsgrad=True,
                                           weight_decay=weight_decay, capturable=self.use_graph, fused=self.fused_adam)
+        self._params_flat = [p for g in self.optimizer.param_groups for p in g['params']]
+        # the packed 16-bit weight copies are keyed on the parameters' autograd version counters, which torch's FUSED optimizers
+        # do not advance: a per-optimizer post-step hook does (custom training loops around a fused optimizer need the same hook,
+        # ops.register_version_hook(optimizer))
+        from . import ops as _ops
+        _ops.register_version_hook(self.optimizer)
         self.graph_warmup = 11 if self.distributed else 3
         self._graph = None
         self._static = None
@@ -110,14 +116,11 @@ class Trainer():
         loss, parts = self.loss_manager.compute_loss(out)
         loss.backward()                      # DDP overlaps the gradient all-reduce with the rest of backward
         self.optimizer.step()
-        from . import ops
-        if self.optimizer.defaults.get('fused') and ops._FUSED_HOOK is None:
-            # torch._fused_adam_ updates the parameters WITHOUT advancing their autograd version counters, which is what the packed
-            # 16-bit weight copies of the convolution path are keyed on (ops.conv_pack_from_master, pwc_modules._PackedConv3x3):
-            # the next forward — and, at capture time, the captured step — would keep multiplying by the weights of the step before
-            # (found by test_config3_full_size_step_graphed_equals_eager_and_bf16_tracks_fp32: loss 11.94 instead of 22.35 at step 1).
-            # Normally ops' global optimizer post-step hook has done this already (any training loop, not only this class).
-            torch.autograd.graph.increment_version([p for g in self.optimizer.param_groups for p in g['params']])
+        # (torch._fused_adam_ updates the parameters WITHOUT advancing their autograd version counters, which is what the packed
+        # 16-bit weight copies of the convolution path are keyed on — ops.conv_pack_from_master, pwc_modules._PackedConv3x3: the
+        # next forward, and at capture time the captured step, would keep multiplying by the weights of the step before; found by
+        # test_config3_full_size_step_graphed_equals_eager_and_bf16_tracks_fp32.  The post-step hook registered in __init__ on
+        # THIS optimizer — ops.register_version_hook — has advanced them by now.)
         self._names = ['loss'] + sorted(parts)
         stats = torch.stack([loss.detach().float()] + [parts[k].float() for k in sorted(parts)])
         if self.distributed:                 # loss terms averaged over ranks (one 5-float all-reduce, for logging)
@@ -168,25 +171,49 @@ class Trainer():
                     self._static[k].copy_(v, non_blocking=True)
             self._graph.replay()
             stats = self._static_stats
+            # the replayed Adam kernel has changed every parameter ON THE DEVICE; no host code ran, so nothing advanced their
+            # autograd version counters — which is what the packed weight copies of the inference-style holders
+            # (pwc_modules._PackedConv*: a validation forward between training steps) and GraphedInference.check_weights are keyed
+            # on (eval, replay, eval would have multiplied by the weights of the first eval).  Host-only, microseconds.
+            torch.autograd.graph.increment_version(self._params_flat)
         else:
             self.optimizer.zero_grad(set_to_none=True)
             stats = self._step_body(batch)
             self._eager_steps += 1
             if self.use_graph and self._eager_steps >= self.graph_warmup:
+                err = None
                 try:
                     self._capture(batch)         # (the capture itself does not execute: this step already ran eagerly)
                 except Exception as e:           # e.g. a collective library that cannot be captured: stay eager, say so
+                    err = '%s: %s' % (type(e).__name__, e)
+                # the decision is COLLECTIVE: a rank whose capture failed steps eagerly from here on, and would pair
+                # its python-issued collectives with the other ranks' captured ones (and skip the per-step mismatch-bit exchange
+                # they issue) -> every rank falls back if any rank failed
+                failed_somewhere = self._any_rank(err is not None)
+                if failed_somewhere:
                     import warnings
-                    warnings.warn('hipGraph capture of the training step failed (%s: %s); continuing with eager steps' % (type(e).__name__, e))
+                    err = err or 'the capture failed on another rank'
+                    warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager steps' % err)
                     self.use_graph = False
                     self.capture_fallback = True
-                    self.capture_error = '%s: %s' % (type(e).__name__, e)
+                    self.capture_error = err
                     self._graph = None
                     self._static = self._static_stats = None
+                    self._graph_keepalive = None
                     torch.cuda.synchronize(torch.device(self.device))
         if not sync_stats:
             return stats
         return {k: float(v) for k, v in zip(self._names, stats.cpu())}
+
+    def _any_rank(self, flag):
+        """True if `flag` is true on ANY rank (one MAX all-reduce of a bit under DDP; the local value in a single process)."""
+        if not self.distributed or self.world == 1:
+            return bool(flag)
+        if self._mismatch_flag is None:
+            self._mismatch_flag = torch.zeros(1, dtype=torch.int32, device=self.device if self.device is not None else 'cpu')
+        self._mismatch_flag.fill_(1 if flag else 0)
+        dist.all_reduce(self._mismatch_flag, op=dist.ReduceOp.MAX)
+        return int(self._mismatch_flag.item()) != 0
 
     def _replay_agreed(self, batch):
         """True: replay the captured step; False: this step runs eagerly.  A single process decides by its own batch.  Under DDP
@@ -202,11 +229,7 @@ class Trainer():
                 raise ValueError('rank %d: batch differs from the captured one (keys / shapes / non-tensor values) — under DDP with '
                                  "batch_check='raise' every rank must feed the captured shapes (drop or pad the last partial batch)" % self.rank)
             return True
-        if self._mismatch_flag is None:
-            self._mismatch_flag = torch.zeros(1, dtype=torch.int32, device=self.device if self.device is not None else 'cpu')
-        self._mismatch_flag.fill_(0 if ok else 1)
-        dist.all_reduce(self._mismatch_flag, op=dist.ReduceOp.MAX)
-        return int(self._mismatch_flag.item()) == 0
+        return not self._any_rank(not ok)
 
     def _matches_static(self, batch):
         """The captured step replays on the tensors it was captured with: same keys, same shapes / dtypes, same non-tensor
