@@ -68,8 +68,11 @@ def roofline_probe(B, H, W, dtype, device):
     C, h, w = 32, (H + 3) // 4, (W + 3) // 4
     B = 2 * B            # the launch the model makes: both flow directions stacked along the batch (UPFlow_net._forward_stacked)
     g = torch.Generator(device='cpu').manual_seed(2004)
-    f1 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
-    f2 = torch.randn(B, C, h, w, generator=g).to(device).to(dtype)
+    # (the [features; warped] pair buffer of the level as the step allocates it: row-pitched when the level width is ragged)
+    pair = ops.empty_nchw((2, B, C, h, w), dtype, device)
+    pair[0].copy_(torch.randn(B, C, h, w, generator=g).to(device))
+    pair[1].copy_(torch.randn(B, C, h, w, generator=g).to(device))
+    f1, f2 = pair[0], pair[1]
     out = torch.empty(B, 81, h, w, device=device, dtype=dtype)
     # the kernel INSIDE the timed step is the variant whose loader normalises the features (upf_corr81_norm_forward: 16-bit
     # inference); the plain variant (training, fp32) is reported beside it
@@ -77,6 +80,9 @@ def roofline_probe(B, H, W, dtype, device):
     # ... and at the levels whose flow estimator runs in the channel-octet layout (this one, at config 2) it stores octets
     from upflow_pytorch_amd.model.pwc_modules import c8_level_ok
     c8 = norm and c8_level_ok(B, h, w, dtype)
+    pitched = ops.nchw_pitch(f1) != w
+    if pitched and not c8:
+        f1, f2 = f1.contiguous(), f2.contiguous()                            # (the timed NCHW-output helpers take contiguous features)
     if c8:
         out8 = ops.c8_empty(B, 88, h, w, dtype, device)
         timed = lambda f1_, f2_, out_, slope, nrep: ops.corr81_norm_forward_c8_timed(f1_, f2_, out8, slope, nrep=nrep)
@@ -84,8 +90,9 @@ def roofline_probe(B, H, W, dtype, device):
         timed = ops.corr81_norm_forward_timed if norm else ops.corr81_forward_timed
     timed(f1, f2, out, 0.1, nrep=20)                                         # warm
     avg_us, min_us = timed(f1, f2, out, 0.1, nrep=200)
-    nchw_norm_us = ops.corr81_norm_forward_timed(f1, f2, out, 0.1, nrep=200)[0] if c8 else None
-    plain_us = ops.corr81_forward_timed(f1, f2, out, 0.1, nrep=200)[0] if norm else avg_us
+    fc1, fc2 = (f1.contiguous(), f2.contiguous()) if pitched else (f1, f2)
+    nchw_norm_us = ops.corr81_norm_forward_timed(fc1, fc2, out, 0.1, nrep=200)[0] if c8 else None
+    plain_us = ops.corr81_forward_timed(fc1, fc2, out, 0.1, nrep=200)[0] if norm else avg_us
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
     cold = []
     for _ in range(30):
@@ -117,6 +124,8 @@ def roofline_probe(B, H, W, dtype, device):
     # (octet output: the kernel STORES 88 positions per pixel — the 7 zero positions of the 11th octet — while `achieved` prices
     # the 81 algorithmic channels; stored / algorithmic bytes = (2C + 88) / (2C + 81))
     extra = {'nchw_output_variant_us': round(nchw_norm_us, 2), 'stored_over_algorithmic_bytes': round((2 * C + 88) / (2 * C + 81), 4)} if c8 else {}
+    if pitched:
+        extra['feature_row_pitch'] = ops.nchw_pitch(f1)
     return {'bound': 'hbm', 'kernel': kname, 'shape': [B, C, h, w], **extra,
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2),
@@ -387,6 +396,33 @@ def train_probe(device, steps=30):
         return {'error': '%s: %s' % (type(e).__name__, e)}
 
 
+def eval_probe(net, H, W, device, iters=40):
+    """The reference's evaluation workload (test.py:40-47: batch 1, one frame pair at a time, inputs resident in HBM): ms per
+    pair of upflow_pytorch_amd.test.Test_model.eval_forward through runtime.ShapeCachedInference (one captured graph per frame
+    size, ONE step in flight: the latency a caller of eval_forward sees) against the eager forward (one ctypes launch per kernel)."""
+    from upflow_pytorch_amd import synthetic as _weights
+    from upflow_pytorch_amd.test import Test_model
+    try:
+        a, b = _weights.make_images(77, 1, H, W)
+        a, b = a.to(device), b.to(device)
+        res = {}
+        for name, graph in (('graph', True), ('eager', False)):
+            tm = Test_model(pretrain_path=None, dtype=next(net.parameters()).dtype, graph=graph, device=device, net=net)
+            for _ in range(5):
+                tm.eval_forward(a, b, 0)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                tm.eval_forward(a, b, 0)
+            torch.cuda.synchronize(device)
+            res[name] = (time.perf_counter() - t0) / iters * 1e3
+        return {'workload': 'Test_model.eval_forward, batch 1, %dx%d, one pair at a time (test.py:40-47)' % (H, W),
+                'graph_ms_per_pair': round(res['graph'], 3), 'eager_ms_per_pair': round(res['eager'], 3),
+                'graph_pairs_per_s': round(1e3 / res['graph'], 1), 'iters': iters}
+    except Exception as e:                                   # (an extra: it must never take the headline line down)
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it: re-execute this command under torch.distributed.run with
     one rank per GPU of this node (RCCL over xGMI; rendezvous on 127.0.0.1, a free port), pass the ranks' output
@@ -598,6 +634,8 @@ def main():
                 line['literal_split'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if single is not None:
             line['one_step_in_flight'] = single
+        if world == 1 and args.workload == 'kitti_native':
+            line['eval_batch1'] = eval_probe(net, H, W, device)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if world == 1 and not args.no_train_probe and args.workload == 'config2':

@@ -85,6 +85,17 @@ int upf_corr81_norm_forward(const void* f1, const void* f2, void* out,
  * of upf_conv_pack_weights_kmap.  Values are bit-identical to upf_corr81_norm_forward's.  W % 8 == 0. */
 int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* out8, long long out8_batch_stride,
                                int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream);
+/* PITCHED feature rows (round 5): the H rows of every channel plane of f1 / f2 are f_row_pitch elements apart (>= W; plane stride
+ * H * f_row_pitch, item stride C * H * f_row_pitch; 0 = W, i.e. the contiguous forms above).  With a pitch that is a multiple of 8
+ * every row is 16-byte aligned whatever W is, so RAGGED pyramid levels — KITTI's native 375x1242 frames: W = 311, 156, 78, 39, 20,
+ * the frame size the reference's evaluation feeds (test.py:40-47, dataset/kitti_dataset.py:609-631) — keep the aligned loads and,
+ * for the octet form, any W >= 4 is accepted (one 16-byte entry per pixel: the output is aligned for every W).  Nothing depends on
+ * what the pitch padding holds (the loader masks it; the statistics skip it); results are bit-identical to the contiguous forms. */
+int upf_corr81_norm_forward_pitched(const void* f1, const void* f2, int f_row_pitch, void* out,
+                                    int B, int C, int H, int W, int dtype,
+                                    long long out_batch_stride, float leaky_slope, void* workspace, void* stream);
+int upf_corr81_norm_forward_c8_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride,
+                                       int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream);
 /* measurement helper (bench.py): one statistics launch, then nrep launches of the normalising cost volume, each between
  * its own pair of HIP events on `stream` — the kernel that runs inside the inference step */
 int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out,
@@ -95,6 +106,10 @@ int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out,
 int upf_corr81_norm_forward_c8_timed(const void* f1, const void* f2, void* out8, long long out8_batch_stride,
                                      int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream,
                                      int nrep, float* avg_us, float* min_us);
+
+int upf_corr81_norm_forward_c8_timed_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride,
+                                             int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream,
+                                             int nrep, float* avg_us, float* min_us);
 
 /* Launch heuristics of the 16-bit cost volume, for tuning and for the tests to reach every kernel variant:
  *   "variant"  (-1)  -1 = choose by shape; 0..3 = force tile geometry 8x32 / 4x32 / 2x32 / 4x16 where C fits
@@ -153,6 +168,11 @@ int upf_warp_forward(const void* x, const float* flow, void* y,
  * inference path warps straight out of / into the concatenation buffers the convolutions read (no slot copies). */
 int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
                              int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
+/* same with PITCHED rows (round 5): rows of x / y are x_row_pitch / y_row_pitch elements apart (>= W, 0 = W; plane stride H * pitch,
+ * batch strides 0 = C * H * pitch); the flow stays a contiguous fp32 tensor.  With an even y pitch odd-width levels keep the 4-byte
+ * (two-pixel) stores — the pixel beyond W lands in the row's own padding.  Same values as the contiguous forms. */
+int upf_warp_forward_pitched(const void* x, long long x_batch_stride, int x_row_pitch, const float* flow, void* y, long long y_batch_stride,
+                             int y_row_pitch, int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream);
 /* same on CHANNEL-OCTET tensors ("C8": [n][C/8][H][W][8], see upf_conv_forward_c8; bf16 / fp16): x8 / y8 point at the first
  * octet plane of octet slices of C8 buffers (batch strides in elements), n_oct octets.  Values equal the NCHW kernel's. */
 int upf_warp_forward_c8(const void* x8, long long x_batch_stride, const float* flow, void* y8, long long y_batch_stride,
@@ -234,6 +254,14 @@ int upf_conv_pack_weights(const void* w /* [Cout,Cin,k,k] */, void* w_packed, in
 int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
                      void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
                      int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
+/* PITCHED rows (round 5): the rows of x / y are x_row_pitch / y_row_pitch elements apart (>= W / Wo; 0 = contiguous; plane stride
+ * rows * pitch).  A pitch that is a multiple of 8 (with 16-byte aligned bases and batch strides) selects the aligned staging and the
+ * 16-byte epilogue for ANY logical width: the 8-pixel group that straddles W is loaded in place and its trailing pixels replaced by
+ * the zero padding, an output segment that straddles Wo is stored whole (its tail lands in the row's own padding).  Nothing depends
+ * on what the padding holds; results are bit-identical to upf_conv_forward on contiguous copies. */
+int upf_conv_forward_pitched(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
+                             void* y, long long y_batch_stride, int y_row_pitch, int B, int Cin, int Cout, int H, int W,
+                             int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
 
 /* ---- the same convolutions for the fp32 PARITY mode: split-precision products on the fp16 matrix cores  (round 4;
@@ -271,9 +299,12 @@ int upf_mfma_f16_denorm_probe(float* out_device, void* stream);
  *            weights — by an NCHW part (x2, C2 planes; may be absent);  K = pad32(8*n8_oct) + pad32(C2) = upf_conv_c8_k()
  *   output = C8 octets (y_is_c8; channels that pad the last octet are written as zeros) or NCHW planes.
  * upf_conv_pack_weights_kmap gathers the input channels of w through kmap[K] (-1 = zero) into that K order.
- * stride 1, W % 8 == 0, 16-byte aligned operands; kernel 3x3 with dilation 1 (any layout combination) or 2 / 4 / 8 / 16 (C8 in,
+ * stride 1, 16-byte aligned operands; kernel 3x3 with dilation 1 (any layout combination) or 2 / 4 / 8 / 16 (C8 in,
  * C8 out), or 1x1 (NCHW in, C8 out, Cout <= 32); stride 2 for a 3x3 with an NCHW input of > 16 channels and a C8 output of
- * <= 32 (W % 16 == 0).  Everything else: upf_conv_forward. */
+ * <= 32.  Everything else: upf_conv_forward.
+ * Width (round 5): C8 operands take ANY W (a pixel is one 16-byte entry: rows are always aligned); an NCHW input part needs
+ * 16-byte aligned rows — W % 8 == 0, or (upf_conv_forward_c8_pitched) a row pitch that is a multiple of 8 with any logical W;
+ * an NCHW output may be pitched too (y_row_pitch, 0 = Wo). */
 long long upf_conv_packed_bytes_k(int K, int Cout, int kernel_size);
 int upf_conv_c8_k(int n8_oct, int C2);
 int upf_conv_pack_weights_kmap(const void* w /* [Cout,Cin,k,k] */, void* w_packed, int Cin, int Cout, int kernel_size,
@@ -282,6 +313,10 @@ int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, int n8_oct, c
                         const void* w_packed, const float* bias, void* y, long long y_batch_stride, int y_is_c8,
                         int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
                         int dtype, void* stream);
+int upf_conv_forward_c8_pitched(const void* x8, long long x8_batch_stride, int n8_oct, const void* x2, long long x2_batch_stride, int x2_row_pitch, int C2,
+                                const void* w_packed, const float* bias, void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8,
+                                int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
+                                int dtype, void* stream);
 int upf_conv_c8_set_option(const char* name, int value);   /* "rpw4" (1): Cout <= 32 on large grids: 16-row tiles */
 /* Layers with Cout <= 16 (the 2- / 3-channel heads of the dense stacks, 176->8, 160->16; model/pwc_modules.py:262-263,
  * model/upflow.py:36-41) on the 16-output-channel matrix instruction: half the matrix work of a 32-channel block that would be

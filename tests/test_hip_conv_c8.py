@@ -95,10 +95,12 @@ def test_conv1x1_nchw_to_c8(case):
 
 def test_conv_c8_rejects_unsupported():
     from upflow_pytorch_amd import ops
-    x8 = ops.c8_empty(1, 32, 8, 12, torch.bfloat16, 'cuda')           # W % 8 != 0
     w = ops.conv_c8_pack(torch.zeros(8, 32, 3, 3, dtype=torch.bfloat16, device='cuda'), list(range(32)))
+    x2 = torch.zeros(1, 32, 8, 12, dtype=torch.bfloat16, device='cuda')          # an NCHW input with unaligned rows (W % 8 != 0, no pitch)
+    w2 = ops.conv_c8_pack(torch.zeros(8, 32, 3, 3, dtype=torch.bfloat16, device='cuda'), (), list(range(32)))
     with pytest.raises(RuntimeError):
-        ops.conv_c8_forward_raw(x8, None, w, torch.zeros(8, device='cuda'), ops.c8_empty(1, 8, 8, 12, torch.bfloat16, 'cuda'))
+        ops.conv_c8_forward_raw(None, x2, w2, torch.zeros(8, device='cuda'), ops.c8_empty(1, 8, 8, 12, torch.bfloat16, 'cuda'))
+    # (octet inputs of any width are fine since round 5: tests/test_hip_pitched.py)
     x8 = ops.c8_empty(1, 32, 8, 16, torch.bfloat16, 'cuda')
     with pytest.raises(RuntimeError):                                  # dilation 2 needs a C8 output
         ops.conv_c8_forward_raw(x8, None, w, torch.zeros(8, device='cuda'), torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device='cuda'), dilation=2)

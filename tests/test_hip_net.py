@@ -433,3 +433,47 @@ def test_pipelined_map_yields_every_batch_in_order():
     got = [out['flow_f_out'].clone() for out in pipe.map(iter(batches))]
     assert len(got) == 7 and all(torch.equal(g, w) for g, w in zip(got, want))
     assert [o['flow_f_out'].shape for o in pipe.map([])] == []
+
+
+def test_evaluation_path_replays_one_graph_per_frame_size():
+    """The reference's evaluation loop (test.py:40-47, dataset/kitti_dataset.py:382-450): batch 1, frames whose size differs from
+    sequence to sequence (the KITTI 2012 / 2015 sizes below).  upflow_pytorch_amd.test.Test_model.eval_forward goes through
+    runtime.ShapeCachedInference: one captured graph per size, replayed for further pairs of that size, bit-identical to the eager
+    forward; a weight change re-captures; the cache is bounded."""
+    from upflow_pytorch_amd.test import Test_model
+    from upflow_pytorch_amd.dataset.kitti_dataset import kitti_flow
+    net = build('robust', dtype=torch.bfloat16)
+    tm = Test_model(pretrain_path=None, dtype=torch.bfloat16, net=net)
+    sizes = [(375, 1242), (370, 1224), (376, 1241), (375, 1242), (370, 1224), (374, 1238)]
+    pairs = [tuple(t.cuda() for t in _weights.make_smooth_images(80 + i, 1, h, w)) for i, (h, w) in enumerate(sizes)]
+    got = [tm.eval_forward(a, b, 0) for a, b in pairs]
+    assert tm.runner.captures == 4 and sorted(s[2:] for s in tm.runner.shapes()) == sorted(set(sizes))
+    with torch.no_grad():
+        for (a, b), g in zip(pairs, got):
+            want = net({'im1': a, 'im2': b, 'if_loss': False})['flow_f_out']
+            assert g.shape == a.shape[:1] + (2,) + a.shape[2:] and torch.equal(g, want)
+    # the protocol end to end: Evaluation_bench over an in-memory data set of mixed sizes (ground truth = the eager output: EPE 0)
+    class DS(list):
+        pass
+    ds = DS()
+    for (a, b), g in zip(pairs[:3], got[:3]):
+        ones = torch.ones(1, *g.shape[2:])
+        ds.append((a[0].cpu(), b[0].cpu(), g[0].cpu(), ones, g[0].cpu(), ones))
+    bench = kitti_flow.Evaluation_bench('2015_train', if_gpu=True, batch_size=1, dataset=ds)
+    epe_all, f1, epe_noc, epe_occ = bench(tm)
+    assert epe_all == 0.0 and f1 == 0.0 and epe_noc == 0.0
+    assert tm.runner.captures == 4                     # replays only
+    # weights change -> transparent re-capture with the new weights
+    net.load_state_dict({k: (v * 1.25 if k.endswith('weight') else v) for k, v in net.state_dict().items()})
+    a, b = pairs[0]
+    g2 = tm.eval_forward(a, b, 0)
+    with torch.no_grad():
+        want = net({'im1': a, 'im2': b, 'if_loss': False})['flow_f_out']
+    assert torch.equal(g2, want) and not torch.equal(g2, got[0]) and tm.runner.captures == 5 and len(tm.runner.shapes()) == 1
+    # bounded cache
+    from upflow_pytorch_amd.runtime import ShapeCachedInference
+    small = ShapeCachedInference(net, max_shapes=2)
+    for h, w in ((64, 128), (72, 136), (80, 144), (64, 128)):
+        x, y = (t.cuda() for t in _weights.make_smooth_images(5, 1, h, w))
+        small(x, y)
+    assert len(small.shapes()) == 2 and small.captures == 4

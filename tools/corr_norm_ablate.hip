@@ -22,7 +22,7 @@ float run(const bf16_t* f1, const bf16_t* f2, bf16_t* out, const float* ws, int 
   for (auto& e : ev) (void)hipEventCreate(&e);
   for (int i = 0; i < nrep; ++i)
     hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(corrx::NTHREADS), lds, 0, ev[2 * i], ev[2 * i + 1], 0,
-                          f1, f2, out, C, H, W, tiles_x, tiles_y, (long long)81 * H * W, 0.1f, ws, ws + (size_t)B * C * 2, nseg, nblocks);   // (round 4: final (mean, 1/std) pairs)
+                          f1, f2, out, C, H, W, tiles_x, tiles_y, (long long)81 * H * W, 0.1f, ws, ws + (size_t)B * C * 2, nseg, nblocks, W);   // (round 4: final (mean, 1/std) pairs)
   (void)hipDeviceSynchronize();
   std::vector<float> t(nrep);
   for (int i = 0; i < nrep; ++i) (void)hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]);

@@ -26,6 +26,12 @@ SIGNATURES = {
     'upf_corr81_norm_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp],
     'upf_corr81_norm_forward_timed': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
     'upf_corr81_norm_forward_c8_timed': [_vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
+    'upf_corr81_norm_forward_pitched': [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp],
+    'upf_corr81_norm_forward_c8_pitched': [_vp, _vp, _i, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp],
+    'upf_corr81_norm_forward_c8_timed_pitched': [_vp, _vp, _i, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
+    'upf_warp_forward_pitched': [_vp, _ll, _i, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_conv_forward_pitched': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    'upf_conv_forward_c8_pitched': [_vp, _ll, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -164,9 +170,10 @@ def dtype_code(t):
         raise UpflowHipError('unsupported dtype %s (float32 / float16 / bfloat16 only)' % t.dtype)
 
 
-def check_gpu(*tensors):
+def check_gpu(*tensors, contiguous=True):
     """Every operand must be a contiguous tensor on the same GPU (the reference's kernels assume
-    contiguous NCHW, correlation_cuda_kernel.cu:15-39, and never validate; we do)."""
+    contiguous NCHW, correlation_cuda_kernel.cu:15-39, and never validate; we do).  contiguous=False: the caller has checked the
+    layout itself (row-pitched tensors, ops.nchw_pitch)."""
     dev = None
     for t in tensors:
         if t is None:
@@ -174,7 +181,7 @@ def check_gpu(*tensors):
         if not t.is_cuda:
             raise UpflowHipError('upflow_pytorch_amd operators run on the GPU only (got a %s tensor); '
                                  'there is no CPU fallback' % t.device)
-        if not t.is_contiguous():
+        if contiguous and not t.is_contiguous():
             raise UpflowHipError('operand must be contiguous NCHW')
         if dev is None:
             dev = t.device

@@ -119,7 +119,8 @@ __global__ void pack_weights_f32_multi_kernel(PackJobs J) {
 template <typename T, int NOCTS, int D, bool GEN>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
-                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, float slope) {
+                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, float slope,
+                    int xpitch, int ypitch) {
   constexpr int ntaps = (D == 0) ? 1 : 9;
   constexpr int marg = margin_of(D);
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;
@@ -142,7 +143,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   const int slab = blockIdx.y;
   const int cip = pad32(Cin);
   const int nchunks = cip / KCH, nksteps = cip / 16;
-  const int HW = H * W;
+  const int HW = H * xpitch;                          // elements per channel plane of x (rows `xpitch` apart, conv_kernel.hpp)
   const uint32_t plane = (uint32_t)HW * 2u;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
   __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)pad32(Cout) * (uint32_t)cip * 2u, 0x00020000);
@@ -161,8 +162,8 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;   // group fastest: coalesced loads
     const int gy = y0 - D + r, gx = x0 - marg + 8 * g;
     const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
-    off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
+    sh = (in && gx + 8 > W) ? gx + 8 - W : 0;          // (GEN: load shifted left; !GEN: trailing pixels masked — conv_kernel.hpp)
+    off = in ? ((uint32_t)((oct * 8) * HW + gy * xpitch + gx - (GEN ? sh : 0)) * 2u) : 0x80000000u;
     dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);   // entry index * 8 + slot rotation of the group
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
@@ -259,7 +260,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   // wave w finishes output row r = w/2, accumulator registers [8*(w%2), 8*(w%2)+8)
   const int r = wave >> 1, jbase = 4 * (wave & 1);
   Epilogue ep;
-  epilogue_init<T, GEN>(ep, y + (size_t)n * ybs, Cout, H, W, slab, lane, x0);
+  epilogue_init<T, true>(ep, y + (size_t)n * ybs, Cout, H, W, slab, lane, x0, ypitch);
   if (y0 + r < H) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -270,7 +271,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
         v0 += part[((w * 2 + r) * 16 + e0) * 64 + lane];
         v1 += part[((w * 2 + r) * 16 + e1) * 64 + lane];
       }
-      epilogue_store<T, GEN>(ep, v0, v1, epilogue_choff(jbase + jj) * ep.plane2 + (uint32_t)((y0 + r) * W) * 2u, slope);
+      epilogue_store<T, true>(ep, v0, v1, epilogue_choff(jbase + jj) * ep.plane2 + (uint32_t)((y0 + r) * ypitch) * 2u, slope);
     }
   }
 }
@@ -309,7 +310,7 @@ int launch_sk_one(const Args& a) {
   auto kern = &conv_sk_kernel<T, NOCTS, D, GEN>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), cdiv(a.Cout, 32)), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
-                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope);
+                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, a.ypitch);
   return check_launch("conv_forward");
 }
 
@@ -467,9 +468,9 @@ extern "C" int upf_conv_pack_weights_f32_multi(const float* const* w, void* cons
   return check_launch("conv_pack_weights_f32_multi");
 }
 
-extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
-                                void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
-                                int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream) {
+extern "C" int upf_conv_forward_pitched(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
+                                        void* y, long long y_batch_stride, int y_row_pitch, int B, int Cin, int Cout, int H, int W,
+                                        int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream) {
   using namespace upf;
   UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv_forward: null pointer");
   UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL,
@@ -478,14 +479,26 @@ extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const v
   UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_forward: kernel_size %d (1 or 3)", kernel_size);
   UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_forward: dilation %d not in [1,%d]", dilation, conv::MAXD);
   UPF_REQUIRE(stride == 1 || (stride == 2 && dilation == 1 && kernel_size == 3), UPF_EUNSUPPORTED, "conv_forward: stride %d (1, or 2 for a 3x3 with dilation 1)", stride);
-  const bool gen = !(W % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0);   // rows not 16-byte aligned
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (x_row_pitch == 0) x_row_pitch = W;
+  if (y_row_pitch == 0) y_row_pitch = Wo;
+  UPF_REQUIRE(x_row_pitch >= W && y_row_pitch >= Wo, UPF_EINVAL, "conv_forward: row pitch smaller than the row (x %d < %d or y %d < %d)", x_row_pitch, W, y_row_pitch, Wo);
+  const bool gen = !(x_row_pitch % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0);   // rows not 16-byte aligned
   UPF_REQUIRE(!gen || W >= 8, UPF_EUNSUPPORTED, "conv_forward: W = %d < 8 with unaligned rows", W);
-  UPF_REQUIRE((long long)Cin * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: image too large for one buffer descriptor");
+  UPF_REQUIRE((long long)Cin * H * x_row_pitch * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: image too large for one buffer descriptor");
   UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward: leaky_slope %g not in [0,1]", (double)leaky_slope);
-  UPF_REQUIRE((long long)Cout * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: output too large for one buffer descriptor");
+  UPF_REQUIRE((long long)Cout * Ho * y_row_pitch * 2 < (1ll << 31), UPF_EINVAL, "conv_forward: output too large for one buffer descriptor");
   // the kernels compute max(v, v*slope): "no activation" (0) becomes slope 1
   conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W,
-               kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};
+               kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream,
+               x_row_pitch, y_row_pitch};
   if (dtype == UPF_BF16) return gen ? conv::launch<bf16_t, true>(a) : conv::launch<bf16_t, false>(a);
   return gen ? conv::launch<f16_t, true>(a) : conv::launch<f16_t, false>(a);
+}
+
+extern "C" int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_packed, const float* bias,
+                                void* y, long long y_batch_stride, int B, int Cin, int Cout, int H, int W,
+                                int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream) {
+  return upf_conv_forward_pitched(x, x_batch_stride, 0, w_packed, bias, y, y_batch_stride, 0, B, Cin, Cout, H, W, kernel_size, dilation, stride,
+                                  leaky_slope, dtype, stream);
 }

@@ -56,6 +56,7 @@ struct ArgsC8 {
   const void* x2; long long x2bs; int C2;          // NCHW part of the input (XL == 0 or 2)
   const void* wp; const float* bias; void* y; long long ybs;
   int B, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
+  int x2pitch, ypitch;                               // row pitch of the NCHW input part / of an NCHW output (elements; conv_kernel.hpp)
 };
 
 template <typename T, int MTW, int RPW, int S, int NOCTS, int D, int XL, bool YC8, bool N16 = false>
@@ -76,7 +77,7 @@ int launch_one_c8(const ArgsC8& a, int slabs) {
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x2, a.x2bs,
                      (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.C2, a.Cout, a.H, a.W, Ho, Wo, g_ablate, tiles_x, tiles_y, a.slope,
-                     (const T*)a.x8, a.x8bs, a.n8oct);
+                     (const T*)a.x8, a.x8bs, a.n8oct, a.x2pitch, a.ypitch);
   return check_launch("conv_forward_c8");
 }
 
@@ -191,10 +192,10 @@ extern "C" int upf_conv_c8_set_option(const char* name, int value) {
   return prev;
 }
 
-extern "C" int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, int n8_oct, const void* x2, long long x2_batch_stride, int C2,
-                                   const void* w_packed, const float* bias, void* y, long long y_batch_stride, int y_is_c8,
-                                   int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
-                                   int dtype, void* stream) {
+extern "C" int upf_conv_forward_c8_pitched(const void* x8, long long x8_batch_stride, int n8_oct, const void* x2, long long x2_batch_stride, int x2_row_pitch, int C2,
+                                           const void* w_packed, const float* bias, void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8,
+                                           int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
+                                           int dtype, void* stream) {
   using namespace upf;
   UPF_REQUIRE((x8 || x2) && w_packed && bias && y, UPF_EINVAL, "conv_forward_c8: null pointer");
   UPF_REQUIRE((x8 != nullptr) == (n8_oct > 0) && (x2 != nullptr) == (C2 > 0), UPF_EINVAL, "conv_forward_c8: a pointer and its channel count disagree");
@@ -203,17 +204,33 @@ extern "C" int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, in
   UPF_REQUIRE(kernel_size == 3 || kernel_size == 1, UPF_EUNSUPPORTED, "conv_forward_c8: kernel_size %d (1 or 3)", kernel_size);
   UPF_REQUIRE(stride == 1 || (stride == 2 && kernel_size == 3 && dilation == 1 && !x8), UPF_EUNSUPPORTED, "conv_forward_c8: stride %d (1, or 2 for a 3x3 with an NCHW input)", stride);
   UPF_REQUIRE(dilation >= 1 && dilation <= conv::MAXD, UPF_EUNSUPPORTED, "conv_forward_c8: dilation %d not in [1,%d]", dilation, conv::MAXD);
-  UPF_REQUIRE(W % (8 * stride) == 0, UPF_EUNSUPPORTED, "conv_forward_c8: W = %d is not a multiple of %d (use upf_conv_forward)", W, 8 * stride);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (x2_row_pitch == 0) x2_row_pitch = W;
+  if (y_row_pitch == 0) y_row_pitch = Wo;
+  // C8 operands: a pixel is a 16-byte entry, rows are aligned for every W.  The NCHW input part is staged with aligned 16-byte
+  // loads: its row PITCH must be a multiple of 8 elements (the logical W may be ragged; round 5).
+  UPF_REQUIRE(!x2 || (x2_row_pitch >= W && x2_row_pitch % 8 == 0), UPF_EUNSUPPORTED,
+              "conv_forward_c8: the NCHW input's row pitch %d must be a multiple of 8 and >= W = %d (pitched rows, or upf_conv_forward)", x2_row_pitch, W);
+  UPF_REQUIRE(y_is_c8 || y_row_pitch >= Wo, UPF_EINVAL, "conv_forward_c8: output row pitch %d < %d", y_row_pitch, Wo);
   UPF_REQUIRE(!x8 || (aligned_to(x8, 16) && x8_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the C8 input must be 16-byte aligned");
   UPF_REQUIRE(!x2 || (aligned_to(x2, 16) && x2_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the NCHW input must be 16-byte aligned");
   UPF_REQUIRE(!y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8: the C8 output must be 16-byte aligned");
-  UPF_REQUIRE(y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EUNSUPPORTED, "conv_forward_c8: the NCHW output must be 16-byte aligned");
-  UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31) && (long long)C2 * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: image too large for one buffer descriptor");
-  UPF_REQUIRE((long long)((Cout + 7) / 8) * (H / stride + 1) * (W / stride + 1) * 16 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: output too large for one buffer descriptor");
+  UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31) && (long long)C2 * H * x2_row_pitch * 2 < (1ll << 31), UPF_EINVAL, "conv_forward_c8: image too large for one buffer descriptor");
+  UPF_REQUIRE((long long)((Cout + 7) / 8) * (H / stride + 1) * (W / stride + 1) * 16 < (1ll << 31) && (y_is_c8 || (long long)Cout * Ho * y_row_pitch * 2 < (1ll << 31)), UPF_EINVAL,
+              "conv_forward_c8: output too large for one buffer descriptor");
   UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward_c8: leaky_slope %g not in [0,1]", (double)leaky_slope);
   conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, x2, x2_batch_stride, C2, w_packed, bias, y, y_batch_stride,
-                 B, Cout, H, W, kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};
+                 B, Cout, H, W, kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream,
+                 x2_row_pitch, y_row_pitch};
   return dtype == UPF_BF16 ? conv::dispatch_c8<bf16_t>(a, y_is_c8 != 0) : conv::dispatch_c8<f16_t>(a, y_is_c8 != 0);
+}
+
+extern "C" int upf_conv_forward_c8(const void* x8, long long x8_batch_stride, int n8_oct, const void* x2, long long x2_batch_stride, int C2,
+                                   const void* w_packed, const float* bias, void* y, long long y_batch_stride, int y_is_c8,
+                                   int B, int Cout, int H, int W, int kernel_size, int dilation, int stride, float leaky_slope,
+                                   int dtype, void* stream) {
+  return upf_conv_forward_c8_pitched(x8, x8_batch_stride, n8_oct, x2, x2_batch_stride, 0, C2, w_packed, bias, y, y_batch_stride, 0, y_is_c8,
+                                     B, Cout, H, W, kernel_size, dilation, stride, leaky_slope, dtype, stream);
 }
 
 // ---- layers with at most 16 output channels on the 16-channel matrix instruction (conv_kernel<..., N16>) -------------------------
@@ -241,14 +258,13 @@ extern "C" int upf_conv_forward_c8_narrow(const void* x8, long long x8_batch_str
   UPF_REQUIRE(x8 && n8_oct > 0 && w_packed16 && bias && y, UPF_EINVAL, "conv_forward_c8_narrow: null pointer");
   UPF_REQUIRE(B > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_forward_c8_narrow: bad shape B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
   UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_c8_narrow: bf16 / fp16 only");
-  UPF_REQUIRE(W % 8 == 0, UPF_EUNSUPPORTED, "conv_forward_c8_narrow: W = %d is not a multiple of 8", W);
   UPF_REQUIRE(aligned_to(x8, 16) && x8_batch_stride % 8 == 0, UPF_EINVAL, "conv_forward_c8_narrow: the C8 input must be 16-byte aligned");
   UPF_REQUIRE(!y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8_narrow: the C8 output must be 16-byte aligned");
   UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31), UPF_EINVAL, "conv_forward_c8_narrow: input too large for one buffer descriptor");
   UPF_REQUIRE((long long)(y_is_c8 ? (Cout + 7) / 8 * 8 : Cout) * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward_c8_narrow: output too large for one buffer descriptor");
   UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward_c8_narrow: leaky_slope %g not in [0,1]", (double)leaky_slope);
   conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, nullptr, 0, 0, w_packed16, bias, y, y_batch_stride, B, Cout, H, W, 1, 1, 9,
-                 leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream};
+                 leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream, W, W};
   const int blocks16 = (Cout + 15) / 16;
   // 8-row tiles: with 32-channel chunks a 16-row tile's two LDS buffers (87 KB) leave ONE workgroup per CU (measured: no faster
   // than the 32-channel kernel); `narrow_tall` = 1 selects them for experiments

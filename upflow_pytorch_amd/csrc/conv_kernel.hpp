@@ -62,10 +62,26 @@ __device__ __forceinline__ int swz(int col) { return (col & ~7) | ((col + (col >
 // 8 channel rows x 8 pixels (eight 16-byte loads of one 8-pixel group) -> 8 LDS entries of 8 channels x 1 pixel.
 // `enc` = (entry index of the group's first pixel) * 8 + slot rotation (see swz); GEN: `sh` = pixels the load window was
 // shifted left so that it ends at the row end — pixel q sits at column q - sh, columns >= 8 - sh are zero padding.
+// !GEN (rows with a 16-byte aligned PITCH; the logical width W may be ragged, round 5): `sh` = trailing pixels of the group
+// that lie at or beyond W — what the load fetched there (pitch padding, whatever it holds) is replaced by the zero padding.
 template <bool GEN>
-__device__ __forceinline__ void stage_store(uint4* tile, int enc, int sh, const u32x4 (&ch)[8]) {
+__device__ __forceinline__ void stage_store(uint4* tile, int enc, int sh, const u32x4 (&ch_in)[8]) {
   uint4* dst = tile + (enc >> 3);
   const int rot = enc & 7;
+  u32x4 ch[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ch[k] = ch_in[k];
+  if constexpr (!GEN) {
+    if (sh) {                                        // (rare: the last group of a ragged row, right-edge tiles only)
+      const int nv = 8 - sh;                         // valid pixels
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const uint32_t m = (2 * pp + 1 < nv) ? 0xffffffffu : ((2 * pp < nv) ? 0x0000ffffu : 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ch[k][pp] &= m;
+      }
+    }
+  }
 #pragma unroll
   for (int pp = 0; pp < 4; ++pp) {               // dword pp of every channel row = pixels 2pp, 2pp+1
     uint4 e0, e1;
@@ -98,11 +114,11 @@ struct Epilogue {
   uint32_t plane2;         // bytes per output plane
 };
 template <typename T, bool GEN>
-__device__ __forceinline__ void epilogue_init(Epilogue& ep, T* y_img, int Cout, int Ho, int Wo, int slab, int lane, int x0) {
+__device__ __forceinline__ void epilogue_init(Epilogue& ep, T* y_img, int Cout, int Ho, int Wo, int slab, int lane, int x0, int ypitch) {
   const int px = lane & 31, kg = lane >> 5;
   const bool odd = px & 1;
   const int gx = x0 + (px & ~1);
-  ep.plane2 = (uint32_t)(Ho * Wo) * 2u;
+  ep.plane2 = (uint32_t)(Ho * ypitch) * 2u;
   ep.yr = __builtin_amdgcn_make_buffer_rsrc(y_img, 0, (uint32_t)Cout * ep.plane2, 0x00020000);
   const uint32_t off = (uint32_t)(slab * 32 + 4 * kg + (odd ? 1 : 0)) * ep.plane2 + (uint32_t)gx * 2u;
   ep.off32 = (gx + 1 < Wo) ? off : 0x80000000u;
@@ -130,11 +146,13 @@ constexpr int EPI_PITCH = 80;                                  // bytes per (row
 constexpr int EPI_WAVE_BYTES = 2 * 32 * EPI_PITCH;             // two tile rows of one wave
 template <typename T, int RPW>
 __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned char* patch, T* y_img, int Cout, int Ho, int Wo,
-                                              int slab, int lane, int x0, int gy0, int row_step, float slope) {
+                                              int slab, int lane, int x0, int gy0, int row_step, float slope, int ypitch) {
+  // (pitched rows: an 8-pixel segment that starts inside the logical row is stored whole — its tail lands in the row's own
+  // pitch padding, which no consumer depends on)
   const int px = lane & 31, kg = lane >> 5;
   const bool odd = px & 1;
   const uint32_t sel = odd ? 0x03020706u : 0x05040100u;
-  const uint32_t plane2 = (uint32_t)(Ho * Wo) * 2u;
+  const uint32_t plane2 = (uint32_t)(Ho * ypitch) * 2u;
   __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y_img, 0, (uint32_t)Cout * plane2, 0x00020000);
   // write side: this lane's pixel pair of channel (its register pair's channel) -> patch[row][channel][pixel pair]
   unsigned char* wbase = patch + (4 * kg + (odd ? 1 : 0)) * EPI_PITCH + (px & ~1) * 2;
@@ -166,7 +184,7 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(rbase + (rr * 32 + h * 16) * EPI_PITCH);
-        if (gy < Ho) __builtin_amdgcn_raw_buffer_store_b128(v, yr, goff + (uint32_t)(h * 16) * plane2 + (uint32_t)(gy * Wo) * 2u, 0, 0);
+        if (gy < Ho) __builtin_amdgcn_raw_buffer_store_b128(v, yr, goff + (uint32_t)(h * 16) * plane2 + (uint32_t)(gy * ypitch) * 2u, 0, 0);
       }
     }
   }
@@ -218,7 +236,12 @@ template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool 
 __global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
 void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                  T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
-                 int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct) {
+                 int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, int xpitch, int ypitch) {
+  // xpitch / ypitch (round 5): elements between consecutive rows of the NCHW operands x / y (plane stride = rows * pitch).  The
+  // LOGICAL width stays W / Wo: with a pitch that is a multiple of 8 every row is 16-byte aligned whatever W is, so ragged
+  // pyramid levels (KITTI's native 375x1242: W = 621, 311, 156, 78, 39, 20) take the aligned staging (!GEN) and the 16-byte
+  // epilogue, and nothing depends on what the pitch padding holds (staging masks it, the outputs' padding is never read as data).
+  // C8 operands have no pitch: a pixel is one 16-byte entry, their rows are aligned for every W.
   static_assert(XL == 0 || (D >= 0 && !GEN && !ONE), "C8 input: compile-time dilation, aligned rows");
   static_assert(!N16 || (XL == 1 && MTW == 1 && NOCTS == 4 && D == 1 && S == 1 && RPW >= 2), "N16: C8 input, 3x3, dilation 1, stride 1");
   constexpr int ntaps = (D == 0) ? 1 : 9;
@@ -253,11 +276,12 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   const int cip = c8p + ((XL == 1) ? 0 : pad32(Cin));
   const int n8c = c8p / KCH;                                  // chunks staged from the C8 slice
   const int nchunks = ONE ? 1 : cip / KCH, nksteps = cip / 16;
-  const int HW = H * W;
+  const int HW = H * W;                               // entries per octet plane of a C8 operand
+  const int HWx = H * xpitch;                         // elements per channel plane of the NCHW operand
 
   // buffer descriptor over this image's Cin input planes: rows/cols outside the image get offset
   // 0x80000000, channel planes >= Cin fall off the end -> the hardware returns the zero padding
-  const uint32_t plane = (uint32_t)HW * 2u;
+  const uint32_t plane = (uint32_t)HWx * 2u;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
   __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wp), 0, (uint32_t)ntaps * (uint32_t)(N16 ? (Cout + 15) / 16 * 16 : pad32(Cout)) * (uint32_t)cip * 2u, 0x00020000);
 
@@ -290,9 +314,11 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   auto task_geom = [&](int t, uint32_t& off, int& dst, int& sh) {
     const int oct = t / (rows * ngroups), rem = t - oct * (rows * ngroups), r = rem / ngroups, g = rem - r * ngroups;   // group fastest: coalesced loads
     const int gy = PH ? y0 + (r - 1) * RS : S * y0 - d + r, gx = S * x0 - marg + 8 * g;
-    const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W && !(abl & 2);      // !GEN: W % 8 == 0, a group is all in or all out
-    sh = (GEN && in && gx + 8 > W) ? gx + 8 - W : 0;
-    off = in ? ((uint32_t)((oct * 8) * HW + gy * W + gx - sh) * 2u) : 0x80000000u;
+    const bool in = (t < ntasks) && gy >= 0 && gy < H && gx >= 0 && gx < W && !(abl & 2);
+    // the group that straddles the row end: GEN loads it shifted left by sh; !GEN (aligned pitch) loads it in place and
+    // stage_store zeroes its sh trailing pixels
+    sh = (in && gx + 8 > W) ? gx + 8 - W : 0;
+    off = in ? ((uint32_t)((oct * 8) * HWx + gy * xpitch + gx - (GEN ? sh : 0)) * 2u) : 0x80000000u;
     dst = ((oct * rows + r) * XWP + 8 * g) * 8 + ((g >> 1) & 7);   // entry index * 8 + slot rotation of the group
   };
   auto task_load = [&](uint32_t off, int cc, u32x4 (&ch)[8]) {
@@ -514,7 +540,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   if constexpr (N16) {
     // lane: channels slab*16 + 4*ko + i of pixels x0 + p16 (+ 16).  YC8: the quad is half an octet entry -> one 8-byte store;
     // NCHW (the 2- / 3-channel heads): one 2-byte store per channel, channels >= Cout fall off the descriptor.
-    const uint32_t plane16 = (uint32_t)(Ho * Wo) * 16u, plane2 = (uint32_t)(Ho * Wo) * 2u;
+    const uint32_t plane16 = (uint32_t)(Ho * Wo) * 16u, plane2 = (uint32_t)(Ho * ypitch) * 2u;
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * ybs, 0, YC8 ? (uint32_t)((Cout + 7) / 8) * plane16 : (uint32_t)Cout * plane2, 0x00020000);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -532,7 +558,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
             o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]);
             __builtin_amdgcn_raw_buffer_store_b64(o, yr, off, 0, 0);
           } else {
-            const uint32_t off = (gx < Wo) ? (uint32_t)(slab * 16 + 4 * ko) * plane2 + (uint32_t)(gy * Wo + gx) * 2u : 0x80000000u;
+            const uint32_t off = (gx < Wo) ? (uint32_t)(slab * 16 + 4 * ko) * plane2 + (uint32_t)(gy * ypitch + gx) * 2u : 0x80000000u;
             const uint32_t p01 = pack2<T>(v[0], v[1]), p23 = pack2<T>(v[2], v[3]);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)p01, yr, off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(p01 >> 16), yr, off + plane2, 0, 0);
@@ -572,21 +598,23 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     return;
   }
   if constexpr (!GEN) {
-    if ((Wo & 7) == 0) {                             // uniform: 16-byte stores through a per-wave LDS patch
+    // uniform: 16-byte stores through a per-wave LDS patch when the OUTPUT rows are 16-byte aligned (pitch, base, batch stride)
+    if (((ypitch & 7) | (int)(ybs & 7) | (int)(reinterpret_cast<uintptr_t>(y) & 15)) == 0) {
       __syncthreads();                               // every wave is done with the x tile
       epilogue_wide<T, RPW>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
-                            slab, lane, x0, gy0, RS, slope);
+                            slab, lane, x0, gy0, RS, slope, ypitch);
       return;
     }
   }
+  // (always the general form: an aligned input says nothing about the output's width — a pitched x with an un-pitched odd-width y)
   Epilogue ep;
-  epilogue_init<T, GEN>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0);
+  epilogue_init<T, true>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0, ypitch);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     if (gy0 + r * RS < Ho) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        epilogue_store<T, GEN>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * Wo) * 2u, slope);
+        epilogue_store<T, true>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * ypitch) * 2u, slope);
     }
   }
   }  // !N16
@@ -598,6 +626,7 @@ inline int g_sk_grid = 48, g_sk_grid_narrow = 96, g_sk_grid_d4 = 16, g_small_gri
 struct Args {
   const void* x; long long xbs; const void* wp; const float* bias; void* y; long long ybs;
   int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
+  int xpitch, ypitch;                                // elements between rows of x / y (>= W / Wo)
 };
 
 template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false>
@@ -615,7 +644,7 @@ int launch_one(const Args& a, int slabs) {
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
                      (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, D >= 0 ? g_ablate : a.d, tiles_x, tiles_y, a.slope,
-                     (const T*)nullptr, 0ll, 0);
+                     (const T*)nullptr, 0ll, 0, a.xpitch, a.ypitch);
   return check_launch("conv_forward");
 }
 

@@ -98,11 +98,16 @@ struct Task {      // two registers per task: NT = 8 tasks + their 64 raw-data r
 // position p holds (dy = p - 4, dx = +4), octet 10 position 0 holds (+4, +4) and zeros: a wave (= one dy) stores ONE whole
 // 16-byte entry per pixel straight from its registers (no transposition patch) + one 2-byte element.  The convolution that
 // reads the buffer gets this order through its k-map (upf_conv_pack_weights_kmap; ops.corr81_c8_channel_map).
-template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, int TPW = 1, bool OC8 = false>
+// fpitch (round 5): elements between consecutive rows of f1 / f2 (>= W; plane stride H * fpitch).  PADW (!RAGGED, OC8): the LOGICAL
+// width W is ragged but the rows are pitched to whole 16-byte groups — aligned quad loads like the W % 8 == 0 form, the quad that
+// straddles W has its trailing pixels (pitch padding, whatever it holds) replaced by the zero padding, and the octet output, one
+// 16-byte entry per pixel, is aligned for every W: KITTI's native frames (W = 311, 156 at the two fine levels) stay on this path.
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, int TPW = 1, bool OC8 = false, bool PADW = false>
 __global__ __launch_bounds__(NTHREADS, 5)       // <= 102 VGPRs: two 9-wave workgroups per CU
 void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* __restrict__ out,
                         int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope,
-                        const float* __restrict__ ws1, const float* __restrict__ ws2, int nseg, int total_tiles) {
+                        const float* __restrict__ ws1, const float* __restrict__ ws2, int nseg, int total_tiles, int fpitch) {
+  static_assert(!PADW || (!RAGGED && OC8), "PADW: aligned pitched rows, octet output");
   using G = Geo<UW, NU>;
   extern __shared__ __attribute__((aligned(16))) uint2 lds[];
   const int ntiles = tiles_x * tiles_y;                                 // per batch item
@@ -111,7 +116,7 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
   const int KQ = (C + 3) >> 2;
   uint2* const lds_f1 = lds;
   uint2* const lds_f2 = lds + KQ * G::F1_E;
-  const uint32_t plane = (uint32_t)H * (uint32_t)W * 2u;               // bytes per channel plane
+  const uint32_t plane = (uint32_t)H * (uint32_t)fpitch * 2u;          // bytes per channel plane
   const uint32_t item_bytes = (uint32_t)C * plane;
   const int n1 = KQ * G::Q1, N1 = (n1 + 63) & ~63, n2 = KQ * G::Q2;
   float2* const st = reinterpret_cast<float2*>(lds + KQ * G::E + (RAGGED ? 0 : NWAVES * PATCH_BYTES / 8));
@@ -124,7 +129,7 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
   auto issue = [&](int tile, bool live) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / ntiles;
     const int x0 = tx * G::TW, y0 = ty * G::TH;
-    const size_t item = (size_t)n * C * H * W;
+    const size_t item = (size_t)n * C * H * fpitch;
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1 + item), 0, live ? item_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f2 + item), 0, live ? item_bytes : 0u, 0x00020000);
     // (NORM) the item's (mean, 1/std) pairs: channels >= C fall off the descriptor -> (0, 0): (x - 0) * 0 keeps the zero padding
@@ -160,7 +165,7 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
         // (every byte of every load then lies inside the row: nothing is read past the tensor, and the bounds check of
         // the descriptor, which works in whole dwords, never cuts off an odd-sized tensor's last element); the shift
         // is undone in registers when the task lands
-        s.voff = (uint32_t)((kq * 4 * H + gy) * W + gx - (RAGGED ? 4 - nv : 0)) * 2u;
+        s.voff = (uint32_t)((kq * 4 * H + gy) * fpitch + gx - (RAGGED ? 4 - nv : 0)) * 2u;
         s.meta |= nv << 24;
       }
       task[j] = s;
@@ -233,7 +238,7 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
           }
         }
       }
-      if constexpr (RAGGED && NORM) {                     // pixels >= W were normalised zeros: drop them again
+      if constexpr ((RAGGED && NORM) || PADW) {           // pixels >= W were normalised zeros (PADW: or pitch padding): drop them
         const int nv = task[j].nv();
         const uint32_t mx = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
         const uint32_t my = nv >= 4 ? 0xffffffffu : (nv == 3 ? 0x0000ffffu : 0u);

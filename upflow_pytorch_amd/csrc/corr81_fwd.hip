@@ -127,31 +127,32 @@ static int allc_pick(int B, int C, int H, int W, bool ragged, bool norm, bool ch
   return first;
 }
 
-template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, bool OC8 = false>
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, bool OC8 = false, bool PADW = false>
 int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
-                    const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                    const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int fpitch = 0) {
+  if (fpitch == 0) fpitch = W;
   using G = corrx::Geo<UW, NU>;
   const int tiles_x = cdiv(W, G::TW), tiles_y = cdiv(H, G::TH);
   const long long nblocks = (long long)B * tiles_x * tiles_y;
   UPF_REQUIRE(nblocks < (1ll << 31), UPF_EINVAL, "corr81_forward: grid too large");
   const size_t lds = corrx::lds_bytes<UW, NU>((C + 3) / 4, RAGGED, NORM);
   static LdsOptIn opt;
-  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, 1, OC8>;
+  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, 1, OC8, PADW>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   // (the timed entry points pass start / stop events -> hipExtLaunchKernel; everything else takes the ordinary launch path)
   if (ev0 || ev1)
     hipExtLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(corrx::NTHREADS), lds, stream, ev0, ev1, 0,
-                          f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg, (int)nblocks);
+                          f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg, (int)nblocks, fpitch);
   else
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(corrx::NTHREADS), lds, stream,
-                       f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg, (int)nblocks);
+                       f1, f2, out, C, H, W, tiles_x, tiles_y, out_bs, slope, ws1, ws2, nseg, (int)nblocks, fpitch);
   return check_launch("corr81_forward");
 }
 
 template <typename T, bool RAGGED, bool NORM>
 int launch_allc(int v, const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
-                const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, RAGGED, NORM>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1)
+                const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int fpitch = 0) {
+#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, RAGGED, NORM>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch)
   switch (v) {
     case 0: UPF_ALLC(32, 4, 4);
     case 1: UPF_ALLC(32, 2, 8);
@@ -164,10 +165,11 @@ int launch_allc(int v, const T* f1, const T* f2, T* out, int B, int C, int H, in
 }
 
 // normalising cost volume into channel octets (upf_corr81_norm_forward_c8): !RAGGED, NORM, OC8
-template <typename T>
+// (PADW: ragged logical W on pitched rows, corr81_allc_kernel.hpp)
+template <typename T, bool PADW = false>
 int launch_allc_c8(int v, const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
-                   const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
-#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, false, true, true>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1)
+                   const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int fpitch = 0) {
+#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, false, true, true, PADW>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch)
   switch (v) {
     case 0: UPF_ALLC(32, 4, 4);
     case 1: UPF_ALLC(32, 2, 8);
@@ -182,14 +184,17 @@ int launch_allc_c8(int v, const T* f1, const T* f2, T* out, int B, int C, int H,
 // -> UPF_OK / error, or 1 = "not applicable" (C too deep, item too large): the caller takes the chunked kernels
 template <typename T, bool NORM>
 int try_allc(const void* f1, const void* f2, void* out, int B, int C, int H, int W, long long out_bs, float slope,
-             const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-  if ((size_t)C * H * W * 2 >= (1ull << 31)) return 1;                       // buffer-descriptor range
-  const bool ragged = !((W % 8 == 0) && (out_bs % 8 == 0) && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out, 16));
+             const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int fpitch = 0) {
+  if (fpitch == 0) fpitch = W;
+  if ((size_t)C * H * fpitch * 2 >= (1ull << 31)) return 1;                  // buffer-descriptor range
+  // (the NCHW output is written in 8-pixel segments by the aligned form: W % 8 == 0; a pitched input with a ragged W takes the ragged form)
+  const bool ragged = !((W % 8 == 0) && (fpitch % 8 == 0) && (out_bs % 8 == 0) && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out, 16));
   if (ragged && W < 4) return 1;                                             // (rows shorter than a staging quad)
-  const int v = allc_pick(B, C, H, W, ragged, NORM, !ragged);
+  const int v = allc_pick(B, C, H, W, ragged, NORM, !ragged && fpitch == W);
+  if (v == -2 && fpitch != W) return 1;
   if (v < 0) return 1;
-  if (ragged) return launch_allc<T, true, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1);
-  return launch_allc<T, false, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1);
+  if (ragged) return launch_allc<T, true, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch);
+  return launch_allc<T, false, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch);
 }
 
 template <typename T>
@@ -348,77 +353,105 @@ extern "C" long long upf_corr81_norm_workspace_bytes(int B, int C, int H, int W)
   return part * (long long)sizeof(float) + (long long)2 * B * C * (long long)sizeof(float2);
 }
 
-extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
-                                       long long out_batch_stride, float leaky_slope, void* workspace, void* stream) {
+extern "C" int upf_corr81_norm_forward_pitched(const void* f1, const void* f2, int f_row_pitch, void* out, int B, int C, int H, int W, int dtype,
+                                               long long out_batch_stride, float leaky_slope, void* workspace, void* stream) {
   using namespace upf;
   UPF_REQUIRE(f1 && f2 && out && workspace, UPF_EINVAL, "corr81_norm_forward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_norm_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(upf_corr81_norm_supported(C, dtype), UPF_EUNSUPPORTED,
               "corr81_norm_forward: bf16 / fp16 with C <= 208 only (dtype %d, C %d): use upf_normalize_forward + upf_corr81_forward", dtype, C);
-  UPF_REQUIRE((size_t)C * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward: batch item >= 2 GiB");
+  const int fp = f_row_pitch ? f_row_pitch : W;
+  UPF_REQUIRE(fp >= W, UPF_EINVAL, "corr81_norm_forward: row pitch %d < W = %d", fp, W);
+  UPF_REQUIRE((size_t)C * H * fp * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward: batch item >= 2 GiB");
   if (out_batch_stride == 0) out_batch_stride = (long long)corr::ND * H * W;
   UPF_REQUIRE(out_batch_stride >= (long long)corr::ND * H * W, UPF_EINVAL, "corr81_norm_forward: out_batch_stride %lld < 81*H*W", out_batch_stride);
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const long long N = (long long)B * C;
   float2* fin = reinterpret_cast<float2*>(ws + ((size_t)2 * N * misc::stats2_nseg(N, H * W) * 3 + 3) / 4 * 4);    // final (mean, 1/std) pairs behind the partials (16-byte aligned)
-  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s);
+  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s, W, fp);
   int rc = check_launch("corr81_norm_forward (statistics)");
   if (rc != UPF_OK) return rc;
   const float* ws1 = reinterpret_cast<const float*>(fin);            // what the cost volume reads: final pairs of f1's rows ...
   const float* ws2 = reinterpret_cast<const float*>(fin + N);        // ... and of f2's
-  if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
-  else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr);
+  if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
+  else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
   UPF_REQUIRE(rc != 1, UPF_EUNSUPPORTED, "corr81_norm_forward: no kernel variant fits C=%d W=%d (W >= 4 required)", C, W);
   return rc;
 }
 
-extern "C" int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
-                                          int dtype, float leaky_slope, void* workspace, void* stream) {
+extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
+                                       long long out_batch_stride, float leaky_slope, void* workspace, void* stream) {
+  return upf_corr81_norm_forward_pitched(f1, f2, 0, out, B, C, H, W, dtype, out_batch_stride, leaky_slope, workspace, stream);
+}
+
+// octet output: the feature rows must be 16-byte aligned — W % 8 == 0, or (round 5) any W on rows PITCHED to a multiple of 8 elements
+static int norm_c8_check(const void* f1, const void* f2, const void* out8, long long out8_batch_stride, int H, int W, int fp, const char* who) {
+  using namespace upf;
+  UPF_REQUIRE(fp >= W && fp % 8 == 0 && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out8, 16) && out8_batch_stride % 8 == 0, UPF_EUNSUPPORTED,
+              "%s: the feature rows must be 16-byte aligned (W %% 8 == 0, or a row pitch that is a multiple of 8) and the operands 16-byte aligned (W = %d, pitch = %d)", who, W, fp);
+  UPF_REQUIRE(W >= 4, UPF_EUNSUPPORTED, "%s: W = %d < 4", who, W);
+  UPF_REQUIRE(out8_batch_stride >= (long long)11 * H * W * 8, UPF_EINVAL, "%s: out8_batch_stride %lld < 11 octets", who, out8_batch_stride);
+  return UPF_OK;
+}
+
+extern "C" int upf_corr81_norm_forward_c8_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                                  int dtype, float leaky_slope, void* workspace, void* stream) {
   using namespace upf;
   UPF_REQUIRE(f1 && f2 && out8 && workspace, UPF_EINVAL, "corr81_norm_forward_c8: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_norm_forward_c8: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(upf_corr81_norm_supported(C, dtype), UPF_EUNSUPPORTED,
               "corr81_norm_forward_c8: bf16 / fp16 with C <= 208 only (dtype %d, C %d)", dtype, C);
-  UPF_REQUIRE((size_t)C * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward_c8: batch item >= 2 GiB");
-  UPF_REQUIRE(W % 8 == 0 && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out8, 16) && out8_batch_stride % 8 == 0, UPF_EUNSUPPORTED,
-              "corr81_norm_forward_c8: W %% 8 == 0 and 16-byte aligned operands required (W = %d)", W);
-  UPF_REQUIRE(out8_batch_stride >= (long long)11 * H * W * 8, UPF_EINVAL, "corr81_norm_forward_c8: out8_batch_stride %lld < 11 octets", out8_batch_stride);
+  const int fp = f_row_pitch ? f_row_pitch : W;
+  UPF_REQUIRE((size_t)C * H * fp * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward_c8: batch item >= 2 GiB");
+  int rc = norm_c8_check(f1, f2, out8, out8_batch_stride, H, W, fp, "corr81_norm_forward_c8");
+  if (rc != UPF_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const long long N = (long long)B * C;
   float2* fin = reinterpret_cast<float2*>(ws + ((size_t)2 * N * misc::stats2_nseg(N, H * W) * 3 + 3) / 4 * 4);    // final (mean, 1/std) pairs behind the partials (16-byte aligned)
-  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s);
-  int rc = check_launch("corr81_norm_forward_c8 (statistics)");
+  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s, W, fp);
+  rc = check_launch("corr81_norm_forward_c8 (statistics)");
   if (rc != UPF_OK) return rc;
   const float* ws1 = reinterpret_cast<const float*>(fin);            // what the cost volume reads: final pairs of f1's rows ...
   const float* ws2 = reinterpret_cast<const float*>(fin + N);        // ... and of f2's
   const int v = corr::allc_pick(B, C, H, W, false, true, false);
   UPF_REQUIRE(v >= 0, UPF_EUNSUPPORTED, "corr81_norm_forward_c8: no kernel variant fits C=%d", C);
-  if (dtype == UPF_BF16) return corr::launch_allc_c8<bf16_t>(v, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s);
-  return corr::launch_allc_c8<f16_t>(v, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s);
+  const bool padw = (W % 8 != 0);
+  if (dtype == UPF_BF16)
+    return padw ? corr::launch_allc_c8<bf16_t, true>(v, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp)
+                : corr::launch_allc_c8<bf16_t, false>(v, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
+  return padw ? corr::launch_allc_c8<f16_t, true>(v, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp)
+              : corr::launch_allc_c8<f16_t, false>(v, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
+}
+
+extern "C" int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                          int dtype, float leaky_slope, void* workspace, void* stream) {
+  return upf_corr81_norm_forward_c8_pitched(f1, f2, 0, out8, out8_batch_stride, B, C, H, W, dtype, leaky_slope, workspace, stream);
 }
 
 // The NORM cost volume — the variant inside the inference step — timed like upf_corr81_forward_timed: one (untimed) statistics
 // launch, then nrep launches of the cost-volume kernel, each between its own pair of HIP events on the launch stream.
 static int norm_forward_timed_impl(bool c8, const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
                                    long long out_batch_stride, float leaky_slope, void* workspace, void* stream, int nrep,
-                                   float* avg_us, float* min_us) {
+                                   float* avg_us, float* min_us, int fp = 0) {
   using namespace upf;
   UPF_REQUIRE(f1 && f2 && out && workspace && avg_us, UPF_EINVAL, "corr81_norm_forward_timed: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nrep > 0 && nrep <= 1024, UPF_EINVAL, "corr81_norm_forward_timed: bad arguments");
-  UPF_REQUIRE(upf_corr81_norm_supported(C, dtype) && (size_t)C * H * W * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward_timed: unsupported shape / dtype");
+  if (fp == 0) fp = W;
+  UPF_REQUIRE(upf_corr81_norm_supported(C, dtype) && (size_t)C * H * fp * 2 < (1ull << 31), UPF_EUNSUPPORTED, "corr81_norm_forward_timed: unsupported shape / dtype");
   if (c8) {
-    UPF_REQUIRE(W % 8 == 0 && aligned_to(f1, 16) && aligned_to(f2, 16) && aligned_to(out, 16) && out_batch_stride % 8 == 0 &&
-                out_batch_stride >= (long long)11 * H * W * 8, UPF_EUNSUPPORTED, "corr81_norm_forward_c8_timed: octet output needs W %% 8 == 0, aligned operands, 11 octets");
+    const int rc8 = norm_c8_check(f1, f2, out, out_batch_stride, H, W, fp, "corr81_norm_forward_c8_timed");
+    if (rc8 != UPF_OK) return rc8;
   } else if (out_batch_stride == 0) out_batch_stride = (long long)corr::ND * H * W;
+  const bool padw = c8 && (W % 8 != 0);
   const int vc8 = c8 ? corr::allc_pick(B, C, H, W, false, true, false) : 0;
   UPF_REQUIRE(vc8 >= 0, UPF_EUNSUPPORTED, "corr81_norm_forward_c8_timed: no kernel variant fits C=%d", C);
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const long long N = (long long)B * C;
   float2* fin = reinterpret_cast<float2*>(ws + ((size_t)2 * N * misc::stats2_nseg(N, H * W) * 3 + 3) / 4 * 4);    // final (mean, 1/std) pairs behind the partials (16-byte aligned)
-  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s);
+  const int nseg = misc::launch_stats2(f1, f2, ws, fin, N, H * W, dtype, s, W, fp);
   int rc = check_launch("corr81_norm_forward_timed (statistics)");
   if (rc != UPF_OK) return rc;
   const float* ws1 = reinterpret_cast<const float*>(fin);            // what the cost volume reads: final pairs of f1's rows ...
@@ -426,10 +459,12 @@ static int norm_forward_timed_impl(bool c8, const void* f1, const void* f2, void
   hipEvent_t* ev = new hipEvent_t[2 * nrep];
   for (int i = 0; i < 2 * nrep; ++i) (void)hipEventCreate(&ev[i]);
   for (int i = 0; i < nrep && rc == UPF_OK; ++i) {
-    if (c8 && dtype == UPF_BF16) rc = corr::launch_allc_c8<bf16_t>(vc8, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
-    else if (c8) rc = corr::launch_allc_c8<f16_t>(vc8, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
-    else if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
-    else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1]);
+    if (padw && dtype == UPF_BF16) rc = corr::launch_allc_c8<bf16_t, true>(vc8, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
+    else if (padw) rc = corr::launch_allc_c8<f16_t, true>(vc8, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
+    else if (c8 && dtype == UPF_BF16) rc = corr::launch_allc_c8<bf16_t>(vc8, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
+    else if (c8) rc = corr::launch_allc_c8<f16_t>(vc8, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
+    else if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
+    else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
     if (rc == 1) { set_error("corr81_norm_forward_timed: no kernel variant fits C=%d W=%d", C, W); rc = UPF_EUNSUPPORTED; }
   }
   hipError_t e = hipStreamSynchronize(s);
@@ -455,6 +490,11 @@ extern "C" int upf_corr81_norm_forward_timed(const void* f1, const void* f2, voi
 extern "C" int upf_corr81_norm_forward_c8_timed(const void* f1, const void* f2, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
                                                 int dtype, float leaky_slope, void* workspace, void* stream, int nrep, float* avg_us, float* min_us) {
   return norm_forward_timed_impl(true, f1, f2, out8, B, C, H, W, dtype, out8_batch_stride, leaky_slope, workspace, stream, nrep, avg_us, min_us);
+}
+
+extern "C" int upf_corr81_norm_forward_c8_timed_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                                        int dtype, float leaky_slope, void* workspace, void* stream, int nrep, float* avg_us, float* min_us) {
+  return norm_forward_timed_impl(true, f1, f2, out8, B, C, H, W, dtype, out8_batch_stride, leaky_slope, workspace, stream, nrep, avg_us, min_us, f_row_pitch);
 }
 
 extern "C" int upf_corr_set_option(const char* name, int value) {

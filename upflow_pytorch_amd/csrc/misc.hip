@@ -31,6 +31,22 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return r;
 }
 
+// PITCHED planes (round 5): the H rows of a plane are `pitch` elements apart (pitch > W; upf_conv_forward_pitched).  The statistics
+// visit the plane's H*W LOGICAL elements in exactly the order — and with exactly the thread assignment — of the contiguous form
+// (flat index i <-> row i / W, column i % W), so a pitched tensor and its contiguous copy get the same bits; only the addresses
+// differ, and a run of 8 flat elements, which may cross a row end, is gathered element by element.
+struct FlatWalk {
+  int r, c;
+  __device__ __forceinline__ FlatWalk(int i, int W) { r = i / W; c = i - r * W; }
+  __device__ __forceinline__ void step(int qr, int qc, int W) { r += qr; c += qc; if (c >= W) { c -= W; ++r; } }
+  __device__ __forceinline__ size_t at(int pitch) const { return (size_t)r * pitch + c; }
+};
+template <typename T, int V>
+__device__ __forceinline__ void gather_run(const T* __restrict__ plane, FlatWalk w, int W, int pitch, float (&v)[V]) {
+#pragma unroll
+  for (int k = 0; k < V; ++k) { v[k] = Elem<T>::load(plane + w.at(pitch)); w.step(0, 1, W); }
+}
+
 // Rows are split into `nseg` segments so that the grid fills the chip even when B*C is small
 // (config 5: 32 rows of 172,800 elements).  Deterministic two-launch scheme, no atomics:
 //   stats kernel : every (row, segment) workgroup writes (count, mean, M2) of its segment to `ws`;
@@ -42,25 +58,41 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 template <typename T, bool VEC>
 __global__ __launch_bounds__(NT)
 void normalize_stats_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, int nseg, int seglen,
-                            const T* __restrict__ x2 = nullptr, size_t rows1 = ~(size_t)0, float2* __restrict__ fin = nullptr) {
+                            const T* __restrict__ x2 = nullptr, size_t rows1 = ~(size_t)0, float2* __restrict__ fin = nullptr,
+                            int W = 0, int pitch = 0) {
   __shared__ float sh[NT / 64];
   constexpr int V = VEC ? VecIO<T>::N : 1;
   const size_t row = blockIdx.x / nseg;
   const int seg = blockIdx.x - (int)row * nseg;
   const int i0 = seg * seglen, i1 = min(HW, i0 + seglen);
-  const T* xr = (row < rows1) ? x + row * HW : x2 + (row - rows1) * HW;      // (two tensors in one launch: rows >= rows1 -> x2)
+  const bool pitched = W > 0 && pitch != W;                                   // (uniform)
+  const size_t pstride = pitched ? (size_t)(HW / W) * pitch : (size_t)HW;     // elements per (n, c) plane
+  const T* xr = (row < rows1) ? x + row * pstride : x2 + (row - rows1) * pstride;      // (two tensors in one launch: rows >= rows1 -> x2)
   const float cnt = (float)(i1 - i0);
   float mean, m2;
   if constexpr (sizeof(typename Elem<T>::store_t) == 2) {
     // 16-bit features: ONE sweep — sums of (x - K) and (x - K)^2 about a pivot K taken from the segment
     // itself, so that M2 = s2 - s1^2/n loses at most a bit or two (far below the bf16/fp16 output rounding)
-    const float K = Elem<T>::load(xr + i0);
     float s1 = 0.f, s2 = 0.f;
+    float K;
+    if (pitched) {
+      K = Elem<T>::load(xr + FlatWalk(i0, W).at(pitch));
+      FlatWalk w(i0 + threadIdx.x * V, W);
+      const int qr = (NT * V) / W, qc = (NT * V) - qr * W;
+      for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V, w.step(qr, qc, W)) {
+        float v[V];
+        gather_run<T, V>(xr, w, W, pitch, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
+      }
+    } else {
+    K = Elem<T>::load(xr + i0);
     for (int i = i0 + threadIdx.x * V; i < i1; i += NT * V) {
       if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
 #pragma unroll
         for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
       } else { const float d = Elem<T>::load(xr + i) - K; s1 += d; s2 += d * d; }
+    }
     }
     const float t1 = block_sum(s1, sh), t2 = block_sum(s2, sh);
     mean = K + t1 / cnt;
@@ -112,19 +144,32 @@ constexpr int WAVE_ROWS = 8;
 template <typename T, bool VEC>
 __global__ __launch_bounds__(WAVE_ROWS * 64)
 void normalize_stats_wave_kernel(const T* __restrict__ x, float* __restrict__ ws, int HW, size_t rows,
-                                 const T* __restrict__ x2, size_t rows1, float2* __restrict__ fin = nullptr) {
+                                 const T* __restrict__ x2, size_t rows1, float2* __restrict__ fin = nullptr, int W = 0, int pitch = 0) {
   constexpr int V = VEC ? VecIO<T>::N : 1;
   const size_t row = (size_t)blockIdx.x * WAVE_ROWS + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
-  const T* xr = (row < rows1) ? x + row * HW : x2 + (row - rows1) * HW;
+  const bool pitched = W > 0 && pitch != W;
+  const size_t pstride = pitched ? (size_t)(HW / W) * pitch : (size_t)HW;
+  const T* xr = (row < rows1) ? x + row * pstride : x2 + (row - rows1) * pstride;
   const float K = Elem<T>::load(xr);
   float s1 = 0.f, s2 = 0.f;
+  if (pitched) {
+    FlatWalk w(lane * V, W);
+    const int qr = (64 * V) / W, qc = (64 * V) - qr * W;
+    for (int i = lane * V; i < HW; i += 64 * V, w.step(qr, qc, W)) {
+      float v[V];
+      gather_run<T, V>(xr, w, W, pitch, v);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
+    }
+  } else {
   for (int i = lane * V; i < HW; i += 64 * V) {
     if constexpr (VEC) { float v[VecIO<T>::N]; VecIO<T>::load(xr + i, v);
 #pragma unroll
       for (int k = 0; k < V; ++k) { const float d = v[k] - K; s1 += d; s2 += d * d; }
     } else { const float d = Elem<T>::load(xr + i) - K; s1 += d; s2 += d * d; }
+  }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
@@ -400,29 +445,34 @@ static int normalize_nseg(long long N, int HW) {
 // small planes of 16-bit features: the one-wave-per-row kernel (see normalize_stats_wave_kernel)
 static bool stats_wave_form(int nseg, int HW, int dtype) { return nseg == 1 && HW <= 4096 && dtype != UPF_F32; }
 template <typename T>
-static void launch_stats_wave(const T* x1, const T* x2, float* ws, size_t rows, size_t rows1, int HW, bool vec, hipStream_t stream, float2* fin = nullptr) {
+static void launch_stats_wave(const T* x1, const T* x2, float* ws, size_t rows, size_t rows1, int HW, bool vec, hipStream_t stream, float2* fin = nullptr,
+                              int W = 0, int pitch = 0) {
   const unsigned grid = (unsigned)((rows + upf::misc::WAVE_ROWS - 1) / upf::misc::WAVE_ROWS);
-  if (vec) hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, true>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1, fin);
-  else hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, false>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1, fin);
+  if (vec) hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, true>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1, fin, W, pitch);
+  else hipLaunchKernelGGL((upf::misc::normalize_stats_wave_kernel<T, false>), dim3(grid), dim3(upf::misc::WAVE_ROWS * 64), 0, stream, x1, ws, HW, rows, x2, rows1, fin, W, pitch);
 }
 
 // statistics of TWO [N,HW] tensors in one launch -> ws[(2N rows)][nseg][3] partials and fin[2N] final (mean, 1/std) pairs (the
 // statistics kernel writes them itself where a row is one segment; a small second launch merges the partials otherwise);
 // returns nseg (internal.hpp)
-int upf::misc::launch_stats2(const void* x1, const void* x2, float* ws, float2* fin, long long N, int HW, int dtype, hipStream_t stream) {
+int upf::misc::launch_stats2(const void* x1, const void* x2, float* ws, float2* fin, long long N, int HW, int dtype, hipStream_t stream, int W, int pitch) {
   const int nseg = normalize_nseg(2 * N, HW);
   const int seglen = cdiv(HW, nseg);
   const unsigned grid = (unsigned)(2 * N * nseg);
   const int vn = (dtype == UPF_F32) ? 4 : 8;
-  const bool vec = (HW % vn == 0) && (seglen % vn == 0) && aligned_to(x1, 16) && aligned_to(x2, 16);
+  const bool pitched = W > 0 && pitch != W;
+  // (pitched planes: the summation order of the CONTIGUOUS form of the same shape — 8-element runs when its rows would allow vector
+  //  loads — with gathered addresses)
+  const bool vec = (HW % vn == 0) && (seglen % vn == 0) && (pitched || (aligned_to(x1, 16) && aligned_to(x2, 16)));
+  if (!pitched) { W = 0; pitch = 0; }
   if (stats_wave_form(nseg, HW, dtype)) {
-    if (dtype == UPF_BF16) launch_stats_wave<bf16_t>((const bf16_t*)x1, (const bf16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream, fin);
-    else launch_stats_wave<f16_t>((const f16_t*)x1, (const f16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream, fin);
+    if (dtype == UPF_BF16) launch_stats_wave<bf16_t>((const bf16_t*)x1, (const bf16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream, fin, W, pitch);
+    else launch_stats_wave<f16_t>((const f16_t*)x1, (const f16_t*)x2, ws, (size_t)(2 * N), (size_t)N, HW, vec, stream, fin, W, pitch);
     return nseg;
   }
   UPF_DISPATCH(dtype, T,
-               if (vec) hipLaunchKernelGGL((misc::normalize_stats_kernel<T, true>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N, fin);
-               else hipLaunchKernelGGL((misc::normalize_stats_kernel<T, false>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N, fin));
+               if (vec) hipLaunchKernelGGL((misc::normalize_stats_kernel<T, true>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N, fin, W, pitch);
+               else hipLaunchKernelGGL((misc::normalize_stats_kernel<T, false>), dim3(grid), dim3(misc::NT), 0, stream, (const T*)x1, ws, HW, nseg, seglen, (const T*)x2, (size_t)N, fin, W, pitch));
   if (fin && nseg > 1)
     hipLaunchKernelGGL(misc::stats_finalize_kernel, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, stream, (const float*)ws, fin, 2 * N, nseg, HW);
   return nseg;

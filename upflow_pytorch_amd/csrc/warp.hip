@@ -34,17 +34,17 @@ struct PixelTaps {
   bool valid;
 };
 
-__device__ __forceinline__ PixelTaps make_pixel(const float* __restrict__ flow_n, int p, int H, int W, int mask_mode, SampleGeom sg) {
+// xp: row pitch of x in elements (>= W; = W for a contiguous plane)
+__device__ __forceinline__ PixelTaps make_pixel(const float* __restrict__ flow_n, int i, int j, int H, int W, int xp, int mask_mode, SampleGeom sg) {
   PixelTaps r;
-  const int HW = H * W;
-  const int i = p / W, j = p - i * W;
+  const int HW = H * W, p = i * W + j;
   const float fx = flow_n[p], fy = flow_n[HW + p];
   const Taps t = make_taps(j, i, fx, fy, H, W, sg);
   r.valid = taps_valid(t, mask_mode, j, i, fx, fy, H, W);
   const int pc = min(max(t.x0, 0), W - 2);
   const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
-  r.oT = ya * W + pc;
-  r.oB = yb * W + pc;
+  r.oT = ya * xp + pc;
+  r.oB = yb * xp + pc;
   // weight of image column c for the (x0, x0+1) taps of a row whose taps have weights (w_a, w_b)
   auto colw = [&](int c, float w_a, bool in_a, float w_b, bool in_b) {
     return (c == t.x0 && in_a) ? w_a : ((c == t.x0 + 1 && in_b) ? w_b : 0.f);
@@ -85,25 +85,34 @@ __device__ __forceinline__ float sample(const T* __restrict__ plane, const Pixel
 }
 
 // PXT consecutive pixels of a row per thread, W >= 2: 4 when rows keep pixel quads aligned (8-byte stores for 16-bit
-// features, 16-byte for fp32; 4x the gathers in flight per wave), 2 for 16-bit types with even W, else 1.
+// features, 16-byte for fp32; 4x the gathers in flight per wave), 2 for 16-bit types with even rows, else 1.
+// Round 5: rows of x / y are `xp` / `yp` elements apart (the flow is a contiguous fp32 tensor).  A thread owns the pixels
+// [PXT * g, PXT * g + PXT) of ONE row (g < ceil(W / PXT)); with a ragged W and a pitch that covers the rounded-up row the
+// pixels at or beyond W are computed as zeros and stored into the row's own pitch padding — so odd-width pyramid levels
+// (311, 39 ...) keep the 4-byte stores.  For W % PXT == 0 and yp = W this is the flat mapping of rounds 1-4.
 template <typename T, int PXT>
 __global__ __launch_bounds__(THREADS)
 void warp_fwd_kernel(const T* __restrict__ x, long long xbs, const float* __restrict__ flow, T* __restrict__ y, long long ybs,
-                     int C, int H, int W, int cpt, int mask_mode, int shift, SampleGeom sg) {
-  const int HW = H * W;
-  const int p0 = (blockIdx.x * THREADS + threadIdx.x) * PXT;
-  if (p0 >= HW) return;
+                     int C, int H, int W, int cpt, int mask_mode, int shift, SampleGeom sg, int xp, int yp) {
+  const int Wg = (W + PXT - 1) / PXT;
+  const int g0 = blockIdx.x * THREADS + threadIdx.x;
+  if (g0 >= H * Wg) return;
+  const int i = g0 / Wg, j0 = (g0 - i * Wg) * PXT;
   const int n = blockIdx.z;
   const int ns = (n + shift) % (int)gridDim.z;          // source image (batch_shift: sample the OTHER frame of a stacked pair)
   const int c_begin = blockIdx.y * cpt, c_end = min(C, c_begin + cpt);
-  const float* fl = flow + (size_t)n * 2 * HW;
+  const float* fl = flow + (size_t)n * 2 * H * W;
   PixelTaps s[PXT];
 #pragma unroll
-  for (int k = 0; k < PXT; ++k) s[k] = make_pixel(fl, p0 + k, H, W, mask_mode, sg);
-  const T* xb = x + (size_t)ns * xbs + (size_t)c_begin * HW;          // x / y may be channel slices of wider buffers
-  T* yb = y + (size_t)n * ybs + (size_t)c_begin * HW + p0;
+  for (int k = 0; k < PXT; ++k) {
+    if (PXT == 1 || j0 + k < W) s[k] = make_pixel(fl, i, j0 + k, H, W, xp, mask_mode, sg);
+    else { s[k].valid = false; s[k].oT = s[k].oB = 0; s[k].wlT = s[k].whT = s[k].wlB = s[k].whB = 0.f; }
+  }
+  const size_t xplane = (size_t)H * xp, yplane = (size_t)H * yp;
+  const T* xb = x + (size_t)ns * xbs + (size_t)c_begin * xplane;          // x / y may be channel slices of wider buffers
+  T* yb = y + (size_t)n * ybs + (size_t)c_begin * yplane + (size_t)i * yp + j0;
 #pragma unroll 4
-  for (int c = c_begin; c < c_end; ++c, xb += HW, yb += HW) {
+  for (int c = c_begin; c < c_end; ++c, xb += xplane, yb += yplane) {
     float r[PXT];
 #pragma unroll
     for (int k = 0; k < PXT; ++k) r[k] = s[k].valid ? sample<T>(xb, s[k]) : 0.f;
@@ -293,35 +302,45 @@ void warp_c8_kernel(const T* __restrict__ x, long long xbs, const float* __restr
 }  // namespace warp
 }  // namespace upf
 
-extern "C" int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
-                                        int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream) {
+extern "C" int upf_warp_forward_pitched(const void* x, long long x_batch_stride, int x_row_pitch, const float* flow, void* y, long long y_batch_stride,
+                                        int y_row_pitch, int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream) {
   using namespace upf;
   UPF_REQUIRE(x && flow && y, UPF_EINVAL, "warp_forward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, UPF_EINVAL, "warp_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(mask_mode >= UPF_MASK_NONE && mask_mode <= UPF_MASK_ROBUST, UPF_EINVAL, "warp_forward: bad mask_mode %d", mask_mode);
   UPF_REQUIRE(batch_shift >= 0 && batch_shift < B, UPF_EINVAL, "warp_forward: batch_shift %d not in [0,%d)", batch_shift, B);
+  const int xp = x_row_pitch ? x_row_pitch : W, yp = y_row_pitch ? y_row_pitch : W;
+  UPF_REQUIRE(xp >= W && yp >= W, UPF_EINVAL, "warp_forward: row pitch smaller than W (%d, %d < %d)", xp, yp, W);
   const int HW = H * W;
-  const long long xbs = x_batch_stride ? x_batch_stride : (long long)C * HW, ybs = y_batch_stride ? y_batch_stride : (long long)C * HW;
-  UPF_REQUIRE(xbs >= (long long)C * HW && ybs >= (long long)C * HW, UPF_EINVAL, "warp_forward: batch stride smaller than C*H*W");
+  const long long xbs = x_batch_stride ? x_batch_stride : (long long)C * H * xp, ybs = y_batch_stride ? y_batch_stride : (long long)C * H * yp;
+  UPF_REQUIRE(xbs >= (long long)C * H * xp - (xp - W) && ybs >= (long long)C * H * yp - (yp - W), UPF_EINVAL, "warp_forward: batch stride smaller than C*H*pitch");
   hipStream_t st = (hipStream_t)stream;
   const SampleGeom sg = make_sample_geom(H, W);
   if (W < 2) {
+    UPF_REQUIRE(xp == W && yp == W, UPF_EUNSUPPORTED, "warp_forward: W < 2 with pitched rows");
     UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((warp::warp_fwd_narrow_kernel<T>), dim3(cdiv(HW, warp::THREADS), 1, B), dim3(warp::THREADS), 0, st,
                                               (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, mask_mode, batch_shift, sg));
     return check_launch("warp_forward");
   }
   // (4 consecutive pixels per thread with 8 / 16-byte stores were measured SLOWER for 16-bit features, 12.6 -> 16.2 us at
   //  [4,32,96,320]: every gather instruction then spans 4x the cache lines; fp32 gained 12 %: kept for fp32 only)
-  const bool four = (dtype == UPF_F32) && (W % 4 == 0) && aligned_to(y, 16) && ybs % 4 == 0 && (long long)B * HW >= 4 * 64 * 256;
-  const bool two = !four && (dtype != UPF_F32) && (W % 2 == 0) && aligned_to(y, 4) && ybs % 2 == 0;
+  // pixel pairs / quads: the OUTPUT rows must keep them aligned and hold the rounded-up row (W % n == 0, or pitch padding behind it)
+  const bool four = (dtype == UPF_F32) && (yp % 4 == 0) && (W % 4 == 0) && aligned_to(y, 16) && ybs % 4 == 0 && (long long)B * HW >= 4 * 64 * 256;
+  const bool two = !four && (dtype != UPF_F32) && (yp % 2 == 0) && aligned_to(y, 4) && ybs % 2 == 0;     // (yp even => yp >= W rounded up to 2)
   const int pxt = four ? 4 : (two ? 2 : 1);
-  const int cpt = warp::pick_cpt(B, C, HW / pxt);
-  dim3 grid(cdiv(cdiv(HW, pxt), warp::THREADS), cdiv(C, cpt), B);
+  const int ngroups = H * cdiv(W, pxt);
+  const int cpt = warp::pick_cpt(B, C, ngroups);
+  dim3 grid(cdiv(ngroups, warp::THREADS), cdiv(C, cpt), B);
   UPF_DISPATCH(dtype, T,
-               if (four) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 4>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg);
-               else if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg);
-               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg));
+               if (four) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 4>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg, xp, yp);
+               else if (two) hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 2>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg, xp, yp);
+               else hipLaunchKernelGGL((warp::warp_fwd_kernel<T, 1>), grid, dim3(warp::THREADS), 0, st, (const T*)x, xbs, flow, (T*)y, ybs, C, H, W, cpt, mask_mode, batch_shift, sg, xp, yp));
   return check_launch("warp_forward");
+}
+
+extern "C" int upf_warp_forward_strided(const void* x, long long x_batch_stride, const float* flow, void* y, long long y_batch_stride,
+                                        int B, int C, int H, int W, int dtype, int mask_mode, int batch_shift, void* stream) {
+  return upf_warp_forward_pitched(x, x_batch_stride, 0, flow, y, y_batch_stride, 0, B, C, H, W, dtype, mask_mode, batch_shift, stream);
 }
 
 extern "C" int upf_warp_forward(const void* x, const float* flow, void* y, int B, int C, int H, int W,

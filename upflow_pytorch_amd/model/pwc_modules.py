@@ -95,14 +95,15 @@ class FeatureExtractor(nn.Module):
             nn.Sequential(conv(ci, co, stride=2), conv(co, co, isReLU=if_end_relu, if_IN=if_end_norm))
             for ci, co in zip(num_chs[:-1], num_chs[1:]))
 
-    def forward(self, x, outs=None):
-        """outs (inference fast path): per stage, None or the [B, C, H, W] view the stage's output is written to."""
+    def forward(self, x, outs=None, pitched=False):
+        """outs (inference fast path): per stage, None or the [B, C, H, W] view the stage's output is written to.
+        pitched: the stages' own intermediates are allocated with 16-byte aligned rows (ops.empty_nchw) where their width is ragged."""
         pyramid = []
         cache = self.__dict__.setdefault('_fast_cache', {})
         hip = getattr(self, 'hip_convs', True)         # False: PyTorch-ROCm (MIOpen) even where the MFMA kernel applies
         for i, stage in enumerate(self.convs):
-            x = fast_conv_seq(stage[0], x, cache, allow_hip=hip)      # stride-2 conv
-            x = fast_conv_seq(stage[1], x, cache, out=None if outs is None else outs[i], allow_hip=hip)   # stride-1 conv
+            x = fast_conv_seq(stage[0], x, cache, allow_hip=hip, pitched=pitched)      # stride-2 conv
+            x = fast_conv_seq(stage[1], x, cache, out=None if outs is None else outs[i], allow_hip=hip, pitched=pitched)   # stride-1 conv
             pyramid.append(x)
         return pyramid[::-1]
 
@@ -264,15 +265,19 @@ class _PackedConvC8(object):
 
 
 def c8_level_ok(nb, H, W, dtype):
-    """Levels whose dense stacks run in the channel-octet layout (ops.conv_c8_*): 16-bit, rows of whole 8-pixel groups, and a
-    grid that fills the chip (the C8 kernels have no split-K form for the coarse levels)."""
-    return dtype in (torch.bfloat16, torch.float16) and W % 8 == 0 and nb * ((W + 31) // 32) * ((H + 7) // 8) >= 200
+    """Levels whose dense stacks run in the channel-octet layout (ops.conv_c8_*): 16-bit and a grid that fills the chip (the C8
+    kernels have no split-K form for the coarse levels).  Any width (round 5): a pixel of an octet tensor is one 16-byte entry, so
+    its rows are aligned whatever W is; the NCHW tensors that feed the octet kernels (pyramid features, the frames) are kept
+    row-pitched at ragged levels (ops.empty_nchw).  Rounds 3-4 required W % 8 == 0, which no level of a native KITTI frame meets."""
+    return dtype in (torch.bfloat16, torch.float16) and nb * ((W + 31) // 32) * ((H + 7) // 8) >= 200
 
 
-def fast_conv_seq(seq, x, cache, out=None, allow_hip=True):
+def fast_conv_seq(seq, x, cache, out=None, allow_hip=True, pitched=False):
     """Run one `conv(...)` Sequential (Conv2d [+ LeakyReLU]) — through the matrix-core kernel when it is a
     3x3 (stride 1/2, dilation <= 16) or 1x1 convolution in an eligible inference setting, through MIOpen otherwise.  `cache` is a dict
-    that keeps the packed weights per Sequential.  `out`: optional destination (a channel slice of a wider NCHW buffer)."""
+    that keeps the packed weights per Sequential.  `out`: optional destination (a channel slice of a wider NCHW buffer).
+    pitched: a result this function allocates gets 16-byte aligned rows at ragged widths (ops.empty_nchw) — for consumers that are
+    pitch-aware (the convolutions, ops.warp_into, the fused cost volume)."""
     c = seq[0]
     k = c.kernel_size[0]
     if (allow_hip and _fast_conv_ok(x) and c.kernel_size in ((3, 3), (1, 1)) and c.stride[0] == c.stride[1] and c.groups == 1 and len(seq) <= 2
@@ -283,7 +288,7 @@ def fast_conv_seq(seq, x, cache, out=None, allow_hip=True):
         if pc is None:
             pc = cache[id(seq)] = _PackedConv3x3(seq)
         ho, wo = ops.conv3x3_out_hw(x.shape[2], x.shape[3], c.stride[0])
-        y = out if out is not None else torch.empty((x.shape[0], c.out_channels, ho, wo), dtype=x.dtype, device=x.device)
+        y = out if out is not None else ops.empty_nchw((x.shape[0], c.out_channels, ho, wo), x.dtype, x.device, pitched=pitched)
         return pc(x, y)
     if torch.is_grad_enabled() and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and c.weight.dtype == torch.float32:
         y = train_conv_seq(seq, x)                       # training on the matrix cores: 16-bit activations, fp32 master weights

@@ -95,8 +95,9 @@ class network_tools():
                 tap('sgu_x_out', x_out)
             return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)
 
-        def output_conv(self, x, out=None, out8=None):
-            """out8: octet slice of a channel-octet buffer the LAST layer writes instead of `out` (forward_in_buffer_c8)."""
+        def output_conv(self, x, out=None, out8=None, pitched=False):
+            """out8: octet slice of a channel-octet buffer the LAST layer writes instead of `out` (forward_in_buffer_c8).
+            pitched: intermediates with 16-byte aligned rows at ragged widths (ops.empty_nchw)."""
             cache = self.__dict__.setdefault('_fast_cache', {})
             n = len(self.upsample_output_conv)
             for i, seq in enumerate(self.upsample_output_conv):       # matrix-core kernel when eligible
@@ -105,7 +106,7 @@ class network_tools():
                     if pc is None:
                         pc = cache['c8_last'] = _PackedConvC8(seq, (), range(seq[0].in_channels))
                     return pc(None, x, out8)
-                x = fast_conv_seq(seq, x, cache, out=out if i == n - 1 else None)
+                x = fast_conv_seq(seq, x, cache, out=out if i == n - 1 else None, pitched=pitched)
             return x
 
     @classmethod
@@ -367,7 +368,10 @@ class UPFlow_net(tools.abstract_model):
             # batch halve the launch count and double every convolution's batch; `stacked_training = False` restores
             # the reference's per-direction schedule below)
             B = x1_raw.shape[0]
-            X = torch.empty((2 * B,) + tuple(x1_raw.shape[1:]), dtype=cdt, device=x1_raw.device)
+            # (16-bit inference: rows pitched to 16 bytes when the frame width is ragged — KITTI's native 1242 — so that the stem
+            # and the first pyramid stage take the aligned kernels; ops.empty_nchw.  `_no_pitch = True`: contiguous everywhere)
+            X = ops.empty_nchw((2 * B,) + tuple(x1_raw.shape[1:]), cdt, x1_raw.device,
+                               pitched=self._pitched() and not torch.is_grad_enabled() and x1_raw.is_cuda)
             X[:B].copy_(x1_raw)                         # cast + stack in one pass per frame (was: two casts, then a cat)
             X[B:].copy_(x2_raw)
             tdt = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(getattr(self.conf, 'train_conv_dtype', 'fp32'))
@@ -452,6 +456,9 @@ class UPFlow_net(tools.abstract_model):
         f_out, b_out = ops.split_batch(flow_out, B)
         return f_out, b_out, flows[::-1]
 
+    def _pitched(self):
+        return not getattr(self, '_no_pitch', False)
+
     def _tap(self, name, t):
         """Debug tap (tools/pipe_debug3.py): with `net._taps = []` every named intermediate BUFFER of the fast schedule is kept
         (a reference, no copy, no launch) so that two runs can be compared tensor by tensor."""
@@ -473,9 +480,12 @@ class UPFlow_net(tools.abstract_model):
         nlev = self.output_level + 1
         nc = self.dim_corr
         shapes = fpe.out_shapes(X.shape[2], X.shape[3])[::-1]                 # coarsest first, like the pyramid
-        pairs = [torch.empty((2, nb) + shp, dtype=dt, device=dev) for shp in shapes[:nlev]]
+        pit = self._pitched()
+        # [features; warped other frame] per level; rows pitched to 16 bytes at ragged levels (ops.empty_nchw): every consumer —
+        # the next pyramid stage, the 1x1 convolution, the warp, the statistics + cost volume — is pitch-aware
+        pairs = [ops.empty_nchw((2, nb) + shp, dt, dev, pitched=pit) for shp in shapes[:nlev]]
         outs = ([p[0] for p in pairs] + [None] * (len(shapes) - nlev))[::-1]   # stage order: finest first
-        pyramid = fpe(X, outs=outs)
+        pyramid = fpe(X, outs=outs, pitched=pit)
         self._tap('X', X)
         for i_, p_ in enumerate(pyramid):
             self._tap('pyramid%d' % i_, p_)
@@ -487,7 +497,8 @@ class UPFlow_net(tools.abstract_model):
             use_sgu = sgu and level > 0
             # large grids: the SGU stack and the context network run in the channel-octet layout (same arithmetic, same
             # summation order: bit-identical outputs; `_no_c8 = True` keeps NCHW everywhere)
-            c8 = c8_level_ok(nb, H, W, dt) and not getattr(self, '_no_c8', False)
+            # (the octet kernels take any W; the NCHW tensors feeding them need 16-byte aligned rows: W % 8 == 0 or pitched buffers)
+            c8 = c8_level_ok(nb, H, W, dt) and (W % 8 == 0 or (pit and W >= 8)) and not getattr(self, '_no_c8', False)
             # ... and so does the flow estimator when the cost volume can write octets (`_no_c8_est = True`: estimator in NCHW).
             # Its K order differs from the NCHW kernel's (81 cost-volume channels in 11 octets, flows padded to an octet), so
             # this part agrees with the NCHW path to fp32 summation order, not bit for bit.
@@ -532,12 +543,13 @@ class UPFlow_net(tools.abstract_model):
                 # statistics pass + cost volume whose loader normalises: the normalised maps are never materialised
                 ops.corr81_norm_forward_raw(pair[0], pair[1], out=slot[:, :nc], leaky_slope=0.1)
             else:
-                normed = ops.normalize(pair.view(2 * nb, C, H, W))            # rows are (item, channel): one launch pair
+                normed = ops.normalize(pair.reshape(2 * nb, C, H, W))         # rows are (item, channel): one launch pair
                 ops.corr81_forward_raw(normed[:nb], normed[nb:], out=slot[:, :nc], leaky_slope=0.1)
             ops.flow_update(flow_up, out=slot[:, nc + 32:])
             _, res = est.forward_in_buffer(buf)
             ops.flow_update(flow_up, res, out=buf[:, est._n_total:])          # flow_up + res -> context network input
-            fine = self.context_networks.forward_c8(buf) if (c8 and not getattr(self, '_no_c8_ctx', False)) else self.context_networks(buf)
+            # (forward_c8's first layer reads `buf` as NCHW planes: a contiguous buffer has aligned rows only for W % 8 == 0)
+            fine = self.context_networks.forward_c8(buf) if (c8 and W % 8 == 0 and not getattr(self, '_no_c8_ctx', False)) else self.context_networks(buf)
             flow = ops.flow_update(flow_up, res, fine)                        # flow_up + (res + fine)
             flows.append([flow[:B], flow[B:]])
             self._tap('L%d.pair' % level, pair)
@@ -567,15 +579,21 @@ class UPFlow_net(tools.abstract_model):
         H4, W4 = hw4
         dt, dev = X.dtype, X.device
         last = sgi.upsample_output_conv[-1][0]
-        if (c8_level_ok(nb, H4, W4, dt) and not getattr(self, '_no_c8', False) and not getattr(self, '_no_c8_sgu', False) and em.c8_ok() and X.shape[3] % 32 == 0
-                and last.stride[0] == 2 and last.in_channels > 16 and last.out_channels == em._ch_in // 2
-                and ops.conv3x3_out_hw(X.shape[2] // 2, X.shape[3] // 2, 2) == (H4, W4) and X.shape[2] % 2 == 0):
+        hw = (X.shape[2], X.shape[3])
+        for seq_ in sgi.upsample_output_conv:                                   # size of the stem's output (two stride-2 layers)
+            hw = ops.conv3x3_out_hw(hw[0], hw[1], seq_[0].stride[0])
+        pit = self._pitched()
+        # (the stem's last layer reads NCHW rows: 16-byte aligned ones — a width that is a multiple of 8, or pitched intermediates)
+        w_last = ops.conv3x3_out_hw(X.shape[2], X.shape[3], sgi.upsample_output_conv[1][0].stride[0])[1]
+        if (c8_level_ok(nb, H4, W4, dt) and not getattr(self, '_no_c8', False) and not getattr(self, '_no_c8_sgu', False) and em.c8_ok()
+                and (w_last % 8 == 0 or (pit and w_last >= 8))
+                and last.stride[0] == 2 and last.in_channels > 16 and last.out_channels == em._ch_in // 2 and hw == (H4, W4)):
             sbuf8 = ops.c8_empty(nb, em._n_total, H4, W4, dt, dev)
             o0 = (em._n_total - em._ch_in) // 8
-            sgi.output_conv(X, out8=sbuf8[:, o0:o0 + em._ch_in // 16])          # the guidance stem's last layer writes octets
+            sgi.output_conv(X, out8=sbuf8[:, o0:o0 + em._ch_in // 16], pitched=pit)   # the guidance stem's last layer writes octets
             return ('c8', sbuf8)
         sbuf, sslot = em.alloc_buffer(nb, H4, W4, dt, dev)
-        G = sgi.output_conv(X, out=sslot[:, :32])
+        G = sgi.output_conv(X, out=sslot[:, :32], pitched=pit)
         if tuple(G.shape[2:]) != (H4, W4):
             raise RuntimeError('sgu output_conv / flow size mismatch %s vs %s' % (tuple(G.shape), (H4, W4)))
         return ('nchw', sbuf, sslot)

@@ -20,6 +20,55 @@ def _f32(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# pitched NCHW tensors (round 5)
+# ------------------------------------------------------------------------------------------------
+# A 16-bit NCHW tensor of a RAGGED pyramid level (KITTI's native 375x1242 frames: W = 621, 311, 156, 78, 39, 20 — never a multiple
+# of 8, often odd) has rows that are not even 4-byte aligned.  The inference schedule therefore keeps such tensors PITCHED: allocated
+# as [B,C,H,Wp] with Wp = W rounded up to 8 and used through the view [..., :W] (shape [B,C,H,W], strides (C*H*Wp, H*Wp, Wp, 1)).
+# Every row then starts on a 16-byte boundary and the kernels take their aligned forms (include/upflow_hip.h: the *_pitched entry
+# points); nothing depends on what the padding columns hold.  torch operators see an ordinary strided view.
+PITCH_MULTIPLE = 8
+
+
+def empty_nchw(shape, dtype, device, pitched=True):
+    """torch.empty(shape) for a [..., H, W] tensor; `pitched` and a 16-bit dtype and a W >= 8 that is not a multiple of 8: the
+    pitched form described above."""
+    W = shape[-1]
+    if pitched and dtype in (torch.bfloat16, torch.float16) and W >= 8 and W % PITCH_MULTIPLE:
+        Wp = (W + PITCH_MULTIPLE - 1) // PITCH_MULTIPLE * PITCH_MULTIPLE
+        return torch.empty(tuple(shape[:-1]) + (Wp,), dtype=dtype, device=device)[..., :W]
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
+def nchw_pitch(t):
+    """Row pitch (elements) of a [B,C,H,W] tensor that is a channel slice of a (possibly pitched) NCHW buffer — unit-stride rows,
+    planes H * pitch apart, only the batch stride free — or None for any other layout."""
+    if t.dim() != 4:
+        return None
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if W > 1 and sw != 1:
+        return None
+    if H > 1:
+        p = sh
+    elif C > 1:
+        p = sc                      # (a single row per plane: the plane stride is the pitch)
+    else:
+        p = W
+    if p < W or (C > 1 and sc != H * p):
+        return None
+    return p
+
+
+def _pitch_or_raise(t, what):
+    p = nchw_pitch(t)
+    if p is None:
+        raise UpflowHipError('%s must be a channel slice of a (possibly row-pitched) contiguous NCHW buffer, got shape %s strides %s'
+                             % (what, tuple(t.shape), tuple(t.stride())))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------
 # cost volume
 # ------------------------------------------------------------------------------------------------
 def corr81_forward_raw(f1, f2, out=None, leaky_slope=0.0):
@@ -68,7 +117,8 @@ def corr81_norm_forward_raw(f1, f2, out=None, leaky_slope=0.0):
         raise UpflowHipError('corr81_norm: inputs must be two [B,C,H,W] tensors of one dtype, got %s %s / %s %s'
                              % (tuple(f1.shape), f1.dtype, tuple(f2.shape), f2.dtype))
     B, C, H, W = f1.shape
-    dev = _lib.check_gpu(f1, f2)
+    dev = _lib.check_gpu(f1, f2, contiguous=False)
+    fp = _feature_pair_pitch(f1, f2, 'corr81_norm')
     if out is None:
         out = torch.empty((B, 81, H, W), dtype=f1.dtype, device=f1.device)
         bstride = 0
@@ -80,9 +130,19 @@ def corr81_norm_forward_raw(f1, f2, out=None, leaky_slope=0.0):
         bstride = out.stride(0)
     ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
     with torch.cuda.device(dev):
-        _lib.call('upf_corr81_norm_forward', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(out), B, C, H, W,
+        _lib.call('upf_corr81_norm_forward_pitched', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out), B, C, H, W,
                   _lib.dtype_code(f1), bstride, float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
     return out
+
+
+def _feature_pair_pitch(f1, f2, who):
+    """Common row pitch of two whole [B,C,H,W] feature tensors (contiguous, or pitched: empty_nchw) — items C*H*pitch apart."""
+    p1, p2 = nchw_pitch(f1), nchw_pitch(f2)
+    B, C, H, W = f1.shape
+    if p1 is None or p1 != p2 or any(B > 1 and t.stride(0) != C * H * p1 for t in (f1, f2)):
+        raise UpflowHipError('%s: f1 / f2 must be whole NCHW tensors of one row pitch (contiguous or ops.empty_nchw), got strides %s / %s'
+                             % (who, tuple(f1.stride()), tuple(f2.stride())))
+    return p1
 
 
 CORR81_C8_OCTETS = 11
@@ -104,12 +164,15 @@ def corr81_norm_forward_c8(f1, f2, out8, leaky_slope=0.0):
     if f1.shape != f2.shape or f1.dim() != 4 or f1.dtype != f2.dtype:
         raise UpflowHipError('corr81_norm_c8: inputs must be two [B,C,H,W] tensors of one dtype')
     B, C, H, W = f1.shape
-    dev = _lib.check_gpu(f1, f2)
+    dev = _lib.check_gpu(f1, f2, contiguous=False)
     if not out8.is_cuda or tuple(out8.shape) != (B, CORR81_C8_OCTETS, H, W, 8) or not _c8_view_ok(out8) or out8.dtype != f1.dtype:
         raise UpflowHipError('corr81_norm_c8: out8 must be an octet slice [%d,11,%d,%d,8] of a C8 buffer, got %s' % (B, H, W, tuple(out8.shape)))
+    if nchw_pitch(f1) is None or nchw_pitch(f2) is None:
+        f1, f2 = f1.contiguous(), f2.contiguous()
+    fp = _feature_pair_pitch(f1, f2, 'corr81_norm_c8')
     ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
     with torch.cuda.device(dev):
-        _lib.call('upf_corr81_norm_forward_c8', _lib.ptr(f1.contiguous()), _lib.ptr(f2.contiguous()), _lib.ptr(out8), out8.stride(0), B, C, H, W,
+        _lib.call('upf_corr81_norm_forward_c8_pitched', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out8), out8.stride(0), B, C, H, W,
                   _lib.dtype_code(f1), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
     return out8
 
@@ -166,13 +229,14 @@ def corr81_norm_forward_c8_timed(f1, f2, out8, leaky_slope=0.0, nrep=50):
     the levels whose flow estimator runs in the channel-octet layout."""
     import ctypes
     B, C, H, W = f1.shape
-    dev = _lib.check_gpu(f1, f2)
+    dev = _lib.check_gpu(f1, f2, contiguous=False)
     if tuple(out8.shape) != (B, CORR81_C8_OCTETS, H, W, 8) or not _c8_view_ok(out8):
         raise UpflowHipError('corr81_norm_c8_timed: out8 must be an octet slice [%d,11,%d,%d,8]' % (B, H, W))
+    fp = _feature_pair_pitch(f1, f2, 'corr81_norm_c8_timed')
     ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
     avg, mn = ctypes.c_float(), ctypes.c_float()
     with torch.cuda.device(dev):
-        _lib.call('upf_corr81_norm_forward_c8_timed', _lib.ptr(f1), _lib.ptr(f2), _lib.ptr(out8), out8.stride(0), B, C, H, W,
+        _lib.call('upf_corr81_norm_forward_c8_timed_pitched', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out8), out8.stride(0), B, C, H, W,
                   _lib.dtype_code(f1), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev), int(nrep),
                   ctypes.byref(avg), ctypes.byref(mn))
     return avg.value, mn.value
@@ -326,8 +390,9 @@ def _is_channel_slice(t):
 def warp_into(x_view, flow, y_view, mask_mode='literal', batch_shift=0):
     """Inference-only warp whose input / output are channel slices of wider contiguous NCHW buffers (the
     concatenation buffers the convolutions read): no slot copies.  Returns y_view."""
-    if x_view.shape != y_view.shape or not _is_channel_slice(x_view) or not _is_channel_slice(y_view):
+    if x_view.shape != y_view.shape:
         raise UpflowHipError('warp_into: x / y must be equal-shape channel slices of contiguous NCHW buffers')
+    xp, yp = _pitch_or_raise(x_view, 'warp_into: x'), _pitch_or_raise(y_view, 'warp_into: y')
     flow = _f32(flow).contiguous()
     B, C, H, W = x_view.shape
     if flow.shape != (B, 2, H, W):
@@ -336,8 +401,8 @@ def warp_into(x_view, flow, y_view, mask_mode='literal', batch_shift=0):
     if not (x_view.is_cuda and y_view.is_cuda and flow.is_cuda) or x_view.dtype != y_view.dtype:
         raise UpflowHipError('warp_into: GPU tensors of one dtype expected (there is no CPU fallback)')
     with torch.cuda.device(dev):
-        _lib.call('upf_warp_forward_strided', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(flow), _lib.ptr(y_view), y_view.stride(0),
-                  B, C, H, W, _lib.dtype_code(x_view), _MASKS[mask_mode], int(batch_shift), _lib.stream_ptr(dev))
+        _lib.call('upf_warp_forward_pitched', _lib.ptr(x_view), x_view.stride(0) if B > 1 else 0, xp, _lib.ptr(flow), _lib.ptr(y_view),
+                  y_view.stride(0) if B > 1 else 0, yp, B, C, H, W, _lib.dtype_code(x_view), _MASKS[mask_mode], int(batch_shift), _lib.stream_ptr(dev))
     return y_view
 
 
@@ -647,10 +712,11 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
     Ho, Wo = conv3x3_out_hw(H, W, stride)
     if tuple(y_view.shape) != (B, Cout, Ho, Wo):
         raise UpflowHipError('conv: output must be [%d,%d,%d,%d], got %s' % (B, Cout, Ho, Wo, tuple(y_view.shape)))
-    if x_view.stride()[1:] != (H * W, W, 1) or y_view.stride()[1:] != (Ho * Wo, Wo, 1):
-        raise UpflowHipError('conv: operands must be channel slices of contiguous NCHW buffers')
+    xp, yp = _pitch_or_raise(x_view, 'conv: x'), _pitch_or_raise(y_view, 'conv: y')
     dev = x_view.device
     if x_view.dtype == torch.float32:
+        if xp != W or yp != Wo:
+            raise UpflowHipError('conv (fp32, split precision): contiguous rows expected (no row pitch)')
         if y_view.dtype != torch.float32 or packed.dtype != torch.float16:
             raise UpflowHipError('conv (fp32, split precision): fp32 output and weights packed from fp32 expected')
         with torch.cuda.device(dev):
@@ -659,8 +725,8 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
                       float(leaky_slope), int(CONV_X3_NPROD[0]), _lib.stream_ptr(dev))
         return y_view
     with torch.cuda.device(dev):
-        _lib.call('upf_conv_forward', _lib.ptr(x_view), x_view.stride(0), _lib.ptr(packed), _lib.ptr(bias32),
-                  _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
+        _lib.call('upf_conv_forward_pitched', _lib.ptr(x_view), x_view.stride(0), xp, _lib.ptr(packed), _lib.ptr(bias32),
+                  _lib.ptr(y_view), y_view.stride(0), yp, B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
                   float(leaky_slope), _lib.dtype_code(x_view), _lib.stream_ptr(dev))
     return y_view
 
@@ -771,7 +837,7 @@ def _c8_view_ok(t):
 
 def conv_c8_supported(H, W, dtype, Cout, dilation, kernel_size, has_c8_in, has_tail, y_is_c8):
     """What upf_conv_forward_c8 takes (stride 1)."""
-    if dtype not in (torch.bfloat16, torch.float16) or W % 8:
+    if dtype not in (torch.bfloat16, torch.float16) or (W % 8 and has_tail):      # (an NCHW input part needs aligned rows: W % 8 == 0 or a pitch)
         return False
     if kernel_size == 1:
         return (not has_c8_in) and has_tail and y_is_c8 and Cout <= 32
@@ -790,18 +856,20 @@ def conv_c8_forward_raw(x8, x2, packed, bias32, y, dilation=1, leaky_slope=0.0, 
     Ho, Wo = conv3x3_out_hw(H, W, stride)
     if x8 is not None and not _c8_view_ok(x8):
         raise UpflowHipError('conv_c8: x8 must be an octet slice of a contiguous C8 buffer')
-    if x2 is not None and x2.stride()[1:] != (H * W, W, 1):
-        raise UpflowHipError('conv_c8: x2 must be a channel slice of a contiguous NCHW buffer')
+    x2p = _pitch_or_raise(x2, 'conv_c8: x2') if x2 is not None else 0
+    yp = 0
     if y_is_c8:
         if not _c8_view_ok(y) or tuple(y.shape) != (B, (Cout + 7) // 8, Ho, Wo, 8):
             raise UpflowHipError('conv_c8: C8 output must be [%d,%d,%d,%d,8], got %s' % (B, (Cout + 7) // 8, Ho, Wo, tuple(y.shape)))
-    elif tuple(y.shape) != (B, Cout, Ho, Wo) or y.stride()[1:] != (Ho * Wo, Wo, 1):
-        raise UpflowHipError('conv_c8: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, Ho, Wo))
+    else:
+        if tuple(y.shape) != (B, Cout, Ho, Wo):
+            raise UpflowHipError('conv_c8: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, Ho, Wo))
+        yp = _pitch_or_raise(y, 'conv_c8: y')
     dev = ref.device
     with torch.cuda.device(dev):
-        _lib.call('upf_conv_forward_c8', _lib.ptr(x8), x8.stride(0) if x8 is not None else 0, x8.shape[1] if x8 is not None else 0,
-                  _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, x2.shape[1] if x2 is not None else 0,
-                  _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y), y.stride(0), int(y_is_c8), B, Cout, H, W, int(kernel_size),
+        _lib.call('upf_conv_forward_c8_pitched', _lib.ptr(x8), x8.stride(0) if x8 is not None else 0, x8.shape[1] if x8 is not None else 0,
+                  _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, x2p, x2.shape[1] if x2 is not None else 0,
+                  _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y), y.stride(0), yp, int(y_is_c8), B, Cout, H, W, int(kernel_size),
                   int(dilation), int(stride), float(leaky_slope), _lib.dtype_code(ref), _lib.stream_ptr(dev))
     return y
 

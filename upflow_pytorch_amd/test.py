@@ -1,0 +1,64 @@
+"""Evaluation entry point — mirror of `/root/reference/test.py`: `Test_model(pretrain_path)` with the reference's flags
+(test.py:22-30), `eval_forward(im1, im2, gt, ...) -> flow_fw` (:40-47), `kitti_2015_test()` (:54-61).
+
+What differs: the forward runs on the MI355X-native operators, and — because KITTI is evaluated at batch 1 on frames whose
+size changes between sequences — through `runtime.ShapeCachedInference`: one captured hipGraph per frame size, replayed for
+every further pair of that size (`graph=False` restores plain eager calls).  `dtype`: torch.float32 (the parity mode, the
+reference's arithmetic within 1e-4 px), torch.float16 / torch.bfloat16 (the fast modes; README.md "which dtype")."""
+import torch
+
+from .utils.tools import tools
+from .model.upflow import UPFlow_net
+
+PARAM_DICT = {
+    # use cost volume norm                                   (test.py:22-30)
+    'if_norm_before_cost_volume': True,
+    'norm_moments_across_channels': False,
+    'norm_moments_across_images': False,
+    'if_froze_pwc': False,
+    'if_use_cor_pytorch': False,
+    'if_sgu_upsample': True,
+}
+
+
+class Test_model(tools.abs_test_model):
+    def __init__(self, pretrain_path='./scripts/upflow_kitti2015.pth', dtype=torch.float32, graph=True, device='cuda', net=None):
+        super(Test_model, self).__init__()
+        if net is None:
+            net_conf = UPFlow_net.config()
+            net_conf.update(PARAM_DICT, verbose=False)
+            net = net_conf()
+            if pretrain_path is not None:
+                net.load_model(pretrain_path, if_relax=True, if_print=True)
+        net = net.to(device).to(dtype).eval()
+        self.net_work = net
+        self.runner = None
+        if graph:
+            from .runtime import ShapeCachedInference
+            self.runner = ShapeCachedInference(net)
+
+    def eval_forward(self, im1, im2, gt, *args):
+        # === network output                                 (test.py:40-47)
+        with torch.no_grad():
+            if self.runner is not None:
+                output_dict = self.runner(im1, im2)
+                return output_dict['flow_f_out'].clone()      # (the runner owns its outputs: the caller keeps predflow across calls)
+            output_dict = self.net_work({'im1': im1, 'im2': im2, 'if_loss': False})
+            return output_dict['flow_f_out']
+
+    def eval_save_result(self, save_name, predflow, *args, **kwargs):
+        print(save_name)
+
+
+def kitti_2015_test(pretrain_path='./scripts/upflow_kitti2015.pth', dtype=torch.float32, root=None):
+    from .dataset.kitti_dataset import kitti_flow
+    # note that eval batch size should be 1 for KITTI 2012 and KITTI 2015 (image size may be different for different sequence)
+    bench = kitti_flow.Evaluation_bench(name='2015_train', if_gpu=True, batch_size=1, root=root)
+    testmodel = Test_model(pretrain_path=pretrain_path, dtype=dtype)
+    epe_all, f1, epe_noc, epe_occ = bench(testmodel)
+    print('EPE All = %.2f, F1 = %.2f, EPE Noc = %.2f, EPE Occ = %.2f' % (epe_all, f1, epe_noc, epe_occ))
+    return epe_all, f1, epe_noc, epe_occ
+
+
+if __name__ == '__main__':
+    kitti_2015_test()
