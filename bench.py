@@ -43,7 +43,7 @@ FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': Fal
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_net(dtype, device, hip_pyramid_convs=True, fp32_conv='hip_x3'):
+def build_net(dtype, device, hip_pyramid_convs=True, fp32_conv='hip_x3', pyramid_dtype=None):
     from upflow_pytorch_amd import synthetic as _weights
     from upflow_pytorch_amd.model.upflow import UPFlow_net
     conf = UPFlow_net.config()
@@ -51,6 +51,8 @@ def build_net(dtype, device, hip_pyramid_convs=True, fp32_conv='hip_x3'):
     torch.manual_seed(0)
     net = conf()
     net.load_state_dict(_weights.make_state_dict(0, head_scale=0.1))      # random-init weights of the architecture
+    if pyramid_dtype is not None:
+        return net.to(device).to_inference(dtype, DT[pyramid_dtype])
     return net.to(device).to(dtype).eval()
 
 
@@ -356,6 +358,7 @@ def train_main(args, rank, world, device):
                        'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
                        'gradient_allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 4),
                        'gradient_bytes': 4 * sum(p.numel() for p in tr.raw_net.parameters() if p.requires_grad)},
+            'roofline_train': train_roofline(tr.raw_net, B, 256, 832, elapsed / args.steps * 1e3) if dname != 'fp32' else None,
             'final_loss': stats}), flush=True)
     if world > 1:
         torch.distributed.barrier()
@@ -391,7 +394,8 @@ def train_probe(device, steps=30):
         loss = float(stats.cpu()[tr._names.index('loss')]) if 'loss' in tr._names else None
         return {'workload': 'config3: unsupervised training step, 256x832 crops, batch 4, bf16 activations / fp32 master weights, '
                             'forward + losses + backward + Adam(amsgrad) in one hipGraph', 'dtype': 'bf16', 'ms_per_step': round(ms, 3),
-                'frame_pairs_per_s': round(4e3 / ms, 2), 'steps': steps, 'hip_graph': tr.use_graph, 'capture_fallback': tr.capture_fallback, 'final_loss': loss}
+                'frame_pairs_per_s': round(4e3 / ms, 2), 'steps': steps, 'hip_graph': tr.use_graph, 'capture_fallback': tr.capture_fallback, 'final_loss': loss,
+                'roofline_train': train_roofline(tr.raw_net, 4, 256, 832, ms)}
     except Exception as e:                                   # (an extra: it must never take the headline line down)
         return {'error': '%s: %s' % (type(e).__name__, e)}
 
@@ -421,6 +425,20 @@ def eval_probe(net, H, W, device, iters=40):
                 'graph_pairs_per_s': round(1e3 / res['graph'], 1), 'iters': iters}
     except Exception as e:                                   # (an extra: it must never take the headline line down)
         return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
+def train_roofline(net, B, H, W, ms_per_step):
+    """The training step against the matrix-core peak: algorithmic flop of every convolution's forward, data gradient and weight
+    gradient (3 x the forward's 2*k*k*Cin*Cout*pixels; the data gradient of the two layers that read the frames is not needed and
+    not counted) / ms_per_step — the whole step incl. its memory-bound operators, losses and the optimizer, like roofline_step."""
+    fwd, parts = conv_flop_per_step(net, B, H, W)
+    first = 2.0 * 9 * 3 * 16 * 2 * B * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)          # pyramid stage 0, stride 2: no dgrad wrt the frames
+    if net.sgi_model is not None:
+        first += 2.0 * 9 * 3 * 16 * 2 * B * H * W                                         # SGU stem layer 0
+    flop = 3.0 * fwd - first
+    tf = flop / (ms_per_step * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
+            'algorithmic_gflop_per_step': round(flop / 1e9, 1), 'forward_gflop': round(fwd / 1e9, 1)}
 
 
 def self_launch(n):
@@ -463,6 +481,8 @@ def main():
     ap.add_argument('--ramp-seconds', type=float, default=0.5, help='untimed replay before the warm-up steps (clock ramp)')
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
+    ap.add_argument('--pyramid-dtype', default=None, choices=['fp16', 'bf16'],
+                    help='feature pyramid + 1x1 projections in this 16-bit type, everything downstream in --dtype (UPFlow_net.to_inference)')
     ap.add_argument('--batch', type=int, default=None, help='frame pairs per step and GPU (default: the workload\'s)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--streams', type=int, default=4,
@@ -500,7 +520,7 @@ def main():
     dname = args.dtype or dname
     dtype = DT[dname]
     from upflow_pytorch_amd import synthetic as _weights
-    net = build_net(dtype, device, hip_pyramid_convs=not args.torch_pyramid, fp32_conv=args.fp32_conv)
+    net = build_net(dtype, device, hip_pyramid_convs=not args.torch_pyramid, fp32_conv=args.fp32_conv, pyramid_dtype=args.pyramid_dtype)
     im1, im2 = _weights.make_images(2 + rank, B, H, W)                      # every rank its own image pairs (the path shards by pair)
     im1, im2 = im1.to(device), im2.to(device)                               # inputs resident in HBM
 
@@ -580,7 +600,8 @@ def main():
                        'hip_graph': not args.no_graph, 'capture_fallback': False,
                        'steps_in_flight': args.streams if pipelined else 1,
                        'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or (dtype == torch.float32 and args.fp32_conv == 'miopen') else 'HIP (MFMA kernel)',
-                       'fp32_conv': args.fp32_conv if dtype == torch.float32 else None},
+                       'fp32_conv': args.fp32_conv if dtype == torch.float32 else None,
+                       'pyramid_dtype': args.pyramid_dtype},
             'roofline': roofline_probe(B, H, W, dtype, device),
         }
         conv_rf = conv_roofline_probe(B, H, W, dtype, device, args.fp32_conv)

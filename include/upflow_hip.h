@@ -96,6 +96,13 @@ int upf_corr81_norm_forward_pitched(const void* f1, const void* f2, int f_row_pi
                                     long long out_batch_stride, float leaky_slope, void* workspace, void* stream);
 int upf_corr81_norm_forward_c8_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride,
                                        int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream);
+/* MIXED storage types (round 5, the `pyramid_dtype` option: fp16 pyramid features, bf16 decoder buffers): the features are `dtype`,
+ * the cost volume is rounded ONCE from its fp32 sums to `out_dtype` (the other 16-bit type, or the same: the entry points above). */
+int upf_corr81_norm_forward_mixed(const void* f1, const void* f2, int f_row_pitch, void* out,
+                                  int B, int C, int H, int W, int dtype, int out_dtype,
+                                  long long out_batch_stride, float leaky_slope, void* workspace, void* stream);
+int upf_corr81_norm_forward_c8_mixed(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride,
+                                     int B, int C, int H, int W, int dtype, int out_dtype, float leaky_slope, void* workspace, void* stream);
 /* measurement helper (bench.py): one statistics launch, then nrep launches of the normalising cost volume, each between
  * its own pair of HIP events on `stream` — the kernel that runs inside the inference step */
 int upf_corr81_norm_forward_timed(const void* f1, const void* f2, void* out,
@@ -262,6 +269,12 @@ int upf_conv_forward(const void* x, long long x_batch_stride, const void* w_pack
 int upf_conv_forward_pitched(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
                              void* y, long long y_batch_stride, int y_row_pitch, int B, int Cin, int Cout, int H, int W,
                              int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream);
+/* 1x1 convolution, Cout <= 32, whose OUTPUT type is the other 16-bit type (`pyramid_dtype`: the projection of the fp16 pyramid features
+ * into the bf16 estimator / SGU buffers): x, w_packed of `dtype`, fp32 sums rounded once to `out_dtype`; y = NCHW planes (pitched like
+ * upf_conv_forward_pitched) or, y_is_c8, channel octets (x rows 16-byte aligned). */
+int upf_conv1x1_forward_mixed(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
+                              void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8, int B, int Cin, int Cout, int H, int W,
+                              float leaky_slope, int dtype, int out_dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
 
 /* ---- the same convolutions for the fp32 PARITY mode: split-precision products on the fp16 matrix cores  (round 4;

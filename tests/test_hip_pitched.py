@@ -284,3 +284,53 @@ def test_native_kitti_frames_take_the_octet_kernels():
     assert buf8.dim() == 5 and tuple(buf8.shape[2:]) == (94, 311, 8)
     pair = dict(net._taps)['L4.pair']
     assert pair.stride(-2) == 312, 'the level buffers of a ragged level are row-pitched'
+
+
+# ----------------------------------------------------------------------------------------------- mixed storage types (`pyramid_dtype`)
+@pytest.mark.parametrize('shape', [(2, 32, 47, 311), (2, 64, 24, 80), (2, 128, 12, 39), (2, 196, 6, 20), (8, 32, 96, 320)])
+@pytest.mark.parametrize('pitched', [False, True])
+def test_corr81_norm_fp16_features_into_bf16_buffers(shape, pitched):
+    """UPFlow_net.to_inference(bf16, pyramid_dtype=fp16): the cost volume reads fp16 features and rounds its fp32 sums ONCE to
+    bf16 — NCHW and octet output; against the fp16 -> fp16 launch (same sums, rounded to fp16) within one bf16 rounding."""
+    from upflow_pytorch_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    pair = (torch.randn(2, B, C, H, W, generator=g) * 1.3).half().cuda()
+    ref = ops.corr81_norm_forward_raw(pair[0], pair[1], leaky_slope=0.1).float()
+    pp = pitched_copy(pair) if pitched else pair
+    out = torch.empty(B, 81, H, W, dtype=torch.bfloat16, device='cuda')
+    ops.corr81_norm_forward_raw(pp[0], pp[1], out=out, leaky_slope=0.1)
+    tol = 2.0 ** -8 * ref.abs() + 2.0 ** -10 * ref.abs() + 1e-6
+    assert bool(((out.float() - ref).abs() <= tol).all()), float((out.float() - ref).abs().max())
+    if W % 8 == 0 or pitched:
+        out8 = ops.c8_empty(B, 88, H, W, torch.bfloat16, 'cuda')
+        ops.corr81_norm_forward_c8(pp[0], pp[1], out8, leaky_slope=0.1)
+        flat = ops.from_c8(out8)
+        for pos, ch in enumerate(ops.corr81_c8_channel_map()):
+            if ch >= 0:
+                assert torch.equal(bits(flat[:, pos]), bits(out[:, ch])), (pos, ch)
+
+
+@pytest.mark.parametrize('case', [(2, 32, 24, 80), (2, 64, 47, 156), (8, 32, 94, 311), (2, 196, 6, 20), (2, 128, 12, 39), (1, 96, 24, 78)])
+def test_conv1x1_fp16_features_into_bf16_buffers(case):
+    """The 1x1 projection of the fp16 pyramid features into bf16 buffers (NCHW slice and channel octets): fp16 products, fp32 sums,
+    ONE rounding to bf16 — against conv2d on the same fp16 operands."""
+    from upflow_pytorch_amd import ops
+    B, Cin, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).half().cuda()
+    w = (torch.randn(32, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).half().cuda()
+    b = torch.randn(32, generator=g).cuda()
+    want = F.leaky_relu(F.conv2d(x.float(), w.float(), b), 0.1)
+    xp = pitched_copy(x)
+    packed = ops.conv3x3_pack(w)
+    buf = torch.full((B, 40, H, W), 3.0, dtype=torch.bfloat16, device='cuda')
+    ops.conv3x3_forward_raw(xp, packed, b, buf[:, 4:36], 1, 0.1, 1, 1)
+    tol = 2.0 ** -8 * want.abs() + 1e-3
+    assert bool(((buf[:, 4:36].float() - want).abs() <= tol).all()) and bool((buf[:, :4] == 3).all()) and bool((buf[:, 36:] == 3).all())
+    y8 = ops.c8_empty(B, 32, H, W, torch.bfloat16, 'cuda')
+    ops.conv_c8_forward_raw(None, xp, packed, b, y8, dilation=1, leaky_slope=0.1, kernel_size=1)
+    got8 = ops.from_c8(y8)
+    assert bool(((got8.float() - want).abs() <= tol).all())
+    with pytest.raises(RuntimeError):          # only the 1x1 projection is offered with another output type
+        ops.conv3x3_forward_raw(xp, ops.conv3x3_pack((torch.randn(32, Cin, 3, 3) * 0.05).half().cuda()), b, buf[:, 4:36], 1, 0.1, 1, 3)

@@ -116,10 +116,10 @@ __global__ void pack_weights_f32_multi_kernel(PackJobs J) {
 // every wave stages its own chunk into a private LDS region — no workgroup barrier in the loop — and the four
 // partial accumulators are summed through LDS at the end in a fixed order (deterministic).  4x the workgroups,
 // a quarter of the chain each.
-template <typename T, int NOCTS, int D, bool GEN>
+template <typename T, int NOCTS, int D, bool GEN, typename TO = T>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
-                    T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, float slope,
+                    TO* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, float slope,
                     int xpitch, int ypitch) {
   constexpr int ntaps = (D == 0) ? 1 : 9;
   constexpr int marg = margin_of(D);
@@ -260,7 +260,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   // wave w finishes output row r = w/2, accumulator registers [8*(w%2), 8*(w%2)+8)
   const int r = wave >> 1, jbase = 4 * (wave & 1);
   Epilogue ep;
-  epilogue_init<T, true>(ep, y + (size_t)n * ybs, Cout, H, W, slab, lane, x0, ypitch);
+  epilogue_init<TO, true>(ep, y + (size_t)n * ybs, Cout, H, W, slab, lane, x0, ypitch);
   if (y0 + r < H) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -271,7 +271,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
         v0 += part[((w * 2 + r) * 16 + e0) * 64 + lane];
         v1 += part[((w * 2 + r) * 16 + e1) * 64 + lane];
       }
-      epilogue_store<T, true>(ep, v0, v1, epilogue_choff(jbase + jj) * ep.plane2 + (uint32_t)((y0 + r) * ypitch) * 2u, slope);
+      epilogue_store<TO, true>(ep, v0, v1, epilogue_choff(jbase + jj) * ep.plane2 + (uint32_t)((y0 + r) * ypitch) * 2u, slope);
     }
   }
 }
@@ -466,6 +466,78 @@ extern "C" int upf_conv_pack_weights_f32_multi(const float* const* w, void* cons
     else hipLaunchKernelGGL((conv::pack_weights_f32_multi_kernel<f16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, J);
   }
   return check_launch("conv_pack_weights_f32_multi");
+}
+
+// ---- 1x1 convolution whose OUTPUT type differs from its operands' (conv_kernel.hpp: TO) -----------------------------------------
+namespace upf {
+namespace conv {
+template <typename T, typename TO, bool GEN>
+int launch_1x1_mixed(const Args& a) {                  // the ntaps == 1, Cout <= 32 subset of launch()
+  const long long tiles = (long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 8);
+  const bool sk_auto = tiles <= g_sk_grid || tiles <= g_sk_grid_narrow;
+  if (a.Cin > 64 && (g_force_sk < 0 ? sk_auto : g_force_sk == 1)) {
+    const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, 2);
+    size_t lds = (size_t)4 * 4 * 2 * (xw(1, margin_of(0)) + xw(1, margin_of(0)) / 16) * 16;
+    if (lds < 4 * 2 * 16 * 64 * 4) lds = 4 * 2 * 16 * 64 * 4;
+    static LdsOptIn opt;
+    auto kern = &conv_sk_kernel<T, 4, 0, GEN, TO>;
+    opt.ensure(reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), 1), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                       (const T*)a.wp, a.bias, (TO*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, a.ypitch);
+    return check_launch("conv1x1_forward_mixed");
+  }
+  constexpr int TH = 4 * 2;
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
+  size_t lds = (size_t)4 * TH * (xw(1, margin_of(0)) + xw(1, margin_of(0)) / 16) * 16;
+  if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;
+  static LdsOptIn opt;
+  auto kern = &conv_kernel<T, 1, 2, 1, 4, 0, GEN, false, 0, false, false, TO>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), 1), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                     (const T*)a.wp, a.bias, (TO*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, a.H, a.W, g_ablate, tiles_x, tiles_y, a.slope,
+                     (const T*)nullptr, 0ll, 0, a.xpitch, a.ypitch);
+  return check_launch("conv1x1_forward_mixed");
+}
+template <typename T, typename TO>
+int launch_1x1_mixed_c8(const Args& a) {               // NCHW (pitch-aligned rows) -> channel octets of type TO
+  constexpr int TH = 4 * 2;
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
+  const size_t lds = (size_t)4 * TH * (xw(1, margin_of(0)) + xw(1, margin_of(0)) / 16) * 16;
+  static LdsOptIn opt;
+  auto kern = &conv_kernel<T, 1, 2, 1, 4, 0, false, false, 0, true, false, TO>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), 1), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                     (const T*)a.wp, a.bias, (TO*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, a.H, a.W, g_ablate, tiles_x, tiles_y, a.slope,
+                     (const T*)nullptr, 0ll, 0, a.xpitch, a.ypitch);
+  return check_launch("conv1x1_forward_mixed");
+}
+}  // namespace conv
+}  // namespace upf
+
+extern "C" int upf_conv1x1_forward_mixed(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
+                                         void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8, int B, int Cin, int Cout, int H, int W,
+                                         float leaky_slope, int dtype, int out_dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && w_packed && bias && y, UPF_EINVAL, "conv1x1_forward_mixed: null pointer");
+  UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Cout <= 32 && H > 0 && W > 0, UPF_EINVAL, "conv1x1_forward_mixed: bad shape B=%d Cin=%d Cout=%d (<= 32) H=%d W=%d", B, Cin, Cout, H, W);
+  UPF_REQUIRE((dtype == UPF_BF16 || dtype == UPF_F16) && (out_dtype == UPF_BF16 || out_dtype == UPF_F16) && dtype != out_dtype, UPF_EDTYPE,
+              "conv1x1_forward_mixed: bf16 / fp16 operands and the OTHER 16-bit type for y (same types: upf_conv_forward)");
+  if (x_row_pitch == 0) x_row_pitch = W;
+  if (y_row_pitch == 0) y_row_pitch = W;
+  UPF_REQUIRE(x_row_pitch >= W && (y_is_c8 || y_row_pitch >= W), UPF_EINVAL, "conv1x1_forward_mixed: row pitch smaller than the row");
+  const bool gen = !(x_row_pitch % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0);
+  UPF_REQUIRE(!gen || W >= 8, UPF_EUNSUPPORTED, "conv1x1_forward_mixed: W = %d < 8 with unaligned rows", W);
+  UPF_REQUIRE(!y_is_c8 || (!gen && aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EUNSUPPORTED, "conv1x1_forward_mixed: octet output needs 16-byte aligned input rows and output");
+  UPF_REQUIRE((long long)Cin * H * x_row_pitch * 2 < (1ll << 31) && (long long)32 * H * (y_is_c8 ? W : y_row_pitch) * 2 < (1ll << 31), UPF_EINVAL, "conv1x1_forward_mixed: image too large for one buffer descriptor");
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv1x1_forward_mixed: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, 0, 1, 1, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream,
+               x_row_pitch, y_row_pitch};
+  if (dtype == UPF_F16) {
+    if (y_is_c8) return conv::launch_1x1_mixed_c8<f16_t, bf16_t>(a);
+    return gen ? conv::launch_1x1_mixed<f16_t, bf16_t, true>(a) : conv::launch_1x1_mixed<f16_t, bf16_t, false>(a);
+  }
+  if (y_is_c8) return conv::launch_1x1_mixed_c8<bf16_t, f16_t>(a);
+  return gen ? conv::launch_1x1_mixed<bf16_t, f16_t, true>(a) : conv::launch_1x1_mixed<bf16_t, f16_t, false>(a);
 }
 
 extern "C" int upf_conv_forward_pitched(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,

@@ -232,10 +232,12 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
 // 563->2 / 184->3 heads, 176->8, 160->16) on `v_mfma_f32_16x16x32` instead of 32x32x16 — a 16-channel output block, so half the
 // matrix work of the 32-channel block that is mostly padding for them (ablation, 568->2 at 96x320: matrix phase alone 58 us,
 // staging alone 45 us, together 73 us).  blockIdx.y = the 16-channel block; weights packed by pack_weights_kmap16_kernel.
-template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false, bool N16 = false>
+// TO (round 5): storage type of y when it differs from the operands' (the `pyramid_dtype` option: fp16 features and weights, bf16
+// decoder buffers — the 1x1 projection of the pyramid features multiplies in fp16 and rounds its fp32 sums ONCE, to bf16).
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false, bool N16 = false, typename TO = T>
 __global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
 void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
-                 T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
+                 TO* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
                  int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, int xpitch, int ypitch) {
   // xpitch / ypitch (round 5): elements between consecutive rows of the NCHW operands x / y (plane stride = rows * pitch).  The
   // LOGICAL width stays W / Wo: with a pitch that is a multiple of 8 every row is 16-byte aligned whatever W is, so ragged
@@ -555,11 +557,11 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
           if constexpr (YC8) {
             const uint32_t off = (gx < Wo) ? (uint32_t)(slab * 2 + (ko >> 1)) * plane16 + (uint32_t)(gy * Wo + gx) * 16u + (uint32_t)(ko & 1) * 8u : 0x80000000u;
             u32x2 o;
-            o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]);
+            o.x = pack2<TO>(v[0], v[1]); o.y = pack2<TO>(v[2], v[3]);
             __builtin_amdgcn_raw_buffer_store_b64(o, yr, off, 0, 0);
           } else {
             const uint32_t off = (gx < Wo) ? (uint32_t)(slab * 16 + 4 * ko) * plane2 + (uint32_t)(gy * ypitch + gx) * 2u : 0x80000000u;
-            const uint32_t p01 = pack2<T>(v[0], v[1]), p23 = pack2<T>(v[2], v[3]);
+            const uint32_t p01 = pack2<TO>(v[0], v[1]), p23 = pack2<TO>(v[2], v[3]);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)p01, yr, off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(p01 >> 16), yr, off + plane2, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)p23, yr, off + 2u * plane2, 0, 0);
@@ -590,7 +592,7 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
 #pragma unroll
           for (int q = 0; q < 4; ++q) { v[q] = acc[r][4 * g + q]; v[q] = fmaxf(v[q], v[q] * slope); }
           u32x2 o;
-          o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]);
+          o.x = pack2<TO>(v[0], v[1]); o.y = pack2<TO>(v[2], v[3]);
           __builtin_amdgcn_raw_buffer_store_b64(o, yr, lane_off + (uint32_t)g * plane16 + (uint32_t)(gy * Wo) * 16u, 0, 0);
         }
       }
@@ -601,20 +603,20 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     // uniform: 16-byte stores through a per-wave LDS patch when the OUTPUT rows are 16-byte aligned (pitch, base, batch stride)
     if (((ypitch & 7) | (int)(ybs & 7) | (int)(reinterpret_cast<uintptr_t>(y) & 15)) == 0) {
       __syncthreads();                               // every wave is done with the x tile
-      epilogue_wide<T, RPW>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
+      epilogue_wide<TO, RPW>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
                             slab, lane, x0, gy0, RS, slope, ypitch);
       return;
     }
   }
   // (always the general form: an aligned input says nothing about the output's width — a pitched x with an un-pitched odd-width y)
   Epilogue ep;
-  epilogue_init<T, true>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0, ypitch);
+  epilogue_init<TO, true>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0, ypitch);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     if (gy0 + r * RS < Ho) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        epilogue_store<T, true>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * ypitch) * 2u, slope);
+        epilogue_store<TO, true>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * ypitch) * 2u, slope);
     }
   }
   }  // !N16

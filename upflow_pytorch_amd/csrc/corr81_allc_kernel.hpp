@@ -102,9 +102,10 @@ struct Task {      // two registers per task: NT = 8 tasks + their 64 raw-data r
 // width W is ragged but the rows are pitched to whole 16-byte groups — aligned quad loads like the W % 8 == 0 form, the quad that
 // straddles W has its trailing pixels (pitch padding, whatever it holds) replaced by the zero padding, and the octet output, one
 // 16-byte entry per pixel, is aligned for every W: KITTI's native frames (W = 311, 156 at the two fine levels) stay on this path.
-template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, int TPW = 1, bool OC8 = false, bool PADW = false>
+// TO (round 5): storage type of `out` when it differs from the features' (`pyramid_dtype`: fp16 features, bf16 estimator buffers).
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, int TPW = 1, bool OC8 = false, bool PADW = false, typename TO = T>
 __global__ __launch_bounds__(NTHREADS, 5)       // <= 102 VGPRs: two 9-wave workgroups per CU
-void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* __restrict__ out,
+void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, TO* __restrict__ out,
                         int C, int H, int W, int tiles_x, int tiles_y, long long out_bs, float slope,
                         const float* __restrict__ ws1, const float* __restrict__ ws2, int nseg, int total_tiles, int fpitch) {
   static_assert(!PADW || (!RAGGED && OC8), "PADW: aligned pitched rows, octet output");
@@ -316,8 +317,8 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
 #pragma unroll
           for (int t = 0; t < D; ++t) { v[t] = f[t] * invC; v[t] = (slope != 0.f) ? fmaxf(v[t], v[t] * slope) : v[t]; }
           const size_t px = (size_t)y * W + x, oct = (size_t)H * W * 8;
-          *reinterpret_cast<uint4*>(obase + dyi * oct + px * 8) = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
-          const uint32_t last = pack2<T>(v[8], 0.f);
+          *reinterpret_cast<uint4*>(obase + dyi * oct + px * 8) = make_uint4(pack2<TO>(v[0], v[1]), pack2<TO>(v[2], v[3]), pack2<TO>(v[4], v[5]), pack2<TO>(v[6], v[7]));
+          const uint32_t last = pack2<TO>(v[8], 0.f);
           if (dyi < 8) obase[9 * oct + px * 8 + dyi] = (st16)(last & 0xffffu);
           else *reinterpret_cast<uint4*>(obase + 10 * oct + px * 8) = make_uint4(last & 0xffffu, 0u, 0u, 0u);
         }
@@ -329,8 +330,8 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
           for (int t = 0; t < D; ++t) {
             float v = f[t] * invC;
             v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
-            T tmp;
-            Elem<T>::store(&tmp, v);
+            TO tmp;
+            Elem<TO>::store(&tmp, v);
             o[(size_t)t * H * W] = tmp.v;
           }
         }
@@ -339,8 +340,8 @@ void corr81_allc_kernel(const T* __restrict__ f1, const T* __restrict__ f2, T* _
         for (int t = 0; t < D; ++t) {
           float v = f[t] * invC;
           v = (slope != 0.f) ? fmaxf(v, v * slope) : v;
-          T tmp;
-          Elem<T>::store(&tmp, v);
+          TO tmp;
+          Elem<TO>::store(&tmp, v);
           patch[t * 64 + lane] = tmp.v;                                  // [t][row-in-unit][UW px]
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

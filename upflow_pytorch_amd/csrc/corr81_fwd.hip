@@ -127,8 +127,8 @@ static int allc_pick(int B, int C, int H, int W, bool ragged, bool norm, bool ch
   return first;
 }
 
-template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, bool OC8 = false, bool PADW = false>
-int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
+template <typename T, int UW, int NU, int NT, bool RAGGED, bool NORM, bool OC8 = false, bool PADW = false, typename TO = T>
+int launch_allc_one(const T* f1, const T* f2, TO* out, int B, int C, int H, int W, long long out_bs, float slope,
                     const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int fpitch = 0) {
   if (fpitch == 0) fpitch = W;
   using G = corrx::Geo<UW, NU>;
@@ -137,7 +137,7 @@ int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W
   UPF_REQUIRE(nblocks < (1ll << 31), UPF_EINVAL, "corr81_forward: grid too large");
   const size_t lds = corrx::lds_bytes<UW, NU>((C + 3) / 4, RAGGED, NORM);
   static LdsOptIn opt;
-  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, 1, OC8, PADW>;
+  auto kern = &corrx::corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, 1, OC8, PADW, TO>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   // (the timed entry points pass start / stop events -> hipExtLaunchKernel; everything else takes the ordinary launch path)
   if (ev0 || ev1)
@@ -149,10 +149,10 @@ int launch_allc_one(const T* f1, const T* f2, T* out, int B, int C, int H, int W
   return check_launch("corr81_forward");
 }
 
-template <typename T, bool RAGGED, bool NORM>
-int launch_allc(int v, const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
+template <typename T, bool RAGGED, bool NORM, typename TO = T>
+int launch_allc(int v, const T* f1, const T* f2, TO* out, int B, int C, int H, int W, long long out_bs, float slope,
                 const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int fpitch = 0) {
-#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, RAGGED, NORM>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch)
+#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, RAGGED, NORM, false, false, TO>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch)
   switch (v) {
     case 0: UPF_ALLC(32, 4, 4);
     case 1: UPF_ALLC(32, 2, 8);
@@ -166,10 +166,10 @@ int launch_allc(int v, const T* f1, const T* f2, T* out, int B, int C, int H, in
 
 // normalising cost volume into channel octets (upf_corr81_norm_forward_c8): !RAGGED, NORM, OC8
 // (PADW: ragged logical W on pitched rows, corr81_allc_kernel.hpp)
-template <typename T, bool PADW = false>
-int launch_allc_c8(int v, const T* f1, const T* f2, T* out, int B, int C, int H, int W, long long out_bs, float slope,
+template <typename T, bool PADW = false, typename TO = T>
+int launch_allc_c8(int v, const T* f1, const T* f2, TO* out, int B, int C, int H, int W, long long out_bs, float slope,
                    const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int fpitch = 0) {
-#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, false, true, true, PADW>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch)
+#define UPF_ALLC(UW, NU, NT) return launch_allc_one<T, UW, NU, NT, false, true, true, PADW, TO>(f1, f2, out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch)
   switch (v) {
     case 0: UPF_ALLC(32, 4, 4);
     case 1: UPF_ALLC(32, 2, 8);
@@ -182,7 +182,7 @@ int launch_allc_c8(int v, const T* f1, const T* f2, T* out, int B, int C, int H,
 }
 
 // -> UPF_OK / error, or 1 = "not applicable" (C too deep, item too large): the caller takes the chunked kernels
-template <typename T, bool NORM>
+template <typename T, bool NORM, typename TO = T>
 int try_allc(const void* f1, const void* f2, void* out, int B, int C, int H, int W, long long out_bs, float slope,
              const float* ws1, const float* ws2, int nseg, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, int fpitch = 0) {
   if (fpitch == 0) fpitch = W;
@@ -193,8 +193,8 @@ int try_allc(const void* f1, const void* f2, void* out, int B, int C, int H, int
   const int v = allc_pick(B, C, H, W, ragged, NORM, !ragged && fpitch == W);
   if (v == -2 && fpitch != W) return 1;
   if (v < 0) return 1;
-  if (ragged) return launch_allc<T, true, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch);
-  return launch_allc<T, false, NORM>(v, (const T*)f1, (const T*)f2, (T*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch);
+  if (ragged) return launch_allc<T, true, NORM, TO>(v, (const T*)f1, (const T*)f2, (TO*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch);
+  return launch_allc<T, false, NORM, TO>(v, (const T*)f1, (const T*)f2, (TO*)out, B, C, H, W, out_bs, slope, ws1, ws2, nseg, stream, ev0, ev1, fpitch);
 }
 
 template <typename T>
@@ -353,9 +353,11 @@ extern "C" long long upf_corr81_norm_workspace_bytes(int B, int C, int H, int W)
   return part * (long long)sizeof(float) + (long long)2 * B * C * (long long)sizeof(float2);
 }
 
-extern "C" int upf_corr81_norm_forward_pitched(const void* f1, const void* f2, int f_row_pitch, void* out, int B, int C, int H, int W, int dtype,
-                                               long long out_batch_stride, float leaky_slope, void* workspace, void* stream) {
+extern "C" int upf_corr81_norm_forward_mixed(const void* f1, const void* f2, int f_row_pitch, void* out, int B, int C, int H, int W, int dtype, int out_dtype,
+                                             long long out_batch_stride, float leaky_slope, void* workspace, void* stream) {
   using namespace upf;
+  UPF_REQUIRE(out_dtype == dtype || ((dtype == UPF_F16 || dtype == UPF_BF16) && (out_dtype == UPF_F16 || out_dtype == UPF_BF16)), UPF_EDTYPE,
+              "corr81_norm_forward: out_dtype %d (bf16 / fp16)", out_dtype);
   UPF_REQUIRE(f1 && f2 && out && workspace, UPF_EINVAL, "corr81_norm_forward: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_norm_forward: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(upf_corr81_norm_supported(C, dtype), UPF_EUNSUPPORTED,
@@ -374,10 +376,17 @@ extern "C" int upf_corr81_norm_forward_pitched(const void* f1, const void* f2, i
   if (rc != UPF_OK) return rc;
   const float* ws1 = reinterpret_cast<const float*>(fin);            // what the cost volume reads: final pairs of f1's rows ...
   const float* ws2 = reinterpret_cast<const float*>(fin + N);        // ... and of f2's
-  if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
+  if (dtype == UPF_BF16 && out_dtype == UPF_F16) rc = corr::try_allc<bf16_t, true, f16_t>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
+  else if (dtype == UPF_F16 && out_dtype == UPF_BF16) rc = corr::try_allc<f16_t, true, bf16_t>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
+  else if (dtype == UPF_BF16) rc = corr::try_allc<bf16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
   else rc = corr::try_allc<f16_t, true>(f1, f2, out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
   UPF_REQUIRE(rc != 1, UPF_EUNSUPPORTED, "corr81_norm_forward: no kernel variant fits C=%d W=%d (W >= 4 required)", C, W);
   return rc;
+}
+
+extern "C" int upf_corr81_norm_forward_pitched(const void* f1, const void* f2, int f_row_pitch, void* out, int B, int C, int H, int W, int dtype,
+                                               long long out_batch_stride, float leaky_slope, void* workspace, void* stream) {
+  return upf_corr81_norm_forward_mixed(f1, f2, f_row_pitch, out, B, C, H, W, dtype, dtype, out_batch_stride, leaky_slope, workspace, stream);
 }
 
 extern "C" int upf_corr81_norm_forward(const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
@@ -395,9 +404,11 @@ static int norm_c8_check(const void* f1, const void* f2, const void* out8, long 
   return UPF_OK;
 }
 
-extern "C" int upf_corr81_norm_forward_c8_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
-                                                  int dtype, float leaky_slope, void* workspace, void* stream) {
+extern "C" int upf_corr81_norm_forward_c8_mixed(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                                int dtype, int out_dtype, float leaky_slope, void* workspace, void* stream) {
   using namespace upf;
+  UPF_REQUIRE(out_dtype == dtype || ((dtype == UPF_F16 || dtype == UPF_BF16) && (out_dtype == UPF_F16 || out_dtype == UPF_BF16)), UPF_EDTYPE,
+              "corr81_norm_forward_c8: out_dtype %d (bf16 / fp16)", out_dtype);
   UPF_REQUIRE(f1 && f2 && out8 && workspace, UPF_EINVAL, "corr81_norm_forward_c8: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, UPF_EINVAL, "corr81_norm_forward_c8: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   UPF_REQUIRE(upf_corr81_norm_supported(C, dtype), UPF_EUNSUPPORTED,
@@ -418,11 +429,21 @@ extern "C" int upf_corr81_norm_forward_c8_pitched(const void* f1, const void* f2
   const int v = corr::allc_pick(B, C, H, W, false, true, false);
   UPF_REQUIRE(v >= 0, UPF_EUNSUPPORTED, "corr81_norm_forward_c8: no kernel variant fits C=%d", C);
   const bool padw = (W % 8 != 0);
+#define UPF_C8X(TI, TOUT) return padw ? corr::launch_allc_c8<TI, true, TOUT>(v, (const TI*)f1, (const TI*)f2, (TOUT*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp) \
+                                     : corr::launch_allc_c8<TI, false, TOUT>(v, (const TI*)f1, (const TI*)f2, (TOUT*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp)
+  if (dtype == UPF_F16 && out_dtype == UPF_BF16) { UPF_C8X(f16_t, bf16_t); }
+  if (dtype == UPF_BF16 && out_dtype == UPF_F16) { UPF_C8X(bf16_t, f16_t); }
+#undef UPF_C8X
   if (dtype == UPF_BF16)
     return padw ? corr::launch_allc_c8<bf16_t, true>(v, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp)
                 : corr::launch_allc_c8<bf16_t, false>(v, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
   return padw ? corr::launch_allc_c8<f16_t, true>(v, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp)
               : corr::launch_allc_c8<f16_t, false>(v, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out8, B, C, H, W, out8_batch_stride, leaky_slope, ws1, ws2, nseg, s, nullptr, nullptr, fp);
+}
+
+extern "C" int upf_corr81_norm_forward_c8_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                                  int dtype, float leaky_slope, void* workspace, void* stream) {
+  return upf_corr81_norm_forward_c8_mixed(f1, f2, f_row_pitch, out8, out8_batch_stride, B, C, H, W, dtype, dtype, leaky_slope, workspace, stream);
 }
 
 extern "C" int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* out8, long long out8_batch_stride, int B, int C, int H, int W,

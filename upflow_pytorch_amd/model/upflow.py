@@ -233,6 +233,7 @@ class UPFlow_net(tools.abstract_model):
             self.hip_pyramid_convs = True
             self.train_conv_dtype = 'fp32'          # 'bf16' / 'fp16': decoder convolutions under autograd on the matrix cores
             self.fp32_conv = 'hip_x3'               # fp32 inference: 'hip_x3' / 'hip_x3s' split-precision MFMA kernel, 'miopen' PyTorch-ROCm
+            self.fp16_overflow_check = False        # fp16 features / activations: raise if an output is not finite (one reduction + a host sync per forward)
 
         def __call__(self, ):
             return UPFlow_net(self)
@@ -282,6 +283,12 @@ class UPFlow_net(tools.abstract_model):
         flow_f, flow_b, flows = self.forward_2_frame_v3(im1, im2, if_loss=input_dict['if_loss'])
         occ_fw, occ_bw = self.occ_check_model(flow_f=flow_f, flow_b=flow_b)
         out = {'flow_f_out': flow_f, 'flow_b_out': flow_b, 'occ_fw': occ_fw, 'occ_bw': occ_bw}
+        if getattr(self.conf, 'fp16_overflow_check', False) and not torch.cuda.is_current_stream_capturing():
+            # fp16 stores saturate to infinity beyond 65504 (bf16 does not): an overflowing feature or activation reaches the flows as
+            # inf / NaN — every operator here propagates non-finite values — so ONE check of the outputs guards the whole forward
+            if not (bool(torch.isfinite(flow_f).all()) and bool(torch.isfinite(flow_b).all())):
+                raise ops.UpflowHipError('non-finite flow: an fp16 feature / activation overflowed (|x| > 65504) — run this input in '
+                                         'bfloat16 (net.to_inference(torch.bfloat16)) or fp32')
         if input_dict['if_loss']:
             self._losses(input_dict, out, flows, im1_ori.float(), im2_ori.float())
         return out
@@ -357,7 +364,7 @@ class UPFlow_net(tools.abstract_model):
     # -------------------------------------------------------------------------------------------
     def forward_2_frame_v3(self, x1_raw, x2_raw, if_loss=False):
         """Coarse-to-fine bidirectional decode, model/upflow.py:494-533."""
-        cdt = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype      # compute dtype of the convs
+        cdt = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype      # compute dtype of the convs (of the PYRAMID: to_inference)
         from .pwc_modules import fp32_conv_mode
         with fp32_conv_mode(getattr(self.conf, 'fp32_conv', 'hip_x3')):
             return self._forward_2_frame_v3(x1_raw, x2_raw, if_loss, cdt)
@@ -374,6 +381,16 @@ class UPFlow_net(tools.abstract_model):
                                pitched=self._pitched() and not torch.is_grad_enabled() and x1_raw.is_cuda)
             X[:B].copy_(x1_raw)                         # cast + stack in one pass per frame (was: two casts, then a cat)
             X[B:].copy_(x2_raw)
+            ddt = self.flow_estimators.conv1[0].weight.dtype
+            if ddt != cdt:
+                # `pyramid_dtype` (to_inference): the decoder runs in another 16-bit type; its one reader of the frames, the SGU's
+                # guidance stem, gets its own cast of them
+                if torch.is_grad_enabled() or not x1_raw.is_cuda or ddt == torch.float32 or cdt == torch.float32:
+                    raise ops.UpflowHipError('pyramid_dtype: 16-bit GPU inference only')
+                Xd = ops.empty_nchw(tuple(X.shape), ddt, X.device, pitched=self._pitched())
+                Xd[:B].copy_(x1_raw)
+                Xd[B:].copy_(x2_raw)
+                return self._forward_stacked(X, B, frames_dec=Xd)
             tdt = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(getattr(self.conf, 'train_conv_dtype', 'fp32'))
             if tdt is not None and torch.is_grad_enabled() and cdt == torch.float32:
                 # training on the matrix cores: 16-bit activations from the first layer on, fp32 master weights
@@ -409,7 +426,7 @@ class UPFlow_net(tools.abstract_model):
             flow_b_out = self.self_guided_upsample(flow_up_bilinear=flow_b, feature_1=g2, feature_2=g1, output_level_flow=flow_b_out)
         return flow_f_out, flow_b_out, flows[::-1]
 
-    def _forward_stacked(self, X, B, train_dtype=None):
+    def _forward_stacked(self, X, B, train_dtype=None, frames_dec=None):
         """Inference form of forward_2_frame_v3 (model/upflow.py:494-533), same arithmetic, different schedule:
         the two frames are stacked along the batch, X = [im1; im2], so item n < B carries the forward direction
         and item n >= B the backward one.  Every stage then runs ONCE on 2B items with shared weights — feature
@@ -420,7 +437,10 @@ class UPFlow_net(tools.abstract_model):
         if (_fast_conv_ok(X) and X.dtype != torch.float32 and self.conf.if_norm_before_cost_volume and not self.conf.norm_moments_across_channels
                 and not self.conf.norm_moments_across_images and not getattr(self, '_no_fast_stacked', False)
                 and self.feature_pyramid_extractor.out_shapes(X.shape[2], X.shape[3])[-1][2] >= 8):   # every level takes the conv kernel
-            return self._forward_stacked_fast(X, B)
+            return self._forward_stacked_fast(X, B, frames_dec)
+        # (generic schedule with `pyramid_dtype`: the pyramid, the warp and the normalisation run in the pyramid's type; the 1x1 features
+        # and the NORMALISED features are cast to the decoder's on their way into it — the in-buffer schedule above does it without casts)
+        ddt = None if frames_dec is None else frames_dec.dtype
         pyramid = self.feature_pyramid_extractor(X)
         h0, w0 = pyramid[0].shape[2:]
         flow = torch.zeros(2 * B, 2, h0, w0, dtype=torch.float32, device=X.device)
@@ -429,6 +449,8 @@ class UPFlow_net(tools.abstract_model):
         for level in range(self.output_level + 1):
             Fm = pyramid[level]
             A = fast_conv_seq(self.conv_1x1[level], Fm, self.__dict__.setdefault('_fast_cache', {}))
+            if ddt is not None:
+                A = A.to(ddt)
             flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
             if level == 0:
                 Fw = torch.roll(Fm, shifts=B, dims=0)                        # no warp at the coarsest level (:539-541)
@@ -447,11 +469,13 @@ class UPFlow_net(tools.abstract_model):
                     Fn, Fwn = network_tools.normalize_features((Fm, Fw), **kw)
             else:
                 Fn, Fwn = Fm, Fw
+            if ddt is not None:
+                Fn, Fwn = Fn.to(ddt), Fwn.to(ddt)
             flow = self._level_update(Fn, Fwn, A, flow_up, add_to_flow=True)
             flows.append(list(ops.split_batch(flow, B)))
         flow_out = upsample2d_flow_as(flow, X, mode="bilinear", if_rate=True)
         if sgu:
-            G = self.sgi_model.output_conv(X)
+            G = self.sgi_model.output_conv(X if ddt is None else frames_dec)
             flow_out = self.sgi_model(flow, G, G, output_level_flow=flow_out, batch_shift=B)[1]
         f_out, b_out = ops.split_batch(flow_out, B)
         return f_out, b_out, flows[::-1]
@@ -466,14 +490,15 @@ class UPFlow_net(tools.abstract_model):
         if taps is not None:
             taps.append((name, t))
 
-    def _forward_stacked_fast(self, X, B):
+    def _forward_stacked_fast(self, X, B, frames_dec=None):
         """_forward_stacked for bf16/fp16 with the published normalisation flags: same arithmetic, and every
         intermediate is produced IN the buffer its consumer reads — the pyramid's convs write the per-level
         [features; warped other frame] pair buffers that one normalisation launch pair covers, the 1x1 convs write
         the estimator / SGU input slots, the warps write their slots, and the per-level flow bookkeeping is one
         launch per sum (ops.flow_update).  No slot copies, no convert/add chains: ~40 fewer launches per step."""
         nb = 2 * B
-        dev, dt = X.device, X.dtype
+        dev, pdt = X.device, X.dtype                     # pdt: the pyramid's type (features, warped features)
+        dt = pdt if frames_dec is None else frames_dec.dtype      # dt: the decoder's (every estimator / context / SGU buffer)
         cache = self.__dict__.setdefault('_fast_cache', {})
         fpe, est, sgi = self.feature_pyramid_extractor, self.flow_estimators, self.sgi_model
         sgu = self.conf.if_sgu_upsample
@@ -483,7 +508,7 @@ class UPFlow_net(tools.abstract_model):
         pit = self._pitched()
         # [features; warped other frame] per level; rows pitched to 16 bytes at ragged levels (ops.empty_nchw): every consumer —
         # the next pyramid stage, the 1x1 convolution, the warp, the statistics + cost volume — is pitch-aware
-        pairs = [ops.empty_nchw((2, nb) + shp, dt, dev, pitched=pit) for shp in shapes[:nlev]]
+        pairs = [ops.empty_nchw((2, nb) + shp, pdt, dev, pitched=pit) for shp in shapes[:nlev]]
         outs = ([p[0] for p in pairs] + [None] * (len(shapes) - nlev))[::-1]   # stage order: finest first
         pyramid = fpe(X, outs=outs, pitched=pit)
         self._tap('X', X)
@@ -564,7 +589,7 @@ class UPFlow_net(tools.abstract_model):
             # (measured and not kept, round 3: this stem on a side stream = a parallel branch of the captured graph, forked before
             # or after the feature pyramid — 3.075 vs 3.076 ms; and with eager launches on two real streams 3.13 vs 3.14 ms: the step is
             # not idle-CU bound)
-            guide = self._final_guidance(X, nb, tuple(flow.shape[2:]))
+            guide = self._final_guidance(X if frames_dec is None else frames_dec, nb, tuple(flow.shape[2:]))
             if guide[0] == 'c8':
                 flow_out = sgi.forward_in_buffer_c8(flow, guide[1], output_level_flow=flow_out, batch_shift=B)[1]
             else:
@@ -725,6 +750,31 @@ class UPFlow_net(tools.abstract_model):
         fine_1 = self.context_networks(torch.cat([feat_1, (flow_1_up + res_1).to(feat_1.dtype)], dim=1)).float()
         fine_2 = self.context_networks(torch.cat([feat_2, (flow_2_up + res_2).to(feat_2.dtype)], dim=1)).float()
         return flow_1_up, flow_2_up, res_1 + fine_1, res_2 + fine_2
+
+    def to_inference(self, dtype=torch.bfloat16, pyramid_dtype=None, device=None):
+        """Cast the network for 16-bit inference; with `pyramid_dtype` (torch.float16) the feature pyramid and the 1x1 projections —
+        1.5 % of a step's flop, but > 60 % of the bf16 path's distance to the reference (profiles/r04_precision_localise.txt: their
+        weights 0.156 px, their activations 0.091 px of 0.175 px at 384x1280) — keep fp16 weights, features and warped features, the
+        cost volume reads fp16 features (its fp16 matrix instruction) and everything downstream (cost volume output, estimator,
+        context network, SGU) stays `dtype`.  Call it on the fp32 network: the fp16 copies must be rounded from the fp32 weights, not
+        from their bf16 roundings.  Returns self (in eval mode)."""
+        if device is not None:
+            self.to(device)
+        if pyramid_dtype is None or pyramid_dtype == dtype:
+            return self.to(dtype).eval()
+        if dtype not in (torch.bfloat16, torch.float16) or pyramid_dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError('to_inference: dtype / pyramid_dtype must be torch.bfloat16 or torch.float16')
+        src = self.feature_pyramid_extractor.convs[0][0][0].weight.dtype
+        if src != torch.float32:
+            import warnings
+            warnings.warn('to_inference(pyramid_dtype=...) on a network that is already %s: the pyramid keeps that rounding' % src)
+        pyr = {id(m) for part in (self.feature_pyramid_extractor, self.conv_1x1) for m in part.modules()}
+        for m in self.modules():
+            for name, p_ in list(m._parameters.items()):
+                if p_ is not None:
+                    p_.data = p_.data.to(pyramid_dtype if id(m) in pyr else dtype)
+        self.invalidate_packed()
+        return self.eval()
 
     def froze_PWC(self):
         for part in (self.feature_pyramid_extractor, self.flow_estimators, self.context_networks, self.conv_1x1):

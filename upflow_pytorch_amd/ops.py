@@ -123,15 +123,16 @@ def corr81_norm_forward_raw(f1, f2, out=None, leaky_slope=0.0):
         out = torch.empty((B, 81, H, W), dtype=f1.dtype, device=f1.device)
         bstride = 0
     else:
-        if out.shape != (B, 81, H, W) or out.dtype != f1.dtype or out.device != f1.device:
+        # (`out` may be the OTHER 16-bit type: fp16 pyramid features into a bf16 estimator buffer, the `pyramid_dtype` option)
+        if out.shape != (B, 81, H, W) or out.dtype not in (torch.bfloat16, torch.float16) or out.device != f1.device:
             raise UpflowHipError('corr81_norm: bad `out` %s %s' % (tuple(out.shape), out.dtype))
         if out.stride()[1:] != (H * W, W, 1):
             raise UpflowHipError('corr81_norm: `out` must be a channel slice of a contiguous NCHW buffer')
         bstride = out.stride(0)
     ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
     with torch.cuda.device(dev):
-        _lib.call('upf_corr81_norm_forward_pitched', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out), B, C, H, W,
-                  _lib.dtype_code(f1), bstride, float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
+        _lib.call('upf_corr81_norm_forward_mixed', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out), B, C, H, W,
+                  _lib.dtype_code(f1), _lib.dtype_code(out), bstride, float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
     return out
 
 
@@ -165,15 +166,15 @@ def corr81_norm_forward_c8(f1, f2, out8, leaky_slope=0.0):
         raise UpflowHipError('corr81_norm_c8: inputs must be two [B,C,H,W] tensors of one dtype')
     B, C, H, W = f1.shape
     dev = _lib.check_gpu(f1, f2, contiguous=False)
-    if not out8.is_cuda or tuple(out8.shape) != (B, CORR81_C8_OCTETS, H, W, 8) or not _c8_view_ok(out8) or out8.dtype != f1.dtype:
-        raise UpflowHipError('corr81_norm_c8: out8 must be an octet slice [%d,11,%d,%d,8] of a C8 buffer, got %s' % (B, H, W, tuple(out8.shape)))
+    if not out8.is_cuda or tuple(out8.shape) != (B, CORR81_C8_OCTETS, H, W, 8) or not _c8_view_ok(out8) or out8.dtype not in (torch.bfloat16, torch.float16):
+        raise UpflowHipError('corr81_norm_c8: out8 must be an octet slice [%d,11,%d,%d,8] of a 16-bit C8 buffer, got %s' % (B, H, W, tuple(out8.shape)))
     if nchw_pitch(f1) is None or nchw_pitch(f2) is None:
         f1, f2 = f1.contiguous(), f2.contiguous()
     fp = _feature_pair_pitch(f1, f2, 'corr81_norm_c8')
     ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
     with torch.cuda.device(dev):
-        _lib.call('upf_corr81_norm_forward_c8_pitched', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out8), out8.stride(0), B, C, H, W,
-                  _lib.dtype_code(f1), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
+        _lib.call('upf_corr81_norm_forward_c8_mixed', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out8), out8.stride(0), B, C, H, W,
+                  _lib.dtype_code(f1), _lib.dtype_code(out8), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev))
     return out8
 
 
@@ -724,6 +725,14 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
                       _lib.ptr(y_view), y_view.stride(0), B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
                       float(leaky_slope), int(CONV_X3_NPROD[0]), _lib.stream_ptr(dev))
         return y_view
+    if y_view.dtype != x_view.dtype:
+        # the OTHER 16-bit type out (the `pyramid_dtype` option): the 1x1 projections of the pyramid features only
+        if kernel_size != 1 or stride != 1 or Cout > 32 or y_view.dtype not in (torch.bfloat16, torch.float16):
+            raise UpflowHipError('conv: an output type other than the operands\' is offered for 1x1 convolutions with Cout <= 32 only')
+        with torch.cuda.device(dev):
+            _lib.call('upf_conv1x1_forward_mixed', _lib.ptr(x_view), x_view.stride(0), xp, _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y_view),
+                      y_view.stride(0), yp, 0, B, Cin, Cout, H, W, float(leaky_slope), _lib.dtype_code(x_view), _lib.dtype_code(y_view), _lib.stream_ptr(dev))
+        return y_view
     with torch.cuda.device(dev):
         _lib.call('upf_conv_forward_pitched', _lib.ptr(x_view), x_view.stride(0), xp, _lib.ptr(packed), _lib.ptr(bias32),
                   _lib.ptr(y_view), y_view.stride(0), yp, B, Cin, Cout, H, W, int(kernel_size), int(dilation), int(stride),
@@ -866,6 +875,13 @@ def conv_c8_forward_raw(x8, x2, packed, bias32, y, dilation=1, leaky_slope=0.0, 
             raise UpflowHipError('conv_c8: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, Ho, Wo))
         yp = _pitch_or_raise(y, 'conv_c8: y')
     dev = ref.device
+    if y.dtype != ref.dtype:
+        if not (x8 is None and x2 is not None and kernel_size == 1 and stride == 1 and y_is_c8 and Cout <= 32 and y.dtype in (torch.bfloat16, torch.float16)):
+            raise UpflowHipError('conv_c8: an output type other than the operands\' is offered for the 1x1 NCHW -> C8 projection (Cout <= 32) only')
+        with torch.cuda.device(dev):
+            _lib.call('upf_conv1x1_forward_mixed', _lib.ptr(x2), x2.stride(0), x2p, _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y), y.stride(0), 0, 1,
+                      B, x2.shape[1], Cout, H, W, float(leaky_slope), _lib.dtype_code(x2), _lib.dtype_code(y), _lib.stream_ptr(dev))
+        return y
     with torch.cuda.device(dev):
         _lib.call('upf_conv_forward_c8_pitched', _lib.ptr(x8), x8.stride(0) if x8 is not None else 0, x8.shape[1] if x8 is not None else 0,
                   _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, x2p, x2.shape[1] if x2 is not None else 0,
