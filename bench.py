@@ -325,9 +325,12 @@ def train_main(args, rank, world, device):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = tr.step(batch, sync_stats=False)     # (no host round trip inside the timed region; the barrier below synchronises)
+    torch.cuda.synchronize(device)
+    own = time.perf_counter() - t0                   # (under DDP every step ends in a collective: the ranks' own times differ by their last step only)
     barrier()
-    stats = {k: float(v) for k, v in zip(tr._names, stats.cpu())}
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    stats = {k: float(v) for k, v in zip(tr._names, stats.cpu())}
+    spread = rank_spread(own, args.steps, device)
     # the ONE exchange step of the path, timed on its own (outside the timed region): an all-reduce of a gradient-sized
     # fp32 buffer on the process group DDP uses, HIP events around 10 back-to-back calls
     allreduce_ms = None
@@ -352,7 +355,8 @@ def train_main(args, rank, world, device):
             'dtype': dname, 'data': 'synthetic',
             'config': {'workload': 'config3: photometric + smooth + census + pyramid-distillation loss, fwd+bwd+Adam(amsgrad), '
                                    '256x832 crops of 288x864 frames, batch 4 per GPU', 'global_batch': world * B,
-                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world, 'hip_graph': tr.use_graph,
+                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world, 'rank_ms_per_step': spread,
+                       'hip_graph': tr.use_graph,
                        'capture_fallback': tr.capture_fallback,      # True: the hipGraph capture failed and the steps ran eagerly
                        'optimizer': 'torch.optim.Adam(amsgrad, weight_decay 1e-4, %s)' % ('fused: one multi-tensor kernel' if tr.fused_adam else 'foreach'),
                        'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
@@ -458,16 +462,40 @@ def self_launch(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def launch_check(args, rank, world):
-    """--mode launch-check: only the multi-rank plumbing of this file (rendezvous, barrier, max-over-ranks, one JSON
-    line from rank 0) with no GPU work — what tests/test_distributed_cpu.py runs with --backend gloo."""
+def rank_spread(elapsed, steps, device=None):
+    """{'min','max','slowest_rank'} of the ranks' own ms per step (one all_gather): a scaling run is diagnosable from its one line."""
     from upflow_pytorch_amd import parallel
-    if world > 1:
-        torch.distributed.barrier()
+    per = [e / steps * 1e3 for e in parallel.gather_over_ranks(elapsed, device)]
+    return {'min': round(min(per), 3), 'max': round(max(per), 3), 'slowest_rank': per.index(max(per))}
+
+
+def launch_check(args, rank, world):
+    """--mode launch-check: the multi-rank plumbing of this file and nothing else — rendezvous, W warm-up + K timed "steps" (a
+    rank-dependent sleep standing for the GPU work) bracketed by barriers exactly like the real modes, max-over-ranks, the per-rank
+    spread, one JSON line from rank 0 — so that the 1/2/4/8-rank launch path is exercised on a box without GPUs
+    (tests/test_distributed_cpu.py, --backend gloo)."""
+    from upflow_pytorch_amd import parallel
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    step_s = 0.002 * (1 + rank % 3)                       # ranks deliberately differ: the line must report the slowest
+    for _ in range(args.warmup):
+        time.sleep(step_s)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(step_s)
+    own = time.perf_counter() - t0                         # this rank's own steps (before it waits for the others)
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    spread = rank_spread(own, args.steps)
     t = parallel.max_over_ranks(float(rank + 1))
     if rank == 0:
-        print(json.dumps({'metric': 'launch-check', 'n_gpus': world, 'ranks': world, 'max_over_ranks': t,
-                          'backend': torch.distributed.get_backend() if world > 1 else None}), flush=True)
+        print(json.dumps({'metric': 'launch-check', 'n_gpus': world, 'ranks': world, 'max_over_ranks': t, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'rank_ms_per_step': spread,
+                          'backend': torch.distributed.get_backend() if world > 1 else None,
+                          'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT')) if world > 1 else None}), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -478,6 +506,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; value = the median window')
     ap.add_argument('--ramp-seconds', type=float, default=0.5, help='untimed replay before the warm-up steps (clock ramp)')
     ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default=None, choices=sorted(DT))
@@ -561,12 +590,21 @@ def main():
         torch.cuda.synchronize(device)
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    # `--windows` timed windows of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides and reduced with MAX
+    # over ranks; `value` is the MEDIAN window, value_min / value_max the others (one 45 ms sample said nothing about repeatability)
+    windows = []
+    for _w in range(max(1, args.windows)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize(device)
+        own = time.perf_counter() - t0                     # this rank's own steps, before it waits for the others (rank_ms_per_step)
+        barrier()
+        windows.append((parallel.max_over_ranks(time.perf_counter() - t0, device), own))
+    windows.sort()
+    elapsed, own = windows[len(windows) // 2]
+    spread = rank_spread(own, args.steps, device)
     assert torch.isfinite(out['flow_f_out']).all()
     pipelined = (not args.no_graph) and args.streams > 1
     single = None
@@ -590,13 +628,15 @@ def main():
         pairs = world * B * args.steps
         line = {
             'metric': 'frame-pairs/sec at 384x1280 bf16' if args.workload == 'config2' else 'frame-pairs/sec',
-            'value': round(pairs / elapsed, 3), 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'value': round(pairs / elapsed, 3), 'value_min': round(pairs / windows[-1][0], 3), 'value_max': round(pairs / windows[0][0], 3),
+            'windows': len(windows), 'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': dname, 'data': 'synthetic',
             'config': {'workload': '%s: UPFlow_net inference forward (flow fwd+bwd, occlusion masks, SGU on), '
                                    '%dx%d, batch %d per GPU, random-init weights' % (args.workload, H, W, B),
                        'global_batch': world * B, 'parallelism': 'replicas x%d (image pairs sharded, no collective)' % world,
                        'ranks': world, 'backend': (torch.distributed.get_backend() + ' (RCCL)') if world > 1 else None,
+                       'rank_ms_per_step': spread,
                        'hip_graph': not args.no_graph, 'capture_fallback': False,
                        'steps_in_flight': args.streams if pipelined else 1,
                        'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or (dtype == torch.float32 and args.fp32_conv == 'miopen') else 'HIP (MFMA kernel)',

@@ -207,6 +207,40 @@ def test_bench_launches_its_own_ranks():
     assert d['ranks'] == 2 and d['n_gpus'] == 2 and d['max_over_ranks'] == 2.0 and d['backend'] == 'gloo'
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('form', ['self_launch', 'driver'])
+def test_bench_launch_path_at_eight_ranks(form):
+    """The launch path of the driver's 1/2/4/8 scaling run, at EIGHT ranks, on this GPU-less box: rendezvous on
+    127.0.0.1 with a free port, W warm-up + K timed steps between barriers, MAX over ranks, the per-rank spread, ONE JSON line.
+    `driver` = the command the driver issues (python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...); `self_launch` = `python bench.py --gpus 8` spawning its own ranks."""
+    import json
+    import socket
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    tail = [os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '5', '--warmup', '2', '--mode', 'launch-check', '--backend', 'gloo']
+    if form == 'driver':
+        s_ = socket.socket()
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+               '--master-port', str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['ranks'] == 8 and d['n_gpus'] == 8 and d['max_over_ranks'] == 8.0 and d['backend'] == 'gloo' and d['steps'] == 5
+    assert d['master'].startswith('127.0.0.1:')
+    # ranks sleep 2 / 4 / 6 ms per step (rank % 3): the line reports the slowest rank's time and the spread
+    sp = d['rank_ms_per_step']
+    assert sp['max'] >= 5.5 and sp['min'] <= 4.5 and sp['slowest_rank'] % 3 == 2 and d['ms_per_step'] >= sp['max'] - 0.5
+
+
 # ------------------------------------------------------------------------------------------------ batch mismatch under DDP
 class _FakeGraph(object):
     """Stands for a captured hipGraph on a box without a GPU: the decision logic around it is what is tested."""

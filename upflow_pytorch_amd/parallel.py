@@ -51,3 +51,14 @@ def max_over_ranks(value, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value, device=None):
+    """Every rank's python float, in rank order, on every rank (one all_gather of a scalar) — bench.py reports the spread of the
+    per-rank step times beside their maximum, so that a slow rank in a scaling run is visible from the one JSON line."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
