@@ -700,10 +700,67 @@ def golden_eval(tools):
     save('eval_edge', **d)
 
 
+def golden_train_realistic(upflow, pwc, tools):
+    """the training vector at REALISTIC motion.  train_128x192 uses head_scale 0.1 (sub-pixel flows): the
+    boundary-dilated warp never leaves the crop there and the occlusion masks are almost empty.  Here the heads are full scale
+    (mean |flow| ~10 px), the crop is 128x416 with its corner 3 / 2 px from the corner of the 144x448 frame (_weights.TRAIN_HS1):
+    the photometric warp samples outside the crop and is clamped at the frame border (utils/tools.py:351-499), the forward /
+    backward check masks a large share of the pixels (utils/tools.py:501-677), and the warp gradients see flows that leave the
+    frame.  Same recorded quantities as golden_train, plus the statistics that show the regime (share of occluded pixels, share of
+    photometric samples outside the crop / outside the frame)."""
+    import model.upflow as mu
+    old_fwd = robust_mask_patch(pwc)
+    old_up = mu.upsample2d_flow_as
+    mu.upsample2d_flow_as = oop_upsample2d_flow_as
+    try:
+        net = build_net(upflow, extra=_weights.TRAIN_FLAGS, head_scale=1.0)
+        net.train()
+        batch = _weights.make_train_batch(**_weights.TRAIN_HS1)
+        batch['if_loss'] = True
+        out = net(batch)
+        terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')}
+        loss = sum(terms.values())
+        loss.backward()
+        names = sorted(n for n, _ in net.named_parameters())
+        params = dict(net.named_parameters())
+        gnorm = np.array([float(params[n].grad.norm()) for n in names], dtype=np.float64)
+        proj = _weights.grad_projections({n: params[n].grad for n in names})
+        bias = {'gbias_%d' % i: params[n].grad for i, n in enumerate(names) if n.endswith('.bias')}
+        f = out['flow_f_out'].detach()
+        B, _, h, w = f.shape
+        H, W = batch['im1_raw'].shape[2:]
+        sx, sy = _weights.TRAIN_HS1['start_xy']
+        xx = torch.arange(w).view(1, 1, w) + f[:, 0]
+        yy = torch.arange(h).view(1, h, 1) + f[:, 1]
+        out_crop = float(((xx < 0) | (xx > w - 1) | (yy < 0) | (yy > h - 1)).float().mean())
+        out_frame = float(((xx + sx < 0) | (xx + sx > W - 1) | (yy + sy < 0) | (yy + sy > H - 1)).float().mean())
+        regime = np.array([float(f.pow(2).sum(1).sqrt().mean()), float(1.0 - out['occ_fw'].float().mean()), out_crop, out_frame])
+        save('train_128x416_hs1', loss=np.array([float(loss)]), **{k: np.array([float(v)]) for k, v in terms.items()},
+             grad_norms=gnorm, grad_proj=proj, flow_f_out=out['flow_f_out'], flow_b_out=out['flow_b_out'],
+             occ_fw=out['occ_fw'].to(torch.uint8), occ_bw=out['occ_bw'].to(torch.uint8), regime=regime, **bias)
+        print({k: float(v) for k, v in terms.items()}, 'grad norm sum', gnorm.sum())
+        print('regime: mean |flow| %.2f px, occluded %.1f %%, photometric samples outside the crop %.1f %%, outside the frame %.1f %%'
+              % (regime[0], 100 * regime[1], 100 * regime[2], 100 * regime[3]))
+        net.zero_grad()
+        b16 = {k: (v.bfloat16().float() if k in ('im1', 'im2', 'im1_raw', 'im2_raw') else v) for k, v in batch.items()}
+        out16 = net(b16)
+        sum(out16[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')).backward()
+        proj16 = _weights.grad_projections({n: params[n].grad for n in names})
+        cos = (proj * proj16).sum(1) / (np.linalg.norm(proj, axis=1) * np.linalg.norm(proj16, axis=1))
+        print('reference vs reference-with-bf16-rounded-frames: gradient cosine min %.5f median %.5f' % (cos.min(), np.median(cos)))
+        z = dict(np.load(os.path.join(HERE, 'train_128x416_hs1.npz')))
+        z['grad_proj_bf16_frames'] = proj16
+        z['loss_bf16_frames'] = np.array([float(out16[k].mean()) for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')])
+        np.savez_compressed(os.path.join(HERE, 'train_128x416_hs1.npz'), **z)
+    finally:
+        pwc.WarpingLayer_no_div.forward = old_fwd
+        mu.upsample2d_flow_as = old_up
+
+
 def main():
     torch.set_num_threads(8)
     upflow, pwc, tools, Corr_pyTorch = import_reference()
-    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'eval', 'net', 'net384', 'neths1', 'train', 'traj']
+    which = sys.argv[1:] or ['corr', 'warp', 'upsample', 'normalize', 'sgu', 'occ', 'census', 'losses', 'eval', 'net', 'net384', 'neths1', 'train', 'traj', 'trainhs1']
     if 'corr' in which:
         golden_corr(Corr_pyTorch)
     if 'warp' in which:
@@ -732,6 +789,8 @@ def main():
         golden_train(upflow, pwc, tools)
     if 'traj' in which:
         golden_train_trajectory(upflow, pwc, tools)
+    if 'trainhs1' in which:
+        golden_train_realistic(upflow, pwc, tools)
 
 
 if __name__ == '__main__':

@@ -551,3 +551,80 @@ def test_validation_between_replayed_steps_sees_the_current_weights():
     assert not torch.equal(first, second), 'five optimizer steps at lr 1e-3 must move the validation output'
     with pytest.raises(RuntimeError):
         runner.replay()                                  # the captured inference graph reads the packed copies made before
+
+
+def _realistic_step(train_conv_dtype):
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    conf = UPFlow_net.config()
+    d = dict(FLAGS)
+    d.update(_weights.TRAIN_FLAGS)
+    d['train_conv_dtype'] = train_conv_dtype
+    conf.update(d, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=1.0))
+    net = net.cuda().train()
+    batch = {k: v.cuda() for k, v in _weights.make_train_batch(**_weights.TRAIN_HS1).items()}
+    batch['if_loss'] = True
+    out = net(batch)
+    terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')}
+    sum(terms.values()).backward()
+    names = sorted(n for n, _ in net.named_parameters())
+    params = dict(net.named_parameters())
+    return out, terms, names, params
+
+
+def test_train_step_at_realistic_motion_matches_reference():
+    """training parity where the flows LEAVE the crop (tests/golden/train_128x416_hs1.npz: full-scale heads, mean
+    |flow| 11.4 px, crop 3 / 2 px from the frame's corner: 5.5 % of the photometric samples outside the crop, 1 % clamped at the frame
+    border, 94 % of the pixels failing the forward / backward check).  fp32 path (the parity mode) against the reference: flows
+    <= 1e-4 px, occlusion masks, the four loss terms <= 2e-4, every gradient norm <= 1e-2, directions >= 0.9999."""
+    g = load_golden('train_128x416_hs1')
+    out, terms, names, params = _realistic_step('fp32')
+    print('regime (reference): mean |flow| %.2f px, masked %.1f %%, samples outside the crop %.1f %%, outside the frame %.1f %%'
+          % (float(g['regime'][0]), 100 * float(g['regime'][1]), 100 * float(g['regime'][2]), 100 * float(g['regime'][3])))
+    assert oracle.epe(out['flow_f_out'].detach().cpu(), g['flow_f_out']) <= 1e-4
+    assert oracle.epe(out['flow_b_out'].detach().cpu(), g['flow_b_out']) <= 1e-4
+    for k_ in ('occ_fw', 'occ_bw'):
+        assert (out[k_].detach().cpu() != g[k_].float()).float().mean() <= 2e-3, k_
+    for k, v in terms.items():
+        want = float(g[k])
+        print(k, float(v), want)
+        assert abs(float(v) - want) <= 2e-4 * max(1.0, abs(want)), k
+    got = np.array([float(params[n].grad.norm()) for n in names])
+    want = g['grad_norms'].numpy()
+    rel = np.abs(got - want) / np.maximum(want, 1e-3)
+    cos, worst = grad_direction_check({n: params[n].grad for n in names}, g)
+    print('realistic motion, fp32: max rel grad-norm error %.3g (param %s), min cosine %.7f, worst bias-gradient error %.3g'
+          % (rel.max(), names[int(rel.argmax())], cos.min(), worst))
+    # (measured over boxes: norms 2.6e-3 .. 5.3e-3, worst bias gradient 4e-3 .. 8e-3, cosines >= 0.99996.  The fp32 training path runs
+    # its convolutions through PyTorch-ROCm, whose gradient kernels are not reproducible run to run, and at this motion 94 % of the
+    # pixels sit behind hard masks: the reference's OWN gradients move to cosine 0.983 when its frames are rounded to bf16.)
+    assert (got > 0).all() and rel.max() <= 1e-2 and cos.min() >= 0.9999 and worst <= 1.5e-2
+
+
+# measured on MI355X (printed by the test): loss terms within 0.52 %, flow 0.83 px = 7.3 % of the motion (128x416 with random full-scale
+# heads is a chaotic map: the bf16 INFERENCE path is 2.9 % away at 256x256, 1.1 % at 384x1280), gradient norms within 14.8 % (median 4.1 %),
+# gradient cosines min 0.910 / median 0.985 against 0.983 / 0.998 for the reference's own step with bf16-rounded frames — i.e. at
+# realistic motion the bf16 training mode IS further from the reference than an input-rounding-sized perturbation; the small-motion
+# vector (0.2 % / 4 %, on the floor) did not show that.  Bounds = 1.5 x the measurement.
+BF16_HS1 = {'loss': 8e-3, 'epe': 1.25, 'gnorm': 0.22, 'cos_median_slack': 0.02, 'cos_min_slack': 0.11}
+
+
+def test_bf16_training_mode_at_realistic_motion_stays_in_the_envelope():
+    """The bf16 training mode on the same vector: the envelope of test_bf16_training_mode_tracks_the_fp32_reference RESTATED where
+    the masks are active and the warps leave the crop (BF16_HS1 above: the measured distances and what they say)."""
+    g = load_golden('train_128x416_hs1')
+    out, terms, names, params = _realistic_step('bf16')
+    lrel = {k: abs(float(v) - float(g[k])) / max(1.0, abs(float(g[k]))) for k, v in terms.items()}
+    print('loss terms, relative error:', {k: round(v, 5) for k, v in lrel.items()})
+    e = oracle.epe(out['flow_f_out'].detach().cpu(), g['flow_f_out'])
+    got = np.array([float(params[n].grad.norm()) for n in names])
+    want = g['grad_norms'].numpy()
+    rel = np.abs(got - want) / np.maximum(want, 1e-3)
+    cos, worst = grad_direction_check({n: params[n].grad for n in names}, g)
+    ref, r16 = g['grad_proj'].numpy(), g['grad_proj_bf16_frames'].numpy()
+    floor = (ref * r16).sum(1) / (np.linalg.norm(ref, axis=1) * np.linalg.norm(r16, axis=1))
+    print('realistic motion, bf16: loss terms rel. error max %.4f, flow EPE %.4f px, max rel grad-norm error %.3g (param %s) median %.3g, cosine min %.5f median %.5f | reference with bf16 frames: min %.5f median %.5f'
+          % (max(lrel.values()), e, rel.max(), names[int(rel.argmax())], np.median(rel), cos.min(), np.median(cos), floor.min(), np.median(floor)))
+    assert max(lrel.values()) <= BF16_HS1['loss'] and e <= BF16_HS1['epe'] and rel.max() <= BF16_HS1['gnorm']
+    assert np.median(cos) >= np.median(floor) - BF16_HS1['cos_median_slack'] and cos.min() >= floor.min() - BF16_HS1['cos_min_slack']

@@ -169,3 +169,31 @@ def test_fused_optimizer_steps_advance_parameter_versions():
     v3 = qs[0]._version
     opt3.step()
     assert qs[0]._version == v3 + 1
+
+
+def test_training_losses_and_gradients_at_realistic_motion_vs_reference_golden(stub):
+    """The same host logic where the flows are large (tests/golden/train_128x416_hs1.npz: full-scale heads, mean |flow| 11.4 px, a
+    crop 3 / 2 px from the frame's corner — 5.5 % of the photometric samples fall outside the crop, 1 % outside the frame and are
+    clamped, 94 % of the pixels fail the forward / backward check): losses, gradient norms and directions against the reference's."""
+    g = load_golden('train_128x416_hs1')
+    net = _net(dict(_weights.TRAIN_FLAGS)).train()
+    net.load_state_dict(_weights.make_state_dict(0, head_scale=1.0))
+    batch = dict(_weights.make_train_batch(**_weights.TRAIN_HS1))
+    batch['if_loss'] = True
+    out = net(batch)
+    assert oracle.epe(out['flow_f_out'].detach(), g['flow_f_out']) <= 1e-4
+    assert (out['occ_fw'].detach() != g['occ_fw'].float()).float().mean() <= 2e-3
+    terms = {k: out[k].mean() for k in ('photo_loss', 'smooth_loss', 'census_loss', 'msd_loss')}
+    for k, v in terms.items():
+        assert abs(float(v) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(v), float(g[k]))
+    sum(terms.values()).backward()
+    names = sorted(n for n, _ in net.named_parameters())
+    params = dict(net.named_parameters())
+    got = np.array([float(params[n].grad.norm()) for n in names])
+    want = g['grad_norms'].numpy()
+    # (measured: norms within 2.6e-3, worst bias gradient 3.9e-3, cosines >= 0.99999.  Looser than the small-motion vector's 2e-3: with
+    # 94 % of the pixels behind hard masks the reference's OWN gradient moves to cosine 0.983 when its frames are rounded to bf16 —
+    # make_golden.py prints it —, so fp32 summation-order differences show at the 1e-3 level)
+    assert (np.abs(got - want) / np.maximum(want, 1e-3)).max() <= 5e-3
+    cos, worst = _grad_direction_check({n: params[n].grad for n in names}, g)
+    assert cos.min() >= 0.9999 and worst <= 8e-3, (float(cos.min()), names[int(cos.argmin())], worst)

@@ -92,9 +92,11 @@ def make_smooth_images(config_id, B, H, W, shift=2):
     return im1.contiguous(), im2.contiguous()
 
 
-def make_train_batch(B=2, crop_hw=(128, 192), raw_hw=(160, 256), seed=0):
+def make_train_batch(B=2, crop_hw=(128, 192), raw_hw=(160, 256), seed=0, start_xy=None):
     """KITTI-style training batch: crops, the un-cropped frames and the crop offset `start`
-    (scripts/ex_runner.py:146-147).  Smooth texture moved by 2 px so the photometric loss is meaningful."""
+    (scripts/ex_runner.py:146-147).  Smooth texture moved by 2 px so the photometric loss is meaningful.
+    start_xy: crop offset (x, y) inside the un-cropped frame (default: centred) — near the border, flows that leave the crop also leave
+    the frame, which is where tools.boundary_dilated_warp clamps (utils/tools.py:351-499)."""
     g = torch.Generator().manual_seed(4000 + seed)
     H, W = raw_hw
     h, w = crop_hw
@@ -103,9 +105,17 @@ def make_train_batch(B=2, crop_hw=(128, 192), raw_hw=(160, 256), seed=0):
     im1 = big[:, :, 4:4 + H, 4:4 + W].contiguous()
     im2 = big[:, :, 4:4 + H, 2:2 + W].contiguous()
     sy, sx = (H - h) // 2, (W - w) // 2
+    if start_xy is not None:
+        sx, sy = int(start_xy[0]), int(start_xy[1])
     start = torch.tensor([sx, sy], dtype=torch.float32).view(1, 2, 1, 1).repeat(B, 1, 1, 1)
     return {'im1': im1[:, :, sy:sy + h, sx:sx + w].contiguous(), 'im2': im2[:, :, sy:sy + h, sx:sx + w].contiguous(),
             'im1_raw': im1, 'im2_raw': im2, 'start': start}
+
+
+# the realistic-motion training vector (tests/golden/train_128x416_hs1.npz): full-scale heads (head_scale 1: flows
+# of ~10 px), a crop whose corner sits 3 px / 2 px from the frame's, so that the boundary-dilated warp samples outside the crop AND is
+# clamped at the frame border, and the occlusion masks are non-trivial
+TRAIN_HS1 = dict(B=2, crop_hw=(128, 416), raw_hw=(144, 448), seed=3, start_xy=(3, 2))
 
 
 TRAIN_FLAGS = {'photo_loss_census_weight': 1, 'multi_scale_distillation_weight': 1, 'multi_scale_distillation_style': 'upup',
