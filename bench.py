@@ -518,6 +518,7 @@ def main():
                     help='steps in flight (inference): the captured step is replayed round-robin on this many HIP streams, each with its own '
                          'batch buffers (runtime.PipelinedInference); 1 = one step at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-eval-probe', action='store_true', help='skip `eval_batch1` (kitti_native: the batch-1 evaluation path, graph vs eager)')
     ap.add_argument('--no-train-probe', action='store_true', help='skip the config-3 training step reported as `train_step`')
     ap.add_argument('--no-literal-split', action='store_true',
                     help="skip `literal_split` (the same step with the north star's literal split, feature pyramid through PyTorch-ROCm, timed beside the headline)")
@@ -695,7 +696,7 @@ def main():
                 line['literal_split'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if single is not None:
             line['one_step_in_flight'] = single
-        if world == 1 and args.workload == 'kitti_native':
+        if world == 1 and args.workload == 'kitti_native' and not args.no_eval_probe:
             line['eval_batch1'] = eval_probe(net, H, W, device)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()

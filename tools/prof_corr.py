@@ -19,10 +19,13 @@ elif var == 'norm':
 else:
     fwd = lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)
 g = torch.Generator().manual_seed(2004)
-f1 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
-f2 = torch.randn(B, C, H, W, generator=g).cuda().to(dt)
+# (norm_c8 at a ragged width — KITTI's native 94x311 level — takes ROW-PITCHED features, like the step's pair buffers: ops.empty_nchw)
+pair = ops.empty_nchw((2, B, C, H, W), dt, 'cuda', pitched=(var == 'norm_c8')) if dt != torch.float32 else torch.empty(2, B, C, H, W, device='cuda')
+pair[0].copy_(torch.randn(B, C, H, W, generator=g).cuda())
+pair[1].copy_(torch.randn(B, C, H, W, generator=g).cuda())
+f1, f2 = pair[0], pair[1]
 out = torch.empty(B, 81, H, W, device='cuda', dtype=dt)
-out8 = ops.c8_empty(B, 88, H, W, dt, 'cuda') if dt != torch.float32 and W % 8 == 0 else None
+out8 = ops.c8_empty(B, 88, H, W, dt, 'cuda') if dt != torch.float32 else None
 # evict the 256 MiB infinity cache between launches so FETCH_SIZE reflects HBM, not MALL hits
 junk = torch.empty(320 * 1024 * 1024, dtype=torch.uint8, device='cuda')
 for i in range(20):

@@ -45,7 +45,12 @@ def main():
     write_cold = sum(wk[:nw]) / nw
     fetch_bytes = fetch_cold * 1024 * 2
     write_bytes = write_cold * 1024
-    summ = {'shape': [B, C, H, W], 'dtype': dtype, 'kernel': name, 'variant': 'norm_c8' if name.rstrip().endswith(', true, 1, true>') else 'norm' if (name.rstrip().endswith(', true, 1>') or name.rstrip().endswith(', true, 1, false>')) else 'plain', 'algorithmic_bytes': alg_r + alg_w, 'algorithmic_read_bytes': alg_r,
+    # corr81_allc_kernel<T, UW, NU, NT, RAGGED, NORM, TPW, OC8, PADW, TO>
+    targs = [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')] if '<' in name else []
+    norm_ = len(targs) > 5 and targs[5] == 'true'
+    oc8_ = len(targs) > 7 and targs[7] == 'true'
+    variant = 'norm_c8' if (norm_ and oc8_) else 'norm' if norm_ else 'plain'
+    summ = {'shape': [B, C, H, W], 'dtype': dtype, 'kernel': name, 'variant': variant, 'padw': len(targs) > 8 and targs[8] == 'true', 'algorithmic_bytes': alg_r + alg_w, 'algorithmic_read_bytes': alg_r,
             'algorithmic_write_bytes': alg_w, 'fetch_bytes_corrected_x2': fetch_bytes, 'write_bytes': write_bytes,
             'traffic_bytes': fetch_bytes + write_bytes, 'traffic_over_algorithmic': (fetch_bytes + write_bytes) / (alg_r + alg_w),
             'calibration_cast_kernel_fetch_KB': fcal[:2], 'calibration_cast_kernel_bytes_read': 4 * B * C * H * W,
