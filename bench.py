@@ -424,9 +424,21 @@ def eval_probe(net, H, W, device, iters=40):
                 tm.eval_forward(a, b, 0)
             torch.cuda.synchronize(device)
             res[name] = (time.perf_counter() - t0) / iters * 1e3
+        # ... and with four pairs in flight (runtime.PipelinedEvaluation behind Test_model(streams=4).eval_forward_stream): what
+        # Evaluation_bench uses when the test model offers it
+        tm = Test_model(pretrain_path=None, dtype=next(net.parameters()).dtype, device=device, net=net, streams=4)
+        for _ in tm.eval_forward_stream([(a, b)] * 8):
+            pass
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in tm.eval_forward_stream([(a, b)] * (4 * iters)):
+            pass
+        torch.cuda.synchronize(device)
+        res['pipelined'] = (time.perf_counter() - t0) / (4 * iters) * 1e3
         return {'workload': 'Test_model.eval_forward, batch 1, %dx%d, one pair at a time (test.py:40-47)' % (H, W),
                 'graph_ms_per_pair': round(res['graph'], 3), 'eager_ms_per_pair': round(res['eager'], 3),
-                'graph_pairs_per_s': round(1e3 / res['graph'], 1), 'iters': iters}
+                'graph_pairs_per_s': round(1e3 / res['graph'], 1), 'iters': iters,
+                'four_pairs_in_flight_ms_per_pair': round(res['pipelined'], 3), 'four_pairs_in_flight_pairs_per_s': round(1e3 / res['pipelined'], 1)}
     except Exception as e:                                   # (an extra: it must never take the headline line down)
         return {'error': '%s: %s' % (type(e).__name__, e)}
 

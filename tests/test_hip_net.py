@@ -512,3 +512,30 @@ def test_evaluation_path_replays_one_graph_per_frame_size():
         x, y = (t.cuda() for t in _weights.make_smooth_images(5, 1, h, w))
         small(x, y)
     assert len(small.shapes()) == 2 and small.captures == 4
+
+
+def test_pipelined_evaluation_of_mixed_frame_sizes_is_bit_identical_and_in_order():
+    """runtime.PipelinedEvaluation / Test_model(streams=4): the evaluation loop with four frame pairs of MIXED KITTI sizes in flight —
+    every result equals the same pair run alone (eager), in submission order, and Evaluation_bench computes the same numbers as the
+    one-pair-at-a-time loop."""
+    from upflow_pytorch_amd.test import Test_model
+    from upflow_pytorch_amd.dataset.kitti_dataset import kitti_flow
+    net = build('robust', dtype=torch.bfloat16)
+    sizes = [(375, 1242), (370, 1224), (375, 1242), (376, 1241), (375, 1242), (370, 1224), (375, 1242), (375, 1242), (376, 1241)]
+    pairs = [tuple(t.cuda() for t in _weights.make_smooth_images(120 + i, 1, h, w)) for i, (h, w) in enumerate(sizes)]
+    with torch.no_grad():
+        want = [net({'im1': a, 'im2': b, 'if_loss': False})['flow_f_out'].clone() for a, b in pairs]
+    tm = Test_model(pretrain_path=None, dtype=torch.bfloat16, net=net, streams=4)
+    for rep in range(2):                                  # second pass: replays only
+        got = [f.clone() for f in tm.eval_forward_stream(iter(pairs))]
+        assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want)), rep
+    assert tm.pipe.captures == 3
+    # the bench protocol: ground truth = eager flow + a deterministic offset -> identical metrics from both loops
+    ds = []
+    for (a, b), w in zip(pairs[:5], want[:5]):
+        gt = (w[0] + 0.5).cpu()
+        ones = torch.ones(1, *gt.shape[1:])
+        ds.append((a[0].cpu(), b[0].cpu(), gt, ones, gt, ones))
+    seq = kitti_flow.Evaluation_bench('2015_train', batch_size=1, dataset=ds)(Test_model(pretrain_path=None, dtype=torch.bfloat16, net=net))
+    par = kitti_flow.Evaluation_bench('2015_train', batch_size=1, dataset=ds)(tm)
+    assert seq == par and abs(seq[0] - 0.5 * 2 ** 0.5) < 1e-3

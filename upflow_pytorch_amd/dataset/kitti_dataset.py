@@ -198,24 +198,44 @@ class kitti_flow:
                     test_model.eval_save_result(img_name, test_model.eval_forward(im1, im2, 0))
                 return None
             meters = [tools.AverageMeter() for _ in range(4)]
-            index = -1
-            for s in range(0, len(self.dataset), self.batch_size):
-                items = [self.dataset[i] for i in range(s, min(len(self.dataset), s + self.batch_size))]
-                if len({tuple(it[0].shape) for it in items}) != 1:            # KITTI frames differ in size: one by one then
-                    batches = [[t.unsqueeze(0) for t in it] for it in items]
-                else:
-                    batches = [[torch.stack(col) for col in zip(*items)]]
-                for batch in batches:
-                    index += 1
-                    im1, im2, occ, occmask, noc, nocmask = self._dev(*batch)
-                    num = im1.shape[0]
-                    predflow = test_model.eval_forward(im1, im2, occ, occmask, noc, nocmask)
-                    vals = [self.flow_error_avg(occ, predflow, occmask), self.outlier_pct(occ, predflow, occmask),
-                            self.flow_error_avg(noc, predflow, nocmask), self.flow_error_avg(occ, predflow, occmask - nocmask)]
-                    for m, v in zip(meters, vals):
-                        m.update(val=float(v), num=num)
-                    save_name = 'all_%.2f f1_%.1f noc_%.2f occ_%.2f__%d' % (meters[0].val, meters[1].val, meters[2].val, meters[3].val, index)
-                    test_model.eval_save_result(save_name, predflow, occmask=occmask)
+            index = [-1]
+
+            def batches():
+                for s in range(0, len(self.dataset), self.batch_size):
+                    items = [self.dataset[i] for i in range(s, min(len(self.dataset), s + self.batch_size))]
+                    if len({tuple(it[0].shape) for it in items}) != 1:            # KITTI frames differ in size: one by one then
+                        for it in items:
+                            yield self._dev(*[t.unsqueeze(0) for t in it])
+                    else:
+                        yield self._dev(*[torch.stack(col) for col in zip(*items)])
+
+            def score(batch, predflow):
+                index[0] += 1
+                im1, im2, occ, occmask, noc, nocmask = batch
+                num = im1.shape[0]
+                vals = [self.flow_error_avg(occ, predflow, occmask), self.outlier_pct(occ, predflow, occmask),
+                        self.flow_error_avg(noc, predflow, nocmask), self.flow_error_avg(occ, predflow, occmask - nocmask)]
+                for m, v in zip(meters, vals):
+                    m.update(val=float(v), num=num)
+                save_name = 'all_%.2f f1_%.1f noc_%.2f occ_%.2f__%d' % (meters[0].val, meters[1].val, meters[2].val, meters[3].val, index[0])
+                test_model.eval_save_result(save_name, predflow, occmask=occmask)
+
+            stream_fn = getattr(test_model, 'eval_forward_stream', None)
+            if stream_fn is not None and getattr(test_model, 'pipe', None) is not None:
+                # several pairs in flight (not in the reference, whose loop is strictly one pair at a time): the forward of the next
+                # pairs runs while this one is scored; same order, same numbers
+                from collections import deque
+                waiting = deque()
+
+                def pairs():
+                    for b in batches():
+                        waiting.append(b)
+                        yield b[0], b[1]
+                for predflow in stream_fn(pairs()):
+                    score(waiting.popleft(), predflow)
+            else:
+                for batch in batches():
+                    score(batch, test_model.eval_forward(*batch))
             return meters[0].avg, meters[1].avg, meters[2].avg, meters[3].avg
 
         @classmethod
