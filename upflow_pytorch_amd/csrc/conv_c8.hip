@@ -65,7 +65,7 @@ int launch_one_c8(const ArgsC8& a, int slabs) {
   constexpr bool PH = (D >= 2 && S == 1);
   constexpr int DV = PH ? 1 : D;
   constexpr int rowsC = S * (TH - 1) + 2 * DV + 1;
-  constexpr int XWP = xw(S, margin_of(D)) + xw(S, margin_of(D)) / 16;
+  constexpr int XWP = xwp_eff(XL, S, D);
   constexpr int EB = NOCTS * rowsC * XWP, EBP = (EB + 63) & ~63;
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int tiles_x = cdiv(Wo, TW), tiles_y = PH ? cdiv(Ho, D * TH) * D : cdiv(Ho, TH);

@@ -14,6 +14,16 @@ constexpr int MAXD = 16;                  // dilation limit (the context network
 __host__ __device__ constexpr int margin_of(int D) { return (D == 16 || D < 0) ? 16 : 8; }
 // staged columns [S*x0 - marg, S*x0 + S*32 + marg): whole 8-pixel groups -> 16-byte global loads
 __host__ __device__ constexpr int xw(int S, int marg) { return S * TW + 2 * marg; }
+// Round 5: a PURE octet input (XL == 1) is staged by LDS-DMA entry by entry — no 8-pixel groups to keep aligned — so its LDS rows hold
+// only the columns the taps read, [x0 - D, x0 + 32 + D): 34 entries (+1: odd pitch) instead of 51 for dilation 1.  The narrow layers
+// are LDS-capacity limited (two 32-KB buffers per workgroup = two workgroups per CU): at 22 KB per buffer a third workgroup fits.
+#ifndef UPF_C8_TIGHT
+#define UPF_C8_TIGHT 1
+#endif
+__host__ __device__ constexpr bool tight_rows(int XL) { return XL == 1 && UPF_C8_TIGHT != 0; }
+__host__ __device__ constexpr int marg_eff(int XL, int D) { return tight_rows(XL) ? (D > 0 ? D : 0) : margin_of(D); }
+__host__ __device__ constexpr int xw_eff(int XL, int S, int D) { return xw(S, marg_eff(XL, D)); }
+__host__ __device__ constexpr int xwp_eff(int XL, int S, int D) { return tight_rows(XL) ? (xw_eff(XL, S, D) | 1) : xw_eff(XL, S, D) + xw_eff(XL, S, D) / 16; }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -247,11 +257,11 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
   static_assert(XL == 0 || (D >= 0 && !GEN && !ONE), "C8 input: compile-time dilation, aligned rows");
   static_assert(!N16 || (XL == 1 && MTW == 1 && NOCTS == 4 && D == 1 && S == 1 && RPW >= 2), "N16: C8 input, 3x3, dilation 1, stride 1");
   constexpr int ntaps = (D == 0) ? 1 : 9;
-  constexpr int marg = margin_of(D);
+  constexpr int marg = marg_eff(XL, D);
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;     // k-steps of 16 channels / channels per chunk
   constexpr int RG = 4 / MTW, TH = RG * RPW;
-  constexpr int XW = xw(S, marg);
-  constexpr int XWP = XW + XW / 16;                  // LDS row pitch in entries (with the rotated pixel slots of swz: the
+  constexpr int XW = xw_eff(XL, S, D);
+  constexpr int XWP = xwp_eff(XL, S, D);             // LDS row pitch in entries (with the rotated pixel slots of swz: the
                                                      // staging writes of a 16-lane phase hit 16 different bank quads)
   // PH (compile-time dilation >= 2): ROW-PHASE decomposition.  A workgroup's TH output rows are D image rows apart
   // (rows y0 + D*r of one phase y0 % D), so the three kernel rows read ADJACENT staged rows — the vertical halo is 2
