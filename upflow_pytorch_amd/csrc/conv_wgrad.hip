@@ -111,7 +111,7 @@ constexpr int MAXL = 6;
 struct KLevel {
   const void* x; const void* g;
   long long xbs, gbs;
-  int H, W, tiles_x, tiles_y, tile0, pad;
+  int H, W, tiles_x, tiles_y, tile0, ragged;     // ragged: rows / bases not 16-byte aligned (wgrad_pc_kernel<.., RAGGED = true> only)
 };
 struct KLevels {
   KLevel lv[MAXL];
@@ -331,6 +331,11 @@ void wgrad_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cou
 // register sets while tile t+1 is written to the OTHER of two LDS buffers — so that a SIMD always holds one wave of each
 // kind and issues MFMAs and staging instructions side by side; one barrier per tile swaps the buffers.  64 co x 64 ci per
 // workgroup, same partial layout, same XCD-aware tile order as wgrad_kernel<.., MB = 1>.
+// RAGGED here = "some level of this launch is ragged" (KLevel::ragged says which): the producers pick the shifted staging
+// PER TILE by a wave-uniform branch, so aligned and ragged pyramid levels share one launch, one accumulation and one set
+// of partial blocks.  (Round 4 gave the ragged levels — 52, 26, 13 pixels wide, 6 % of a config-3 step's pixels — their own
+// launch and their own K-splits: 25 launches of ~20 us and half of the partial blocks; pushing ALL tiles through the shifted
+// staging instead cost the aligned 94 % more than those launches did.)
 template <typename T, int D, bool RAGGED>
 __global__ __launch_bounds__(2 * NTHREADS, 2)
 void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cout, int nci2, int J, int co2_base) {
@@ -382,6 +387,7 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
     }
     // current pyramid level (tiles of a workgroup only ever move forward through the levels)
     int lev = -1, next_t0 = 0;
+    bool lrag = false;                                                   // the current level takes the shifted staging (uniform)
     const T* lx = nullptr; const T* lg = nullptr;
     long long lxbs = 0, lgbs = 0;
     int H = 1, W = 1, tiles_x = 1, tiles_y = 1, t0 = 0;
@@ -395,6 +401,7 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
           if (i == lev) {
             lx = (const T*)L.lv[i].x; lg = (const T*)L.lv[i].g; lxbs = L.lv[i].xbs; lgbs = L.lv[i].gbs;
             H = L.lv[i].H; W = L.lv[i].W; tiles_x = L.lv[i].tiles_x; tiles_y = L.lv[i].tiles_y; t0 = L.lv[i].tile0;
+            if constexpr (RAGGED) lrag = L.lv[i].ragged != 0;
           }
         next_t0 = 0x7fffffff;
 #pragma unroll
@@ -410,10 +417,12 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
     };
     // a / b for 0 <= a < 2^24 through the reciprocal (exact after one correction step either way)
     auto fdiv = [](int a, int b, float rb) { int q = (int)((float)a * rb); int r = a - q * b; q += (r >= b) - (r < 0); return q; };
-    struct Set { u32x4 px[NXT], pg[NGT]; int sx[RAGGED ? NXT : 1], sg[RAGGED ? NGT : 1]; };
+    struct Set { u32x4 px[NXT], pg[NGT]; int sx[RAGGED ? NXT : 1], sg[RAGGED ? NGT : 1]; bool rag; };
     Set S0, S1;
+    S0.rag = S1.rag = false;
     auto issue = [&](int tile, Set& S) {
       enter_level(tile);
+      if constexpr (RAGGED) S.rag = lrag;
       const int lt = tile - t0;
       const int n = fdiv(lt, tiles_x * tiles_y, rtxy), r2 = lt - n * tiles_x * tiles_y;
       const int ty = fdiv(r2, tiles_x, rtx), tx = r2 - ty * tiles_x;
@@ -423,33 +432,59 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
       const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(lx + (size_t)n * lxbs + (size_t)ci2 * 64 * H * W), 0, live ? xnch * plane : 0u, 0x00020000);
       const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(lg + (size_t)n * lgbs + (size_t)co2 * 64 * H * W), 0, live ? gnch * plane : 0u, 0x00020000);
       const uint32_t torg = (uint32_t)((y0 * W + x0) * 2);
+      if (RAGGED && lrag) {                                              // (uniform branch: a level is ragged or it is not)
 #pragma unroll
-      for (int i = 0; i < NXT; ++i) {
-        const int gy = y0 + xrow[i], gx = x0 + xcol[i];
-        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        int sh = 0;
-        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sx[i] = sh; }
-        const uint32_t off = in ? xrel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
-        S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-      }
+        for (int i = 0; i < NXT; ++i) {
+          const int gy = y0 + xrow[i], gx = x0 + xcol[i];
+          const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+          const int sh = (in && gx + 8 > W) ? gx + 8 - W : 0;
+          S.sx[RAGGED ? i : 0] = sh;
+          const uint32_t off = in ? xrel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
+          S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+        }
 #pragma unroll
-      for (int i = 0; i < NGT; ++i) {
-        const int gy = y0 + grow[i], gx = x0 + gcol[i];
-        const bool in = gy < H && gx < W;
-        int sh = 0;
-        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sg[i] = sh; }
-        const uint32_t off = in ? grel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
-        S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
+        for (int i = 0; i < NGT; ++i) {
+          const int gy = y0 + grow[i], gx = x0 + gcol[i];
+          const bool in = gy < H && gx < W;
+          const int sh = (in && gx + 8 > W) ? gx + 8 - W : 0;
+          S.sg[RAGGED ? i : 0] = sh;
+          const uint32_t off = in ? grel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
+          S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NXT; ++i) {
+          const int gy = y0 + xrow[i], gx = x0 + xcol[i];
+          const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+          const uint32_t off = in ? xrel[i] + torg : 0x80000000u;
+          S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NGT; ++i) {
+          const int gy = y0 + grow[i], gx = x0 + gcol[i];
+          const bool in = gy < H && gx < W;
+          const uint32_t off = in ? grel[i] + torg : 0x80000000u;
+          S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
+        }
       }
     };
     auto land = [&](const Set& S, uint4* buf) {
       uint4* xs = buf; uint4* gs = buf + G::X_BLOCKS;
+      if (RAGGED && S.rag) {
 #pragma unroll
-      for (int i = 0; i < NXT; ++i)
-        if (xslot[i] >= 0) xs[xslot[i]] = __builtin_bit_cast(uint4, RAGGED ? shr_pixels(S.px[i], S.sx[RAGGED ? i : 0]) : S.px[i]);
+        for (int i = 0; i < NXT; ++i)
+          if (xslot[i] >= 0) xs[xslot[i]] = __builtin_bit_cast(uint4, shr_pixels(S.px[i], S.sx[RAGGED ? i : 0]));
 #pragma unroll
-      for (int i = 0; i < NGT; ++i)
-        if (gslot[i] >= 0) gs[gslot[i]] = __builtin_bit_cast(uint4, RAGGED ? shr_pixels(S.pg[i], S.sg[RAGGED ? i : 0]) : S.pg[i]);
+        for (int i = 0; i < NGT; ++i)
+          if (gslot[i] >= 0) gs[gslot[i]] = __builtin_bit_cast(uint4, shr_pixels(S.pg[i], S.sg[RAGGED ? i : 0]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < NXT; ++i)
+          if (xslot[i] >= 0) xs[xslot[i]] = __builtin_bit_cast(uint4, S.px[i]);
+#pragma unroll
+        for (int i = 0; i < NGT; ++i)
+          if (gslot[i] >= 0) gs[gslot[i]] = __builtin_bit_cast(uint4, S.pg[i]);
+      }
     };
     // tile k of this workgroup = first + k * J (dead beyond niter: a null descriptor, zeros).  Set k & 1 carries tile k.
     issue(first, S0);
@@ -590,13 +625,18 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
 // loads per split in flight, and its NT x 4 results are 36 consecutive floats of dw.  The four waves of a workgroup take
 // every fourth split and are summed through LDS in wave order.  (The first version — one thread per element, a dependent
 // chain of 4-byte loads over the splits, 36-byte-strided stores — ran at 1 TB/s: 36 us per layer, 1.15 ms per step.)
-template <int NT>
+template <int NT, int SL>
 __global__ __launch_bounds__(256)
 void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ksplit, int Cout, int Cin, int cop, int s2d) {
-  __shared__ float4 sh[3][NT][64];
+  // SL slices of the split range per item, 256 / SL items per workgroup.  SL = 4 streams the wide layers (many items: the grid
+  // fills the chip, a thread walks ksplit / 4 splits); the narrow layers (Cout <= 32: 3 ... 70 workgroups of SL = 4, each thread
+  // a chain of 6-16 dependent rounds of loads: 19-35 us for a few MB, round 5's timeline) take SL = 16: four times the
+  // workgroups, a quarter of the rounds.  Summation order: slice s holds splits s, s + SL, ... in order; slices are added in order.
+  constexpr int IPW = 256 / SL;
+  __shared__ float4 sh[SL - 1][NT][IPW];
   const int cip = (Cin + 63) / 64 * 64, c4n = cip / 4;
-  const int q = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const long long item = blockIdx.x * 64ll + q;
+  const int q = threadIdx.x % IPW, slice = threadIdx.x / IPW;
+  const long long item = blockIdx.x * (long long)IPW + q;
   const bool live = item < (long long)Cout * c4n;
   const int co = live ? (int)(item / c4n) : 0, c4 = live ? (int)(item - (long long)co * c4n) : 0;
   float4 acc[NT];
@@ -605,7 +645,7 @@ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ 
   const size_t tstride = (size_t)cop * cip, kstride = (size_t)NT * tstride;
   if (live) {
     const float* p = partial + (size_t)co * cip + (size_t)c4 * 4 + (size_t)slice * kstride;
-    for (int k = slice; k < ksplit; k += 4, p += 4 * kstride) {
+    for (int k = slice; k < ksplit; k += SL, p += SL * kstride) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const float4 v = *reinterpret_cast<const float4*>(p + t * tstride);
@@ -622,11 +662,13 @@ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ 
   float out[4][NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const float4 a = sh[0][t][q], b = sh[1][t][q], c = sh[2][t][q];
-    out[0][t] = ((acc[t].x + a.x) + b.x) + c.x;
-    out[1][t] = ((acc[t].y + a.y) + b.y) + c.y;
-    out[2][t] = ((acc[t].z + a.z) + b.z) + c.z;
-    out[3][t] = ((acc[t].w + a.w) + b.w) + c.w;
+    float4 r = acc[t];
+#pragma unroll
+    for (int s = 0; s < SL - 1; ++s) {
+      const float4 a = sh[s][t][q];
+      r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+    }
+    out[0][t] = r.x; out[1][t] = r.y; out[2][t] = r.z; out[3][t] = r.w;
   }
   if constexpr (NT == 9) {
     if (s2d) {
@@ -824,6 +866,13 @@ void launch_group(const upf_wgrad_level* lv, const int* idx, int n, float* ws, i
   hipLaunchKernelGGL(kern, dim3(ksplit * nco2 * nci2), dim3(NTHREADS * MB), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8);
 }
 
+static bool level_ragged(const upf_wgrad_level& a, int Cin, int Cout) {
+  const long long xbs = a.x_batch_stride ? a.x_batch_stride : (long long)Cin * a.H * a.W;
+  const long long gbs = a.g_batch_stride ? a.g_batch_stride : (long long)Cout * a.H * a.W;
+  return !(a.W % 8 == 0 && xbs % 8 == 0 && gbs % 8 == 0 && aligned_to(a.x, 16) && aligned_to(a.grad_pre, 16));
+}
+static int level_tiles(const upf_wgrad_level& a, int dd) { return a.B * cdiv(a.W, TWP) * dd * cdiv(cdiv(a.H, dd), TR); }
+
 // More than 16 block pairs cannot run two tile lanes per XCD (32 CUs): a 567 -> 128 layer (18 pairs) would leave 14 of 32
 // CUs idle.  Its co blocks then go in separate launches (9 pairs, 3 lanes, 27 CUs per XCD); X is read once per launch.
 static bool pc_split_co(int nco2, int nci2) { return nco2 > 1 && nco2 * nci2 > 16 && nci2 <= 16; }
@@ -844,6 +893,7 @@ void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws
     k.H = a.H; k.W = a.W;
     k.tiles_x = cdiv(a.W, TWP); k.tiles_y = DD * cdiv(cdiv(a.H, DD), TR);
     k.tile0 = t0;
+    k.ragged = level_ragged(a, Cin, Cout) ? 1 : 0;
     t0 += a.B * k.tiles_x * k.tiles_y;
   }
   L.n = n; L.ntiles = t0;
@@ -860,25 +910,23 @@ void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws
   }
 }
 
-static bool level_ragged(const upf_wgrad_level& a, int Cin, int Cout) {
-  const long long xbs = a.x_batch_stride ? a.x_batch_stride : (long long)Cin * a.H * a.W;
-  const long long gbs = a.g_batch_stride ? a.g_batch_stride : (long long)Cout * a.H * a.W;
-  return !(a.W % 8 == 0 && xbs % 8 == 0 && gbs % 8 == 0 && aligned_to(a.x, 16) && aligned_to(a.grad_pre, 16));
-}
-static int level_tiles(const upf_wgrad_level& a, int dd) { return a.B * cdiv(a.W, TWP) * dd * cdiv(cdiv(a.H, dd), TR); }
 
-// The plan of one multi-level weight gradient: aligned levels in one launch, ragged ones in a second, their K-splits
-// back to back in the workspace, one reduction over all of them.
+// The plan of one multi-level weight gradient.  Producer / consumer kernel (the default): ALL levels in one launch — one K
+// dimension, one set of partial blocks — with the shifted staging chosen per tile (`mixed`: some level is ragged).
+// wgrad_kernel (UPF_WGRAD_MODE=1, kept for A/B runs): aligned levels in one launch, ragged ones in a second, their K-splits
+// back to back in the workspace.  One reduction over all partial blocks either way.
 struct Plan {
   int ia[MAXL], na = 0, ir[MAXL], nr = 0, ks_a = 0, ks_r = 0;
+  bool mixed = false;
 };
 static Plan make_plan(const upf_wgrad_level* lv, int n, int Cin, int Cout, int kernel_size, int dilation) {
   Plan p;
   const int dd = kernel_size == 1 ? 1 : dilation, nt = kernel_size == 1 ? 1 : 9;
   int ta = 0, tr = 0;
   for (int i = 0; i < n; ++i) {
-    if (level_ragged(lv[i], Cin, Cout)) { p.ir[p.nr++] = i; tr += level_tiles(lv[i], dd); }
-    else { p.ia[p.na++] = i; ta += level_tiles(lv[i], dd); }
+    const bool rag = level_ragged(lv[i], Cin, Cout);
+    if (rag && wgrad_mode() != 0) { p.ir[p.nr++] = i; tr += level_tiles(lv[i], dd); }
+    else { p.ia[p.na++] = i; ta += level_tiles(lv[i], dd); p.mixed = p.mixed || rag; }
   }
   const int cob = co_block(Cout);
   int nblocks = cdiv(Cout, cob) * cdiv(Cin, 64);
@@ -895,8 +943,8 @@ int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cou
   const int cob = co_block(Cout), cop = cdiv(Cout, cob) * cob;
   const size_t per_split = (size_t)G::NT * cop * (cdiv(Cin, 64) * 64);
   if (wgrad_mode() == 0) {
-    if (p.na) launch_group_pc<T, D, false>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
-    if (p.nr) launch_group_pc<T, D, true>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
+    if (p.mixed) launch_group_pc<T, D, true>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
+    else launch_group_pc<T, D, false>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
   } else if (cob == 128) {
     if (p.na) launch_group<T, D, false, 2>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
     if (p.nr) launch_group<T, D, true, 2>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
@@ -905,7 +953,11 @@ int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cou
     if (p.nr) launch_group<T, D, true, 1>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
   }
   const long long items = (long long)Cout * (cdiv(Cin, 64) * 16);
-  hipLaunchKernelGGL(wgrad_reduce_kernel<G::NT>, dim3((unsigned)((items + 63) / 64)), dim3(256), 0, stream, ws, dw, p.ks_a + p.ks_r, Cout, Cin, cop, s2d);
+  const int ks = p.ks_a + p.ks_r;
+  if (items <= 64 * 128 && ks >= 16)        // narrow layers: 16 slices per item (see the kernel)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<G::NT, 16>), dim3((unsigned)((items + 15) / 16)), dim3(256), 0, stream, ws, dw, ks, Cout, Cin, cop, s2d);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<G::NT, 4>), dim3((unsigned)((items + 63) / 64)), dim3(256), 0, stream, ws, dw, ks, Cout, Cin, cop, s2d);
   return check_launch("conv_wgrad");
 }
 
