@@ -91,6 +91,12 @@ __device__ __forceinline__ uint4 window(const uint4& p2, const uint4& p1, const 
 // RAGGED (any W >= 8, any alignment): the 8-pixel block that straddles the row end is loaded shifted left so that it
 // ENDS at the row end (2-byte-aligned 16-byte buffer loads are legal on gfx950) and shifted back in registers, zeros
 // filling the pixels beyond the row.
+// a wave-uniform pointer, in scalar registers whatever the compiler's divergence analysis concluded
+template <typename P> __device__ __forceinline__ P* uniform_ptr(P* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (P*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ u32x4 shr_pixels(u32x4 v, int sh) {            // 128-bit logical shift right by sh pixels (16 bits each)
   const unsigned long long lo = ((unsigned long long)v[1] << 32) | v[0], hi = ((unsigned long long)v[3] << 32) | v[2];
   unsigned long long rl, rh;
@@ -351,7 +357,9 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bpair = slot % nblocks, jj = slot / nblocks;
   const int ks_id = xcd * J + jj;
-  const int co2 = bpair / nci2 + co2_base, ci2 = bpair % nci2;
+  // experiments (UPF_WGRAD_ABLATE, read by the host): 1 = no matrix phase, 2 = null descriptors (loads return zeros, no traffic)
+  const int abl = co2_base >> 16;
+  const int co2 = bpair / nci2 + (co2_base & 0xffff), ci2 = bpair % nci2;
   const int t_lo = (int)((long long)L.ntiles * xcd / 8), t_hi = (int)((long long)L.ntiles * (xcd + 1) / 8);
   const int first = t_lo + jj;
   const int niter = first < t_hi ? (t_hi - first + J - 1) / J : 0;       // tiles of this workgroup (uniform)
@@ -423,52 +431,48 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
     auto issue = [&](int tile, Set& S) {
       enter_level(tile);
       if constexpr (RAGGED) S.rag = lrag;
+      // (the two divisions run on the vector unit — there is no scalar float — so their wave-uniform results are moved back to
+      // scalar registers explicitly: left in vector registers they make the buffer descriptors below "divergent", and hipcc
+      // then wraps EVERY staging load in a waterfall loop — 4 v_readfirstlane, 2 v_cmp, exec juggling and a branch per load, 13
+      // of them per tile in each producer wave, issued on the SIMDs the consumers' MFMAs need: rounds 2-4 shipped that)
       const int lt = tile - t0;
-      const int n = fdiv(lt, tiles_x * tiles_y, rtxy), r2 = lt - n * tiles_x * tiles_y;
-      const int ty = fdiv(r2, tiles_x, rtx), tx = r2 - ty * tiles_x;
+      const int n = __builtin_amdgcn_readfirstlane(fdiv(lt, tiles_x * tiles_y, rtxy)), r2 = lt - n * tiles_x * tiles_y;
+      const int ty = __builtin_amdgcn_readfirstlane(fdiv(r2, tiles_x, rtx)), tx = r2 - ty * tiles_x;
       const int phase = ty % DD, q = ty / DD;                            // (compile-time divisor)
       const int y0 = phase + DD * q * TR, x0 = tx * TWP;
-      const bool live = tile < t_hi;
-      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(lx + (size_t)n * lxbs + (size_t)ci2 * 64 * H * W), 0, live ? xnch * plane : 0u, 0x00020000);
-      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(lg + (size_t)n * lgbs + (size_t)co2 * 64 * H * W), 0, live ? gnch * plane : 0u, 0x00020000);
-      const uint32_t torg = (uint32_t)((y0 * W + x0) * 2);
-      if (RAGGED && lrag) {                                              // (uniform branch: a level is ragged or it is not)
+      const bool live = tile < t_hi && !(abl & 2);                      // (dead: null descriptors, every load returns zeros)
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<T*>(lx + (size_t)n * lxbs + (size_t)ci2 * 64 * H * W)), 0,
+                                                                          __builtin_amdgcn_readfirstlane(live ? xnch * plane : 0u), 0x00020000);
+      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<T*>(lg + (size_t)n * lgbs + (size_t)co2 * 64 * H * W)), 0,
+                                                                          __builtin_amdgcn_readfirstlane(live ? gnch * plane : 0u), 0x00020000);
+      const uint32_t torg = (uint32_t)__builtin_amdgcn_readfirstlane((y0 * W + x0) * 2);
+      // ONE load sequence for aligned and ragged levels (sh = 0 wherever a block does not straddle the row end — always, on an
+      // aligned level): with the loads duplicated in the two arms of a branch hipcc schedules them in different orders, and its
+      // wait-count insertion then has to assume the worst position of every register at the join (vmcnt(13) ... (2) instead
+      // of (25) ... (13): the landing drained the other set's loads).  The uniform branch is in land(), around the shifts.
 #pragma unroll
-        for (int i = 0; i < NXT; ++i) {
-          const int gy = y0 + xrow[i], gx = x0 + xcol[i];
-          const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-          const int sh = (in && gx + 8 > W) ? gx + 8 - W : 0;
-          S.sx[RAGGED ? i : 0] = sh;
-          const uint32_t off = in ? xrel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
-          S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-        }
+      for (int i = 0; i < NXT; ++i) {
+        const int gy = y0 + xrow[i], gx = x0 + xcol[i];
+        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        int sh = 0;
+        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sx[i] = sh; }
+        const uint32_t off = in ? xrel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
+        S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      }
 #pragma unroll
-        for (int i = 0; i < NGT; ++i) {
-          const int gy = y0 + grow[i], gx = x0 + gcol[i];
-          const bool in = gy < H && gx < W;
-          const int sh = (in && gx + 8 > W) ? gx + 8 - W : 0;
-          S.sg[RAGGED ? i : 0] = sh;
-          const uint32_t off = in ? grel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
-          S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NXT; ++i) {
-          const int gy = y0 + xrow[i], gx = x0 + xcol[i];
-          const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-          const uint32_t off = in ? xrel[i] + torg : 0x80000000u;
-          S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NGT; ++i) {
-          const int gy = y0 + grow[i], gx = x0 + gcol[i];
-          const bool in = gy < H && gx < W;
-          const uint32_t off = in ? grel[i] + torg : 0x80000000u;
-          S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
-        }
+      for (int i = 0; i < NGT; ++i) {
+        const int gy = y0 + grow[i], gx = x0 + gcol[i];
+        const bool in = gy < H && gx < W;
+        int sh = 0;
+        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sg[i] = sh; }
+        const uint32_t off = in ? grel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
+        S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
       }
     };
     auto land = [&](const Set& S, uint4* buf) {
+#ifdef UPF_WGRAD_NO_LAND                                                 // experiment build: the staging loads alone (tools/wgrad_ablate.py)
+      return;
+#endif
       uint4* xs = buf; uint4* gs = buf + G::X_BLOCKS;
       if (RAGGED && S.rag) {
 #pragma unroll
@@ -492,17 +496,21 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
     land(S0, smem);                                                      // tile 0 -> buffer 0
     issue(first + 2 * J, S0);
     __syncthreads();
+    // Both halves of an iteration run UNCONDITIONALLY (a tile beyond the last one is dead: zeros into a buffer nobody reads any
+    // more; the consumers take the matching barrier).  Rounds 2-4 skipped the second half after an odd last tile — and hipcc's
+    // wait-count insertion, which must assume at the loop header that the skipped path was taken (then S1's loads are the most
+    // RECENT ones), drained the whole queue (s_waitcnt vmcnt(12) ... vmcnt(0)) before landing S1 in EVERY iteration: the
+    // loads of the other set, issued half an iteration earlier, never stayed in flight across a landing, and a tile took
+    // loads + LDS writes in series (2.0 us; loads alone 1.2, writes alone 0.4: tools/wgrad_ablate.py).  Now vmcnt(25) ... (13).
     for (int it = 0; it < niter; it += 2) {
       // consumers multiply tile `it` out of buffer 0
       land(S1, smem + BUF);                                              // tile it+1 -> buffer 1
       issue(first + (it + 3) * J, S1);
       __syncthreads();
-      if (it + 1 < niter) {
-        // consumers multiply tile it+1 out of buffer 1
-        land(S0, smem);                                                  // tile it+2 -> buffer 0
-        issue(first + (it + 4) * J, S0);
-        __syncthreads();
-      }
+      // consumers multiply tile it+1 out of buffer 1
+      land(S0, smem);                                                    // tile it+2 -> buffer 0
+      issue(first + (it + 4) * J, S0);
+      __syncthreads();
     }
     return;
   }
@@ -601,23 +609,28 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
     }
   };
   __syncthreads();                                                       // tile 0 is in buffer 0
+  // a consumer wave whose 32 output channels (or 32 input channels) are all padding — Cout <= 32: half of the waves of every
+  // narrow layer — has nothing to multiply: it only takes the barriers (its LDS reads and MFMA issue slots go to the others)
+  const bool work = !(abl & 1) && co2 * 64 + cob * 32 < Cout && ci2 * 64 + cib * 32 < Cin;
   for (int it = 0; it < niter; it += 2) {
-    multiply(smem);
+    if (work) multiply(smem);
     __syncthreads();
-    if (it + 1 < niter) {
-      multiply(smem + BUF);
-      __syncthreads();
-    }
+    if (work && it + 1 < niter) multiply(smem + BUF);
+    __syncthreads();
   }
+  // partial block; rows / columns beyond Cout / Cin are never read by the reduction and are not written (a 563 -> 2 layer
+  // used to write 32 MB of zeros per launch)
   float* pb = partial + (size_t)ks_id * G::NT * cop * cip;
   const int ci = ci2 * 64 + cib * 32 + ch;
+  if (ci < ((Cin + 3) & ~3)) {
 #pragma unroll
-  for (int t = 0; t < G::NT; ++t)
+    for (int t = 0; t < G::NT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = co2 * 64 + cob * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-      pb[((size_t)t * cop + co) * cip + ci] = acc[t][e];
-    }
+      for (int e = 0; e < 16; ++e) {
+        const int co = co2 * 64 + cob * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+        if (co < Cout) pb[((size_t)t * cop + co) * cip + ci] = acc[t][e];
+      }
+  }
 }
 
 // dw[co][ci][tap] = sum over the K-splits, fixed order.  A thread owns 4 consecutive ci of one co for ALL taps: its reads
@@ -634,7 +647,7 @@ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ 
   // workgroups, a quarter of the rounds.  Summation order: slice s holds splits s, s + SL, ... in order; slices are added in order.
   constexpr int IPW = 256 / SL;
   __shared__ float4 sh[SL - 1][NT][IPW];
-  const int cip = (Cin + 63) / 64 * 64, c4n = cip / 4;
+  const int cip = (Cin + 63) / 64 * 64, c4n = (Cin + 3) / 4;               // (columns beyond Cin are padding: not written, not read)
   const int q = threadIdx.x % IPW, slice = threadIdx.x / IPW;
   const long long item = blockIdx.x * (long long)IPW + q;
   const bool live = item < (long long)Cout * c4n;
@@ -902,11 +915,12 @@ void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws
   static LdsOptIn opt;
   auto kern = &wgrad_pc_kernel<T, D, RAGGED>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds_bytes);
+  static const int abl = [] { const char* e = getenv("UPF_WGRAD_ABLATE"); return e ? atoi(e) << 16 : 0; }();
   if (pc_split_co(nco2, nci2)) {                 // one launch per co block (see pc_split_co)
     for (int c = 0; c < nco2; ++c)
-      hipLaunchKernelGGL(kern, dim3(ksplit * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, c);
+      hipLaunchKernelGGL(kern, dim3(ksplit * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, c | abl);
   } else {
-    hipLaunchKernelGGL(kern, dim3(ksplit * nco2 * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, 0);
+    hipLaunchKernelGGL(kern, dim3(ksplit * nco2 * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, abl);
   }
 }
 
@@ -952,7 +966,7 @@ int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cou
     if (p.na) launch_group<T, D, false, 1>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
     if (p.nr) launch_group<T, D, true, 1>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
   }
-  const long long items = (long long)Cout * (cdiv(Cin, 64) * 16);
+  const long long items = (long long)Cout * cdiv(Cin, 4);
   const int ks = p.ks_a + p.ks_r;
   if (items <= 64 * 128 && ks >= 16)        // narrow layers: 16 slices per item (see the kernel)
     hipLaunchKernelGGL((wgrad_reduce_kernel<G::NT, 16>), dim3((unsigned)((items + 15) / 16)), dim3(256), 0, stream, ws, dw, ks, Cout, Cin, cop, s2d);
