@@ -113,7 +113,7 @@ __device__ __forceinline__ u32x4 shr_pixels(u32x4 v, int sh) {            // 128
 // contraction over the pixels of every level.  A launch takes up to MAXL (x, g) pairs of different sizes; tile indices run
 // through the levels back to back (tile0 = first tile of a level) and a workgroup's tiles ks_id, ks_id + ksplit, ... are
 // spread over all of them.
-constexpr int MAXL = 6;
+constexpr int MAXL = 6, LT_STRIDE = 16;                  // (LT_STRIDE: ints per row of wgrad_pc_kernel's level table in LDS)
 struct KLevel {
   const void* x; const void* g;
   long long xbs, gbs;
@@ -365,129 +365,159 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
   const int niter = first < t_hi ? (t_hi - first + J - 1) / J : 0;       // tiles of this workgroup (uniform)
   const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
 
+  // Level table in LDS (behind the two staging buffers): the producers fetch a level's parameters when their tile index crosses
+  // into it.  (Rounds 2-5 selected them out of the kernel arguments with a compare / select tree in EVERY tile, which kept
+  // ~100 scalars live across the loop: the register allocator spilled them into vector lanes — 118 v_readlane per tile.)
+  int* ltab = reinterpret_cast<int*>(smem + 2 * BUF);
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      int* r = ltab + i * LT_STRIDE;
+      const unsigned long long px = (unsigned long long)L.lv[i].x, pg = (unsigned long long)L.lv[i].g;
+      r[0] = (int)(uint32_t)px; r[1] = (int)(uint32_t)(px >> 32); r[2] = (int)(uint32_t)pg; r[3] = (int)(uint32_t)(pg >> 32);
+      r[4] = (int)(uint32_t)L.lv[i].xbs; r[5] = (int)(uint32_t)((unsigned long long)L.lv[i].xbs >> 32);
+      r[6] = (int)(uint32_t)L.lv[i].gbs; r[7] = (int)(uint32_t)((unsigned long long)L.lv[i].gbs >> 32);
+      r[8] = L.lv[i].H; r[9] = L.lv[i].W; r[10] = L.lv[i].tiles_x; r[11] = L.lv[i].tiles_y;
+      r[12] = L.lv[i].tile0; r[13] = L.lv[i].ragged; r[14] = (i + 1 < L.n) ? L.lv[i + 1 < MAXL ? i + 1 : i].tile0 : 0x7fffffff; r[15] = 0;
+    }
+  }
+  __syncthreads();
+
   if (wave >= 4) {
     // ================= producers
+    // A producer wave shares its SIMD with a consumer wave and one wave issues at most one vector instruction every four
+    // cycles, so the producers are bound by their INSTRUCTION COUNT long before memory (tools/wgrad_ablate.py: with null
+    // descriptors — no traffic at all — and no matrix phase the kernel took 92 % of its full time).  Per tile and thread: the
+    // tile decode (two reciprocals), then for an INTERIOR tile (no staged block leaves the image: most of them) 13 loads whose
+    // vector offset is a per-level constant and whose tile origin rides in the scalar offset operand — no vector arithmetic —
+    // and 13 LDS writes.  Only border tiles compute per-block validity (and, on ragged levels, the shift of a straddling block).
+    static_assert((64 * G::XR * G::XB) % NTHREADS == 0 && (64 * TR * G::GB) % NTHREADS == 0, "every producer thread has the same number of live tasks");
     const int ptid = tid - NTHREADS;
-    const uint32_t xnch = (uint32_t)max(min(Cin - ci2 * 64, 64), 0), gnch = (uint32_t)max(min(Cout - co2 * 64, 64), 0);
-    // staging tasks of this thread (the same for every tile): LDS slot, and — per pyramid level — the byte offset of the
-    // task's 16-byte block relative to the tile origin (y0, x0) plus its row / column relative to that origin, so that a
-    // tile costs one add and two unsigned range checks per task instead of the full index arithmetic
-    int xslot[NXT], xrow[NXT], xcol[NXT], gslot[NGT], grow[NGT], gcol[NGT];
-    uint32_t xrel[NXT], grel[NGT];
-    int xch[NXT], gch[NGT];
+    const int xnch = max(min(Cin - ci2 * 64, 64), 0), gnch = max(min(Cout - co2 * 64, 64), 0);
+    constexpr uint32_t OOB = 0x80000000u;
+    // tasks of this thread (the same for every tile): LDS slot; row / column relative to the tile origin, packed
+    int xslot[NXT], xrc[NXT], gslot[NGT], grc[NGT];
 #pragma unroll
     for (int i = 0; i < NXT; ++i) {
       const int t = ptid + i * NTHREADS;
       const int c = t / (G::XR * G::XB), rem = t - c * (G::XR * G::XB), sr = rem / G::XB, bb = rem - sr * G::XB;
-      xslot[i] = (t < 64 * G::XR * G::XB) ? c * G::XCH + sr * G::XB + bb : -1;
-      xch[i] = c;
-      xrow[i] = (D == 0) ? sr : (sr - 1) * DD;
-      xcol[i] = 8 * bb - HALO;
+      xslot[i] = c * G::XCH + sr * G::XB + bb;
+      xrc[i] = ((((D == 0) ? sr : (sr - 1) * DD) + 64) << 16) | (8 * bb - HALO + 64);       // (+64: both halves non-negative)
     }
 #pragma unroll
     for (int i = 0; i < NGT; ++i) {
       const int t = ptid + i * NTHREADS;
       const int c = t / (TR * G::GB), rem = t - c * (TR * G::GB), k = rem / G::GB, bb = rem - k * G::GB;
-      gslot[i] = (t < 64 * TR * G::GB) ? c * G::GCH + k * G::GB + bb : -1;
-      gch[i] = c;
-      grow[i] = k * DD;
-      gcol[i] = 8 * bb;
+      gslot[i] = c * G::GCH + k * G::GB + bb;
+      grc[i] = ((k * DD + 64) << 16) | (8 * bb + 64);
     }
-    // current pyramid level (tiles of a workgroup only ever move forward through the levels)
+    // per level: vector offsets of the tasks relative to the tile origin, shifted up by `bias` bytes so that they are never
+    // negative (the descriptor's base is moved down by the same amount); OOB for the channels beyond Cin / Cout
+    uint32_t xrel[NXT], grel[NGT];
     int lev = -1, next_t0 = 0;
-    bool lrag = false;                                                   // the current level takes the shifted staging (uniform)
+    bool lrag = false;
     const T* lx = nullptr; const T* lg = nullptr;
     long long lxbs = 0, lgbs = 0;
-    int H = 1, W = 1, tiles_x = 1, tiles_y = 1, t0 = 0;
+    int H = 1, W = 1, tiles_x = 1, txy = 1, t0 = 0, bias = 0;
     float rtx = 1.f, rtxy = 1.f;
     uint32_t plane = 0;
+    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto enter_level = [&](int tile) {
-      while (lev + 1 < L.n && tile >= next_t0) {
+      while (tile >= next_t0) {                                          // (uniform; next_t0 of the last level: INT_MAX)
         ++lev;
-#pragma unroll
-        for (int i = 0; i < MAXL; ++i)
-          if (i == lev) {
-            lx = (const T*)L.lv[i].x; lg = (const T*)L.lv[i].g; lxbs = L.lv[i].xbs; lgbs = L.lv[i].gbs;
-            H = L.lv[i].H; W = L.lv[i].W; tiles_x = L.lv[i].tiles_x; tiles_y = L.lv[i].tiles_y; t0 = L.lv[i].tile0;
-            if constexpr (RAGGED) lrag = L.lv[i].ragged != 0;
-          }
-        next_t0 = 0x7fffffff;
-#pragma unroll
-        for (int i = 1; i < MAXL; ++i)
-          if (i == lev + 1 && i < L.n) next_t0 = L.lv[i].tile0;
+        const int4* r = reinterpret_cast<const int4*>(ltab + lev * LT_STRIDE);
+        const int4 a = r[0], b = r[1], c = r[2], d = r[3];
+        lx = (const T*)(((unsigned long long)(uint32_t)rfl(a.y) << 32) | (uint32_t)rfl(a.x));
+        lg = (const T*)(((unsigned long long)(uint32_t)rfl(a.w) << 32) | (uint32_t)rfl(a.z));
+        lxbs = (long long)(((unsigned long long)(uint32_t)rfl(b.y) << 32) | (uint32_t)rfl(b.x));
+        lgbs = (long long)(((unsigned long long)(uint32_t)rfl(b.w) << 32) | (uint32_t)rfl(b.z));
+        H = rfl(c.x); W = rfl(c.y); tiles_x = rfl(c.z); txy = tiles_x * rfl(c.w);
+        t0 = rfl(d.x); next_t0 = rfl(d.z);
+        if constexpr (RAGGED) lrag = rfl(d.y) != 0;
         plane = (uint32_t)H * (uint32_t)W * 2u;
-        rtx = 1.0f / (float)tiles_x; rtxy = 1.0f / (float)(tiles_x * tiles_y);
+        bias = 2 * (DD * W + HALO + 8);
+        rtx = 1.0f / (float)tiles_x; rtxy = 1.0f / (float)txy;
 #pragma unroll
-        for (int i = 0; i < NXT; ++i) xrel[i] = (uint32_t)xch[i] * plane + (uint32_t)((xrow[i] * W + xcol[i]) * 2);
+        for (int i = 0; i < NXT; ++i) {
+          const int ch = (ptid + i * NTHREADS) / (G::XR * G::XB), row = (xrc[i] >> 16) - 64, col = (xrc[i] & 0xffff) - 64;
+          xrel[i] = ch < xnch ? (uint32_t)ch * plane + (uint32_t)((row * W + col) * 2 + bias) : OOB;
+        }
 #pragma unroll
-        for (int i = 0; i < NGT; ++i) grel[i] = (uint32_t)gch[i] * plane + (uint32_t)((grow[i] * W + gcol[i]) * 2);
+        for (int i = 0; i < NGT; ++i) {
+          const int ch = (ptid + i * NTHREADS) / (TR * G::GB), row = (grc[i] >> 16) - 64, col = (grc[i] & 0xffff) - 64;
+          grel[i] = ch < gnch ? (uint32_t)ch * plane + (uint32_t)((row * W + col) * 2 + bias) : OOB;
+        }
       }
     };
     // a / b for 0 <= a < 2^24 through the reciprocal (exact after one correction step either way)
     auto fdiv = [](int a, int b, float rb) { int q = (int)((float)a * rb); int r = a - q * b; q += (r >= b) - (r < 0); return q; };
-    struct Set { u32x4 px[NXT], pg[NGT]; int sx[RAGGED ? NXT : 1], sg[RAGGED ? NGT : 1]; bool rag; };
+    // one staged tile in flight: the loaded blocks and, for a border tile of a ragged level, the left shift of every block (4 bits each)
+    struct Set { u32x4 px[NXT], pg[NGT]; unsigned long long shx; uint32_t shg; bool rag; };
     Set S0, S1;
-    S0.rag = S1.rag = false;
+    S0.rag = S1.rag = false; S0.shx = S1.shx = 0; S0.shg = S1.shg = 0;
     auto issue = [&](int tile, Set& S) {
       enter_level(tile);
-      if constexpr (RAGGED) S.rag = lrag;
-      // (the two divisions run on the vector unit — there is no scalar float — so their wave-uniform results are moved back to
-      // scalar registers explicitly: left in vector registers they make the buffer descriptors below "divergent", and hipcc
-      // then wraps EVERY staging load in a waterfall loop — 4 v_readfirstlane, 2 v_cmp, exec juggling and a branch per load, 13
-      // of them per tile in each producer wave, issued on the SIMDs the consumers' MFMAs need: rounds 2-4 shipped that)
       const int lt = tile - t0;
-      const int n = __builtin_amdgcn_readfirstlane(fdiv(lt, tiles_x * tiles_y, rtxy)), r2 = lt - n * tiles_x * tiles_y;
-      const int ty = __builtin_amdgcn_readfirstlane(fdiv(r2, tiles_x, rtx)), tx = r2 - ty * tiles_x;
+      const int n = rfl(fdiv(lt, txy, rtxy)), r2 = lt - n * txy;
+      const int ty = rfl(fdiv(r2, tiles_x, rtx)), tx = r2 - ty * tiles_x;
       const int phase = ty % DD, q = ty / DD;                            // (compile-time divisor)
       const int y0 = phase + DD * q * TR, x0 = tx * TWP;
       const bool live = tile < t_hi && !(abl & 2);                      // (dead: null descriptors, every load returns zeros)
-      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<T*>(lx + (size_t)n * lxbs + (size_t)ci2 * 64 * H * W)), 0,
-                                                                          __builtin_amdgcn_readfirstlane(live ? xnch * plane : 0u), 0x00020000);
-      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<T*>(lg + (size_t)n * lgbs + (size_t)co2 * 64 * H * W)), 0,
-                                                                          __builtin_amdgcn_readfirstlane(live ? gnch * plane : 0u), 0x00020000);
-      const uint32_t torg = (uint32_t)__builtin_amdgcn_readfirstlane((y0 * W + x0) * 2);
-      // ONE load sequence for aligned and ragged levels (sh = 0 wherever a block does not straddle the row end — always, on an
-      // aligned level): with the loads duplicated in the two arms of a branch hipcc schedules them in different orders, and its
-      // wait-count insertion then has to assume the worst position of every register at the join (vmcnt(13) ... (2) instead
-      // of (25) ... (13): the landing drained the other set's loads).  The uniform branch is in land(), around the shifts.
+      const char* xb = reinterpret_cast<const char*>(lx + (size_t)n * lxbs + (size_t)ci2 * 64 * H * W) - bias;
+      const char* gb = reinterpret_cast<const char*>(lg + (size_t)n * lgbs + (size_t)co2 * 64 * H * W) - bias;
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(xb)), 0, rfl(live ? (int)((uint32_t)xnch * plane) + bias : 0), 0x00020000);
+      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(gb)), 0, rfl(live ? (int)((uint32_t)gnch * plane) + bias : 0), 0x00020000);
+      const int torg = rfl((y0 * W + x0) * 2);                           // the tile origin: scalar offset operand of every load
+      const bool interior = (D == 0 ? true : y0 >= DD) && y0 + (D == 0 ? TR - 1 : TR * DD) < H && x0 >= HALO && x0 + TWP + HALO <= W;
+      uint32_t vx[NXT], vg[NGT];
+      if (interior) {
 #pragma unroll
-      for (int i = 0; i < NXT; ++i) {
-        const int gy = y0 + xrow[i], gx = x0 + xcol[i];
-        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        int sh = 0;
-        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sx[i] = sh; }
-        const uint32_t off = in ? xrel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
-        S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-      }
+        for (int i = 0; i < NXT; ++i) vx[i] = xrel[i];
 #pragma unroll
-      for (int i = 0; i < NGT; ++i) {
-        const int gy = y0 + grow[i], gx = x0 + gcol[i];
-        const bool in = gy < H && gx < W;
-        int sh = 0;
-        if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; S.sg[i] = sh; }
-        const uint32_t off = in ? grel[i] + torg - (uint32_t)(2 * sh) : 0x80000000u;
-        S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0);
+        for (int i = 0; i < NGT; ++i) vg[i] = grel[i];
+        if constexpr (RAGGED) S.rag = false;
+      } else {
+        unsigned long long shx = 0; uint32_t shg = 0;
+#pragma unroll
+        for (int i = 0; i < NXT; ++i) {
+          const int gy = y0 + (xrc[i] >> 16) - 64, gx = x0 + (xrc[i] & 0xffff) - 64;
+          const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+          int sh = 0;
+          if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; shx |= (unsigned long long)sh << (4 * i); }
+          vx[i] = in ? xrel[i] - (uint32_t)(2 * sh) : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NGT; ++i) {
+          const int gy = y0 + (grc[i] >> 16) - 64, gx = x0 + (grc[i] & 0xffff) - 64;
+          const bool in = gy < H && gx < W;
+          int sh = 0;
+          if constexpr (RAGGED) { sh = (in && gx + 8 > W) ? gx + 8 - W : 0; shg |= (uint32_t)sh << (4 * i); }
+          vg[i] = in ? grel[i] - (uint32_t)(2 * sh) : OOB;
+        }
+        if constexpr (RAGGED) { S.rag = lrag; S.shx = shx; S.shg = shg; }
       }
+      // ONE load sequence behind the branch (loads inside its arms would be scheduled differently in each, and the wait-count
+      // insertion would have to assume the worst position of every register at the join)
+#pragma unroll
+      for (int i = 0; i < NXT; ++i) S.px[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, vx[i], torg, 0);
+#pragma unroll
+      for (int i = 0; i < NGT; ++i) S.pg[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, vg[i], torg, 0);
     };
     auto land = [&](const Set& S, uint4* buf) {
-#ifdef UPF_WGRAD_NO_LAND                                                 // experiment build: the staging loads alone (tools/wgrad_ablate.py)
+#ifdef UPF_WGRAD_NO_LAND                                                 // experiment build: no LDS staging writes
       return;
 #endif
       uint4* xs = buf; uint4* gs = buf + G::X_BLOCKS;
       if (RAGGED && S.rag) {
 #pragma unroll
-        for (int i = 0; i < NXT; ++i)
-          if (xslot[i] >= 0) xs[xslot[i]] = __builtin_bit_cast(uint4, shr_pixels(S.px[i], S.sx[RAGGED ? i : 0]));
+        for (int i = 0; i < NXT; ++i) xs[xslot[i]] = __builtin_bit_cast(uint4, shr_pixels(S.px[i], (int)((S.shx >> (4 * i)) & 15)));
 #pragma unroll
-        for (int i = 0; i < NGT; ++i)
-          if (gslot[i] >= 0) gs[gslot[i]] = __builtin_bit_cast(uint4, shr_pixels(S.pg[i], S.sg[RAGGED ? i : 0]));
+        for (int i = 0; i < NGT; ++i) gs[gslot[i]] = __builtin_bit_cast(uint4, shr_pixels(S.pg[i], (int)((S.shg >> (4 * i)) & 15)));
       } else {
 #pragma unroll
-        for (int i = 0; i < NXT; ++i)
-          if (xslot[i] >= 0) xs[xslot[i]] = __builtin_bit_cast(uint4, S.px[i]);
+        for (int i = 0; i < NXT; ++i) xs[xslot[i]] = __builtin_bit_cast(uint4, S.px[i]);
 #pragma unroll
-        for (int i = 0; i < NGT; ++i)
-          if (gslot[i] >= 0) gs[gslot[i]] = __builtin_bit_cast(uint4, S.pg[i]);
+        for (int i = 0; i < NGT; ++i) gs[gslot[i]] = __builtin_bit_cast(uint4, S.pg[i]);
       }
     };
     // tile k of this workgroup = first + k * J (dead beyond niter: a null descriptor, zeros).  Set k & 1 carries tile k.
@@ -500,8 +530,7 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
     // more; the consumers take the matching barrier).  Rounds 2-4 skipped the second half after an odd last tile — and hipcc's
     // wait-count insertion, which must assume at the loop header that the skipped path was taken (then S1's loads are the most
     // RECENT ones), drained the whole queue (s_waitcnt vmcnt(12) ... vmcnt(0)) before landing S1 in EVERY iteration: the
-    // loads of the other set, issued half an iteration earlier, never stayed in flight across a landing, and a tile took
-    // loads + LDS writes in series (2.0 us; loads alone 1.2, writes alone 0.4: tools/wgrad_ablate.py).  Now vmcnt(25) ... (13).
+    // loads of the other set, issued half an iteration earlier, never stayed in flight across a landing.  Now vmcnt(25) ... (13).
     for (int it = 0; it < niter; it += 2) {
       // consumers multiply tile `it` out of buffer 0
       land(S1, smem + BUF);                                              // tile it+1 -> buffer 1
@@ -911,7 +940,7 @@ void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws
   }
   L.n = n; L.ntiles = t0;
   const int nco2 = cdiv(Cout, 64), nci2 = cdiv(Cin, 64);
-  constexpr int lds_bytes = 2 * (G::X_BLOCKS + G::G_BLOCKS) * 16;
+  constexpr int lds_bytes = 2 * (G::X_BLOCKS + G::G_BLOCKS) * 16 + MAXL * LT_STRIDE * 4;      // two staging buffers + the level table
   static LdsOptIn opt;
   auto kern = &wgrad_pc_kernel<T, D, RAGGED>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds_bytes);
