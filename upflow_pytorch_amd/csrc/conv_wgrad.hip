@@ -25,6 +25,7 @@
 // 52, 26 and 13 pixels wide — take the RAGGED staging variant).
 #include "common.hpp"
 #include <cstring>
+#include <cstdio>
 #include <stdlib.h>
 
 namespace upf {
@@ -344,7 +345,7 @@ void wgrad_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cou
 // staging instead cost the aligned 94 % more than those launches did.)
 template <typename T, int D, bool RAGGED>
 __global__ __launch_bounds__(2 * NTHREADS, 2)
-void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cout, int nci2, int J, int co2_base) {
+void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int Cout, int nci2, int J_ns, int co2_base) {
   using G = Geo<D>;
   constexpr int DD = (D == 0) ? 1 : D;
   constexpr int HALO = halo_of(D);
@@ -353,14 +354,17 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
   constexpr int BUF = G::X_BLOCKS + G::G_BLOCKS;                            // 16-byte blocks per LDS buffer
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];            // two buffers: [X | g] [X | g]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblocks = gridDim.x / (8 * J);
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  // J_ns = J | NS << 16: the tile range is cut into NS slices (8 = one per XCD, the mapping described at wgrad_kernel; fewer for
+  // the layers whose K is a handful of tiles: see pick_split) and J workgroups per block pair walk a slice side by side
+  const int J = J_ns & 0xffff, NS = J_ns >> 16;
+  const int nblocks = gridDim.x / (NS * J);
+  const int xcd = blockIdx.x % NS, slot = blockIdx.x / NS;
   const int bpair = slot % nblocks, jj = slot / nblocks;
   const int ks_id = xcd * J + jj;
   // experiments (UPF_WGRAD_ABLATE, read by the host): 1 = no matrix phase, 2 = null descriptors (loads return zeros, no traffic)
   const int abl = co2_base >> 16;
   const int co2 = bpair / nci2 + (co2_base & 0xffff), ci2 = bpair % nci2;
-  const int t_lo = (int)((long long)L.ntiles * xcd / 8), t_hi = (int)((long long)L.ntiles * (xcd + 1) / 8);
+  const int t_lo = (int)((long long)L.ntiles * xcd / NS), t_hi = (int)((long long)L.ntiles * (xcd + 1) / NS);
   const int first = t_lo + jj;
   const int niter = first < t_hi ? (t_hi - first + J - 1) / J : 0;       // tiles of this workgroup (uniform)
   const int cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
@@ -920,7 +924,7 @@ static int level_tiles(const upf_wgrad_level& a, int dd) { return a.B * cdiv(a.W
 static bool pc_split_co(int nco2, int nci2) { return nco2 > 1 && nco2 * nci2 > 16 && nci2 <= 16; }
 
 template <typename T, int D, bool RAGGED>
-void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws, int ksplit, int Cin, int Cout, hipStream_t stream) {
+void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws, int ns, int J, bool split_co, int Cin, int Cout, hipStream_t stream) {
   using G = Geo<D>;
   constexpr int DD = (D == 0) ? 1 : D;
   KLevels L;
@@ -945,11 +949,12 @@ void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws
   auto kern = &wgrad_pc_kernel<T, D, RAGGED>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds_bytes);
   static const int abl = [] { const char* e = getenv("UPF_WGRAD_ABLATE"); return e ? atoi(e) << 16 : 0; }();
-  if (pc_split_co(nco2, nci2)) {                 // one launch per co block (see pc_split_co)
+  const int ksplit = ns * J, J_ns = J | (ns << 16);
+  if (split_co) {                                // one launch per co block (see pc_split_co)
     for (int c = 0; c < nco2; ++c)
-      hipLaunchKernelGGL(kern, dim3(ksplit * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, c | abl);
+      hipLaunchKernelGGL(kern, dim3(ksplit * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, J_ns, c | abl);
   } else {
-    hipLaunchKernelGGL(kern, dim3(ksplit * nco2 * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, ksplit / 8, abl);
+    hipLaunchKernelGGL(kern, dim3(ksplit * nco2 * nci2), dim3(2 * NTHREADS), lds_bytes, stream, L, ws, Cin, Cout, nci2, J_ns, abl);
   }
 }
 
@@ -961,7 +966,31 @@ void launch_group_pc(const upf_wgrad_level* lv, const int* idx, int n, float* ws
 struct Plan {
   int ia[MAXL], na = 0, ir[MAXL], nr = 0, ks_a = 0, ks_r = 0;
   bool mixed = false;
+  int ns = 8, J = 1;                    // producer / consumer kernel: ks_a = ns * J
+  bool split_co = false;
 };
+
+// Producer / consumer kernel: how many slices of the tile range (ns) and workgroups per block pair and slice (J).  Every
+// workgroup ends by writing its 64 x 64 x taps fp32 block, which the reduction reads back: with the chip filled whatever the
+// layer (round 4: ns = 8, J = 32 / block pairs) a 96 -> 96 layer at 16x52 — 64 tiles — wrote and re-read 38 MB for 1 GFLOP, and
+// the twelve single-level layers of the feature pyramid took 25-80 us each.  Cost model (us): tiles per workgroup x the
+// measured tile time + the partial blocks both ways at ~3.5 TB/s; UPF_WGRAD_SPLIT="ns,J" overrides (A/B runs).
+static void pick_split(int ntiles, int nb_launch, int nb_total, int ntaps, int& ns_out, int& J_out) {
+  static const char* ov = getenv("UPF_WGRAD_SPLIT");
+  if (ov) { int a = 8, b = 1; if (sscanf(ov, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1) { ns_out = a; J_out = b; return; } }
+  const double tile_us = ntaps == 9 ? 1.8 : 0.5, block_us = (double)ntaps * 64 * 64 * 4 * 2 / 3.5e6;
+  double best = 1e30;
+  for (int ns = 8; ns >= 1; ns >>= 1) {
+    if (ns < 8 && ntiles > 64) break;                                    // (fewer slices than XCDs only where K is a handful of tiles)
+    for (int J = 1; J <= 32; ++J) {
+      if (ns * J * nb_launch > 256 && J > 1) break;                      // one workgroup per CU
+      const int tiles_wg = cdiv(cdiv(ntiles, ns), J);
+      const double waves = (double)cdiv(ns * J * nb_launch, 256);
+      const double t = waves * tiles_wg * tile_us + (double)ns * J * nb_total * block_us + (tiles_wg * J * ns > ntiles + ns * J ? 0.5 : 0.0);
+      if (t < best - 1e-9) { best = t; ns_out = ns; J_out = J; }
+    }
+  }
+}
 static Plan make_plan(const upf_wgrad_level* lv, int n, int Cin, int Cout, int kernel_size, int dilation) {
   Plan p;
   const int dd = kernel_size == 1 ? 1 : dilation, nt = kernel_size == 1 ? 1 : 9;
@@ -973,7 +1002,12 @@ static Plan make_plan(const upf_wgrad_level* lv, int n, int Cin, int Cout, int k
   }
   const int cob = co_block(Cout);
   int nblocks = cdiv(Cout, cob) * cdiv(Cin, 64);
-  if (wgrad_mode() == 0 && pc_split_co(cdiv(Cout, 64), cdiv(Cin, 64))) nblocks = cdiv(Cin, 64);      // workgroups per launch
+  if (wgrad_mode() == 0) {
+    p.split_co = pc_split_co(cdiv(Cout, 64), cdiv(Cin, 64)) && ta >= 256;
+    pick_split(ta, p.split_co ? cdiv(Cin, 64) : nblocks, nblocks, nt, p.ns, p.J);
+    p.ks_a = p.ns * p.J;
+    return p;
+  }
   if (p.na) p.ks_a = pick_ksplit(ta, nblocks, nt, cob);
   if (p.nr) p.ks_r = pick_ksplit(tr, nblocks, nt, cob);
   return p;
@@ -986,8 +1020,8 @@ int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cou
   const int cob = co_block(Cout), cop = cdiv(Cout, cob) * cob;
   const size_t per_split = (size_t)G::NT * cop * (cdiv(Cin, 64) * 64);
   if (wgrad_mode() == 0) {
-    if (p.mixed) launch_group_pc<T, D, true>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
-    else launch_group_pc<T, D, false>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
+    if (p.mixed) launch_group_pc<T, D, true>(lv, p.ia, p.na, ws, p.ns, p.J, p.split_co, Cin, Cout, stream);
+    else launch_group_pc<T, D, false>(lv, p.ia, p.na, ws, p.ns, p.J, p.split_co, Cin, Cout, stream);
   } else if (cob == 128) {
     if (p.na) launch_group<T, D, false, 2>(lv, p.ia, p.na, ws, p.ks_a, Cin, Cout, stream);
     if (p.nr) launch_group<T, D, true, 2>(lv, p.ir, p.nr, ws + (size_t)p.ks_a * per_split, p.ks_r, Cin, Cout, stream);
