@@ -379,6 +379,12 @@ typedef struct {
 long long upf_conv_wgrad_multi_workspace_bytes(const upf_wgrad_level* levels, int nlevels, int Cin, int Cout, int kernel_size, int dilation);
 int upf_conv_wgrad_multi(const upf_wgrad_level* levels /* host array */, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
                          int kernel_size, int dilation, int dtype, void* stream);
+/* ... and, in the same reduction launch, the second stage of the layer's BIAS gradient (upf_conv_bias_grad_finish over
+ * 1..8 first-stage buffers; model/pwc_modules.py:250-286 — every decoder layer has a bias): one launch fewer per layer and step.
+ * npartials = 0: exactly upf_conv_wgrad_multi. */
+int upf_conv_wgrad_multi_bias(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
+                              int kernel_size, int dilation, const float* const* bias_partials /* host array */, int npartials, float* grad_bias,
+                              int dtype, void* stream);
 /* Stride-2 3x3 layers (feature pyramid, SGU guidance; model/pwc_modules.py:95, model/upflow.py:53-55) take the stride-1
  * gradient kernels through their space-to-depth form: xs[(ci,p,q), i, j] = x[ci, 2i+p, 2j+q] (upf_space_to_depth2; inverse = 1
  * for the way back) convolved at stride 1 with a kernel that is w at 9 of its 36 (phase, tap) positions.

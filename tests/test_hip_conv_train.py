@@ -153,6 +153,28 @@ def test_wgrad_multi_level(cfg, dtype):
     assert (one - ref1).abs().max() <= 2e-4 * max(1.0, float(ref1.abs().max()))
 
 
+@pytest.mark.parametrize('cfg', [(115, 128, 3, 1), (563, 2, 3, 1), (196, 300, 1, 1), (32, 32, 3, 4)])
+def test_wgrad_multi_with_fused_bias_finish(cfg):
+    """upf_conv_wgrad_multi_bias: the reduction launch also finishes the bias gradient — the weight gradient is bit-identical to
+    the launch without it, the bias gradient bit-identical to upf_conv_bias_grad_finish over the same first-stage buffers."""
+    from upflow_pytorch_amd import ops
+    Cin, Cout, k, d = cfg
+    g = torch.Generator().manual_seed(7 + Cin + Cout)
+    uses, parts = [], []
+    for (B, H, W) in [(2, 32, 104), (2, 16, 52), (2, 8, 26), (2, 4, 13)]:
+        x = torch.randn(B, Cin, H, W, generator=g).bfloat16().cuda()
+        gy = (torch.randn(B, Cout, H, W, generator=g) * 0.25).bfloat16().cuda()
+        uses.append((x, gy))
+        parts.append(ops.act_grad(gy, dst=False, want_bias=True)[1])
+    gw, gb = ops.conv_wgrad_multi(uses, Cin, Cout, k, d, bias_parts=parts)
+    assert torch.equal(gw, ops.conv_wgrad_multi(uses, Cin, Cout, k, d))
+    assert torch.equal(gb, ops.conv_bias_grad_finish(parts, Cout))
+    ref = sum(gy.float().sum((0, 2, 3)) for _, gy in uses)
+    assert (gb - ref).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(ops.UpflowHipError):
+        ops.conv_wgrad_multi(uses, Cin, Cout, k, d, bias_parts=parts * 3)
+
+
 def _dense_stack(ch_in, dev):
     from upflow_pytorch_amd.model.pwc_modules import FlowEstimatorDense_v2
     torch.manual_seed(ch_in)

@@ -67,6 +67,7 @@ SIGNATURES = {
     'upf_conv_wgrad': [_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_bias_grad': [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp],
     'upf_conv_wgrad_multi': [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_conv_wgrad_multi_bias': [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp],
     'upf_space_to_depth2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_wgrad_s2d': [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
     'upf_act_grad': [_vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _f, _i, _vp],

@@ -671,9 +671,28 @@ void wgrad_pc_kernel(const KLevels L, float* __restrict__ partial, int Cin, int 
 // loads per split in flight, and its NT x 4 results are 36 consecutive floats of dw.  The four waves of a workgroup take
 // every fourth split and are summed through LDS in wave order.  (The first version — one thread per element, a dependent
 // chain of 4-byte loads over the splits, 36-byte-strided stores — ran at 1 TB/s: 36 us per layer, 1.15 ms per step.)
+// second stage of the bias gradient over the first-stage sums (C x BIAS_NCH, act_grad_kernel / bias_grad_partial_kernel) of several
+// uses of one bias (the pyramid levels), in the order given
+constexpr int MAXP = 8, BIAS_NCH = 32;
+struct BiasParts { const float* p[MAXP]; int n; float* db; };
+__device__ __forceinline__ void bias_finish(const BiasParts& P, int co, int Cout) {
+  if (co >= Cout) return;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i)
+    if (i < P.n) {
+      float t = 0.f;
+      for (int k = 0; k < BIAS_NCH; ++k) t += P.p[i][co * BIAS_NCH + k];
+      s += t;
+    }
+  P.db[co] = s;
+}
+
 template <int NT, int SL>
 __global__ __launch_bounds__(256)
-void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ksplit, int Cout, int Cin, int cop, int s2d) {
+void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ksplit, int Cout, int Cin, int cop, int s2d, int nwblocks, const BiasParts BP) {
+  // (the blocks behind the weight items finish the layer's BIAS gradient — one launch fewer per layer and step)
+  if ((int)blockIdx.x >= nwblocks) { bias_finish(BP, ((int)blockIdx.x - nwblocks) * 256 + (int)threadIdx.x, Cout); return; }
   // SL slices of the split range per item, 256 / SL items per workgroup.  SL = 4 streams the wide layers (many items: the grid
   // fills the chip, a thread walks ksplit / 4 splits); the narrow layers (Cout <= 32: 3 ... 70 workgroups of SL = 4, each thread
   // a chain of 6-16 dependent rounds of loads: 19-35 us for a few MB, round 5's timeline) take SL = 16: four times the
@@ -761,7 +780,6 @@ __global__ void leaky_bwd_kernel(const T* __restrict__ gy, const T* __restrict__
 // db[co] = sum over n, pixels of g[n, co, :].  Two launches, fixed summation order: (channel, chunk) workgroups reduce
 // 1/NCH of a channel's pixels each (one workgroup per channel left 2..128 workgroups on 256 CUs: 69 us per layer),
 // then one thread per channel adds the NCH partial sums in order.
-constexpr int BIAS_NCH = 32;
 template <typename T>
 __global__ __launch_bounds__(256)
 void bias_grad_partial_kernel(const T* __restrict__ g, long long gbs, float* __restrict__ part, int B, int HW) {
@@ -848,22 +866,7 @@ void act_grad_kernel(const T* __restrict__ src, long long sbs, const T* __restri
   if (threadIdx.x == 0) part[co * BIAS_NCH + chunk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// second stage over the first-stage sums of several uses of one bias (the pyramid levels), in the order given
-constexpr int MAXP = 8;
-struct BiasParts { const float* p[MAXP]; int n; };
-__global__ void bias_grad_multi_final_kernel(const BiasParts P, float* __restrict__ db, int Cout) {
-  const int co = blockIdx.x * blockDim.x + threadIdx.x;
-  if (co >= Cout) return;
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i)
-    if (i < P.n) {
-      float t = 0.f;
-      for (int k = 0; k < BIAS_NCH; ++k) t += P.p[i][co * BIAS_NCH + k];
-      s += t;
-    }
-  db[co] = s;
-}
+__global__ void bias_grad_multi_final_kernel(const BiasParts P, int Cout) { bias_finish(P, blockIdx.x * blockDim.x + threadIdx.x, Cout); }
 
 // K-splits = 8 XCDs x J: J concurrent tiles per XCD such that J x (block pairs) workgroups fill its 32 CUs (the kernel
 // keeps a whole tile in registers: 1 workgroup per CU is resident), bounded by the tiles an XCD has and by 40 MB of fp32
@@ -1014,7 +1017,8 @@ static Plan make_plan(const upf_wgrad_level* lv, int n, int Cin, int Cout, int k
 }
 
 template <typename T, int D>
-int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cout, int kernel_size, int dilation, hipStream_t stream, int s2d = 0) {
+int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cout, int kernel_size, int dilation, hipStream_t stream, int s2d = 0,
+        const BiasParts* bias = nullptr) {
   using G = Geo<D>;
   const Plan p = make_plan(lv, n, Cin, Cout, kernel_size, dilation);
   const int cob = co_block(Cout), cop = cdiv(Cout, cob) * cob;
@@ -1031,10 +1035,17 @@ int run(const upf_wgrad_level* lv, int n, float* dw, float* ws, int Cin, int Cou
   }
   const long long items = (long long)Cout * cdiv(Cin, 4);
   const int ks = p.ks_a + p.ks_r;
-  if (items <= 64 * 128 && ks >= 16)        // narrow layers: 16 slices per item (see the kernel)
-    hipLaunchKernelGGL((wgrad_reduce_kernel<G::NT, 16>), dim3((unsigned)((items + 15) / 16)), dim3(256), 0, stream, ws, dw, ks, Cout, Cin, cop, s2d);
-  else
-    hipLaunchKernelGGL((wgrad_reduce_kernel<G::NT, 4>), dim3((unsigned)((items + 63) / 64)), dim3(256), 0, stream, ws, dw, ks, Cout, Cin, cop, s2d);
+  BiasParts BP;
+  memset(&BP, 0, sizeof(BP));
+  if (bias) BP = *bias;
+  const int nbias = bias ? cdiv(Cout, 256) : 0;
+  if (items <= 64 * 128 && ks >= 16) {      // narrow layers: 16 slices per item (see the kernel)
+    const int nw = (int)((items + 15) / 16);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<G::NT, 16>), dim3((unsigned)(nw + nbias)), dim3(256), 0, stream, ws, dw, ks, Cout, Cin, cop, s2d, nw, BP);
+  } else {
+    const int nw = (int)((items + 63) / 64);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<G::NT, 4>), dim3((unsigned)(nw + nbias)), dim3(256), 0, stream, ws, dw, ks, Cout, Cin, cop, s2d, nw, BP);
+  }
   return check_launch("conv_wgrad");
 }
 
@@ -1070,21 +1081,38 @@ extern "C" long long upf_conv_wgrad_multi_workspace_bytes(const upf_wgrad_level*
   return (long long)(p.ks_a + p.ks_r) * nt * (cdiv(Cout, cob) * cob) * (cdiv(Cin, 64) * 64) * (long long)sizeof(float);
 }
 
-extern "C" int upf_conv_wgrad_multi(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
-                                    int kernel_size, int dilation, int dtype, void* stream) {
+extern "C" int upf_conv_wgrad_multi_bias(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
+                                         int kernel_size, int dilation, const float* const* bias_partials, int npartials, float* grad_bias,
+                                         int dtype, void* stream) {
   using namespace upf;
   UPF_REQUIRE(grad_w && workspace, UPF_EINVAL, "conv_wgrad: null pointer");
   if (int rc = wgrad_check_levels(levels, nlevels, Cin, Cout, kernel_size, dilation, dtype)) return rc;
+  wgrad::BiasParts BP;
+  memset(&BP, 0, sizeof(BP));
+  if (npartials) {
+    UPF_REQUIRE(bias_partials && grad_bias && npartials >= 1 && npartials <= wgrad::MAXP, UPF_EINVAL, "conv_wgrad_multi_bias: 1..%d bias partial buffers and grad_bias", wgrad::MAXP);
+    for (int i = 0; i < npartials; ++i) {
+      UPF_REQUIRE(bias_partials[i], UPF_EINVAL, "conv_wgrad_multi_bias: null partial buffer");
+      BP.p[i] = bias_partials[i];
+    }
+    BP.n = npartials; BP.db = grad_bias;
+  }
+  const wgrad::BiasParts* bp = npartials ? &BP : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const int D = kernel_size == 1 ? 0 : dilation;
-#define UPF_WG(DV) case DV: return dtype == UPF_BF16 ? wgrad::run<bf16_t, DV>(levels, nlevels, grad_w, (float*)workspace, Cin, Cout, kernel_size, dilation, s) \
-                                                     : wgrad::run<f16_t, DV>(levels, nlevels, grad_w, (float*)workspace, Cin, Cout, kernel_size, dilation, s);
+#define UPF_WG(DV) case DV: return dtype == UPF_BF16 ? wgrad::run<bf16_t, DV>(levels, nlevels, grad_w, (float*)workspace, Cin, Cout, kernel_size, dilation, s, 0, bp) \
+                                                     : wgrad::run<f16_t, DV>(levels, nlevels, grad_w, (float*)workspace, Cin, Cout, kernel_size, dilation, s, 0, bp);
   switch (D) {
     UPF_WG(0) UPF_WG(1) UPF_WG(2) UPF_WG(4) UPF_WG(8) UPF_WG(16)
   }
 #undef UPF_WG
   set_error("conv_wgrad: internal routing error");
   return UPF_EUNSUPPORTED;
+}
+
+extern "C" int upf_conv_wgrad_multi(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout,
+                                    int kernel_size, int dilation, int dtype, void* stream) {
+  return upf_conv_wgrad_multi_bias(levels, nlevels, grad_w, workspace, Cin, Cout, kernel_size, dilation, nullptr, 0, nullptr, dtype, stream);
 }
 
 extern "C" int upf_conv_wgrad_s2d(const upf_wgrad_level* levels, int nlevels, float* grad_w, void* workspace, int Cin, int Cout, int dtype, void* stream) {
@@ -1150,8 +1178,8 @@ extern "C" int upf_conv_bias_grad_finish(const float* const* partials, int npart
     UPF_REQUIRE(partials[i], UPF_EINVAL, "conv_bias_grad_finish: null partial buffer");
     P.p[i] = partials[i];
   }
-  P.n = npartials;
-  hipLaunchKernelGGL(wgrad::bias_grad_multi_final_kernel, dim3(cdiv(Cout, 128)), dim3(128), 0, (hipStream_t)stream, P, grad_bias, Cout);
+  P.n = npartials; P.db = grad_bias;
+  hipLaunchKernelGGL(wgrad::bias_grad_multi_final_kernel, dim3(cdiv(Cout, 128)), dim3(128), 0, (hipStream_t)stream, P, Cout);
   return check_launch("conv_bias_grad_finish");
 }
 
