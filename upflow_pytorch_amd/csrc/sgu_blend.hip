@@ -318,6 +318,63 @@ void upsample_bwd_wg_kernel(const float* __restrict__ gy, float* __restrict__ gx
   gx[idx] = acc;
 }
 
+// Band variant (round 5; every footprint larger than a few pixels): the two interpolations are SEPARABLE —
+//     gx[a][b] = sum_j wx(j, b) * ( sum_i wy(i, a) * gy[i][j] )
+// — so a workgroup of 1024 threads takes one input row a and NB consecutive input columns: threads = 4 row groups x 256
+// output columns (two columns each: coalesced 1 KB row segments, four row groups in flight), the column sums of the row groups
+// are added in LDS in fixed order, and 16 lanes per input pixel contract them with the column weights (xor-shuffle tree).
+// Every output pixel is read once per input row that uses it (twice in all) instead of once per INPUT PIXEL that uses it (four
+// times, by one thread per footprint pixel with an integer division each), and the pyramid-distillation resizes — 4x13 ... 64x208
+// flows to 256x832, 52 / 17 / 21 / 12 / 12 us per launch in a config-3 step — stop being latency chains of one workgroup per
+// input pixel.  Weights: the forward's own make_lerp (scales precomputed on the host with the identical IEEE division).
+constexpr int BAND_T = 1024, BAND_COLS = 512, BAND_ROWS = 1024;
+__global__ __launch_bounds__(BAND_T)
+void upsample_bwd_band_kernel(const float* __restrict__ gy, float* __restrict__ gx, int C, int h, int w, int H, int W, int if_rate,
+                              int NB, int nbb, float sy, float sx) {
+  __shared__ float cs[4][BAND_COLS];
+  __shared__ float wys[BAND_ROWS];
+  const int tid = threadIdx.x, rg = tid >> 8, cj = tid & 255;
+  const int bb = blockIdx.x % nbb, a = (blockIdx.x / nbb) % h;
+  const long long nc = blockIdx.x / ((long long)nbb * h);
+  const int b0 = bb * NB, b1 = min(w, b0 + NB);
+  int ilo, ihi, jlo, jhi, t0, t1;
+  upsample_bwd_range(a, h, H, ilo, ihi);
+  upsample_bwd_range(b0, w, W, jlo, t0);
+  upsample_bwd_range(b1 - 1, w, W, t1, jhi);
+  const int nrows = ihi - ilo + 1;
+  const bool table = nrows <= BAND_ROWS;
+  if (table)
+    for (int t = tid; t < nrows; t += BAND_T) wys[t] = upsample_bwd_weight(make_lerp_scaled(ilo + t, h, sy), a);
+  __syncthreads();
+  const float* g = gy + (size_t)nc * H * W;
+  const int j0 = jlo + cj, j1 = j0 + 256;
+  const bool in0 = j0 <= jhi, in1 = j1 <= jhi;
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int i = ilo + rg; i <= ihi; i += 4) {
+    const float wy = table ? wys[i - ilo] : upsample_bwd_weight(make_lerp_scaled(i, h, sy), a);
+    if (wy == 0.f) continue;
+    const float* row = g + (size_t)i * W;
+    if (in0) acc0 += row[j0] * wy;
+    if (in1) acc1 += row[j1] * wy;
+  }
+  cs[rg][cj] = acc0; cs[rg][cj + 256] = acc1;
+  __syncthreads();
+  if (tid < BAND_COLS) cs[0][tid] = ((cs[0][tid] + cs[1][tid]) + cs[2][tid]) + cs[3][tid];
+  __syncthreads();
+  const int b = b0 + (tid >> 4), r = tid & 15;
+  float acc = 0.f;
+  if (b < b1) {
+    int jl, jh;
+    upsample_bwd_range(b, w, W, jl, jh);
+    for (int j = jl + r; j <= jh; j += 16) acc += cs[0][j - jlo] * upsample_bwd_weight(make_lerp_scaled(j, w, sx), b);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (r != 0 || b >= b1) return;
+  if (if_rate) acc *= ((int)(nc % C) == 0) ? (float)((double)W / (double)w) : (float)((double)H / (double)h);
+  gx[(nc * h + a) * w + b] = acc;
+}
+
 // g_logit *= s (1 - s), s = sigmoid(logit): the mask channel of the final-level blend after its resize gradient
 template <typename T>
 __global__ void sigmoid_grad_kernel(const T* __restrict__ x_out, float* __restrict__ g_xo, int hw, long long total) {
@@ -414,6 +471,20 @@ static int launch_upsample_backward(const float* grad_y, float* gx, long long BC
   // footprint of one input pixel ~ (2H/h) x (2W/w) outputs: 1 / 4 / 16 lanes per input pixel, a workgroup beyond a few hundred
   const long long fp = (2LL * cdiv(H, h) + 2) * (2LL * cdiv(W, w) + 2);
   auto groups = [&](int G) { return dim3((unsigned)((total + sgu::THREADS / G - 1) / (sgu::THREADS / G))); };
+  // band kernel: NB input columns per workgroup such that their output columns fit its 512-column strip
+  // (from the 8x resize up: at 4x — ten output rows per input row — the per-pixel groups below are faster: 9.9 against 16.6 us)
+  if (fp > 200 && w > 1 && W > 1) {
+    const double inv = (double)(W - 1) / (double)(w - 1);
+    int NB = (int)((sgu::BAND_COLS - 8) / inv) - 1;
+    if (NB > 64) NB = 64;
+    if (NB > w) NB = w;
+    const long long nbb = NB >= 1 ? cdiv(w, NB) : 0, nwg = BC * h * nbb;
+    if (NB >= 1 && nwg < (1LL << 31)) {
+      hipLaunchKernelGGL(sgu::upsample_bwd_band_kernel, dim3((unsigned)nwg), dim3(sgu::BAND_T), 0, stream, grad_y, gx, C, h, w, H, W, if_rate, NB, (int)nbb,
+                         lerp_scale(h, H), lerp_scale(w, W));
+      return 0;
+    }
+  }
   if (fp > 512 && total < (1LL << 31))
     hipLaunchKernelGGL(sgu::upsample_bwd_wg_kernel, dim3((unsigned)total), dim3(sgu::THREADS), 0, stream, grad_y, gx, C, h, w, H, W, if_rate, total);
   else if (fp > 200)
