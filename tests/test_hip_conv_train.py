@@ -153,6 +153,26 @@ def test_wgrad_multi_level(cfg, dtype):
     assert (one - ref1).abs().max() <= 2e-4 * max(1.0, float(ref1.abs().max()))
 
 
+@pytest.mark.parametrize('cfg', [(3, 16, 3, 1, 4), (12, 16, 3, 1, 8), (16, 16, 3, 2, 4), (16, 32, 3, 1, 8), (32, 32, 1, 1, 2), (16, 3, 3, 1, 4), (16, 16, 3, 1, 6)])
+def test_wgrad_of_narrow_layers(cfg):
+    """Layers with <= 32 input and output channels (the feature pyramid's first levels, the heads): aligned and ragged widths,
+    channel slices of wider buffers, several batch sizes == the per-image fp32 reference; deterministic."""
+    from upflow_pytorch_amd import ops
+    Cin, Cout, k, d, B = cfg
+    g = torch.Generator().manual_seed(Cin * 100 + Cout + B)
+    for sizes in ([(64, 104)], [(24, 40), (12, 26), (6, 13)]):
+        uses, ref = [], 0
+        for (H, W) in sizes:
+            xw = torch.randn(B, Cin + 5, H, W, generator=g).bfloat16().cuda()
+            gw_ = (torch.randn(B, Cout + 2, H, W, generator=g) * 0.25).bfloat16().cuda()
+            x, gy = xw[:, 2:2 + Cin], gw_[:, 1:1 + Cout]
+            uses.append((x, gy))
+            ref = ref + torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin, k, k), gy.float(), padding=d * (k - 1) // 2, dilation=d)
+        got = ops.conv_wgrad_multi(uses, Cin, Cout, k, d)
+        assert (got - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max())), (sizes, float((got - ref).abs().max()))
+        assert torch.equal(got, ops.conv_wgrad_multi(uses, Cin, Cout, k, d))
+
+
 @pytest.mark.parametrize('cfg', [(115, 128, 3, 1), (563, 2, 3, 1), (196, 300, 1, 1), (32, 32, 3, 4)])
 def test_wgrad_multi_with_fused_bias_finish(cfg):
     """upf_conv_wgrad_multi_bias: the reduction launch also finishes the bias gradient — the weight gradient is bit-identical to

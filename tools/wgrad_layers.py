@@ -20,9 +20,9 @@ batch = synthetic_train_batch(4, seed=0, device=dev)
 tr.step(batch)
 calls = []
 orig_multi, orig_s2d = ops.conv_wgrad_multi, ops.conv_wgrad_s2d
-def rec_multi(uses, Cin, Cout, k, dilation):
+def rec_multi(uses, Cin, Cout, k, dilation, **kw):
     calls.append(('multi', [tuple(x.shape) + (x.stride(0), g.stride(0)) for x, g in uses], Cin, Cout, k, dilation))
-    return orig_multi(uses, Cin, Cout, k, dilation)
+    return orig_multi(uses, Cin, Cout, k, dilation, **kw)
 def rec_s2d(xs, g, Cin, Cout):
     calls.append(('s2d', [tuple(xs.shape) + (xs.stride(0), g.stride(0))], Cin, Cout, 3, 1))
     return orig_s2d(xs, g, Cin, Cout)
