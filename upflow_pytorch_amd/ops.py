@@ -1339,52 +1339,46 @@ def conv_bias_grad_finish(parts, Cout):
     return total
 
 
+def _wgrad_levels(chunk, Cin, Cout):
+    """ctypes array of upf_wgrad_level for the uses [(x, g), ...] (checked: channel slices of the right shapes)."""
+    arr = (_lib.WgradLevel * len(chunk))()
+    for a, (x, g) in zip(arr, chunk):
+        if not (_is_slice(x) and _is_slice(g)) or x.shape[1] != Cin or g.shape[1] != Cout or x.shape[0] != g.shape[0] or x.shape[2:] != g.shape[2:]:
+            raise UpflowHipError('conv_wgrad_multi: x / g must be [B,Cin,H,W] / [B,Cout,H,W] channel slices')
+        a.x, a.x_batch_stride, a.grad_pre, a.g_batch_stride = x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0)
+        a.B, a.H, a.W = x.shape[0], x.shape[2], x.shape[3]
+    return arr
+
+
 def conv_wgrad_multi(uses, Cin, Cout, k, dilation, bias_parts=None):
     """fp32 [Cout,Cin,k,k] weight gradient over several uses [(x, g), ...] of one convolution (x: [B,Cin,H,W] slices,
     g: [B,Cout,H,W] slices of the gradient entering the pre-activation; sizes may differ per use — the pyramid levels):
     one K dimension, shared K-split launches and one ordered reduction (upf_conv_wgrad_multi).
-    bias_parts (1..8 first-stage [Cout,32] buffers of act_grad): the bias gradient is finished by the SAME reduction launch
-    (upf_conv_wgrad_multi_bias) and the result is (grad_w, grad_b)."""
+    bias_parts (1..8 first-stage [Cout,32] buffers of act_grad, with at most 6 uses): the bias gradient is finished by the SAME
+    reduction launch (upf_conv_wgrad_multi_bias) and the result is (grad_w, grad_b)."""
     dev = uses[0][0].device
     d = dilation if k == 3 else 1
-    total = None
-    if bias_parts is not None:
-        if not (1 <= len(bias_parts) <= 8 and len(uses) <= 6):
-            raise UpflowHipError('conv_wgrad_multi: the fused bias finish takes 1..8 partial buffers and one chunk of levels')
-        with torch.cuda.device(dev):
-            arr = (_lib.WgradLevel * len(uses))()
-            for a, (x, g) in zip(arr, uses):
-                if not (_is_slice(x) and _is_slice(g)) or x.shape[1] != Cin or g.shape[1] != Cout or x.shape[0] != g.shape[0] or x.shape[2:] != g.shape[2:]:
-                    raise UpflowHipError('conv_wgrad_multi: x / g must be [B,Cin,H,W] / [B,Cout,H,W] channel slices')
-                a.x, a.x_batch_stride, a.grad_pre, a.g_batch_stride = x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0)
-                a.B, a.H, a.W = x.shape[0], x.shape[2], x.shape[3]
-            nbytes = _lib.lib().upf_conv_wgrad_multi_workspace_bytes(arr, len(uses), Cin, Cout, k, d)
-            if nbytes < 0:
-                raise UpflowHipError('conv_wgrad_multi: bad level list')
-            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-            gw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev)
-            gb = torch.empty((Cout,), dtype=torch.float32, device=dev)
-            parr = (_lib._vp * len(bias_parts))(*[p.data_ptr() for p in bias_parts])
-            _lib.call('upf_conv_wgrad_multi_bias', arr, len(uses), _lib.ptr(gw), _lib.ptr(ws), Cin, Cout, k, d, parr, len(bias_parts), _lib.ptr(gb),
-                      _lib.dtype_code(uses[0][0]), _lib.stream_ptr(dev))
-        return gw, gb
+    if bias_parts is not None and not (1 <= len(bias_parts) <= 8 and len(uses) <= 6):
+        raise UpflowHipError('conv_wgrad_multi: the fused bias finish takes 1..8 partial buffers and one chunk of levels')
+    total, gb = None, None
     with torch.cuda.device(dev):
         for i in range(0, len(uses), 6):
             chunk = uses[i:i + 6]
-            arr = (_lib.WgradLevel * len(chunk))()
-            for a, (x, g) in zip(arr, chunk):
-                if not (_is_slice(x) and _is_slice(g)) or x.shape[1] != Cin or g.shape[1] != Cout or x.shape[0] != g.shape[0] or x.shape[2:] != g.shape[2:]:
-                    raise UpflowHipError('conv_wgrad_multi: x / g must be [B,Cin,H,W] / [B,Cout,H,W] channel slices')
-                a.x, a.x_batch_stride, a.grad_pre, a.g_batch_stride = x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0)
-                a.B, a.H, a.W = x.shape[0], x.shape[2], x.shape[3]
+            arr = _wgrad_levels(chunk, Cin, Cout)
             nbytes = _lib.lib().upf_conv_wgrad_multi_workspace_bytes(arr, len(chunk), Cin, Cout, k, d)
             if nbytes < 0:
                 raise UpflowHipError('conv_wgrad_multi: bad level list')
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             gw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dev)
-            _lib.call('upf_conv_wgrad_multi', arr, len(chunk), _lib.ptr(gw), _lib.ptr(ws), Cin, Cout, k, d, _lib.dtype_code(chunk[0][0]), _lib.stream_ptr(dev))
+            if bias_parts is not None:
+                gb = torch.empty((Cout,), dtype=torch.float32, device=dev)
+                parr = (_lib._vp * len(bias_parts))(*[p.data_ptr() for p in bias_parts])
+                _lib.call('upf_conv_wgrad_multi_bias', arr, len(chunk), _lib.ptr(gw), _lib.ptr(ws), Cin, Cout, k, d, parr, len(bias_parts), _lib.ptr(gb),
+                          _lib.dtype_code(chunk[0][0]), _lib.stream_ptr(dev))
+            else:
+                _lib.call('upf_conv_wgrad_multi', arr, len(chunk), _lib.ptr(gw), _lib.ptr(ws), Cin, Cout, k, d, _lib.dtype_code(chunk[0][0]), _lib.stream_ptr(dev))
             total = gw if total is None else total + gw
-    return total
+    return (total, gb) if bias_parts is not None else total
 
 
 # ---- parameter gradients of SHARED convolutions: one contraction per step -----------------------------------------------
