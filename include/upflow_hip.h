@@ -369,8 +369,9 @@ int upf_conv_wgrad(const void* x, long long x_batch_stride, const void* grad_pre
 /* One weight gradient over SEVERAL uses of the same weights (the decoder is shared by the five pyramid levels,
  * model/upflow.py:535-573): the pixels of every level are one K dimension, so the levels share the K-split launches, the
  * partial blocks and the one ordered reduction (instead of a launch pair per level plus fp32 adds of the results).
- * 1..6 levels of any sizes (each: upf_conv_wgrad_supported); aligned and ragged levels go in one launch each.  The
- * workspace size depends on the pointers' alignment: query it with the same level array. */
+ * 1..6 levels of any sizes (each: upf_conv_wgrad_supported); aligned and ragged levels share ONE launch (the staging of a
+ * ragged level's border blocks is chosen per tile).  Query the workspace size with the same level array.
+ * Environment (A/B runs): UPF_WGRAD_SPLIT="slices,J" overrides the K-split, UPF_WGRAD_ABLATE the experiments of tools/wgrad_ablate.py. */
 typedef struct {
   const void* x;        long long x_batch_stride;      /* [B, Cin, H, W] slice, batch stride in elements (0 = dense) */
   const void* grad_pre; long long g_batch_stride;      /* [B, Cout, H, W] slice */
