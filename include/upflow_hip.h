@@ -462,6 +462,20 @@ int upf_robust_loss_forward(const float* x, const float* y, const float* occ, fl
 int upf_robust_loss_backward(const float* x, const float* y, const float* occ, const float* coef,
                              float* grad_x, float* grad_y, int B, int C, int HW, float eps, float q, void* stream);
 
+/* Pyramid-distillation term, style 'upup' (model/upflow.py:461-487, network_tools.photo_loss_multi_type 'abs_robust' on
+ * upsample_flow(level flow, label)), ONE direction, all levels:
+ *   out2[0] = weight * sum_l [ sum (|up(x_l) - y| + eps)^q * occ ] / den,   out2[1] = den = sum occ + 1e-6  (occ NULL: B*2*H*W)
+ * x_low[l] [B,2,hs[l],ws[l]] fp32 (1..6 levels, ws >= 2), up = bilinear, align_corners, times the size ratio per component
+ * (pwc_modules.py:77-90); y [B,2,H,W] the detached label, occ [B,1,H,W] or NULL.  Forward: one pass over the label + one finishing
+ * launch (partials: upf_msd_upup_partials(B,H,W) x 7 floats).  Backward: grad_x_low[l] = d out2[0] / d x_low[l] * grad_out[0],
+ * one launch for all levels (deterministic gathers).  x_low / grad_x_low / hs / ws are HOST arrays. */
+int upf_msd_upup_partials(int B, int H, int W);
+int upf_msd_upup_forward(const float* const* x_low, const int* hs, const int* ws, int nlevels, const float* y, const float* occ,
+                         float* partials, float* out2, int B, int H, int W, float weight, float eps, float q, void* stream);
+int upf_msd_upup_backward(const float* const* x_low, float* const* grad_x_low, const int* hs, const int* ws, int nlevels, const float* y,
+                          const float* occ, const float* grad_out, const float* fwd_out2, int B, int H, int W, float weight, float eps, float q,
+                          void* stream);
+
 /* first-order edge-aware smoothness, network_tools.edge_aware_smoothness_order1 (model/upflow.py:197-216):
  *   partials[k] = { sum |pred(i,j)-pred(i+1,j)| * exp(-mean_c |img(i,j)-img(i+1,j)|),  the same along j };
  * loss = sum_x / (B*Cp*(H-1)*W) + sum_y / (B*Cp*H*(W-1)).  img [B,Ci,H,W], pred [B,Cp,H,W].

@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), 'missing symbol %s' % n
     bound = set(_lib.SIGNATURES) | {'upf_version', 'upf_last_error', 'upf_normalize_workspace_bytes', 'upf_conv_packed_bytes', 'upf_conv_x3_packed_bytes',
-             'upf_conv_set_option', 'upf_conv_c8_set_option', 'upf_conv_x3_set_option', 'upf_conv_packed_bytes_k', 'upf_conv_packed_bytes_k16', 'upf_conv_c8_k', 'upf_corr_set_option', 'upf_loss_partials', 'upf_conv_wgrad_supported', 'upf_conv_wgrad_workspace_bytes', 'upf_conv_wgrad_multi_workspace_bytes', 'upf_conv_bias_grad_workspace_bytes', 'upf_warp_backward_workspace_bytes', 'upf_sgu_blend_backward_workspace_bytes', 'upf_sgu_blend_forward_workspace_bytes', 'upf_corr81_norm_supported', 'upf_corr81_norm_workspace_bytes'}
+             'upf_conv_set_option', 'upf_conv_c8_set_option', 'upf_conv_x3_set_option', 'upf_conv_packed_bytes_k', 'upf_conv_packed_bytes_k16', 'upf_conv_c8_k', 'upf_corr_set_option', 'upf_loss_partials', 'upf_msd_upup_partials', 'upf_conv_wgrad_supported', 'upf_conv_wgrad_workspace_bytes', 'upf_conv_wgrad_multi_workspace_bytes', 'upf_conv_bias_grad_workspace_bytes', 'upf_warp_backward_workspace_bytes', 'upf_sgu_blend_backward_workspace_bytes', 'upf_sgu_blend_forward_workspace_bytes', 'upf_corr81_norm_supported', 'upf_corr81_norm_workspace_bytes'}
     assert bound == set(names), (bound ^ set(names))
 
 

@@ -524,6 +524,37 @@ def test_flow_upsample_backward_matches_autograd(shape, if_rate):
     assert torch.equal(gx, gx2), 'backward must be deterministic'
 
 
+@pytest.mark.parametrize('shape', [((256, 832), [(4, 13), (8, 26), (16, 52), (32, 104), (64, 208)]), ((37, 53), [(5, 7), (19, 27), (37, 53)]), ((64, 96), [(16, 24)])])
+@pytest.mark.parametrize('use_occ', [True, False])
+def test_fused_distillation_term_matches_the_composition(shape, use_occ):
+    """upf_msd_upup_forward / _backward (one direction of the 'upup' pyramid-distillation term, model/upflow.py:461-487) == the
+    composition it replaces: flow_upsample -> abs_robust sums -> s / (s_occ + 1e-6), summed over the levels, and its autograd
+    gradients with respect to every level flow; deterministic."""
+    from upflow_pytorch_amd import ops
+    (H, W), levels = shape
+    B = 2
+    g = torch.Generator().manual_seed(H * 7 + W)
+    y = (torch.randn(B, 2, H, W, generator=g) * 3).cuda()
+    occ = (torch.rand(B, 1, H, W, generator=g) > 0.3).float().cuda() if use_occ else None
+    xs = [(torch.randn(B, 2, h, w, generator=g) * 0.5).cuda().requires_grad_(True) for h, w in levels]
+    weight = 0.7
+    assert ops.msd_upup_supported(y, xs)
+    got = ops.msd_upup_loss(xs, y, occ, weight)
+    ggot = torch.autograd.grad(got, xs)
+    ref = 0
+    for x in xs:
+        s, s_occ = ops.robust_loss_sums(ops.flow_upsample(x, H, W, True), y, occ, q=0.4, eps=0.01)
+        ref = ref + (s / (s_occ + 1e-6) if use_occ else s / float(y.numel()))
+    ref = weight * ref
+    gref = torch.autograd.grad(ref, xs)
+    assert abs(float(got) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (float(got), float(ref))
+    for a, b in zip(ggot, gref):
+        assert relerr(a.cpu(), b.cpu()) <= 2e-4, float((a - b).abs().max())
+    assert float(got) == float(ops.msd_upup_loss(xs, y, occ, weight))
+    again = torch.autograd.grad(ops.msd_upup_loss(xs, y, occ, weight), xs)
+    assert all(torch.equal(a, b) for a, b in zip(ggot, again))
+
+
 def test_new_entry_points_reject_bad_arguments():
     """upf_warp_forward_strided / upf_flow_update / upf_conv_set_option fail loudly (RuntimeError) on misuse."""
     from upflow_pytorch_amd import ops, _lib

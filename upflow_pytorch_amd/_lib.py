@@ -78,6 +78,8 @@ SIGNATURES = {
     'upf_boundary_warp_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_robust_loss_forward': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     'upf_robust_loss_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
+    'upf_msd_upup_forward': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp],
+    'upf_msd_upup_backward': [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp],
     'upf_smooth_edge1_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_smooth_edge1_backward': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_div_selftest': [_i, _vp, _vp],
@@ -136,6 +138,8 @@ def lib():
         L.upf_conv_bias_grad_workspace_bytes.restype = _ll
         L.upf_loss_partials.argtypes = [_ll]
         L.upf_loss_partials.restype = _i
+        L.upf_msd_upup_partials.argtypes = [_i, _i, _i]
+        L.upf_msd_upup_partials.restype = _i
         L.upf_conv_packed_bytes.argtypes = [_i, _i, _i]
         L.upf_conv_packed_bytes.restype = _ll
         L.upf_conv_x3_packed_bytes.argtypes = [_i, _i, _i]

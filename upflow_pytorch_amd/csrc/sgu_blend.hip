@@ -375,6 +375,163 @@ void upsample_bwd_band_kernel(const float* __restrict__ gy, float* __restrict__ 
   gx[(nc * h + a) * w + b] = acc;
 }
 
+// ---- pyramid-distillation term, style 'upup' (model/upflow.py:461-487): every level's flow, up-sampled to the label's size, against
+// the detached final flow under the occlusion mask:   weight * sum_l  [ sum (|up(x_l) - y| + eps)^q * occ ] / (sum occ + 1e-6).
+// The reference composition — up-sample, robust sum, three scalar kernels per level and direction, and their backward — is 20
+// launches and a full-resolution intermediate written and read twice per level and direction (0.57 ms of a 10.2 ms config-3
+// step).  Here, per direction: ONE forward pass over the label reads y and occ once and interpolates all levels on the fly (the
+// level maps are a few KB: cache resident); one finishing launch; ONE backward launch whose workgroups are the band kernel's
+// (a low-resolution row and column strip each, all levels side by side in the grid) with the robust term's derivative evaluated
+// in place of a stored gradient.
+constexpr int MSD_MAXL = 6, MSD_T = 256;
+struct MsdLevels {
+  const float* x[MSD_MAXL]; float* gx[MSD_MAXL];
+  int h[MSD_MAXL], w[MSD_MAXL], NB[MSD_MAXL], nbb[MSD_MAXL];
+  float sy[MSD_MAXL], sx[MSD_MAXL], rx[MSD_MAXL], ry[MSD_MAXL];
+  unsigned blk0[MSD_MAXL + 1];
+  int n;
+};
+// x^e for x > 0 through the hardware's log2 / exp2 (1 ulp each): the libm powf of the composition is ~60 instructions, and the term
+// is evaluated ~20 M times per direction in the backward (the launch was 122 us, bound by it)
+__device__ __forceinline__ float msd_pow(float x, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x)); }
+__device__ __forceinline__ float msd_up(const float* __restrict__ xl, int w, const Lerp& ly, const Lerp& lx) {
+  const float* s0 = xl + ly.i0 * w; const float* s1 = xl + ly.i1 * w;
+  return ly.l0 * (lx.l0 * s0[lx.i0] + lx.l1 * s0[lx.i1]) + ly.l1 * (lx.l0 * s1[lx.i0] + lx.l1 * s1[lx.i1]);       // (upsample_fwd_kernel's expression)
+}
+// partials[block][MSD_MAXL + 1] = { sum_l over the block's pixels ..., sum occ }
+__global__ __launch_bounds__(MSD_T)
+void msd_fwd_kernel(const MsdLevels L, const float* __restrict__ y, const float* __restrict__ occ, float* __restrict__ partials,
+                    int H, int W, long long npix, float eps, float q) {
+  __shared__ float sh[MSD_T / 64];
+  const int HW = H * W;
+  float s[MSD_MAXL], so = 0.f;
+#pragma unroll
+  for (int l = 0; l < MSD_MAXL; ++l) s[l] = 0.f;
+  for (long long p = blockIdx.x * (long long)MSD_T + threadIdx.x; p < npix; p += (long long)gridDim.x * MSD_T) {
+    const long long n = p / HW;
+    const int r = (int)(p - n * HW), i = r / W, j = r - i * W;
+    const float o = occ ? occ[p] : 1.0f;
+    so += o;
+    const float y0 = y[(size_t)(n * 2) * HW + r], y1 = y[(size_t)(n * 2 + 1) * HW + r];
+#pragma unroll
+    for (int l = 0; l < MSD_MAXL; ++l)
+      if (l < L.n) {
+        const Lerp ly = make_lerp_scaled(i, L.h[l], L.sy[l]), lx = make_lerp_scaled(j, L.w[l], L.sx[l]);
+        const size_t hw = (size_t)L.h[l] * L.w[l];
+        const float v0 = msd_up(L.x[l] + (size_t)(n * 2) * hw, L.w[l], ly, lx) * L.rx[l];
+        const float v1 = msd_up(L.x[l] + (size_t)(n * 2 + 1) * hw, L.w[l], ly, lx) * L.ry[l];
+        const float t = msd_pow(fabsf(v0 - y0) + eps, q) + msd_pow(fabsf(v1 - y1) + eps, q);
+        s[l] += t * o;
+      }
+  }
+  auto bsum = [&](float v) {
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < MSD_T / 64; ++k) r += sh[k];
+    return r;
+  };
+  float* out = partials + (size_t)blockIdx.x * (MSD_MAXL + 1);
+#pragma unroll
+  for (int l = 0; l < MSD_MAXL; ++l) { const float v = bsum(s[l]); if (threadIdx.x == 0) out[l] = v; }
+  const float v = bsum(so);
+  if (threadIdx.x == 0) out[MSD_MAXL] = v;
+}
+// out[0] = weight * sum_l S_l / den,  out[1] = den   (den = sum occ + 1e-6, or den_const > 0: the element count without a mask)
+__global__ __launch_bounds__(MSD_T)
+void msd_finish_kernel(const float* __restrict__ partials, int nb, int nl, float weight, float den_const, float* __restrict__ out) {
+  __shared__ float sh[MSD_T / 64];
+  __shared__ float tot[MSD_MAXL + 1];
+  for (int k = 0; k <= MSD_MAXL; ++k) {
+    float v = 0.f;
+    for (int b = threadIdx.x; b < nb; b += MSD_T) v += partials[(size_t)b * (MSD_MAXL + 1) + k];
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tot[k] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float den = den_const > 0.f ? den_const : tot[MSD_MAXL] + 1e-6f;
+  float acc = 0.f;
+  for (int l = 0; l < nl; ++l) acc += tot[l] / den;
+  out[0] = weight * acc; out[1] = den;
+}
+// backward: workgroup -> (level, plane nc, input row a, column strip); see upsample_bwd_band_kernel
+__global__ __launch_bounds__(BAND_T)
+void msd_bwd_kernel(const MsdLevels L, const float* __restrict__ y, const float* __restrict__ occ, const float* __restrict__ gout,
+                    const float* __restrict__ fwd_out /* [1] = den */, float weight, int H, int W, float eps, float q) {
+  __shared__ float cs[4][BAND_COLS];
+  __shared__ float wys[BAND_ROWS];
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < MSD_MAXL; ++k) if (k < L.n && blockIdx.x >= L.blk0[k]) l = k;
+  const float* xl = L.x[0]; float* gxl = L.gx[0];
+  int h = L.h[0], w = L.w[0], NB = L.NB[0], nbb = L.nbb[0]; float sy = L.sy[0], sx = L.sx[0], rx = L.rx[0], ry = L.ry[0]; unsigned b0blk = L.blk0[0];
+#pragma unroll
+  for (int k = 1; k < MSD_MAXL; ++k)
+    if (k == l) { xl = L.x[k]; gxl = L.gx[k]; h = L.h[k]; w = L.w[k]; NB = L.NB[k]; nbb = L.nbb[k]; sy = L.sy[k]; sx = L.sx[k]; rx = L.rx[k]; ry = L.ry[k]; b0blk = L.blk0[k]; }
+  const unsigned bid = blockIdx.x - b0blk;
+  const int tid = threadIdx.x, rg = tid >> 8, cj = tid & 255;
+  const int bb = bid % nbb, a = (bid / nbb) % h;
+  const int nc = bid / ((unsigned)nbb * h), n = nc >> 1, c = nc & 1;
+  const int b0 = bb * NB, b1 = min(w, b0 + NB);
+  int ilo, ihi, jlo, jhi, t0, t1;
+  upsample_bwd_range(a, h, H, ilo, ihi);
+  upsample_bwd_range(b0, w, W, jlo, t0);
+  upsample_bwd_range(b1 - 1, w, W, t1, jhi);
+  const int nrows = ihi - ilo + 1;
+  const bool table = nrows <= BAND_ROWS;
+  if (table)
+    for (int t = tid; t < nrows; t += BAND_T) wys[t] = upsample_bwd_weight(make_lerp_scaled(ilo + t, h, sy), a);
+  __syncthreads();
+  const size_t HW = (size_t)H * W;
+  const float* yc = y + ((size_t)n * 2 + c) * HW;
+  const float* oc = occ ? occ + (size_t)n * HW : nullptr;
+  const float* xc = xl + (size_t)nc * h * w;
+  const float rate = c == 0 ? rx : ry;
+  const int j0 = jlo + cj, j1 = j0 + 256;
+  const bool in0 = j0 <= jhi, in1 = j1 <= jhi;
+  const Lerp lx0 = make_lerp_scaled(in0 ? j0 : jlo, w, sx), lx1 = make_lerp_scaled(in1 ? j1 : jlo, w, sx);
+  // d/dx of (|x - y| + eps)^q * occ at one label pixel (robust_bwd_kernel's expression without the scalar coefficient)
+  auto dterm = [&](const Lerp& ly, const Lerp& lx, int i, int j) {
+    const float d = msd_up(xc, w, ly, lx) * rate - yc[(size_t)i * W + j];
+    const float o = oc ? oc[(size_t)i * W + j] : 1.0f;
+    const float sg = (d > 0.f) ? 1.0f : ((d < 0.f) ? -1.0f : 0.f);
+    return o * q * msd_pow(fabsf(d) + eps, q - 1.0f) * sg;
+  };
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int i = ilo + rg; i <= ihi; i += 4) {
+    const Lerp ly = make_lerp_scaled(i, h, sy);
+    const float wy = table ? wys[i - ilo] : upsample_bwd_weight(ly, a);
+    if (wy == 0.f) continue;
+    if (in0) acc0 += dterm(ly, lx0, i, j0) * wy;
+    if (in1) acc1 += dterm(ly, lx1, i, j1) * wy;
+  }
+  cs[rg][cj] = acc0; cs[rg][cj + 256] = acc1;
+  __syncthreads();
+  if (tid < BAND_COLS) cs[0][tid] = ((cs[0][tid] + cs[1][tid]) + cs[2][tid]) + cs[3][tid];
+  __syncthreads();
+  const int b = b0 + (tid >> 4), r = tid & 15;
+  float acc = 0.f;
+  if (b < b1) {
+    int jl, jh;
+    upsample_bwd_range(b, w, W, jl, jh);
+    for (int j = jl + r; j <= jh; j += 16) acc += cs[0][j - jlo] * upsample_bwd_weight(make_lerp_scaled(j, w, sx), b);
+  }
+#pragma unroll
+  for (int o2 = 8; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);
+  if (r != 0 || b >= b1) return;
+  const float coef = gout[0] * weight / fwd_out[1];
+  gxl[((size_t)nc * h + a) * w + b] = acc * rate * coef;
+}
+
 // g_logit *= s (1 - s), s = sigmoid(logit): the mask channel of the final-level blend after its resize gradient
 template <typename T>
 __global__ void sigmoid_grad_kernel(const T* __restrict__ x_out, float* __restrict__ g_xo, int hw, long long total) {
@@ -519,6 +676,65 @@ extern "C" int upf_sgu_blend_backward(const float* flow_init, const void* x_out,
     UPF_DISPATCH(dtype, T, hipLaunchKernelGGL((sgu::sigmoid_grad_kernel<T>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, (const T*)x_out, g_x_out32, h * w, nm));
   }
   return check_launch("sgu_blend_backward");
+}
+
+static int msd_levels(upf::sgu::MsdLevels& L, const float* const* x_low, float* const* gx_low, const int* hs, const int* ws, int nl, int B, int H, int W) {
+  using namespace upf;
+  UPF_REQUIRE(x_low && hs && ws && nl >= 1 && nl <= sgu::MSD_MAXL && B > 0 && H > 1 && W > 1, UPF_EINVAL, "msd_upup: 1..%d levels, a label of at least 2x2", sgu::MSD_MAXL);
+  L = upf::sgu::MsdLevels{};
+  unsigned blk = 0;
+  for (int l = 0; l < nl; ++l) {
+    UPF_REQUIRE(x_low[l] && hs[l] >= 1 && ws[l] >= 2 && hs[l] <= H && ws[l] <= W, UPF_EUNSUPPORTED, "msd_upup: level %d (%dx%d) must be no larger than the label and at least 2 wide", l, hs[l], ws[l]);
+    L.x[l] = x_low[l]; L.gx[l] = gx_low ? gx_low[l] : nullptr;
+    L.h[l] = hs[l]; L.w[l] = ws[l];
+    L.sy[l] = lerp_scale(hs[l], H); L.sx[l] = lerp_scale(ws[l], W);
+    L.rx[l] = (float)((double)W / (double)ws[l]); L.ry[l] = (float)((double)H / (double)hs[l]);
+    const double inv = (double)(W - 1) / (double)(ws[l] - 1);
+    int NB = (int)((sgu::BAND_COLS - 8) / inv) - 1;
+    if (NB > 64) NB = 64;
+    if (NB > ws[l]) NB = ws[l];
+    UPF_REQUIRE(NB >= 1, UPF_EUNSUPPORTED, "msd_upup: resize ratio too large for the band kernel (level %d)", l);
+    L.NB[l] = NB; L.nbb[l] = cdiv(ws[l], NB);
+    L.blk0[l] = blk;
+    const long long nwg = (long long)B * 2 * hs[l] * L.nbb[l];
+    UPF_REQUIRE((long long)blk + nwg < (1ll << 31), UPF_EINVAL, "msd_upup: grid too large");
+    blk += (unsigned)nwg;
+  }
+  L.blk0[nl] = blk;
+  for (int l = nl + 1; l <= sgu::MSD_MAXL; ++l) L.blk0[l] = blk;
+  L.n = nl;
+  return UPF_OK;
+}
+
+extern "C" int upf_msd_upup_partials(int B, int H, int W) {
+  const long long b = ((long long)B * H * W + upf::sgu::MSD_T - 1) / upf::sgu::MSD_T;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int upf_msd_upup_forward(const float* const* x_low, const int* hs, const int* ws, int nlevels, const float* y, const float* occ,
+                                    float* partials, float* out2, int B, int H, int W, float weight, float eps, float q, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(y && partials && out2, UPF_EINVAL, "msd_upup_forward: null pointer");
+  sgu::MsdLevels L;
+  if (int rc = msd_levels(L, x_low, nullptr, hs, ws, nlevels, B, H, W)) return rc;
+  const int nb = upf_msd_upup_partials(B, H, W);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sgu::msd_fwd_kernel, dim3(nb), dim3(sgu::MSD_T), 0, s, L, y, occ, partials, H, W, (long long)B * H * W, eps, q);
+  hipLaunchKernelGGL(sgu::msd_finish_kernel, dim3(1), dim3(sgu::MSD_T), 0, s, (const float*)partials, nb, nlevels, weight,
+                     occ ? 0.f : (float)((double)B * 2 * H * W), out2);
+  return check_launch("msd_upup_forward");
+}
+
+extern "C" int upf_msd_upup_backward(const float* const* x_low, float* const* grad_x_low, const int* hs, const int* ws, int nlevels, const float* y,
+                                     const float* occ, const float* grad_out, const float* fwd_out2, int B, int H, int W, float weight, float eps, float q,
+                                     void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(y && grad_out && fwd_out2 && grad_x_low, UPF_EINVAL, "msd_upup_backward: null pointer");
+  sgu::MsdLevels L;
+  if (int rc = msd_levels(L, x_low, grad_x_low, hs, ws, nlevels, B, H, W)) return rc;
+  for (int l = 0; l < nlevels; ++l) UPF_REQUIRE(grad_x_low[l], UPF_EINVAL, "msd_upup_backward: null gradient buffer (level %d)", l);
+  hipLaunchKernelGGL(sgu::msd_bwd_kernel, dim3(L.blk0[nlevels]), dim3(sgu::BAND_T), 0, (hipStream_t)stream, L, y, occ, grad_out, fwd_out2, weight, H, W, eps, q);
+  return check_launch("msd_upup_backward");
 }
 
 extern "C" int upf_flow_upsample_forward(const float* x, float* y, int B, int C, int h, int w, int H, int W,

@@ -342,7 +342,16 @@ class UPFlow_net(tools.abstract_model):
             out['census_loss'] = None
         # pyramid distillation (model/upflow.py:461-487): detached final flow teaches every level
         if c.multi_scale_distillation_weight > 0:
-            label_f, label_b = flow_f.clone().detach(), flow_b.clone().detach()
+            label_f, label_b = flow_f.detach(), flow_b.detach()
+            lv_f, lv_b = [f for f, _ in flows], [b for _, b in flows]
+            if (c.multi_scale_distillation_style == 'upup' and not getattr(self, '_no_fused_msd', False) and hasattr(ops, 'msd_upup_supported')
+                    and ops.msd_upup_supported(label_f, lv_f) and ops.msd_upup_supported(label_b, lv_b)):
+                # one pass over the label per direction instead of up-sample + robust sum + scalar kernels per level (ops.MsdUpupFunction)
+                use = c.multi_scale_distillation_occ
+                out['msd_loss'] = (ops.msd_upup_loss(lv_f, label_f, occ_fw if use else None, c.multi_scale_distillation_weight)
+                                   + ops.msd_upup_loss(lv_b, label_b, occ_bw if use else None, c.multi_scale_distillation_weight))
+                return
+            label_f, label_b = label_f.clone(), label_b.clone()
             terms = []
             for lvl_f, lvl_b in flows:
                 if c.multi_scale_distillation_style == 'down':

@@ -1046,6 +1046,78 @@ def robust_loss_sums(x, y, occ=None, q=0.4, eps=0.01):
     return RobustLossFunction.apply(x, y, occ, q, eps)
 
 
+class MsdUpupFunction(Function):
+    """One direction of the pyramid-distillation term, style 'upup' (model/upflow.py:461-487): weight * sum over the levels of
+    abs_robust(upsample_flow(level flow -> label size), label, occ) — one pass over the label, one finishing launch, one backward
+    launch for all levels (upf_msd_upup_forward / _backward).  apply(y, occ, weight, q, eps, *level_flows) -> scalar."""
+
+    @staticmethod
+    def forward(ctx, y, occ, weight, q, eps, *levels):
+        y = _f32(y).contiguous()
+        B, C, H, W = y.shape
+        if C != 2 or not levels or len(levels) > 6:
+            raise UpflowHipError('msd_upup: a [B,2,H,W] label and 1..6 level flows expected')
+        xs = [_f32(x).contiguous() for x in levels]
+        for x in xs:
+            if x.dim() != 4 or x.shape[0] != B or x.shape[1] != 2:
+                raise UpflowHipError('msd_upup: level flows must be [B,2,h,w], got %s' % (tuple(x.shape),))
+        if occ is not None:
+            occ = _f32(occ).contiguous()
+            if tuple(occ.shape) != (B, 1, H, W):
+                raise UpflowHipError('msd_upup: occlusion mask must be [B,1,H,W], got %s' % (tuple(occ.shape),))
+            if occ.requires_grad:
+                raise UpflowHipError('msd_upup: the occlusion weights are treated as constants (hard masks)')
+        dev = _lib.check_gpu(y, occ, *xs)
+        n = len(xs)
+        nb = _lib.lib().upf_msd_upup_partials(B, H, W)
+        partials = torch.empty((nb, 7), dtype=torch.float32, device=y.device)
+        out2 = torch.empty((2,), dtype=torch.float32, device=y.device)
+        xp = (_lib._vp * n)(*[x.data_ptr() for x in xs])
+        hs = (_lib._c.c_int * n)(*[x.shape[2] for x in xs])
+        ws = (_lib._c.c_int * n)(*[x.shape[3] for x in xs])
+        with torch.cuda.device(dev):
+            _lib.call('upf_msd_upup_forward', xp, hs, ws, n, _lib.ptr(y), _lib.ptr(occ), _lib.ptr(partials), _lib.ptr(out2), B, H, W,
+                      float(weight), float(eps), float(q), _lib.stream_ptr(dev))
+        ctx.save_for_backward(y, occ, out2, *xs)
+        ctx.cfg = (float(weight), float(q), float(eps))
+        ctx.set_materialize_grads(False)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.saved_tensors) - 3
+        if g is None:
+            return (None,) * (5 + n)
+        y, occ, out2 = ctx.saved_tensors[:3]
+        xs = ctx.saved_tensors[3:]
+        weight, q, eps = ctx.cfg
+        B, _, H, W = y.shape
+        g = _f32(g).reshape(1).contiguous()
+        dev = _lib.check_gpu(y, g)
+        gxs = [torch.empty_like(x) for x in xs]
+        xp = (_lib._vp * n)(*[x.data_ptr() for x in xs])
+        gp = (_lib._vp * n)(*[x.data_ptr() for x in gxs])
+        hs = (_lib._c.c_int * n)(*[x.shape[2] for x in xs])
+        ws = (_lib._c.c_int * n)(*[x.shape[3] for x in xs])
+        with torch.cuda.device(dev):
+            _lib.call('upf_msd_upup_backward', xp, gp, hs, ws, n, _lib.ptr(y), _lib.ptr(occ), _lib.ptr(g), _lib.ptr(out2), B, H, W,
+                      weight, eps, q, _lib.stream_ptr(dev))
+        return (None, None, None, None, None) + tuple(gx if ctx.needs_input_grad[5 + i] else None for i, gx in enumerate(gxs))
+
+
+def msd_upup_supported(y, levels):
+    """The fused distillation term applies: GPU tensors, a [B,2,H,W] label, 1..6 level flows no larger than it and >= 2 wide."""
+    return (y.is_cuda and y.dim() == 4 and y.shape[1] == 2 and 1 <= len(levels) <= 6 and y.shape[2] > 1 and y.shape[3] > 1
+            and all(x.is_cuda and x.dim() == 4 and x.shape[1] == 2 and 2 <= x.shape[3] <= y.shape[3] and 1 <= x.shape[2] <= y.shape[2]
+                    and (y.shape[3] - 1) / (x.shape[3] - 1) <= 250 for x in levels))
+
+
+def msd_upup_loss(levels, y, occ=None, weight=1.0, q=0.4, eps=0.01):
+    """weight * sum_l photo_loss_multi_type(upsample_flow(levels[l], y), y, occ, 'abs_robust') for ONE flow direction
+    (model/upflow.py:461-487 with multi_scale_distillation_style 'upup'); differentiable wrt the level flows."""
+    return MsdUpupFunction.apply(y, occ, weight, q, eps, *levels)
+
+
 class SmoothEdge1Function(Function):
     @staticmethod
     def forward(ctx, img, pred):

@@ -62,3 +62,24 @@ def gather_over_ranks(value, device=None):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(o.item()) for o in out]
+
+
+class no_gc_during_capture(object):
+    """with no_gc_during_capture(): ... — python's cyclic garbage collector switched off for the duration of a hipGraph capture
+    (after one explicit collection).  A collection that runs INSIDE a capture can free objects whose destructors issue HIP calls that
+    are illegal while a stream captures in the global mode — an older Trainer's or GraphedInference's hipGraph, caught by a
+    reference cycle, is destroyed (hipGraphExecDestroy) — and the error, thrown from a destructor, aborts the process.  Seen twice in
+    ~20 runs of tests/test_hip_train.py (round 5; the backward thread of a capture, "Garbage-collecting" on top of the stack)."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False

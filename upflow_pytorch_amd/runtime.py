@@ -43,7 +43,8 @@ class GraphedInference:
         # captures: under the default (global) capture mode that hipEventQuery aborts the capture (train.Trainer does the same)
         import torch.distributed as dist
         mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
-        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode=mode):
+        from .parallel import no_gc_during_capture
+        with no_gc_during_capture(), torch.no_grad(), torch.cuda.graph(g, capture_error_mode=mode):
             self.out = self._forward()
         self.graph = g
         # The graph has the addresses of the PACKED weight operands baked in (allocated by the warm-up forwards, outside the graph's

@@ -140,7 +140,8 @@ class Trainer():
         # default (global) capture mode that hipEventQuery is an error that aborts the process
         try:
             # (also when this trainer is not distributed but the process holds a process group: its threads are there all the same)
-            with torch.cuda.graph(g, capture_error_mode='thread_local' if (self.distributed or (dist.is_available() and dist.is_initialized())) else 'global'):
+            with parallel.no_gc_during_capture(), \
+                    torch.cuda.graph(g, capture_error_mode='thread_local' if (self.distributed or (dist.is_available() and dist.is_initialized())) else 'global'):
                 self._static_stats = self._step_body(self._static)
         finally:
             # packed-weight cache entries made DURING the capture point into graph-pool memory whose packing kernels were
