@@ -346,30 +346,24 @@ void census_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g
   const float* b = g2 + (size_t)n * HW;
   const float* Gn = G + (size_t)n * HW;
   const float aq = a[q], bq = b[q], Gq = Gn[q];
+  // q is the CENTRE of its own 49 terms (neighbour value at q+k, zero outside the image: du/dI(q) = -1) and the NEIGHBOUR of offset k
+  // of every centre p = q - k inside the image (du/dI(q) = +1, u = I(q) - I(p)).  The second family needs no evaluation of its own:
+  // with k' = -k it is the pair (q, q+k') seen from the other end, u -> -u, and c is ODD in (u1, u2) — every operation of census_c
+  // commutes with the sign exactly — so
+  //     dI(q) = - sum_k c_k(q) * ( G(q) + [q+k inside] G(q+k) )
+  // (round 5: half the evaluations — 2 rsq + 1 rcp each — and a third of the loads of the first version: 88 -> 45 us).
   float s1 = 0.f, s2 = 0.f;
   for (int dy = -R; dy <= R; ++dy)
     for (int dx = -R; dx <= R; ++dx) {
+      const int y = i + dy, x = j + dx;
+      const bool in = y >= 0 && y < H && x >= 0 && x < W;
+      const int pp = in ? y * W + x : q;
+      const float va = in ? a[pp] : 0.f, vb = in ? b[pp] : 0.f;
       float c1, c2;
-      // (1) q as the CENTRE of its own term k = (dy,dx): neighbour value at q+k (zero outside), du/dI(q) = -1
-      {
-        const int y = i + dy, x = j + dx;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const float va = in ? a[y * W + x] : 0.f, vb = in ? b[y * W + x] : 0.f;
-        census_c(va - aq, vb - bq, c1, c2);
-        if (W1) s1 -= Gq * c1;
-        if (W2) s2 -= Gq * c2;
-      }
-      // (2) q as the NEIGHBOUR of offset k of the centre p = q - k (if p is inside the image), du/dI(q) = +1
-      {
-        const int y = i - dy, x = j - dx;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-          const int pp = y * W + x;
-          census_c(aq - a[pp], bq - b[pp], c1, c2);
-          const float Gp = Gn[pp];
-          if (W1) s1 += Gp * c1;
-          if (W2) s2 += Gp * c2;
-        }
-      }
+      census_c(va - aq, vb - bq, c1, c2);
+      const float gsum = Gq + (in ? Gn[pp] : 0.f);
+      if (W1) s1 -= gsum * c1;
+      if (W2) s2 -= gsum * c2;
     }
   if (W1) gg1[(size_t)n * HW + q] = s1;
   if (W2) gg2[(size_t)n * HW + q] = s2;
