@@ -8,7 +8,7 @@ OBJS=""
 for f in api corr81_fwd corr81_bwd conv3x3 conv_c8 conv_x3 conv_wgrad warp sgu_blend misc loss; do
   if [[ " $* " == *" $f "* ]]; then
     git show $REF:upflow_pytorch_amd/csrc/$f.hip > $T/$f.hip
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -I$P/csrc -I$R/include -Xclang -target-feature -Xclang -packed-fp32-ops -c $T/$f.hip -o $T/$f.o 2>/dev/null
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -I$P/csrc -I$R/include -Xclang -target-feature -Xclang -packed-fp32-ops $( [[ " sgu_blend loss misc warp corr81_fwd corr81_bwd " == *" $f "* ]] && python -c "from upflow_pytorch_amd import _build; print(\" \".join(dict(_build.SOURCES)[\"$f.hip\"]))" ) -c $T/$f.hip -o $T/$f.o 2>/dev/null
     OBJS="$OBJS $T/$f.o"
   else
     OBJS="$OBJS $P/build/$f.o"

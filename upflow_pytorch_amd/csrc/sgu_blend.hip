@@ -122,8 +122,10 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
                       unsigned long long* __restrict__ g_init, float* __restrict__ g_full, float* __restrict__ g_xo,
                       int h, int w, int Hf, int Wf, SampleGeom geo) {
   const int HW = Hf * Wf, hw = h * w;
-  const int p = blockIdx.x * THREADS + threadIdx.x;
-  if (p >= HW) return;
+  const int p_raw = blockIdx.x * THREADS + threadIdx.x;
+  const bool inside = p_raw < HW;
+  const int p = inside ? p_raw : HW - 1;              // (no early exits: every lane takes part in the lane shifts below)
+  const int lane = threadIdx.x & 63;
   const int n = blockIdx.y;
   const int i = p / Wf, j = p - i * Wf;
   float ifx, ify, m;
@@ -141,23 +143,41 @@ void blend_bwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
   const float om = 1.0f - m;
   float gix = 0.f, giy = 0.f, gm = 0.f;
   unsigned long long* gi = g_init + (size_t)n * 2 * HW;
+  // HALF the tap atomics (round 5, as in warp_bwd_kernel): the interpolation map is an up-sampled low-resolution field, so the lanes
+  // of a wave (consecutive pixels of a row) sample consecutive pixels — the right-hand taps of pixel j are the left-hand taps of
+  // pixel j + 1.  Each lane hands the fixed-point values of its right-hand contributions to the next lane, which adds them to its
+  // own left-hand ones where the ADDRESSES agree (anything else keeps its own atomic).  Integer additions of the values the two
+  // atomics would have added: every accumulator, and with it every output bit, is unchanged.
+  const bool tin[4] = {inside && t.in[0], inside && t.in[1], inside && t.in[2], inside && t.in[3]};
+  const int o0n = __shfl_down(o[0], 1), o2n = __shfl_down(o[2], 1);
+  const int in0n = __shfl_down((int)tin[0], 1), in2n = __shfl_down((int)tin[2], 1);
+  const bool m1 = lane < 63 && tin[1] && in0n && o[1] == o0n;
+  const bool m3 = lane < 63 && tin[3] && in2n && o[3] == o2n;
+  const bool p1 = __shfl_up((int)m1, 1) && lane > 0, p3 = __shfl_up((int)m3, 1) && lane > 0;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const float* f = f0 + c * HW;
-    const float g = g_up[((size_t)n * 2 + c) * HW + p];
+    const float g = inside ? g_up[((size_t)n * 2 + c) * HW + p] : 0.f;
     float warped = 0.f;
+    long long q[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (!t.in[k]) continue;
+      if (!tin[k]) continue;
       const float v = f[o[k]];
       warped += v * t.w[k];
-      fix_add(gi + c * HW + o[k], om * g * t.w[k]);
+      q[k] = fix_q(om * g * t.w[k]);
       gix += v * dwx[k] * g;
       giy += v * dwy[k] * g;
     }
-    fix_add(gi + c * HW + p, m * g);
+    const long long r1 = __shfl_up(q[1], 1), r3 = __shfl_up(q[3], 1);
+    if (tin[0]) fix_emit(gi + c * HW + o[0], q[0], p1 ? r1 : 0ll);
+    if (tin[1] && !m1) fix_emit(gi + c * HW + o[1], q[1], 0ll);
+    if (tin[2]) fix_emit(gi + c * HW + o[2], q[2], p3 ? r3 : 0ll);
+    if (tin[3] && !m3) fix_emit(gi + c * HW + o[3], q[3], 0ll);
+    if (inside) fix_add(gi + c * HW + p, m * g);
     gm += g * (f[p] - warped);
   }
+  if (!inside) return;
   const float mx = ((float)(Wf - 1) * 0.5f) * (2.0f / (float)max(Wf - 1, 1));
   const float my = ((float)(Hf - 1) * 0.5f) * (2.0f / (float)max(Hf - 1, 1));
   gix *= om * mx;
