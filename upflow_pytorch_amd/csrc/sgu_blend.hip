@@ -487,7 +487,8 @@ void msd_finish_kernel(const float* __restrict__ partials, int nb, int nl, float
 __global__ __launch_bounds__(BAND_T)
 void msd_bwd_kernel(const MsdLevels L, const float* __restrict__ y, const float* __restrict__ occ, const float* __restrict__ gout,
                     const float* __restrict__ fwd_out /* [1] = den */, float weight, int H, int W, float eps, float q) {
-  __shared__ float cs[4][BAND_COLS];
+  // (both flow components of an image in ONE workgroup: they share the interpolation geometry, the mask and the row / column weights)
+  __shared__ float cs[2][4][BAND_COLS];
   __shared__ float wys[BAND_ROWS];
   int l = 0;
 #pragma unroll
@@ -500,7 +501,7 @@ void msd_bwd_kernel(const MsdLevels L, const float* __restrict__ y, const float*
   const unsigned bid = blockIdx.x - b0blk;
   const int tid = threadIdx.x, rg = tid >> 8, cj = tid & 255;
   const int bb = bid % nbb, a = (bid / nbb) % h;
-  const int nc = bid / ((unsigned)nbb * h), n = nc >> 1, c = nc & 1;
+  const int n = bid / ((unsigned)nbb * h);
   const int b0 = bb * NB, b1 = min(w, b0 + NB);
   int ilo, ihi, jlo, jhi, t0, t1;
   upsample_bwd_range(a, h, H, ilo, ihi);
@@ -511,45 +512,54 @@ void msd_bwd_kernel(const MsdLevels L, const float* __restrict__ y, const float*
   if (table)
     for (int t = tid; t < nrows; t += BAND_T) wys[t] = upsample_bwd_weight(make_lerp_scaled(ilo + t, h, sy), a);
   __syncthreads();
-  const size_t HW = (size_t)H * W;
-  const float* yc = y + ((size_t)n * 2 + c) * HW;
+  const size_t HW = (size_t)H * W, hw = (size_t)h * w;
+  const float* y0p = y + (size_t)n * 2 * HW;
   const float* oc = occ ? occ + (size_t)n * HW : nullptr;
-  const float* xc = xl + (size_t)nc * h * w;
-  const float rate = c == 0 ? rx : ry;
+  const float* x0p = xl + (size_t)n * 2 * hw;
   const int j0 = jlo + cj, j1 = j0 + 256;
   const bool in0 = j0 <= jhi, in1 = j1 <= jhi;
   const Lerp lx0 = make_lerp_scaled(in0 ? j0 : jlo, w, sx), lx1 = make_lerp_scaled(in1 ? j1 : jlo, w, sx);
-  // d/dx of (|x - y| + eps)^q * occ at one label pixel (robust_bwd_kernel's expression without the scalar coefficient)
-  auto dterm = [&](const Lerp& ly, const Lerp& lx, int i, int j) {
-    const float d = msd_up(xc, w, ly, lx) * rate - yc[(size_t)i * W + j];
-    const float o = oc ? oc[(size_t)i * W + j] : 1.0f;
-    const float sg = (d > 0.f) ? 1.0f : ((d < 0.f) ? -1.0f : 0.f);
-    return o * q * msd_pow(fabsf(d) + eps, q - 1.0f) * sg;
+  // d/dx of (|x - y| + eps)^q * occ at one label pixel, both components (robust_bwd_kernel's expression without the scalar coefficient)
+  auto dterm = [&](const Lerp& ly, const Lerp& lx, int i, int j, float wy, float& a0, float& a1) {
+    const size_t pix = (size_t)i * W + j;
+    const float o = (oc ? oc[pix] : 1.0f) * q * wy;
+    const float d0 = msd_up(x0p, w, ly, lx) * rx - y0p[pix], d1 = msd_up(x0p + hw, w, ly, lx) * ry - y0p[HW + pix];
+    const float s0 = (d0 > 0.f) ? 1.0f : ((d0 < 0.f) ? -1.0f : 0.f), s1 = (d1 > 0.f) ? 1.0f : ((d1 < 0.f) ? -1.0f : 0.f);
+    a0 += o * msd_pow(fabsf(d0) + eps, q - 1.0f) * s0;
+    a1 += o * msd_pow(fabsf(d1) + eps, q - 1.0f) * s1;
   };
-  float acc0 = 0.f, acc1 = 0.f;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};              // [component][column]
   for (int i = ilo + rg; i <= ihi; i += 4) {
     const Lerp ly = make_lerp_scaled(i, h, sy);
     const float wy = table ? wys[i - ilo] : upsample_bwd_weight(ly, a);
     if (wy == 0.f) continue;
-    if (in0) acc0 += dterm(ly, lx0, i, j0) * wy;
-    if (in1) acc1 += dterm(ly, lx1, i, j1) * wy;
+    if (in0) dterm(ly, lx0, i, j0, wy, acc[0][0], acc[1][0]);
+    if (in1) dterm(ly, lx1, i, j1, wy, acc[0][1], acc[1][1]);
   }
-  cs[rg][cj] = acc0; cs[rg][cj + 256] = acc1;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) { cs[c][rg][cj] = acc[c][0]; cs[c][rg][cj + 256] = acc[c][1]; }
   __syncthreads();
-  if (tid < BAND_COLS) cs[0][tid] = ((cs[0][tid] + cs[1][tid]) + cs[2][tid]) + cs[3][tid];
+  {
+    const int c = tid >> 9, t = tid & (BAND_COLS - 1);       // 1024 threads = 2 components x 512 columns
+    cs[c][0][t] = ((cs[c][0][t] + cs[c][1][t]) + cs[c][2][t]) + cs[c][3][t];
+  }
   __syncthreads();
   const int b = b0 + (tid >> 4), r = tid & 15;
-  float acc = 0.f;
+  float s0 = 0.f, s1 = 0.f;
   if (b < b1) {
     int jl, jh;
     upsample_bwd_range(b, w, W, jl, jh);
-    for (int j = jl + r; j <= jh; j += 16) acc += cs[0][j - jlo] * upsample_bwd_weight(make_lerp_scaled(j, w, sx), b);
+    for (int j = jl + r; j <= jh; j += 16) {
+      const float wx = upsample_bwd_weight(make_lerp_scaled(j, w, sx), b);
+      s0 += cs[0][0][j - jlo] * wx; s1 += cs[1][0][j - jlo] * wx;
+    }
   }
 #pragma unroll
-  for (int o2 = 8; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);
+  for (int o2 = 8; o2 > 0; o2 >>= 1) { s0 += __shfl_xor(s0, o2, 64); s1 += __shfl_xor(s1, o2, 64); }
   if (r != 0 || b >= b1) return;
   const float coef = gout[0] * weight / fwd_out[1];
-  gxl[((size_t)nc * h + a) * w + b] = acc * rate * coef;
+  gxl[((size_t)(n * 2) * h + a) * w + b] = s0 * rx * coef;
+  gxl[((size_t)(n * 2 + 1) * h + a) * w + b] = s1 * ry * coef;
 }
 
 // g_logit *= s (1 - s), s = sigmoid(logit): the mask channel of the final-level blend after its resize gradient
@@ -716,7 +726,7 @@ static int msd_levels(upf::sgu::MsdLevels& L, const float* const* x_low, float* 
     UPF_REQUIRE(NB >= 1, UPF_EUNSUPPORTED, "msd_upup: resize ratio too large for the band kernel (level %d)", l);
     L.NB[l] = NB; L.nbb[l] = cdiv(ws[l], NB);
     L.blk0[l] = blk;
-    const long long nwg = (long long)B * 2 * hs[l] * L.nbb[l];
+    const long long nwg = (long long)B * hs[l] * L.nbb[l];          // one workgroup per (image, input row, column strip): both components
     UPF_REQUIRE((long long)blk + nwg < (1ll << 31), UPF_EINVAL, "msd_upup: grid too large");
     blk += (unsigned)nwg;
   }
