@@ -185,6 +185,9 @@ class network_tools():
         occ_weight = occ_mask
         if photo_loss_type == 'abs_robust':
             # sub / abs / add / pow / mul / sum of the reference as ONE deterministic reduction (csrc/loss.hip)
+            if x.is_cuda and hasattr(ops, 'robust_loss_ratio') and not getattr(cls, '_no_fused_ratio', False):
+                # the reduction AND its denominator in two launches each way (ops.RobustRatioFunction)
+                return ops.robust_loss_ratio(x, y, occ_mask if photo_loss_use_occ else None, q=photo_loss_delta, eps=0.01)
             s, s_occ = ops.robust_loss_sums(x, y, occ_mask if photo_loss_use_occ else None, q=photo_loss_delta, eps=0.01)
             return s / (s_occ + 1e-6) if photo_loss_use_occ else s / float(x.numel())
         elif photo_loss_type == 'charbonnier':

@@ -10,6 +10,10 @@ class _GreyFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, image):
+        if image.is_cuda and image.dtype == torch.float32:
+            from .. import ops
+            if hasattr(ops, 'grey'):
+                return ops.grey(image)                # (the same expression, one launch: csrc/loss.hip grey_kernel)
         r, g, b = image[:, 0:1], image[:, 1:2], image[:, 2:3]
         return 0.2989 * r + 0.5870 * g + 0.1140 * b
 
@@ -93,6 +97,8 @@ class loss_functions():
         if (not charbonnier_or_abs_robust) and if_use_occ and dist.is_cuda and dist.dtype == torch.float32:
             # sum((|d| + 0.01)^q * m) / (sum(m) * 2 + 1e-6), utils/loss.py:28-31, as the one-launch reduction of csrc/loss.hip
             # (ops.robust_loss_sums with y = 0) instead of nine element-wise / reduction launches each way
+            if hasattr(ops, 'robust_loss_ratio'):
+                return ops.robust_loss_ratio(dist, None, mask * valid, q=q, eps=0.01, den_scale=2.0)
             s, s_m = ops.robust_loss_sums(dist, _zeros_like_cached(dist), mask * valid, q=q, eps=0.01)
             return s / (s_m * 2 + 1e-6)
         if (not charbonnier_or_abs_robust) and (not if_use_occ) and dist.is_cuda and dist.dtype == torch.float32:
