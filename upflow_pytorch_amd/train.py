@@ -33,7 +33,8 @@ class Loss_manager():
                 continue
             if not torch.is_tensor(v):          # e.g. smooth_loss == 0 (python int) when both smooth weights are <= 0
                 v = like.new_tensor(float(v)) if like is not None else torch.as_tensor(float(v))
-            v = v.mean()
+            if v.dim() > 0:                  # (a 0-dim term is its own mean: no reduction launch each way)
+                v = v.mean()
             parts[k] = v.detach()
             total = v if total is None else total + v
         return total, parts
