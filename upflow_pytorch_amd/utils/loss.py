@@ -106,6 +106,8 @@ class loss_functions():
             # multi-block `mean()` zeroes its semaphores with a memset node, the node class that was seen mis-ordered inside
             # replayed hipGraphs on this ROCm (api.hip: zero_fill_u64_kernel): inside a captured training step whose allocation
             # pattern had shifted it returned 9.8e3 for inputs whose mean is 2.0 — tools/frozen_graph_probe.py.)
+            if averge and hasattr(ops, 'robust_loss_ratio'):
+                return ops.robust_loss_ratio(dist, None, None, q=q, eps=0.01)            # (sum / numel in the same two launches)
             s, _ = ops.robust_loss_sums(dist, _zeros_like_cached(dist), None, q=q, eps=0.01)
             return s / dist.numel() if averge else s
         return cls.photo_loss_function(diff=dist, mask=mask * valid, q=q, charbonnier_or_abs_robust=charbonnier_or_abs_robust,
