@@ -1528,13 +1528,52 @@ def conv_wgrad_multi(uses, Cin, Cout, k, dilation, bias_parts=None):
 # (model/upflow.py:535-573).  Autograd would compute a weight gradient per use and add them; here every use only records
 # its (x, g) pair and its bias partial sums in the parameter's sink, and a gate node between the parameter and its uses —
 # which autograd runs after ALL uses — does the one multi-level contraction.
+class _TailGroup(object):
+    """The NARROW TAIL of a dense stack — conv_last, conv5, ... while their output channels add up to <= 64 — as ONE weight-gradient
+    contraction.  The layers of a stack read nested channel suffixes of one buffer and their pre-activation gradients are adjacent
+    slices of P (DenseStackTrainFunction), so  g = P[:, :sum Cout], x = the last layer's input (the whole buffer)  is a layer with
+    <= 64 output channels whose gradient holds every member's as a block: dW_k = dW[co_k : co_k + Cout_k, Cin - Cin_k :].  The
+    weight-gradient kernel works on 64 co x 64 ci blocks, and a launch with 2 ... 32 live output channels costs what one with 64 does
+    (its time is the staging of X): the SGU estimator's four tail layers (3 + 8 + 16 + 32 channels, 70 + 70 + 70 + 58 us) and the
+    flow estimator's two (2 + 32 channels, 110 + 121 us) become one launch each (round 5)."""
+
+    def __init__(self, members):
+        self.members = members                       # [(sink, co_offset, Cout, Cin)], the last layer first
+        self.cout = sum(m[2] for m in members)
+        self.cin = members[0][3]
+        self.uses, self.result, self.pending = [], None, 0
+
+    def take(self, sink):
+        if self.result is None:
+            self.result = conv_wgrad_multi(self.uses, self.cin, self.cout, 3, 1)
+            self.uses, self.pending = [], len(self.members)
+        for (m, co, cout, cin) in self.members:
+            if m is sink:
+                gw = self.result[co:co + cout, self.cin - cin:].contiguous()
+                break
+        else:
+            raise UpflowHipError('_TailGroup: not a member')
+        self.pending -= 1
+        if self.pending == 0:
+            self.result = None
+        return gw
+
+
 class _ParamSink(object):
     def __init__(self, weight, bias, dilation):
         self.weight, self.bias, self.dilation = weight, bias, int(dilation)
         self.uses, self.bias_parts = [], []
+        self.group = None                            # _TailGroup: this layer's weight gradient is a block of the group's
 
     def finish(self):
         Cout, Cin, k, _ = self.weight.shape
+        if self.group is not None and (self.group.uses or self.group.result is not None):
+            gw = self.group.take(self)
+            if self.uses:                            # (uses beyond the group's six levels kept their own contraction)
+                gw = gw + conv_wgrad_multi(self.uses, Cin, Cout, k, self.dilation)
+            gb = conv_bias_grad_finish(self.bias_parts, Cout) if self.bias_parts else None
+            self.uses, self.bias_parts = [], []
+            return gw, gb
         if self.uses and self.bias_parts and len(self.uses) <= 6 and len(self.bias_parts) <= 8:
             gw, gb = conv_wgrad_multi(self.uses, Cin, Cout, k, self.dilation, bias_parts=self.bias_parts)     # (one reduction launch for both)
         else:
@@ -1898,6 +1937,24 @@ class DenseStackTrainFunction(Function):
         for k in range(nf - 1, -1, -1):
             poff[k] = acc
             acc += f[k]
+        # the narrow tail (conv_last, conv5, ...: output channels adding up to <= 64) as one contraction: _TailGroup
+        iw_of = lambda k: 1 + nin + (1 if has_tail else 0) + 2 * k
+        tail, csum = [], 0
+        for k in [nf] + list(range(nf - 1, -1, -1)):
+            ck = oc if k == nf else f[k]
+            if sinks[k] is None or not ctx.needs_input_grad[iw_of(k)] or csum + ck > 64:
+                break
+            tail.append(k); csum += ck
+        grouped = set()
+        if len(tail) >= 2 and not getattr(DenseStackTrainFunction, 'no_tail_group', False):
+            grp = sinks[nf].group
+            if grp is None:
+                grp = _TailGroup([(sinks[k], poff[k], (oc if k == nf else f[k]), nt - hi_of[k]) for k in tail])
+                for k in tail:
+                    sinks[k].group = grp
+            if len(grp.uses) < 6:
+                grp.uses.append((buf[:, :nt], P[:, :csum]))
+                grouped = set(tail)
         for k in range(nf + 1):
             xk = buf[:, hi_of[k]:nt]
             gk = P[:, poff[k]:poff[k] + (oc if k == nf else f[k])]
@@ -1905,7 +1962,7 @@ class DenseStackTrainFunction(Function):
             iw = 1 + nin + (1 if has_tail else 0) + 2 * k
             gw = gb = None
             if sinks[k] is not None:
-                if ctx.needs_input_grad[iw]:
+                if ctx.needs_input_grad[iw] and k not in grouped:
                     sinks[k].uses.append((xk, gk))
                 if ctx.needs_input_grad[iw + 1]:
                     sinks[k].bias_parts.append(parts[k])
