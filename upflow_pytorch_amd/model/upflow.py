@@ -22,6 +22,7 @@ Extra (non-reference) config flags, all defaulting to the reference's behaviour:
                                             16-bit = decoder activations in that type, fp32 master weights, forward /
                                             data-gradient / weight-gradient of the decoder convolutions on the MFMA kernels
 """
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -185,8 +186,8 @@ class network_tools():
         occ_weight = occ_mask
         if photo_loss_type == 'abs_robust':
             # sub / abs / add / pow / mul / sum of the reference as ONE deterministic reduction (csrc/loss.hip)
-            if x.is_cuda and hasattr(ops, 'robust_loss_ratio') and not getattr(cls, '_no_fused_ratio', False):
-                # the reduction AND its denominator in two launches each way (ops.RobustRatioFunction)
+            if x.is_cuda and hasattr(ops, 'robust_loss_ratio') and os.environ.get('UPF_FUSED_RATIO') == '1':
+                # the reduction AND its denominator in two launches each way (ops.RobustRatioFunction) — OPT-IN: see utils/loss.py
                 return ops.robust_loss_ratio(x, y, occ_mask if photo_loss_use_occ else None, q=photo_loss_delta, eps=0.01)
             s, s_occ = ops.robust_loss_sums(x, y, occ_mask if photo_loss_use_occ else None, q=photo_loss_delta, eps=0.01)
             return s / (s_occ + 1e-6) if photo_loss_use_occ else s / float(x.numel())
@@ -347,7 +348,7 @@ class UPFlow_net(tools.abstract_model):
         if c.multi_scale_distillation_weight > 0:
             label_f, label_b = flow_f.detach(), flow_b.detach()
             lv_f, lv_b = [f for f, _ in flows], [b for _, b in flows]
-            if (c.multi_scale_distillation_style == 'upup' and not getattr(self, '_no_fused_msd', False) and hasattr(ops, 'msd_upup_supported')
+            if (c.multi_scale_distillation_style == 'upup' and not getattr(self, '_no_fused_msd', False) and not os.environ.get('UPF_NO_FUSED_MSD') and hasattr(ops, 'msd_upup_supported')
                     and ops.msd_upup_supported(label_f, lv_f) and ops.msd_upup_supported(label_b, lv_b)):
                 # one pass over the label per direction instead of up-sample + robust sum + scalar kernels per level (ops.MsdUpupFunction)
                 use = c.multi_scale_distillation_occ
