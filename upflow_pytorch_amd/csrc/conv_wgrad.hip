@@ -814,17 +814,19 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __
 // order as bias_grad_partial_kernel.  V = elements per access (4: rows of 4k pixels at 8-byte aligned slices, else 1).
 template <typename T> __device__ __forceinline__ float bits_f(unsigned short b) { T t; t.v = b; return Elem<T>::load(&t); }
 template <typename T> __device__ __forceinline__ float round16(float v) { T t; Elem<T>::store(&t, v); return Elem<T>::load(&t); }
-template <typename T, int V>
-__global__ __launch_bounds__(256)
+// NTH threads per (channel, chunk) workgroup: 256, or 1024 where the grid is small and the chunks are long (16 ... 32 channels at 1/2
+// ... 1/4 resolution: 512 workgroups of 256 threads streamed 41 MB in 63 us)
+template <typename T, int V, int NTH = 256>
+__global__ __launch_bounds__(NTH)
 void act_grad_kernel(const T* __restrict__ src, long long sbs, const T* __restrict__ add, long long abs_, const T* __restrict__ y, long long ybs,
                      T* __restrict__ dst, long long dbs, float* __restrict__ part, int B, int HW, float slope) {
-  __shared__ float sh[4];
+  __shared__ float sh[NTH / 64];
   const int co = blockIdx.x, chunk = blockIdx.y;
   const long long total = (long long)B * (HW / V), per = (total + BIAS_NCH - 1) / BIAS_NCH;
   const long long e0 = chunk * per, e1 = min(total, e0 + per);
   const int hwv = HW / V;
   float s = 0.f;
-  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+  for (long long e = e0 + threadIdx.x; e < e1; e += NTH) {
     const long long n = e / hwv;
     const size_t o = (size_t)co * HW + (size_t)(e - n * hwv) * V;
     float v[V];
@@ -863,7 +865,12 @@ void act_grad_kernel(const T* __restrict__ src, long long sbs, const T* __restri
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) part[co * BIAS_NCH + chunk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+#pragma unroll
+    for (int k = 4; k < NTH / 64; k += 4) t += (sh[k] + sh[k + 1]) + (sh[k + 2] + sh[k + 3]);
+    part[co * BIAS_NCH + chunk] = t;
+  }
 }
 
 __global__ void bias_grad_multi_final_kernel(const BiasParts P, int Cout) { bias_finish(P, blockIdx.x * blockDim.x + threadIdx.x, Cout); }
@@ -1162,10 +1169,14 @@ extern "C" int upf_act_grad(const void* src, long long src_batch_stride, const v
                   (!add || aligned_to(add, 8)) && (!y || aligned_to(y, 8));
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(C, wgrad::BIAS_NCH);
+  // few channels, long chunks: 1024 threads per workgroup (see the kernel)
+  const bool wide = v4 && C * wgrad::BIAS_NCH <= 1024 && (long long)B * (HW / 4) / wgrad::BIAS_NCH >= 4096;
 #define UPF_AG(TT, VV) hipLaunchKernelGGL((wgrad::act_grad_kernel<TT, VV>), grid, dim3(256), 0, s, (const TT*)src, sbs, (const TT*)add, abs_, (const TT*)y, ybs, (TT*)dst, dbs, bias_partial, B, HW, slope)
-  if (dtype == UPF_BF16) { if (v4) UPF_AG(bf16_t, 4); else UPF_AG(bf16_t, 1); }
-  else { if (v4) UPF_AG(f16_t, 4); else UPF_AG(f16_t, 1); }
+#define UPF_AGW(TT) hipLaunchKernelGGL((wgrad::act_grad_kernel<TT, 4, 1024>), grid, dim3(1024), 0, s, (const TT*)src, sbs, (const TT*)add, abs_, (const TT*)y, ybs, (TT*)dst, dbs, bias_partial, B, HW, slope)
+  if (dtype == UPF_BF16) { if (wide) UPF_AGW(bf16_t); else if (v4) UPF_AG(bf16_t, 4); else UPF_AG(bf16_t, 1); }
+  else { if (wide) UPF_AGW(f16_t); else if (v4) UPF_AG(f16_t, 4); else UPF_AG(f16_t, 1); }
 #undef UPF_AG
+#undef UPF_AGW
   return check_launch("act_grad");
 }
 
