@@ -205,6 +205,41 @@ def _dense_stack(ch_in, dev):
     return m
 
 
+# (B, Cin, Cout, H, W): one 16-channel chunk (wide epilogue), two / four / one channel blocks per workgroup, 16-row tiles,
+# split-K, ragged rows (even and odd widths) in the tiled and the split-K kernel, input and outputs as odd channel slices
+GATED = [(2, 2, 32, 16, 64), (2, 34, 64, 16, 32), (8, 66, 96, 64, 160), (1, 40, 32, 24, 64), (4, 40, 32, 128, 256), (1, 290, 128, 64, 64),
+         (2, 130, 96, 16, 52), (2, 226, 64, 8, 13), (2, 20, 32, 12, 26), (2, 450, 128, 4, 13), (1, 7, 3, 9, 40)]
+
+
+@pytest.mark.parametrize('case', GATED)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_gated_convolution_equals_convolution_then_act_grad(case, dtype):
+    """upf_conv_forward_gated (the mask / residual arithmetic of upf_act_grad in the convolution's epilogue) is BIT-identical to
+    upf_conv_forward followed by upf_act_grad in place, for every kernel variant the data-gradient convolutions take — with and
+    without the addend, and with every operand a channel slice of a wider buffer."""
+    from upflow_pytorch_amd import ops
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(B, Cin + 3, H, W).to(dtype).cuda()[:, 1:1 + Cin]
+    w = (rnd(Cout, Cin, 3, 3) / (3.0 * Cin ** 0.5)).to(dtype).cuda()
+    packed = ops.conv3x3_pack(w)
+    bias = (rnd(Cout) * 0.1).cuda()
+    act = rnd(B, Cout + 2, H, W).to(dtype).cuda()[:, 2:]
+    act[:, :, ::3, ::5] = 0                                              # exact zeros take the slope
+    add = rnd(B, Cout + 4, H, W).to(dtype).cuda()[:, 3:3 + Cout]
+    for use_add in (False, True):
+        a = add if use_add else None
+        two = torch.full((B, Cout + 2, H, W), 7.0, dtype=dtype, device='cuda')
+        ops.conv3x3_forward_raw(x, packed, bias, two[:, 1:1 + Cout], 1, 0.0, 1, 3)
+        ops.act_grad(two[:, 1:1 + Cout], act, 0.1, add=a, dst=two[:, 1:1 + Cout])
+        one = torch.full((B, Cout + 2, H, W), 7.0, dtype=dtype, device='cuda')
+        ops.conv3x3_forward_gated_raw(x, packed, bias, one[:, 1:1 + Cout], a, act, 0.1)
+        assert torch.equal(one, two), (case, use_add, float((one.float() - two.float()).abs().max()))
+    with pytest.raises(ops.UpflowHipError):
+        ops.conv3x3_forward_gated_raw(x, packed, bias, one[:, 1:1 + Cout], None, act[:, :, :, :W - 1], 0.1)
+
+
 @pytest.mark.parametrize('geom', [(2, 16, 24), (2, 8, 26), (1, 4, 13), (2, 32, 104)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_dense_stack_in_buffer_matches_layerwise_autograd(geom, dtype):
@@ -258,6 +293,18 @@ def test_dense_stack_in_buffer_matches_layerwise_autograd(geom, dtype):
         assert rel(a, r) <= 1.1 * rel(b, r) + 1e-4, (i, rel(a, r), rel(b, r))
     again = torch.autograd.grad(m.forward_train([c, A, flow], flow_tail=flow), [c, A, flow] + params, (g_buf, g_out))
     assert all(torch.equal(a, b) for a, b in zip(grads, again))
+    # the schedule with the separate mask / residual passes (round 4): the same data and weight gradients bit for bit; the bias
+    # gradients are the same sums in another order
+    ops.DenseStackTrainFunction.no_gated_dgrad = True
+    try:
+        sep = torch.autograd.grad(m.forward_train([c, A, flow], flow_tail=flow), [c, A, flow] + params, (g_buf, g_out))
+    finally:
+        ops.DenseStackTrainFunction.no_gated_dgrad = False
+    for i, (a, b) in enumerate(zip(grads, sep)):
+        if i >= 3 and a.dim() == 1:
+            assert (a - b).abs().max() <= 1e-4 * max(1.0, float(b.abs().max())), i
+        else:
+            assert torch.equal(a, b), i
 
 
 def test_shared_conv_grads_defers_to_one_contraction():

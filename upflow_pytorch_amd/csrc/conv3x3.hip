@@ -116,11 +116,12 @@ __global__ void pack_weights_f32_multi_kernel(PackJobs J) {
 // every wave stages its own chunk into a private LDS region — no workgroup barrier in the loop — and the four
 // partial accumulators are summed through LDS at the end in a fixed order (deterministic).  4x the workgroups,
 // a quarter of the chain each.
-template <typename T, int NOCTS, int D, bool GEN, typename TO = T>
+template <typename T, int NOCTS, int D, bool GEN, typename TO = T, typename G = NoGate>
 __global__ __launch_bounds__(NTHREADS, 2)
 void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
                     TO* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, float slope,
-                    int xpitch, int ypitch) {
+                    int xpitch, int ypitch, const G gate) {
+  static_assert(!G::on || sizeof(TO) == sizeof(T), "gated epilogue: operands of one type");
   constexpr int ntaps = (D == 0) ? 1 : 9;
   constexpr int marg = margin_of(D);
   constexpr int KS = NOCTS / 2, KCH = NOCTS * 8;
@@ -261,6 +262,8 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
   const int r = wave >> 1, jbase = 4 * (wave & 1);
   Epilogue ep;
   epilogue_init<TO, true>(ep, y + (size_t)n * ybs, Cout, H, W, slab, lane, x0, ypitch);
+  GateRsrc gr;
+  if constexpr (G::on) gr = gate_init<T>(gate, n, (uint32_t)Cout * ep.plane2);
   if (y0 + r < H) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -271,7 +274,7 @@ void conv_sk_kernel(const T* __restrict__ x, long long xbs, const T* __restrict_
         v0 += part[((w * 2 + r) * 16 + e0) * 64 + lane];
         v1 += part[((w * 2 + r) * 16 + e1) * 64 + lane];
       }
-      epilogue_store<TO, true>(ep, v0, v1, epilogue_choff(jbase + jj) * ep.plane2 + (uint32_t)((y0 + r) * ypitch) * 2u, slope);
+      epilogue_store<TO, true, G::on>(ep, v0, v1, epilogue_choff(jbase + jj) * ep.plane2 + (uint32_t)((y0 + r) * ypitch) * 2u, slope, &gr);
     }
   }
 }
@@ -306,11 +309,25 @@ int launch_sk_one(const Args& a) {
   constexpr int rows = 2 + 2 * D;
   size_t lds = (size_t)4 * NOCTS * rows * (xw(1, margin_of(D)) + xw(1, margin_of(D)) / 16) * 16;
   if (lds < 4 * 2 * 16 * 64 * 4) lds = 4 * 2 * 16 * 64 * 4;       // the partial-sum exchange reuses the region
+  if (a.gate_y) {
+    if constexpr (D == 1) {
+      static LdsOptIn gopt;
+      auto gkern = &conv_sk_kernel<T, NOCTS, D, GEN, T, ActGate<T>>;
+      gopt.ensure(reinterpret_cast<const void*>(gkern), lds);
+      const ActGate<T> gate{(const T*)a.gate_add, a.gate_abs, (const T*)a.gate_y, a.gate_ybs, a.gate_slope};
+      hipLaunchKernelGGL(gkern, dim3((unsigned)(a.B * tiles_x * tiles_y), cdiv(a.Cout, 32)), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                         (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, a.ypitch, gate);
+      return check_launch("conv_forward_gated");
+    } else {
+      set_error("conv_forward_gated: 3x3, stride 1, dilation 1 only");
+      return UPF_EUNSUPPORTED;
+    }
+  }
   static LdsOptIn opt;
   auto kern = &conv_sk_kernel<T, NOCTS, D, GEN>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), cdiv(a.Cout, 32)), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
-                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, a.ypitch);
+                     (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, a.ypitch, NoGate{});
   return check_launch("conv_forward");
 }
 
@@ -483,7 +500,7 @@ int launch_1x1_mixed(const Args& a) {                  // the ntaps == 1, Cout <
     auto kern = &conv_sk_kernel<T, 4, 0, GEN, TO>;
     opt.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), 1), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
-                       (const T*)a.wp, a.bias, (TO*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, a.ypitch);
+                       (const T*)a.wp, a.bias, (TO*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, a.ypitch, NoGate{});
     return check_launch("conv1x1_forward_mixed");
   }
   constexpr int TH = 4 * 2;
@@ -564,6 +581,33 @@ extern "C" int upf_conv_forward_pitched(const void* x, long long x_batch_stride,
   conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W,
                kernel_size == 1 ? 0 : dilation, stride, kernel_size * kernel_size, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream,
                x_row_pitch, y_row_pitch};
+  if (dtype == UPF_BF16) return gen ? conv::launch<bf16_t, true>(a) : conv::launch<bf16_t, false>(a);
+  return gen ? conv::launch<f16_t, true>(a) : conv::launch<f16_t, false>(a);
+}
+
+// The 3x3 stride-1 convolution with the gated epilogue (conv_kernel.hpp ActGate): y = ((conv(x) rounded to 16 bits) + add, rounded)
+// x (act > 0 ? 1 : mask_slope).  add (optional) and act are [B,Cout,H,W] channel slices with y's row pitch.  Replaces, for the
+// data-gradient convolutions of the dense stacks, the separate pass of upf_act_grad (whose bias partial sums are then taken by
+// ONE pass over the whole stack's gradients).
+extern "C" int upf_conv_forward_gated(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
+                                      void* y, long long y_batch_stride, int y_row_pitch, const void* add, long long add_batch_stride,
+                                      const void* act, long long act_batch_stride, float mask_slope,
+                                      int B, int Cin, int Cout, int H, int W, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && w_packed && bias && y && act, UPF_EINVAL, "conv_forward_gated: null pointer");
+  UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL,
+              "conv_forward_gated: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_gated: bf16 / fp16 only");
+  if (x_row_pitch == 0) x_row_pitch = W;
+  if (y_row_pitch == 0) y_row_pitch = W;
+  UPF_REQUIRE(x_row_pitch >= W && y_row_pitch >= W, UPF_EINVAL, "conv_forward_gated: row pitch smaller than the row");
+  const bool gen = !(x_row_pitch % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0);
+  UPF_REQUIRE(!gen || W >= 8, UPF_EUNSUPPORTED, "conv_forward_gated: W = %d < 8 with unaligned rows", W);
+  UPF_REQUIRE((long long)Cin * H * x_row_pitch * 2 < (1ll << 31) && (long long)Cout * H * y_row_pitch * 2 < (1ll << 31), UPF_EINVAL,
+              "conv_forward_gated: image too large for one buffer descriptor");
+  UPF_REQUIRE(aligned_to(add, 2) && aligned_to(act, 2) && mask_slope >= 0.f && mask_slope <= 1.f, UPF_EINVAL, "conv_forward_gated: bad gate operands");
+  conv::Args a{x, x_batch_stride, w_packed, bias, y, y_batch_stride, B, Cin, Cout, H, W, 1, 1, 9, 1.f, (hipStream_t)stream, x_row_pitch, y_row_pitch};
+  a.gate_add = add; a.gate_abs = add_batch_stride; a.gate_y = act; a.gate_ybs = act_batch_stride; a.gate_slope = mask_slope;
   if (dtype == UPF_BF16) return gen ? conv::launch<bf16_t, true>(a) : conv::launch<bf16_t, false>(a);
   return gen ? conv::launch<f16_t, true>(a) : conv::launch<f16_t, false>(a);
 }

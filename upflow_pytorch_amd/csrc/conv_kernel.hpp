@@ -117,6 +117,38 @@ __device__ __forceinline__ void stage_store(uint4* tile, int enc, int sh, const 
 // one v_perm): the even lane stores pixels (px, px+1) of the even registers' channels, the odd lane pixels (px-1, px) of
 // the odd registers' — 4-byte stores, half as many.  Stores go through a buffer descriptor over the image's Cout output
 // planes, so channels >= Cout and columns >= Wo are dropped by the bounds check instead of by branches.
+// ---- gated epilogue (round 5; training only).  The data-gradient convolutions of a dense stack were each followed by one pass
+// (upf_act_grad) over their output: + the gradient arriving from outside the stack, x the LeakyReLU mask of the forward
+// activation.  Removing those passes from the captured config-3 step took 1.13 ms off 9.51 (tools/act_grad_cost_probe.py), so the
+// two operands are applied HERE, to the 16-bit values the epilogue is about to store — the same arithmetic on the same rounded
+// values, in the same order, as the pass it replaces (conv_wgrad.hip act_grad_kernel): bit-identical outputs.
+struct NoGate { static constexpr bool on = false; };
+template <typename T> struct ActGate {
+  static constexpr bool on = true;
+  const T* add; long long abs_;        // optional [B,Cout,Ho,Wo] channel slice added first (16-bit sum, rounded)
+  const T* y; long long ybs;           // forward activation output: elements with !(y > 0) are scaled by slope
+  float slope;
+};
+struct GateRsrc { __amdgpu_buffer_rsrc_t ar, mr; float slope; };
+template <typename T, typename G>
+__device__ __forceinline__ GateRsrc gate_init(const G& g, int n, uint32_t bytes) {
+  GateRsrc r;
+  r.ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.add ? g.add + (size_t)n * g.abs_ : g.y), 0, g.add ? bytes : 0u, 0x00020000);
+  r.mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.y + (size_t)n * g.ybs), 0, bytes, 0x00020000);
+  r.slope = g.slope;
+  return r;
+}
+template <typename T> __device__ __forceinline__ float gate_f(uint32_t bits16) { T t; t.v = (unsigned short)bits16; return Elem<T>::load(&t); }
+// v, a, q: two 16-bit elements each (value, addend, forward activation)
+template <typename T>
+__device__ __forceinline__ uint32_t gate2(uint32_t v, uint32_t a, uint32_t q, float slope) {
+  const uint32_t s = pack2<T>(gate_f<T>(v & 0xffffu) + gate_f<T>(a & 0xffffu), gate_f<T>(v >> 16) + gate_f<T>(a >> 16));
+  float f0 = gate_f<T>(s & 0xffffu), f1 = gate_f<T>(s >> 16);
+  if (!(gate_f<T>(q & 0xffffu) > 0.f)) f0 *= slope;
+  if (!(gate_f<T>(q >> 16) > 0.f)) f1 *= slope;
+  return pack2<T>(f0, f1);
+}
+
 struct Epilogue {
   __amdgpu_buffer_rsrc_t yr;
   uint32_t off32, off16;   // this lane's byte offset at (first channel of its pair set, row 0, its pixel pair) or 0x80000000
@@ -137,12 +169,21 @@ __device__ __forceinline__ void epilogue_init(Epilogue& ep, T* y_img, int Cout, 
 }
 // v0, v1: channels c and c+1 of this lane's pixel (registers e = 2j, 2j+1); soff: uniform byte offset of
 // (channel offset of register 2j, output row) = ({0,2,8,10,16,18,24,26}[j] * Ho*Wo + gy*Wo) * 2
-template <typename T, bool GEN>
-__device__ __forceinline__ void epilogue_store(const Epilogue& ep, float v0, float v1, uint32_t soff, float slope) {
+template <typename T, bool GEN, bool GATED = false>
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, float v0, float v1, uint32_t soff, float slope, const GateRsrc* g = nullptr) {
   v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);                  // slope = 1 -> identity
   const uint32_t p = pack2<T>(v0, v1);                                     // lo = channel c, hi = channel c+1 of pixel px
   const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-  const uint32_t out = __builtin_amdgcn_perm(recv, p, ep.sel);
+  uint32_t out = __builtin_amdgcn_perm(recv, p, ep.sel);
+  if constexpr (GATED) {
+    // (one of the two offsets is the out-of-range marker and reads 0)
+    uint32_t a = __builtin_amdgcn_raw_buffer_load_b32(g->ar, ep.off32 + soff, 0, 0), q = __builtin_amdgcn_raw_buffer_load_b32(g->mr, ep.off32 + soff, 0, 0);
+    if constexpr (GEN) {
+      a |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(g->ar, ep.off16 + soff, 0, 0);
+      q |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(g->mr, ep.off16 + soff, 0, 0);
+    }
+    out = gate2<T>(out, a, q, g->slope);
+  }
   __builtin_amdgcn_raw_buffer_store_b32(out, ep.yr, ep.off32 + soff, 0, 0);
   if constexpr (GEN) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)out, ep.yr, ep.off16 + soff, 0, 0);
 }
@@ -154,9 +195,9 @@ __device__ __forceinline__ uint32_t epilogue_choff(int j) { return (uint32_t)((2
 // (8 pixels) per lane: 4x fewer store instructions, each covering whole 64-byte row segments.
 constexpr int EPI_PITCH = 80;                                  // bytes per (row, channel) in the patch
 constexpr int EPI_WAVE_BYTES = 2 * 32 * EPI_PITCH;             // two tile rows of one wave
-template <typename T, int RPW>
+template <typename T, int RPW, bool GATED = false>
 __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned char* patch, T* y_img, int Cout, int Ho, int Wo,
-                                              int slab, int lane, int x0, int gy0, int row_step, float slope, int ypitch) {
+                                              int slab, int lane, int x0, int gy0, int row_step, float slope, int ypitch, const GateRsrc* g = nullptr) {
   // (pitched rows: an 8-pixel segment that starts inside the logical row is stored whole — its tail lands in the row's own
   // pitch padding, which no consumer depends on)
   const int px = lane & 31, kg = lane >> 5;
@@ -193,8 +234,16 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
       const int gy = gy0 + (rb + rr) * row_step;               // uniform
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(rbase + (rr * 32 + h * 16) * EPI_PITCH);
-        if (gy < Ho) __builtin_amdgcn_raw_buffer_store_b128(v, yr, goff + (uint32_t)(h * 16) * plane2 + (uint32_t)(gy * ypitch) * 2u, 0, 0);
+        u32x4 v = *reinterpret_cast<const u32x4*>(rbase + (rr * 32 + h * 16) * EPI_PITCH);
+        const uint32_t off = goff + (uint32_t)(h * 16) * plane2 + (uint32_t)(gy * ypitch) * 2u;
+        if constexpr (GATED) {
+          if (gy < Ho) {
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(g->ar, off, 0, 0), q = __builtin_amdgcn_raw_buffer_load_b128(g->mr, off, 0, 0);
+            v.x = gate2<T>(v.x, a.x, q.x, g->slope); v.y = gate2<T>(v.y, a.y, q.y, g->slope);
+            v.z = gate2<T>(v.z, a.z, q.z, g->slope); v.w = gate2<T>(v.w, a.w, q.w, g->slope);
+          }
+        }
+        if (gy < Ho) __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
       }
     }
   }
@@ -244,11 +293,12 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
 // staging alone 45 us, together 73 us).  blockIdx.y = the 16-channel block; weights packed by pack_weights_kmap16_kernel.
 // TO (round 5): storage type of y when it differs from the operands' (the `pyramid_dtype` option: fp16 features and weights, bf16
 // decoder buffers — the 1x1 projection of the pyramid features multiplies in fp16 and rounds its fp32 sums ONCE, to bf16).
-template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false, bool N16 = false, typename TO = T>
-__global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
-void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
-                 TO* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
-                 int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, int xpitch, int ypitch) {
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE, int XL, bool YC8, bool N16, typename TO, typename G>
+__device__ __forceinline__
+void conv_body(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
+               TO* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
+               int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, int xpitch, int ypitch, const G gate) {
+  static_assert(!G::on || (XL == 0 && !YC8 && !N16 && sizeof(TO) == sizeof(T)), "gated epilogue: NCHW operands of one type");
   // xpitch / ypitch (round 5): elements between consecutive rows of the NCHW operands x / y (plane stride = rows * pitch).  The
   // LOGICAL width stays W / Wo: with a pitch that is a multiple of 8 every row is 16-byte aligned whatever W is, so ragged
   // pyramid levels (KITTI's native 375x1242: W = 621, 311, 156, 78, 39, 20) take the aligned staging (!GEN) and the 16-byte
@@ -613,23 +663,50 @@ void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ w
     // uniform: 16-byte stores through a per-wave LDS patch when the OUTPUT rows are 16-byte aligned (pitch, base, batch stride)
     if (((ypitch & 7) | (int)(ybs & 7) | (int)(reinterpret_cast<uintptr_t>(y) & 15)) == 0) {
       __syncthreads();                               // every wave is done with the x tile
-      epilogue_wide<TO, RPW>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
-                            slab, lane, x0, gy0, RS, slope, ypitch);
+      if constexpr (G::on) {
+        const GateRsrc gr = gate_init<T>(gate, n, (uint32_t)Cout * (uint32_t)(Ho * ypitch) * 2u);
+        epilogue_wide<TO, RPW, true>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
+                                    slab, lane, x0, gy0, RS, slope, ypitch, &gr);
+      } else {
+        epilogue_wide<TO, RPW>(acc, reinterpret_cast<unsigned char*>(xs) + wave * EPI_WAVE_BYTES, y + (size_t)n * ybs, Cout, Ho, Wo,
+                              slab, lane, x0, gy0, RS, slope, ypitch);
+      }
       return;
     }
   }
   // (always the general form: an aligned input says nothing about the output's width — a pitched x with an un-pitched odd-width y)
   Epilogue ep;
   epilogue_init<TO, true>(ep, y + (size_t)n * ybs, Cout, Ho, Wo, slab, lane, x0, ypitch);
+  GateRsrc gr;
+  if constexpr (G::on) gr = gate_init<T>(gate, n, (uint32_t)Cout * ep.plane2);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     if (gy0 + r * RS < Ho) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        epilogue_store<TO, true>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * ypitch) * 2u, slope);
+        epilogue_store<TO, true, G::on>(ep, acc[r][2 * j], acc[r][2 * j + 1], epilogue_choff(j) * ep.plane2 + (uint32_t)((gy0 + r * RS) * ypitch) * 2u, slope, &gr);
     }
   }
   }  // !N16
+}
+
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false, int XL = 0, bool YC8 = false, bool N16 = false, typename TO = T>
+__global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
+void conv_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
+                 TO* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
+                 int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, int xpitch, int ypitch) {
+  conv_body<T, MTW, RPW, S, NOCTS, D, GEN, ONE, XL, YC8, N16, TO, NoGate>(x, xbs, wp, bias, y, ybs, Cin, Cout, H, W, Ho, Wo, d_rt, tiles_x, tiles_y, slope,
+                                                                          x8, x8bs, n8oct, xpitch, ypitch, NoGate{});
+}
+
+// the same kernel with the gated epilogue (NCHW operands: the data-gradient convolutions of the dense stacks)
+template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false>
+__global__ __launch_bounds__(NTHREADS, (ONE && (MTW == 1 || (MTW == 2 && S == 1))) ? 4 : 2)
+void conv_gated_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias,
+                       T* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
+                       int tiles_x, int tiles_y, float slope, int xpitch, int ypitch, const ActGate<T> gate) {
+  conv_body<T, MTW, RPW, S, NOCTS, D, GEN, ONE, 0, false, false, T, ActGate<T>>(x, xbs, wp, bias, y, ybs, Cin, Cout, H, W, Ho, Wo, d_rt, tiles_x, tiles_y, slope,
+                                                                                nullptr, 0ll, 0, xpitch, ypitch, gate);
 }
 
 // launch heuristics and experiment switches (upf_conv_set_option)
@@ -639,6 +716,8 @@ struct Args {
   const void* x; long long xbs; const void* wp; const float* bias; void* y; long long ybs;
   int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
   int xpitch, ypitch;                                // elements between rows of x / y (>= W / Wo)
+  // gated epilogue (gate_y != nullptr; 3x3, stride 1, dilation 1 only): see ActGate
+  const void* gate_add = nullptr; long long gate_abs = 0; const void* gate_y = nullptr; long long gate_ybs = 0; float gate_slope = 0.f;
 };
 
 template <typename T, int MTW, int RPW, int S, int NOCTS, int D, bool GEN, bool ONE = false>
@@ -651,6 +730,21 @@ int launch_one(const Args& a, int slabs) {
   size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + xw(S, margin_of(D)) / 16) * 16;
   if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;        // the wide epilogue's patches reuse the region
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
+  if (a.gate_y) {
+    if constexpr (S == 1 && D == 1) {
+      static LdsOptIn gopt;
+      auto gkern = &conv_gated_kernel<T, MTW, RPW, S, NOCTS, D, GEN, ONE>;
+      gopt.ensure(reinterpret_cast<const void*>(gkern), lds);
+      const ActGate<T> gate{(const T*)a.gate_add, a.gate_abs, (const T*)a.gate_y, a.gate_ybs, a.gate_slope};
+      hipLaunchKernelGGL(gkern, dim3((unsigned)(a.B * tiles_x * tiles_y), slabs), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                         (const T*)a.wp, a.bias, (T*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, Ho, Wo, g_ablate, tiles_x, tiles_y, a.slope,
+                         a.xpitch, a.ypitch, gate);
+      return check_launch("conv_forward_gated");
+    } else {
+      set_error("conv_forward_gated: 3x3, stride 1, dilation 1 only");
+      return UPF_EUNSUPPORTED;
+    }
+  }
   static LdsOptIn opt;
   auto kern = &conv_kernel<T, MTW, RPW, S, NOCTS, D, GEN, ONE>;
   opt.ensure(reinterpret_cast<const void*>(kern), lds);

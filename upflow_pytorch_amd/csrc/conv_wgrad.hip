@@ -1170,7 +1170,7 @@ extern "C" int upf_act_grad(const void* src, long long src_batch_stride, const v
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(C, wgrad::BIAS_NCH);
   // few channels, long chunks: 1024 threads per workgroup (see the kernel)
-  const bool wide = v4 && C * wgrad::BIAS_NCH <= 1024 && (long long)B * (HW / 4) / wgrad::BIAS_NCH >= 4096;
+  const bool wide = v4 && C * wgrad::BIAS_NCH <= 1024 && (long long)B * (HW / 4) / wgrad::BIAS_NCH >= 2048;
 #define UPF_AG(TT, VV) hipLaunchKernelGGL((wgrad::act_grad_kernel<TT, VV>), grid, dim3(256), 0, s, (const TT*)src, sbs, (const TT*)add, abs_, (const TT*)y, ybs, (TT*)dst, dbs, bias_partial, B, HW, slope)
 #define UPF_AGW(TT) hipLaunchKernelGGL((wgrad::act_grad_kernel<TT, 4, 1024>), grid, dim3(1024), 0, s, (const TT*)src, sbs, (const TT*)add, abs_, (const TT*)y, ybs, (TT*)dst, dbs, bias_partial, B, HW, slope)
   if (dtype == UPF_BF16) { if (wide) UPF_AGW(bf16_t); else if (v4) UPF_AG(bf16_t, 4); else UPF_AG(bf16_t, 1); }
