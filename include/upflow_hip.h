@@ -403,7 +403,8 @@ int upf_act_grad(const void* src, long long src_batch_stride, const void* add, l
                  float slope, int dtype, void* stream);
 /* The 3x3 stride-1 convolution with upf_act_grad's arithmetic in its epilogue (round 5): y = (round16(round16(conv(x)) + add))
  * * (act > 0 ? 1 : mask_slope), bit-identical to upf_conv_forward_pitched (bias as given, no activation) followed by
- * upf_act_grad(src = dst = y, add, y := act, mask_slope).  add (optional) and act: [B,Cout,H,W] channel slices with y's row pitch.
+ * upf_act_grad(src = dst = y, add, y := act, mask_slope).  add and act (either may be NULL, not both): [B,Cout,H,W] channel slices
+ * with y's row pitch.
  * The data-gradient convolutions of the dense stacks (reference: autograd through model/pwc_modules.py's estimator / context
  * stacks); their bias sums are then ONE upf_act_grad(dst = NULL) pass over the stack's whole gradient buffer. */
 int upf_conv_forward_gated(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,

@@ -236,8 +236,14 @@ def test_gated_convolution_equals_convolution_then_act_grad(case, dtype):
         one = torch.full((B, Cout + 2, H, W), 7.0, dtype=dtype, device='cuda')
         ops.conv3x3_forward_gated_raw(x, packed, bias, one[:, 1:1 + Cout], a, act, 0.1)
         assert torch.equal(one, two), (case, use_add, float((one.float() - two.float()).abs().max()))
+    # the addend alone (no mask) = the 16-bit tensor add
+    ops.conv3x3_forward_raw(x, packed, bias, two[:, 1:1 + Cout], 1, 0.0, 1, 3)
+    ops.conv3x3_forward_gated_raw(x, packed, bias, one[:, 1:1 + Cout], add, None, 0.1)
+    assert torch.equal(one[:, 1:1 + Cout], two[:, 1:1 + Cout] + add)
     with pytest.raises(ops.UpflowHipError):
         ops.conv3x3_forward_gated_raw(x, packed, bias, one[:, 1:1 + Cout], None, act[:, :, :, :W - 1], 0.1)
+    with pytest.raises(ops.UpflowHipError):
+        ops.conv3x3_forward_gated_raw(x, packed, bias, one[:, 1:1 + Cout], None, None, 0.1)
 
 
 @pytest.mark.parametrize('geom', [(2, 16, 24), (2, 8, 26), (1, 4, 13), (2, 32, 104)])

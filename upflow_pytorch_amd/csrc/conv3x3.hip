@@ -309,7 +309,7 @@ int launch_sk_one(const Args& a) {
   constexpr int rows = 2 + 2 * D;
   size_t lds = (size_t)4 * NOCTS * rows * (xw(1, margin_of(D)) + xw(1, margin_of(D)) / 16) * 16;
   if (lds < 4 * 2 * 16 * 64 * 4) lds = 4 * 2 * 16 * 64 * 4;       // the partial-sum exchange reuses the region
-  if (a.gate_y) {
+  if (a.gate_y || a.gate_add) {
     if constexpr (D == 1) {
       static LdsOptIn gopt;
       auto gkern = &conv_sk_kernel<T, NOCTS, D, GEN, T, ActGate<T>>;
@@ -594,7 +594,8 @@ extern "C" int upf_conv_forward_gated(const void* x, long long x_batch_stride, i
                                       const void* act, long long act_batch_stride, float mask_slope,
                                       int B, int Cin, int Cout, int H, int W, int dtype, void* stream) {
   using namespace upf;
-  UPF_REQUIRE(x && w_packed && bias && y && act, UPF_EINVAL, "conv_forward_gated: null pointer");
+  UPF_REQUIRE(x && w_packed && bias && y && (act || add), UPF_EINVAL, "conv_forward_gated: null pointer");
+  if (!act) mask_slope = 1.f;                        // no mask: every element takes the "slope" 1
   UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, UPF_EINVAL,
               "conv_forward_gated: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
   UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_gated: bf16 / fp16 only");

@@ -126,15 +126,16 @@ struct NoGate { static constexpr bool on = false; };
 template <typename T> struct ActGate {
   static constexpr bool on = true;
   const T* add; long long abs_;        // optional [B,Cout,Ho,Wo] channel slice added first (16-bit sum, rounded)
-  const T* y; long long ybs;           // forward activation output: elements with !(y > 0) are scaled by slope
+  const T* y; long long ybs;           // optional forward activation output: elements with !(y > 0) are scaled by slope
   float slope;
 };
 struct GateRsrc { __amdgpu_buffer_rsrc_t ar, mr; float slope; };
 template <typename T, typename G>
 __device__ __forceinline__ GateRsrc gate_init(const G& g, int n, uint32_t bytes) {
   GateRsrc r;
+  // (an absent operand: a descriptor of zero bytes — every load returns 0; without y the host passes slope 1)
   r.ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.add ? g.add + (size_t)n * g.abs_ : g.y), 0, g.add ? bytes : 0u, 0x00020000);
-  r.mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.y + (size_t)n * g.ybs), 0, bytes, 0x00020000);
+  r.mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.y ? g.y + (size_t)n * g.ybs : g.add), 0, g.y ? bytes : 0u, 0x00020000);
   r.slope = g.slope;
   return r;
 }
@@ -716,7 +717,7 @@ struct Args {
   const void* x; long long xbs; const void* wp; const float* bias; void* y; long long ybs;
   int B, Cin, Cout, H, W, d, stride, ntaps; float slope; hipStream_t stream;
   int xpitch, ypitch;                                // elements between rows of x / y (>= W / Wo)
-  // gated epilogue (gate_y != nullptr; 3x3, stride 1, dilation 1 only): see ActGate
+  // gated epilogue (gate_add or gate_y != nullptr; 3x3, stride 1, dilation 1 only): see ActGate
   const void* gate_add = nullptr; long long gate_abs = 0; const void* gate_y = nullptr; long long gate_ybs = 0; float gate_slope = 0.f;
 };
 
@@ -730,7 +731,7 @@ int launch_one(const Args& a, int slabs) {
   size_t lds = (size_t)NOCTS * rows * (xw(S, margin_of(D)) + xw(S, margin_of(D)) / 16) * 16;
   if (lds < 4 * EPI_WAVE_BYTES) lds = 4 * EPI_WAVE_BYTES;        // the wide epilogue's patches reuse the region
   UPF_REQUIRE(lds <= 160 * 1024, UPF_EUNSUPPORTED, "conv_forward: tile does not fit LDS (dilation %d, stride %d)", a.d, S);
-  if (a.gate_y) {
+  if (a.gate_y || a.gate_add) {
     if constexpr (S == 1 && D == 1) {
       static LdsOptIn gopt;
       auto gkern = &conv_gated_kernel<T, MTW, RPW, S, NOCTS, D, GEN, ONE>;

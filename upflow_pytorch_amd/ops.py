@@ -744,23 +744,25 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
 def conv3x3_forward_gated_raw(x_view, packed, bias32, y_view, add, act, mask_slope):
     """3x3 stride-1 convolution whose epilogue is `act_grad`'s arithmetic (upf_conv_forward_gated): y = round16(round16(conv) + add)
     * (act > 0 ? 1 : mask_slope) — bit-identical to conv3x3_forward_raw followed by act_grad(y, act, mask_slope, add, dst=y).
-    add (or None), act: [B,Cout,H,W] channel slices of y's dtype and row pitch."""
+    add, act (either may be None): [B,Cout,H,W] channel slices of y's dtype and row pitch."""
     B, Cin, H, W = x_view.shape
     Cout = y_view.shape[1]
     if tuple(y_view.shape) != (B, Cout, H, W):
         raise UpflowHipError('conv (gated): output must be [%d,%d,%d,%d], got %s' % (B, Cout, H, W, tuple(y_view.shape)))
     xp, yp = _pitch_or_raise(x_view, 'conv (gated): x'), _pitch_or_raise(y_view, 'conv (gated): y')
+    if add is None and act is None:
+        raise UpflowHipError('conv (gated): neither add nor act given')
     for t, name in ((add, 'add'), (act, 'act')):
-        if t is None and name == 'add':
+        if t is None:
             continue
-        if t is None or tuple(t.shape) != (B, Cout, H, W) or t.dtype != y_view.dtype or _pitch_or_raise(t, 'conv (gated): ' + name) != yp:
+        if tuple(t.shape) != (B, Cout, H, W) or t.dtype != y_view.dtype or _pitch_or_raise(t, 'conv (gated): ' + name) != yp:
             raise UpflowHipError('conv (gated): %s must be a [%d,%d,%d,%d] channel slice of the output\'s dtype and row pitch' % (name, B, Cout, H, W))
     if x_view.dtype not in (torch.bfloat16, torch.float16) or y_view.dtype != x_view.dtype or not x_view.is_cuda:
         raise UpflowHipError('conv (gated): 16-bit GPU operands of one type expected (there is no CPU fallback)')
     dev = x_view.device
     with torch.cuda.device(dev):
         _lib.call('upf_conv_forward_gated', _lib.ptr(x_view), x_view.stride(0), xp, _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y_view),
-                  y_view.stride(0), yp, _lib.ptr(add), (add.stride(0) if add is not None else 0), _lib.ptr(act), act.stride(0),
+                  y_view.stride(0), yp, _lib.ptr(add), (add.stride(0) if add is not None else 0), _lib.ptr(act), (act.stride(0) if act is not None else 0),
                   float(mask_slope), B, Cin, Cout, H, W, _lib.dtype_code(x_view), _lib.stream_ptr(dev))
     return y_view
 
@@ -1957,12 +1959,17 @@ class DenseStackTrainFunction(Function):
             x0 = nt - ch_in
             packed = _stacked_dgrad_pack([masters[j] for j in order], lo, [hi_of[j] for j in order], x0, ch_in, dt)
             gx = torch.empty((B, ch_in, H, W), dtype=dt, device=dev)
-            conv3x3_forward_raw(P, packed, zero, gx, 1, 0.0, 1, 3)
+            summed = gated and g_buf is not None     # the 16-bit tensor add below, in the convolution's epilogue
+            if summed:
+                conv3x3_forward_gated_raw(P, packed, zero, gx, g_buf[:, x0:x0 + ch_in], None, 1.0)
+            else:
+                conv3x3_forward_raw(P, packed, zero, gx, 1, 0.0, 1, 3)
             o = 0
             for i in range(nin):
                 if ctx.needs_input_grad[1 + i]:
                     gi = gx[:, o:o + cin[i]]
-                    gi = (gi + g_buf[:, x0 + o:x0 + o + cin[i]]) if g_buf is not None else gi.contiguous()
+                    if not summed:                   # (summed: the channel slice itself — the consumers take slices)
+                        gi = (gi + g_buf[:, x0 + o:x0 + o + cin[i]]) if g_buf is not None else gi.contiguous()
                     grads_in[i] = gi.to(in_dtypes[i])
                 o += cin[i]
         if has_tail and ctx.needs_input_grad[1 + nin]:
