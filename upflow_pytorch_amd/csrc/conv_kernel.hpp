@@ -216,6 +216,20 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
 #pragma unroll
   for (int rb = 0; rb < RPW; rb += 2) {
     const int nrr = (rb + 2 <= RPW) ? 2 : 1;         // (compile-time after unrolling: an odd RPW ends on a single row)
+    // gate operands of this row pair: issued before the transposition so that they arrive under it (rows >= Ho read the next
+    // plane or zeros and are not stored)
+    u32x4 ga[2][2], gq[2][2];
+    if constexpr (GATED) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (rr >= nrr) continue;
+          const uint32_t off = goff + (uint32_t)(h * 16) * plane2 + (uint32_t)((gy0 + (rb + rr) * row_step) * ypitch) * 2u;
+          ga[rr][h] = __builtin_amdgcn_raw_buffer_load_b128(g->ar, off, 0, 0);
+          gq[rr][h] = __builtin_amdgcn_raw_buffer_load_b128(g->mr, off, 0, 0);
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -238,11 +252,9 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[RPW], unsigned
         u32x4 v = *reinterpret_cast<const u32x4*>(rbase + (rr * 32 + h * 16) * EPI_PITCH);
         const uint32_t off = goff + (uint32_t)(h * 16) * plane2 + (uint32_t)(gy * ypitch) * 2u;
         if constexpr (GATED) {
-          if (gy < Ho) {
-            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(g->ar, off, 0, 0), q = __builtin_amdgcn_raw_buffer_load_b128(g->mr, off, 0, 0);
-            v.x = gate2<T>(v.x, a.x, q.x, g->slope); v.y = gate2<T>(v.y, a.y, q.y, g->slope);
-            v.z = gate2<T>(v.z, a.z, q.z, g->slope); v.w = gate2<T>(v.w, a.w, q.w, g->slope);
-          }
+          const u32x4 a = ga[rr][h], q = gq[rr][h];
+          v.x = gate2<T>(v.x, a.x, q.x, g->slope); v.y = gate2<T>(v.y, a.y, q.y, g->slope);
+          v.z = gate2<T>(v.z, a.z, q.z, g->slope); v.w = gate2<T>(v.w, a.w, q.w, g->slope);
         }
         if (gy < Ho) __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
       }
