@@ -361,6 +361,14 @@ int upf_conv_pack_weights_f32(const float* w /* [Cout,Cin,k,k] fp32 */, void* w_
  * fp32 master weights after the optimiser step */
 int upf_conv_pack_weights_f32_multi(const float* const* w, void* const* w_packed, const int* Cin, const int* Cout, const int* kernel_size,
                                     const int* dgrad, int njobs, int dtype, void* stream);
+/* The data-gradient operands of a DENSE STACK in one launch (round 5).  Layers j = 0..nlayers-1 ([Cout_j, Cin_j, 3, 3] fp32 masters,
+ * ordered like the stack's gradient buffer: last layer first) read the buffer channels [first_channel_j, first_channel_j + Cin_j).
+ * Slice t = buffer channels [slice_channel_t, + slice_width_t), read by the first nconsumers_t layers: w_packed[t] (upf_conv_packed_bytes(
+ * sum Cout_j, slice_width_t, 3) bytes) = upf_conv_pack_weights_f32(dgrad = 1) of the concatenation along Cout of
+ * w_j[:, slice_channel_t - first_channel_j : + slice_width_t] — bit-identical, without the concatenation.  nlayers, nslices <= 8. */
+int upf_conv_pack_stacked_dgrad(const float* const* w, const int* Cin, const int* Cout, const int* first_channel, int nlayers,
+                                void* const* w_packed, const int* slice_channel, const int* slice_width, const int* nconsumers,
+                                int nslices, int dtype, void* stream);
 int upf_leaky_backward(const void* grad_y, const void* y, void* grad_pre, long long n, float slope, int dtype, void* stream);
 int upf_conv_wgrad_supported(int Cin, int Cout, int H, int W, int kernel_size, int dilation, int stride, int dtype);
 long long upf_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int kernel_size, int dilation);

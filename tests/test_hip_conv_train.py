@@ -299,6 +299,15 @@ def test_dense_stack_in_buffer_matches_layerwise_autograd(geom, dtype):
         assert rel(a, r) <= 1.1 * rel(b, r) + 1e-4, (i, rel(a, r), rel(b, r))
     again = torch.autograd.grad(m.forward_train([c, A, flow], flow_tail=flow), [c, A, flow] + params, (g_buf, g_out))
     assert all(torch.equal(a, b) for a, b in zip(grads, again))
+    # the data-gradient operands packed one by one (concatenation + pack per slice) instead of in one launch: the same bits
+    ops.DenseStackTrainFunction.no_stack_pack = True
+    ops.train_caches_clear()
+    try:
+        one_by_one = torch.autograd.grad(m.forward_train([c, A, flow], flow_tail=flow), [c, A, flow] + params, (g_buf, g_out))
+    finally:
+        ops.DenseStackTrainFunction.no_stack_pack = False
+        ops.train_caches_clear()
+    assert all(torch.equal(a, b) for a, b in zip(grads, one_by_one))
     # the schedule with the separate mask / residual passes (round 4): the same data and weight gradients bit for bit; the bias
     # gradients are the same sums in another order
     ops.DenseStackTrainFunction.no_gated_dgrad = True
@@ -380,6 +389,32 @@ def test_space_to_depth_and_stride2_gradients(shape, dtype):
     assert (gx.float() - gx_ref).abs().max() <= 2 * eps * max(1.0, float(gx_ref.abs().max()))
     assert gw.shape == w.shape and (gw - gw_ref).abs().max() <= 2e-4 * max(1.0, float(gw_ref.abs().max())), float((gw - gw_ref).abs().max())
     assert (gb - gpre.sum((0, 2, 3))).abs().max() <= 1e-4 * max(1.0, float(gpre.sum((0, 2, 3)).abs().max()))
+
+
+def test_stacked_dgrad_pack_equals_concatenate_then_pack():
+    """upf_conv_pack_stacked_dgrad (every data-gradient operand of a dense stack in one launch, the concatenation as an index
+    computation) writes bit for bit what torch.cat + upf_conv_pack_weights_f32(dgrad = 1) wrote per slice."""
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(5)
+    cin0, f = 21, [40, 33, 24, 16, 8]
+    nt = cin0 + sum(f)
+    lo = [sum(f[k + 1:]) for k in range(5)]
+    hi = {k: lo[k] + f[k] for k in range(5)}
+    hi[5] = 0
+    w = {k: torch.randn(f[k], nt - hi[k], 3, 3, generator=g).cuda() for k in range(5)}
+    w[5] = torch.randn(3, nt, 3, 3, generator=g).cuda()
+    order = [5, 4, 3, 2, 1, 0]
+    for dtype in (torch.bfloat16, torch.float16):
+        slices = [(lo[k], f[k], pos) for pos, k in enumerate(order[1:], start=1)] + [(nt - cin0, cin0, 6)]
+        got = ops._stack_dgrad_packs([w[j] for j in order], [hi[j] for j in order], slices, dtype)
+        for (c0, width, npos), t in zip(slices, got):
+            want = ops._stacked_dgrad_pack([w[j] for j in order[:npos]], lo, [hi[j] for j in order[:npos]], c0, width, dtype)
+            assert torch.equal(t[:want.numel()], want), (c0, width, npos)
+        assert ops._stack_dgrad_packs([w[j] for j in order], [hi[j] for j in order], slices, dtype) is got      # cached
+    ops.train_caches_clear()
+    with pytest.raises(ops.UpflowHipError):                                     # a slice outside a consumer's input
+        ops._stack_dgrad_packs([w[5], w[4]], [0, hi[4]], [(lo[4], f[4], 2)], torch.bfloat16)
+    ops.train_caches_clear()
 
 
 def test_pack_weights_multi_equals_the_single_packs():

@@ -59,6 +59,7 @@ SIGNATURES = {
     'upf_conv_x3_forward': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_mfma_f16_denorm_probe': [_vp, _vp],
     'upf_conv_pack_weights_f32': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'upf_conv_pack_stacked_dgrad': [_c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _i, _vp],
     'upf_conv_pack_weights_f32_multi': [_c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _i, _vp],
     'upf_conv_pack_weights_kmap': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp],
     'upf_conv_forward_c8': [_vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],

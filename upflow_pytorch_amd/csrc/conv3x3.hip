@@ -110,6 +110,47 @@ __global__ void pack_weights_f32_multi_kernel(PackJobs J) {
   pack_weights_f32_body<T>(J.w[j], (T*)J.wp[j], J.Cin[j], J.Cout[j], J.ntaps[j], J.dgrad[j], blockIdx.x - J.blk0[j], J.blk0[j + 1] - J.blk0[j]);
 }
 
+// The data-gradient operands of a DENSE STACK in one launch (upf_conv_pack_stacked_dgrad; ops.DenseStackTrainFunction).  The
+// gradient of buffer slice k is one convolution of the pre-activation gradients of the layers after k with the rows of their
+// kernels that read slice k, stacked along K: operand k = pack(dgrad of cat_j(w_j[:, col_k - hi_j : + f_k])) for the first
+// npos_k layers of one ordered list (last layer first).  Was a torch.cat and a pack launch per slice (24 launches per step for
+// the two stacks); here the concatenation is an index computation.
+constexpr int STACK_LAYERS = 8, STACK_TARGETS = 8;
+struct StackPack {
+  const float* w[STACK_LAYERS];                      // [Cout_j, Cin_j, 3, 3] fp32 masters, in gradient-buffer order
+  int Cin[STACK_LAYERS], Cout[STACK_LAYERS], hi[STACK_LAYERS];   // hi: first buffer channel layer j reads
+  void* wp[STACK_TARGETS];
+  int col[STACK_TARGETS], f[STACK_TARGETS], npos[STACK_TARGETS];  // buffer channels [col, col + f), consumers = layers [0, npos)
+  unsigned blk0[STACK_TARGETS + 1];
+  int nt;
+};
+template <typename T>
+__global__ void pack_stacked_dgrad_kernel(StackPack J) {
+  int t = 0;
+  while (t + 1 < J.nt && blockIdx.x >= J.blk0[t + 1]) ++t;          // (workgroup-uniform)
+  int K = 0;
+  for (int j = 0; j < J.npos[t]; ++j) K += J.Cout[j];
+  const int f = J.f[t], col = J.col[t];
+  const int cip = pad32(K), cop = pad32(f), nk = cip / 16;
+  const long long total = 9ll * cop * cip;
+  const unsigned nblocks = J.blk0[t + 1] - J.blk0[t];
+  T* wp = (T*)J.wp[t];
+  for (long long i = (blockIdx.x - J.blk0[t]) * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)nblocks * blockDim.x) {
+    const int j8 = (int)(i & 7), px = (int)((i >> 3) & 31), kg = (int)((i >> 8) & 1);
+    const long long b = i >> 9;
+    const int tap = (int)(b % 9), kstep = (int)((b / 9) % nk), slab = (int)(b / (9ll * nk));
+    const int co = slab * 32 + px;
+    int ci = kstep * 16 + kg * 8 + j8;
+    float v = 0.f;
+    if (ci < K && co < f) {
+      int j = 0;
+      while (ci >= J.Cout[j]) { ci -= J.Cout[j]; ++j; }
+      v = J.w[j][((size_t)ci * J.Cin[j] + (col - J.hi[j] + co)) * 9 + (8 - tap)];
+    }
+    Elem<T>::store(wp + i, v);
+  }
+}
+
 // Split-K variant for the COARSE pyramid levels (a handful of pixel tiles on 256 CUs: the kernel above is then a
 // serial chain of Cin/32 chunks, ~1.5 us each, on a few dozen workgroups).  Here a workgroup owns a 2 x 32 pixel
 // tile and 32 output channels, and its four waves split the INPUT-CHANNEL chunks (wave w takes chunks w, w+4, ...):
@@ -483,6 +524,40 @@ extern "C" int upf_conv_pack_weights_f32_multi(const float* const* w, void* cons
     else hipLaunchKernelGGL((conv::pack_weights_f32_multi_kernel<f16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, J);
   }
   return check_launch("conv_pack_weights_f32_multi");
+}
+
+extern "C" int upf_conv_pack_stacked_dgrad(const float* const* w, const int* Cin, const int* Cout, const int* first_channel, int nlayers,
+                                           void* const* w_packed, const int* slice_channel, const int* slice_width, const int* nconsumers,
+                                           int nslices, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(w && Cin && Cout && first_channel && w_packed && slice_channel && slice_width && nconsumers, UPF_EINVAL, "conv_pack_stacked_dgrad: null pointer");
+  UPF_REQUIRE(nlayers > 0 && nlayers <= conv::STACK_LAYERS && nslices > 0 && nslices <= conv::STACK_TARGETS, UPF_EINVAL,
+              "conv_pack_stacked_dgrad: %d layers (<= %d), %d slices (<= %d)", nlayers, conv::STACK_LAYERS, nslices, conv::STACK_TARGETS);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_pack_stacked_dgrad: packs to bf16 / fp16");
+  conv::StackPack J;
+  for (int j = 0; j < nlayers; ++j) {
+    UPF_REQUIRE(w[j] && Cin[j] > 0 && Cout[j] > 0 && first_channel[j] >= 0, UPF_EINVAL, "conv_pack_stacked_dgrad: layer %d: bad arguments", j);
+    J.w[j] = w[j]; J.Cin[j] = Cin[j]; J.Cout[j] = Cout[j]; J.hi[j] = first_channel[j];
+  }
+  unsigned nb = 0;
+  for (int t = 0; t < nslices; ++t) {
+    UPF_REQUIRE(w_packed[t] && slice_width[t] > 0 && nconsumers[t] > 0 && nconsumers[t] <= nlayers, UPF_EINVAL, "conv_pack_stacked_dgrad: slice %d: bad arguments", t);
+    int K = 0;
+    for (int j = 0; j < nconsumers[t]; ++j) {
+      // every consumer reads the whole slice: [slice_channel, + width) inside its input range [first_channel, first_channel + Cin)
+      UPF_REQUIRE(slice_channel[t] >= first_channel[j] && slice_channel[t] + slice_width[t] <= first_channel[j] + Cin[j], UPF_EINVAL,
+                  "conv_pack_stacked_dgrad: slice %d is not inside the input of layer %d", t, j);
+      K += Cout[j];
+    }
+    J.wp[t] = w_packed[t]; J.col[t] = slice_channel[t]; J.f[t] = slice_width[t]; J.npos[t] = nconsumers[t];
+    const long long total = 9ll * conv::pad32(slice_width[t]) * conv::pad32(K);
+    J.blk0[t] = nb;
+    nb += (unsigned)((total + 255) / 256 > 256 ? 256 : (total + 255) / 256);
+  }
+  J.blk0[nslices] = nb; J.nt = nslices;
+  if (dtype == UPF_BF16) hipLaunchKernelGGL((conv::pack_stacked_dgrad_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, J);
+  else hipLaunchKernelGGL((conv::pack_stacked_dgrad_kernel<f16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, J);
+  return check_launch("conv_pack_stacked_dgrad");
 }
 
 // ---- 1x1 convolution whose OUTPUT type differs from its operands' (conv_kernel.hpp: TO) -----------------------------------------

@@ -1850,6 +1850,47 @@ def _stacked_dgrad_pack(masters, lo, hi_of, lo_k, f_k, dtype):
     return packed
 
 
+def _stack_dgrad_packs(masters, hi, slices, dtype):
+    """Every data-gradient operand of a dense stack in ONE launch (upf_conv_pack_stacked_dgrad).  masters: the layers' fp32
+    kernels in gradient-buffer order (last layer first), hi[j] the first buffer channel layer j reads; slices: [(first buffer
+    channel, width, number of consumers = a prefix of masters)].  -> one packed operand per slice, bit-identical to
+    _stacked_dgrad_pack's.  Cached per parameter versions (the same operands serve every pyramid level of a step)."""
+    import ctypes
+    ids = tuple(id(w) for w in masters) + tuple(slices) + (dtype,)
+    key = (tuple(w._version for w in masters), tuple(w.data_ptr() for w in masters))
+    slot = _STACK_PACK_CACHE.get(ids)
+    if slot is not None and slot[0] == key and all(r() is w for r, w in zip(slot[1], masters)):
+        return slot[3]
+    dev = _lib.check_gpu(*masters)
+    nl, ns = len(masters), len(slices)
+    for w in masters:
+        if w.dtype != torch.float32 or not w.is_contiguous() or w.shape[2:] != (3, 3):
+            raise UpflowHipError('dense stack: contiguous fp32 3x3 master kernels expected')
+    sizes = []
+    for (c0, width, npos) in slices:
+        nbytes = _lib.lib().upf_conv_packed_bytes(sum(w.shape[0] for w in masters[:npos]), width, 3)
+        sizes.append((nbytes // 2 + 7) // 8 * 8)
+    pool = torch.empty((sum(sizes),), dtype=dtype, device=masters[0].device)
+    outs, o = [], 0
+    for n in sizes:
+        outs.append(pool[o:o + n])
+        o += n
+    wp = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in masters])
+    ci = (ctypes.c_int * nl)(*[w.shape[1] for w in masters])
+    co = (ctypes.c_int * nl)(*[w.shape[0] for w in masters])
+    hh = (ctypes.c_int * nl)(*[int(h) for h in hi])
+    op = (ctypes.c_void_p * ns)(*[t.data_ptr() for t in outs])
+    sc = (ctypes.c_int * ns)(*[int(c[0]) for c in slices])
+    sw = (ctypes.c_int * ns)(*[int(c[1]) for c in slices])
+    sn = (ctypes.c_int * ns)(*[int(c[2]) for c in slices])
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv_pack_stacked_dgrad', wp, ci, co, hh, nl, op, sc, sw, sn, ns, _lib.dtype_code(pool), _lib.stream_ptr(dev))
+    if len(_STACK_PACK_CACHE) > 1024:
+        _STACK_PACK_CACHE.clear()
+    _STACK_PACK_CACHE[ids] = (key, [weakref.ref(w) for w in masters], pool, outs)     # (slot [2]: the ONE allocation, train_caches_*)
+    return outs
+
+
 class DenseStackTrainFunction(Function):
     """The dense estimator stacks (FlowEstimatorDense / the SGU mask estimator: `x = cat([conv_k(x), x])` five times, then
     conv_last; model/pwc_modules.py:250-286) under autograd without a single concatenation, in the buffer layout of the
@@ -1935,9 +1976,16 @@ class DenseStackTrainFunction(Function):
         # the mask / residual pass of each layer inside its data-gradient convolution's epilogue (upf_conv_forward_gated; the
         # separate passes cost 1.1 ms of a 9.5 ms config-3 step), the bias sums of all layers by ONE pass over P afterwards
         gated = not (getattr(DenseStackTrainFunction, 'no_gated_dgrad', False) or os.environ.get('UPF_NO_GATED_DGRAD'))
+        # every data-gradient operand of the stack from one launch (the first level of a step packs, the others hit the cache)
+        x0 = nt - ch_in
+        one_pack = len(order) <= 8 and not (getattr(DenseStackTrainFunction, 'no_stack_pack', False) or os.environ.get('UPF_NO_STACK_PACK'))
+        if one_pack:
+            with torch.no_grad():
+                packs = _stack_dgrad_packs([masters[j] for j in order], [hi_of[j] for j in order],
+                                           [(lo[k], f[k], pos) for pos, k in enumerate(order[1:], start=1)] + [(x0, ch_in, len(order))], dt)
         for pos, k in enumerate(order[1:], start=1):
             ms = [masters[j] for j in order[:pos]]
-            packed = _stacked_dgrad_pack(ms, lo, [hi_of[j] for j in order[:pos]], lo[k], f[k], dt)
+            packed = packs[pos - 1] if one_pack else _stacked_dgrad_pack(ms, lo, [hi_of[j] for j in order[:pos]], lo[k], f[k], dt)
             dst = P[:, filled:filled + f[k]]
             add_k = g_buf[:, lo[k]:lo[k] + f[k]] if g_buf is not None else None
             if gated:
@@ -1956,8 +2004,7 @@ class DenseStackTrainFunction(Function):
         grads_in = [None] * nin
         g_tail_in = None
         if any(ctx.needs_input_grad[1:1 + nin]):
-            x0 = nt - ch_in
-            packed = _stacked_dgrad_pack([masters[j] for j in order], lo, [hi_of[j] for j in order], x0, ch_in, dt)
+            packed = packs[-1] if one_pack else _stacked_dgrad_pack([masters[j] for j in order], lo, [hi_of[j] for j in order], x0, ch_in, dt)
             gx = torch.empty((B, ch_in, H, W), dtype=dt, device=dev)
             summed = gated and g_buf is not None     # the 16-bit tensor add below, in the convolution's epilogue
             if summed:
