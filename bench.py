@@ -415,7 +415,7 @@ def eval_probe(net, H, W, device, iters=40):
         a, b = a.to(device), b.to(device)
         res = {}
         for name, graph in (('graph', True), ('eager', False)):
-            tm = Test_model(pretrain_path=None, dtype=next(net.parameters()).dtype, graph=graph, device=device, net=net)
+            tm = Test_model(pretrain_path=None, dtype=None, graph=graph, device=device, net=net)      # (dtype None: the supplied network keeps its — possibly mixed — types)
             for _ in range(5):
                 tm.eval_forward(a, b, 0)
             torch.cuda.synchronize(device)
@@ -426,7 +426,7 @@ def eval_probe(net, H, W, device, iters=40):
             res[name] = (time.perf_counter() - t0) / iters * 1e3
         # ... and with four pairs in flight (runtime.PipelinedEvaluation behind Test_model(streams=4).eval_forward_stream): what
         # Evaluation_bench uses when the test model offers it
-        tm = Test_model(pretrain_path=None, dtype=next(net.parameters()).dtype, device=device, net=net, streams=4)
+        tm = Test_model(pretrain_path=None, dtype=None, device=device, net=net, streams=4)
         for _ in tm.eval_forward_stream([(a, b)] * 8):
             pass
         torch.cuda.synchronize(device)

@@ -81,6 +81,33 @@ def test_conv_pitched_as_channel_slices_of_wider_pitched_buffers():
     assert bool((big[:, :8] == 3).all()), 'wrote outside its channel slice'
 
 
+def test_a_column_crop_of_a_wider_live_buffer_is_rejected_as_an_output():
+    """`big[..., :W]` has the strides of a pitched tensor, but its "padding" columns are live data that the whole-segment
+    stores of the pitched kernels would overwrite: outputs must be contiguous rows or padded as ops.empty_nchw pads them."""
+    from upflow_pytorch_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 1, 32, 12, 37
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.zeros(C).cuda()
+    packed = ops.conv3x3_pack(w)
+    for Wbig in (W + 11, 64, W + 8):
+        big = torch.full((B, C, H, Wbig), 5.0, dtype=torch.bfloat16, device='cuda')
+        with pytest.raises(ops.UpflowHipError):
+            ops.conv3x3_forward_raw(x, packed, b, big[..., :W], 1, 0.1)
+        with pytest.raises(ops.UpflowHipError):
+            ops.warp_into(x, torch.zeros(B, 2, H, W, device='cuda'), big[..., :W], 'literal')
+        assert bool((big == 5).all())
+    # as an INPUT such a view is fine (nothing is written), and the empty_nchw padding is accepted as an output
+    big = torch.full((B, C, H, 64), float('nan'), dtype=torch.bfloat16, device='cuda')
+    big[..., :W] = x
+    want = torch.empty(B, C, H, W, dtype=torch.bfloat16, device='cuda')
+    ops.conv3x3_forward_raw(x, packed, b, want, 1, 0.1)
+    got = ops.empty_nchw((B, C, H, W), torch.bfloat16, 'cuda')
+    ops.conv3x3_forward_raw(big[..., :W], packed, b, got, 1, 0.1)
+    assert torch.equal(bits(got), bits(want))
+
+
 # ----------------------------------------------------------------------------------------------- convolution, NCHW -> C8 and C8 -> *
 @pytest.mark.parametrize('case', [(2, 32, 32, 12, 39, 1), (1, 64, 32, 23, 78, 1), (1, 196, 32, 6, 20, 1), (2, 32, 32, 47, 311, 1), (1, 96, 20, 9, 156, 1),
                                   (2, 32, 32, 47, 155, 3), (1, 32, 32, 188, 621, 3)])

@@ -483,7 +483,8 @@ def test_captured_graph_survives_cache_clears_allocator_churn_and_an_eager_step(
         if frozen:                                            # frozen pyramid / decoder: their packs are cache hits inside the capture
             tr.raw_net.froze_PWC()
             # True: the multi-launch (foreach) optimizer; 'fused': the one-kernel optimizer the Trainer uses by default, which does
-            # not advance the parameters' version counters itself (train.py bumps them: the packed weight copies are keyed on them)
+            # not advance the parameters' version counters itself (the Trainer's `optimizer` setter registers ops.register_version_hook on
+            # whatever optimizer it is given: the packed weight copies are keyed on those counters)
             tr.optimizer = torch.optim.Adam([p for p in tr.net.parameters() if p.requires_grad], lr=tr.optimizer.param_groups[0]['lr'],
                                             amsgrad=True, weight_decay=1e-4, capturable=True, fused=(frozen == 'fused'))
         if frozen == 'bumped':

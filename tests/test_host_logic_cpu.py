@@ -171,6 +171,34 @@ def test_fused_optimizer_steps_advance_parameter_versions():
     assert qs[0]._version == v3 + 1
 
 
+def test_trainer_registers_the_version_hook_on_a_replaced_optimizer():
+    """`tr.optimizer = <new fused optimizer>` used to leave the new optimizer without the version hook and the replay
+    path with the OLD optimizer's parameter list; the Trainer's `optimizer` setter does both now."""
+    import torch
+    from upflow_pytorch_amd.train import Trainer
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.ones(3))
+            self.b = torch.nn.Parameter(torch.ones(2))
+
+        def forward(self, d):
+            return {'photo_loss': (self.a * d['im1']).sum() + self.b.sum(), 'smooth_loss': None, 'census_loss': None, 'msd_loss': None}
+
+    net = Tiny()
+    tr = Trainer(net, distributed=False, fused_adam=False)
+    assert [id(p) for p in tr._params_flat] == [id(net.a), id(net.b)]
+    new = torch.optim.SGD([net.a], lr=0.1)
+    new.defaults['fused'] = True                              # (a real fused optimizer needs a GPU; the hook reads defaults only)
+    tr.optimizer = new
+    assert getattr(new, '_upf_version_hook', None) is not None
+    assert [id(p) for p in tr._params_flat] == [id(net.a)]
+    v = net.a._version
+    tr.step({'im1': torch.ones(3)})
+    assert net.a._version == v + 2                            # SGD's own update + the hook
+
+
 def test_training_losses_and_gradients_at_realistic_motion_vs_reference_golden(stub):
     """The same host logic where the flows are large (tests/golden/train_128x416_hs1.npz: full-scale heads, mean |flow| 11.4 px, a
     crop 3 / 2 px from the frame's corner — 5.5 % of the photometric samples fall outside the crop, 1 % outside the frame and are

@@ -69,6 +69,21 @@ def _pitch_or_raise(t, what):
     return p
 
 
+def _out_pitch_or_raise(t, what):
+    """_pitch_or_raise for a tensor a kernel WRITES.  The pitched kernels store whole 8-pixel segments (wide epilogue) / pixel pairs
+    (warp) and let the tail land in columns [W, pitch) of the row: harmless in the padding ops.empty_nchw creates (pitch a multiple
+    of 8, fewer than 8 padding columns) and in contiguous rows (pitch == W: the kernels then take their exact-width stores), but a
+    column crop of a wider LIVE buffer (`big[..., :W]`) has the same strides and its "padding" is somebody's data:
+    rejected, as every round before the pitched forms did."""
+    p = _pitch_or_raise(t, what)
+    W = t.shape[3]
+    if p != W and (p % PITCH_MULTIPLE or p - W >= PITCH_MULTIPLE):
+        raise UpflowHipError('%s: output rows must be contiguous or padded as ops.empty_nchw pads them (pitch %% %d == 0, pitch - W < %d); '
+                             'got W = %d, pitch = %d — a column crop of a wider buffer would have its neighbours overwritten'
+                             % (what, PITCH_MULTIPLE, PITCH_MULTIPLE, W, p))
+    return p
+
+
 # ------------------------------------------------------------------------------------------------
 # cost volume
 # ------------------------------------------------------------------------------------------------
@@ -394,7 +409,7 @@ def warp_into(x_view, flow, y_view, mask_mode='literal', batch_shift=0):
     concatenation buffers the convolutions read): no slot copies.  Returns y_view."""
     if x_view.shape != y_view.shape:
         raise UpflowHipError('warp_into: x / y must be equal-shape channel slices of contiguous NCHW buffers')
-    xp, yp = _pitch_or_raise(x_view, 'warp_into: x'), _pitch_or_raise(y_view, 'warp_into: y')
+    xp, yp = _pitch_or_raise(x_view, 'warp_into: x'), _out_pitch_or_raise(y_view, 'warp_into: y')
     flow = _f32(flow).contiguous()
     B, C, H, W = x_view.shape
     if flow.shape != (B, 2, H, W):
@@ -714,7 +729,7 @@ def conv3x3_forward_raw(x_view, packed, bias32, y_view, dilation=1, leaky_slope=
     Ho, Wo = conv3x3_out_hw(H, W, stride)
     if tuple(y_view.shape) != (B, Cout, Ho, Wo):
         raise UpflowHipError('conv: output must be [%d,%d,%d,%d], got %s' % (B, Cout, Ho, Wo, tuple(y_view.shape)))
-    xp, yp = _pitch_or_raise(x_view, 'conv: x'), _pitch_or_raise(y_view, 'conv: y')
+    xp, yp = _pitch_or_raise(x_view, 'conv: x'), _out_pitch_or_raise(y_view, 'conv: y')
     dev = x_view.device
     if x_view.dtype == torch.float32:
         if xp != W or yp != Wo:
@@ -749,7 +764,7 @@ def conv3x3_forward_gated_raw(x_view, packed, bias32, y_view, add, act, mask_slo
     Cout = y_view.shape[1]
     if tuple(y_view.shape) != (B, Cout, H, W):
         raise UpflowHipError('conv (gated): output must be [%d,%d,%d,%d], got %s' % (B, Cout, H, W, tuple(y_view.shape)))
-    xp, yp = _pitch_or_raise(x_view, 'conv (gated): x'), _pitch_or_raise(y_view, 'conv (gated): y')
+    xp, yp = _pitch_or_raise(x_view, 'conv (gated): x'), _out_pitch_or_raise(y_view, 'conv (gated): y')
     if add is None and act is None:
         raise UpflowHipError('conv (gated): neither add nor act given')
     for t, name in ((add, 'add'), (act, 'act')):
@@ -900,7 +915,7 @@ def conv_c8_forward_raw(x8, x2, packed, bias32, y, dilation=1, leaky_slope=0.0, 
     else:
         if tuple(y.shape) != (B, Cout, Ho, Wo):
             raise UpflowHipError('conv_c8: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, Ho, Wo))
-        yp = _pitch_or_raise(y, 'conv_c8: y')
+        yp = _out_pitch_or_raise(y, 'conv_c8: y')
     dev = ref.device
     if y.dtype != ref.dtype:
         if not (x8 is None and x2 is not None and kernel_size == 1 and stride == 1 and y_is_c8 and Cout <= 32 and y.dtype in (torch.bfloat16, torch.float16)):

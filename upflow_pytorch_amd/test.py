@@ -26,13 +26,19 @@ class Test_model(tools.abs_test_model):
         """streams > 1: `Evaluation_bench` keeps that many frame pairs in flight (runtime.PipelinedEvaluation, through
         eval_forward_stream) instead of one at a time — same results, ~1.7x the pairs per second at KITTI's frame size."""
         super(Test_model, self).__init__()
+        supplied = net is not None
         if net is None:
             net_conf = UPFlow_net.config()
             net_conf.update(PARAM_DICT, verbose=False)
             net = net_conf()
             if pretrain_path is not None:
                 net.load_model(pretrain_path, if_relax=True, if_print=True)
-        net = net.to(device).to(dtype).eval()
+        # a supplied network that is already 16-bit — possibly MIXED (UPFlow_net.to_inference(dtype, pyramid_dtype=...)) — keeps its
+        # types: `.to(dtype)` would flatten the fp16 pyramid into the decoder's type and evaluate another configuration (ADVICE r5)
+        if supplied and (dtype is None or any(p_.dtype != torch.float32 for p_ in net.parameters())):
+            net = net.to(device).eval()
+        else:
+            net = net.to(device).to(dtype).eval()
         self.net_work = net
         self.runner = None
         self.pipe = None
@@ -43,15 +49,17 @@ class Test_model(tools.abs_test_model):
                 self.pipe = PipelinedEvaluation(net, streams=streams)
 
     def eval_forward_stream(self, pairs):
-        """pairs: iterable of (im1, im2) -> generator of flow_fw, in order, with several pairs in flight.  A yielded tensor is owned
-        by its slot: valid until the generator is advanced.  (Not in the reference: its loop is one pair at a time.)"""
+        """pairs: iterable of (im1, im2) -> generator of flow_fw, in order, with several pairs in flight; every yielded tensor is the
+        caller's own copy, as eval_forward's is.  (Not in the reference: its loop is one pair at a time.)"""
         if self.pipe is None:
             for im1, im2 in pairs:
                 yield self.eval_forward(im1, im2, 0)
             return
         with torch.no_grad():
             for out in self.pipe.map(pairs):
-                yield out['flow_f_out']
+                # (a copy, like eval_forward's: the slot's output is overwritten when the generator advances, and eval_save_result
+                # — a hook whose documented purpose is to store / save predflows — may keep it; 3.7 MB per KITTI pair.  ADVICE r5)
+                yield out['flow_f_out'].clone()
 
     def eval_forward(self, im1, im2, gt, *args):
         # === network output                                 (test.py:40-47)

@@ -88,12 +88,7 @@ class Trainer():
         self.fused_adam = on_gpu if fused_adam is None else bool(fused_adam)
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr_arg, amsgrad=True,
                                           weight_decay=weight_decay, capturable=self.use_graph, fused=self.fused_adam)
-        self._params_flat = [p for g in self.optimizer.param_groups for p in g['params']]
-        # the packed 16-bit weight copies are keyed on the parameters' autograd version counters, which torch's FUSED optimizers
-        # do not advance: a per-optimizer post-step hook does (custom training loops around a fused optimizer need the same hook,
-        # ops.register_version_hook(optimizer))
-        from . import ops as _ops
-        _ops.register_version_hook(self.optimizer)
+        # (the `optimizer` setter below registered the version-counter hook on it and took its parameter list)
         self.graph_warmup = 11 if self.distributed else 3
         self._graph = None
         self._static = None
@@ -101,6 +96,22 @@ class Trainer():
         self._eager_steps = 0
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=scheduler_gamma)
         self.loss_manager = Loss_manager()
+
+    @property
+    def optimizer(self):
+        return self._optimizer
+
+    @optimizer.setter
+    def optimizer(self, opt):
+        """The packed 16-bit weight copies are keyed on the parameters' autograd version counters, which torch's FUSED optimizers
+        do not advance: a per-optimizer post-step hook does (ops.register_version_hook; custom training loops around a fused
+        optimizer need the same hook).  ANY optimizer assigned to the trainer — the one built in __init__ or a replacement
+        (`tr.optimizer = torch.optim.Adam(..., fused=True)`) — gets the hook, and the replay path's parameter list follows it
+        (a replaced fused optimizer had neither, and the step kept multiplying by the step-0 packed weights)."""
+        from . import ops as _ops
+        self._optimizer = opt
+        _ops.register_version_hook(opt)
+        self._params_flat = [p for g in opt.param_groups for p in g['params']]
 
     def shard(self, batch):
         """This rank's contiguous-strided slice of a GLOBAL batch dict (DistributedSampler-style)."""
