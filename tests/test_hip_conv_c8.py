@@ -148,13 +148,16 @@ def test_whole_net_c8_levels_are_bit_identical_to_nchw():
     assert c8_level_ok(4, 96, 320, torch.bfloat16) and not c8_level_ok(4, 24, 80, torch.bfloat16)
     net._no_c8_est = True              # (the estimator's octet form has another K order: its own test below)
     from upflow_pytorch_amd.model import pwc_modules
-    monkey_narrow = pwc_modules._NO_NARROW[0]
+    monkey_narrow, monkey_merge = pwc_modules._NO_NARROW[0], pwc_modules.MERGE_TAIL[0]
     pwc_modules._NO_NARROW[0] = True   # (so has the 16-channel instruction of the <= 16-channel layers: test_conv_c8_narrow_layers)
-    with torch.no_grad():
-        a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
-        net._no_c8 = True
-        b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
-    pwc_modules._NO_NARROW[0] = monkey_narrow
+    pwc_modules.MERGE_TAIL[0] = False  # (... and the merged narrow tail of the octet stacks, round 6: test_merged_tail_* below)
+    try:
+        with torch.no_grad():
+            a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+            net._no_c8 = True
+            b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+    finally:
+        pwc_modules._NO_NARROW[0], pwc_modules.MERGE_TAIL[0] = monkey_narrow, monkey_merge
     for k in ('flow_f_out', 'flow_b_out', 'occ_fw', 'occ_bw'):
         assert torch.equal(a[k], b[k]), k
     assert torch.isfinite(a['flow_f_out']).all() and float(a['flow_f_out'].abs().mean()) > 0
@@ -293,3 +296,117 @@ def test_conv_c8_narrow_layers(case, dt):
     assert float((got != ref).float().mean()) < 0.02                         # ... and that rarely
     if y_c8 and Cout % 8:
         assert float(ya[:, -1, :, :, Cout % 8:].float().abs().max()) == 0.0  # padding channels of the last output octet: exact zeros
+
+
+# ----------------------------------------------------------------------------------------------- the merged narrow tail (round 6)
+def _stack_reference(stack, x, dt):
+    """The dense stack layer by layer through conv2d in fp32 on 16-bit-rounded activations (what every layer-per-pass path computes up
+    to fp32 summation order) -> (list of the conv outputs as dt tensors, x_out fp32)."""
+    feats = x
+    outs = []
+    for name in stack._NAMES:
+        c = getattr(stack, name)[0]
+        y = F.leaky_relu(F.conv2d(feats.float(), c.weight.float(), c.bias.float(), padding=1), 0.1).to(dt)
+        outs.append(y)
+        feats = torch.cat([y, feats], 1)
+    c = stack.conv_last[0]
+    return outs, F.conv2d(feats.float(), c.weight.float(), c.bias.float(), padding=1)
+
+
+@pytest.mark.parametrize('kind', ['sgu', 'est'])
+@pytest.mark.parametrize('shape', [(2, 48, 160), (1, 16, 32), (1, 23, 77), (8, 96, 320), (1, 9, 24)])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_merged_tail_of_a_dense_stack_matches_the_layer_per_pass_form(kind, shape, dt):
+    """_PackedTailC8: conv_m + the shared-input partials of the later layers in ONE pass, the later layers finished from the partial
+    (upf_conv_forward_c8_split / _narrow_init) — against the same stack with every layer its own pass and against conv2d.  Same fp32
+    sums in another order: the 16-bit outputs agree to a rounding step where a sum lands next to a rounding boundary."""
+    from upflow_pytorch_amd import ops
+    from upflow_pytorch_amd.model import pwc_modules
+    from upflow_pytorch_amd.model.pwc_modules import FlowEstimatorDense_v2, _PackedTailC8
+    B, H, W = shape
+    if kind == 'est' and B * H * W > 2 * 48 * 160 and dt == torch.float16:
+        pytest.skip('large estimator case: bf16 only')
+    torch.manual_seed(B * 1000 + H + W)
+    if kind == 'sgu':
+        stack = FlowEstimatorDense_v2(64, f_channels=(32, 32, 32, 16, 8), out_channel=3)       # model/upflow.py:24-60
+        assert _PackedTailC8.plan([32, 32, 32, 16, 8, 3]) == (3, [4, 5])
+    else:
+        stack = FlowEstimatorDense_v2(120, f_channels=(128, 128, 96, 64, 32), out_channel=2)   # pwc_modules.py:250-286 (input padded to octets)
+        assert _PackedTailC8.plan([128, 128, 96, 64, 32, 2]) == (2, [5])
+    for m in stack.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+            torch.nn.init.normal_(m.bias, std=0.1)
+    stack = stack.cuda().to(dt).eval()
+    x = torch.randn(B, stack._ch_in, H, W, device='cuda').to(dt)
+    with torch.no_grad():
+        ref_outs, ref_last = _stack_reference(stack, x, dt)
+    n_in = stack._ch_in // 8
+    nconv = sum(stack._f) // 8
+    res = {}
+    for merge in (False, True):
+        buf8 = torch.full((B, nconv + n_in + 1, H, W, 8), float('nan'), dtype=dt, device='cuda')
+        buf8[:, nconv:nconv + n_in] = ops.to_c8(x)
+        stack._no_merge_tail = not merge
+        with torch.no_grad():
+            out = stack.forward_in_buffer_c8(buf8)
+        assert torch.isnan(buf8[:, nconv + n_in:].float()).all()                          # nothing written past the buffer's octets
+        res[merge] = (ops.from_c8(buf8[:, :nconv]).float(), out.float())
+    holders = stack.__dict__['_packed8'][None][0]
+    assert isinstance(holders[-1], _PackedTailC8) and len(holders) == 7
+    ref_last = ref_last.detach()
+    scale = float(ref_last.abs().max())
+    # merged vs layer-per-pass: the conv outputs that precede the tail are the same launches -> identical; the tail's within a rounding step
+    # (conv_m itself: the same sum on the 32-channel instruction — the layer-per-pass form of a <= 16-channel layer uses the 16-channel
+    # one, which adds 32 input channels per instruction instead of 16)
+    tail = holders[-1]
+    nt = sum(tail.widths[tail.m:5])                              # buffer order: [conv5 | conv4 | ...]
+    assert torch.equal(res[True][0][:, nt:], res[False][0][:, nt:])
+    all_ref = torch.cat(ref_outs[::-1], 1).float()
+    eps = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    for got in (res[True][0], res[False][0]):
+        assert (got - all_ref).abs().max() <= 2 * eps * float(all_ref.abs().max()) + 1e-3
+    for got in (res[True][1], res[False][1]):
+        assert (got - ref_last).abs().max() <= 4 * eps * scale + 1e-3, float((got - ref_last).abs().max())
+    # the merged form is not further from conv2d than the layer-per-pass form (mean error, 10 % slack)
+    e_m = float((res[True][1] - ref_last).abs().mean()); e_s = float((res[False][1] - ref_last).abs().mean())
+    assert e_m <= 1.1 * e_s + 1e-5, (e_m, e_s)
+
+
+def test_whole_net_with_merged_tails_stays_within_the_16_bit_envelope():
+    """The default schedule (merged narrow tails in the octet stacks of the fine levels) against the layer-per-pass schedule and against
+    the fp32 forward: as close to fp32 as the layer-per-pass schedule is."""
+    import _weights
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.model import pwc_modules
+    conf = UPFlow_net.config()
+    conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False, 'norm_moments_across_images': False,
+                 'if_sgu_upsample': True, 'warp_mask_mode': 'robust'}, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0))
+    net = net.cuda().eval()
+    im1, im2 = _weights.make_images(2, 4, 384, 1280)
+    with torch.no_grad():
+        ref = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        net = net.bfloat16()
+        calls = []
+        orig = pwc_modules._PackedTailC8.main_pass
+        pwc_modules._PackedTailC8.main_pass = lambda self, *a, **k: (calls.append(self.cmain), orig(self, *a, **k))[1]
+        try:
+            a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        finally:
+            pwc_modules._PackedTailC8.main_pass = orig
+        prev = pwc_modules.MERGE_TAIL[0]
+        pwc_modules.MERGE_TAIL[0] = False
+        try:
+            b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        finally:
+            pwc_modules.MERGE_TAIL[0] = prev
+    assert sorted(calls) == [16, 16, 16, 96, 96]               # SGU stack (conv4's pass) at the two fine levels + the final up-sampling; estimator (conv3's pass) at the two fine levels
+    for k in ('flow_f_out', 'flow_b_out'):
+        ea = float((a[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())
+        eb = float((b[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())
+        eab = float((a[k].float() - b[k].float()).pow(2).sum(1).sqrt().mean())
+        print('%s: EPE vs fp32: merged tails %.5f px, layer per pass %.5f px; merged vs layer per pass %.5f px' % (k, ea, eb, eab))
+        assert torch.isfinite(a[k]).all()
+        assert ea <= 1.25 * eb + 1e-4 and eab <= 1.5 * eb + 1e-4

@@ -274,8 +274,9 @@ def test_native_kitti_frames_pitched_octet_path_vs_the_ragged_path(size, dtype):
         # bit identity needs the same tile shapes on both sides, as in test_whole_net_c8_levels_are_bit_identical_to_nchw: the
         # 16-channel matrix instruction of the <= 16-channel layers and the 16-row tiles of large grids (which the octet kernels
         # run on 16-channel chunks) sum in another order
-        saved = (pwc_modules._NO_NARROW[0], ops.conv_c8_set_option('rpw4', 0), ops.conv_set_option('rpw4_min', 1 << 30))
+        saved = (pwc_modules._NO_NARROW[0], ops.conv_c8_set_option('rpw4', 0), ops.conv_set_option('rpw4_min', 1 << 30), pwc_modules.MERGE_TAIL[0])
         pwc_modules._NO_NARROW[0] = True
+        pwc_modules.MERGE_TAIL[0] = False        # (the merged narrow tail of the octet stacks, round 6: another summation order too)
         try:
             for m in net.modules():
                 m.__dict__.pop('_packed8', None)
@@ -287,6 +288,7 @@ def test_native_kitti_frames_pitched_octet_path_vs_the_ragged_path(size, dtype):
             ragged = net({'im1': im1, 'im2': im2, 'if_loss': False})
         finally:
             pwc_modules._NO_NARROW[0] = saved[0]
+            pwc_modules.MERGE_TAIL[0] = saved[3]
             ops.conv_c8_set_option('rpw4', saved[1])
             ops.conv_set_option('rpw4_min', saved[2])
     for k in ('flow_f_out', 'flow_b_out', 'occ_fw', 'occ_bw'):

@@ -15,6 +15,7 @@ net = bench.build_net(bench.DT[dname], dev)
 im1, im2 = synthetic.make_images(2, B, H, W)
 im1, im2 = im1.to(dev), im2.to(dev)
 variants = sys.argv[1:] or ['', '']
+STREAMS = int(os.environ.get('UPF_AB_STREAMS', '1'))
 runners = []
 for v in variants:
     opts = dict(kv.split('=') for kv in v.split(',') if kv)
@@ -22,11 +23,26 @@ for v in variants:
     net._no_c8_est = bool(int(opts.pop('no_c8_est', 0)))  # (model switch: the flow estimator of the fine levels in NCHW)
     from upflow_pytorch_amd.model import pwc_modules
     pwc_modules._NO_NARROW[0] = bool(int(opts.pop('no_narrow', 0)))   # (Cout <= 16 octet layers on the 32-channel kernel)
+    pwc_modules.MERGE_TAIL[0] = not bool(int(opts.pop('no_merge', 0)))  # (merged narrow tails of the octet stacks, round 6)
     for m in net.modules():
         m.__dict__.pop('_packed8', None)                  # (packed operands are cached per module: rebuild for this variant)
     prev = {k: ops.conv_set_option(k, int(val)) for k, val in opts.items()}
-    r = GraphedInference(net, B, H, W, device=dev)
-    r.load(im1, im2)
+    if STREAMS > 1:                                       # UPF_AB_STREAMS=4: the headline's form, S captured steps in flight on S streams
+        from upflow_pytorch_amd.runtime import PipelinedInference
+        pipe = PipelinedInference(net, B, H, W, streams=STREAMS, device=dev)
+        tickets = [pipe.submit(im1, im2) for _ in range(STREAMS)]
+
+        class _R(object):
+            def __init__(self, pipe, tickets):
+                self.pipe, self.tickets = pipe, tickets
+
+            def replay(self):
+                for t_ in self.tickets:
+                    self.pipe.replay(t_)
+        r = _R(pipe, tickets)
+    else:
+        r = GraphedInference(net, B, H, W, device=dev)
+        r.load(im1, im2)
     r.replay(); torch.cuda.synchronize()
     runners.append(r)
     for k, val in prev.items():
@@ -46,4 +62,4 @@ for _ in range(ROUNDS):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / N
         best[i] = min(best[i], dt); tot[i] += dt
 for i, v in enumerate(variants):
-    print('%-40s mean %.3f ms (%.1f pairs/s)   best %.3f ms' % (v or '(defaults)', tot[i] / ROUNDS * 1e3, B / (tot[i] / ROUNDS), best[i] * 1e3), flush=True)
+    print('%-40s mean %.3f ms (%.1f pairs/s)   best %.3f ms%s' % (v or '(defaults)', tot[i] / ROUNDS * 1e3, STREAMS * B / (tot[i] / ROUNDS), best[i] * 1e3, ' [%d steps in flight per replay]' % STREAMS if STREAMS > 1 else ''), flush=True)

@@ -276,3 +276,103 @@ extern "C" int upf_conv_forward_c8_narrow(const void* x8, long long x8_batch_str
   UPF_N16(f16_t)
 #undef UPF_N16
 }
+
+// ---- merged narrow tail of a dense stack (conv_kernel.hpp: SplitOut / AccInit; round 6) -----------------------------------------
+namespace upf {
+namespace conv {
+
+template <typename T, int MTW, int RPW, int NOCTS>
+int launch_split(const ArgsC8& a, const SplitOut& so) {
+  constexpr int TH = (4 / MTW) * RPW;
+  constexpr int rowsC = (TH - 1) + 2 + 1;
+  constexpr int XWP = xwp_eff(1, 1, 1);
+  constexpr int EB = NOCTS * rowsC * XWP, EBP = (EB + 63) & ~63;
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
+  const size_t lds = (size_t)2 * EBP * 16;
+  static LdsOptIn opt;
+  auto kern = &conv_split_kernel<T, MTW, RPW, NOCTS>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), (unsigned)cdiv(cdiv(a.Cout, 32), MTW)), dim3(NTHREADS), lds, a.stream, (const T*)a.wp, a.bias, (T*)a.y, a.ybs,
+                     a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, (const T*)a.x8, a.x8bs, a.n8oct, so);
+  return check_launch("conv_forward_c8_split");
+}
+
+// the launch shapes launch_c8 gives the same layer without the partial rows
+template <typename T>
+int dispatch_split(const ArgsC8& a, const SplitOut& so) {
+  const int mt = cdiv(a.Cout, 32);
+  const long long tiles = (long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 8);
+  int mtw = mt >= 3 ? 4 : mt;
+  if (tiles <= g_small_grid && mt > 1) mtw = 2;
+  if (mtw == 4) return launch_split<T, 4, 8, 2>(a, so);
+  if (mtw == 2) return launch_split<T, 2, 4, 4>(a, so);
+  if (g_c8_rpw4 && (long long)a.B * cdiv(a.W, TW) * cdiv(a.H, 16) >= g_rpw4_min) return launch_split<T, 1, 4, 2>(a, so);
+  return launch_split<T, 1, 2, 4>(a, so);
+}
+
+template <typename T, int RPW, bool YC8>
+int launch_accinit(const ArgsC8& a, const AccInit& ai) {
+  constexpr int TH = 4 * RPW;
+  constexpr int rowsC = (TH - 1) + 2 + 1;
+  constexpr int XWP = xwp_eff(1, 1, 1);
+  constexpr int EB = 4 * rowsC * XWP, EBP = (EB + 63) & ~63;
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
+  const size_t lds = (size_t)2 * EBP * 16;
+  static LdsOptIn opt;
+  auto kern = &conv_accinit_kernel<T, RPW, YC8>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), (unsigned)cdiv(a.Cout, 16)), dim3(NTHREADS), lds, a.stream, (const T*)a.wp, (T*)a.y, a.ybs,
+                     a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, (const T*)a.x8, a.x8bs, a.n8oct, ai);
+  return check_launch("conv_forward_c8_narrow_init");
+}
+
+}  // namespace conv
+}  // namespace upf
+
+extern "C" int upf_conv_forward_c8_split(const void* x8, long long x8_batch_stride, int n8_oct, const void* w_packed, const float* bias,
+                                         void* y8, long long y_batch_stride, int C_main, float* partial, long long partial_batch_stride, int partial_pitch,
+                                         int B, int Cout, int H, int W, float leaky_slope, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x8 && n8_oct > 0 && w_packed && bias && y8 && partial, UPF_EINVAL, "conv_forward_c8_split: null pointer");
+  UPF_REQUIRE(B > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_forward_c8_split: bad shape B=%d H=%d W=%d", B, H, W);
+  UPF_REQUIRE(C_main > 0 && C_main % 8 == 0 && Cout > C_main && Cout <= 128, UPF_EINVAL,
+              "conv_forward_c8_split: C_main = %d must be a positive multiple of 8 below Cout = %d <= 128", C_main, Cout);
+  UPF_REQUIRE(partial_pitch % 4 == 0 && partial_pitch >= (Cout - C_main + 3) / 4 * 4, UPF_EINVAL,
+              "conv_forward_c8_split: partial pitch %d must be a multiple of 4 floats holding the %d partial channels", partial_pitch, Cout - C_main);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_c8_split: bf16 / fp16 only");
+  UPF_REQUIRE(aligned_to(x8, 16) && x8_batch_stride % 8 == 0 && aligned_to(y8, 16) && y_batch_stride % 8 == 0 && aligned_to(partial, 16) && partial_batch_stride % 4 == 0,
+              UPF_EINVAL, "conv_forward_c8_split: operands must be 16-byte aligned");
+  UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31) && (long long)H * W * partial_pitch * 4 < (1ll << 31), UPF_EINVAL,
+              "conv_forward_c8_split: image too large for one buffer descriptor");
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward_c8_split: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, nullptr, 0, 0, w_packed, bias, y8, y_batch_stride, B, Cout, H, W, 1, 1, 9,
+                 leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream, W, W};
+  const conv::SplitOut so{partial, partial_batch_stride, partial_pitch, C_main};
+  return dtype == UPF_BF16 ? conv::dispatch_split<bf16_t>(a, so) : conv::dispatch_split<f16_t>(a, so);
+}
+
+extern "C" int upf_conv_forward_c8_narrow_init(const void* x8, long long x8_batch_stride, int n8_oct, const void* w_packed16,
+                                               const float* partial, long long partial_batch_stride, int partial_pitch, int partial_offset,
+                                               void* y, long long y_batch_stride, int y_is_c8, int B, int Cout, int H, int W, float leaky_slope,
+                                               int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x8 && n8_oct > 0 && w_packed16 && partial && y, UPF_EINVAL, "conv_forward_c8_narrow_init: null pointer");
+  UPF_REQUIRE(B > 0 && Cout > 0 && Cout <= 16 && H > 0 && W > 0, UPF_EINVAL, "conv_forward_c8_narrow_init: bad shape B=%d Cout=%d (<= 16) H=%d W=%d", B, Cout, H, W);
+  UPF_REQUIRE(partial_pitch % 4 == 0 && partial_offset % 4 == 0 && partial_offset >= 0 && partial_offset + (Cout + 3) / 4 * 4 <= partial_pitch, UPF_EINVAL,
+              "conv_forward_c8_narrow_init: partial pitch %d / offset %d must be multiples of 4 floats holding the layer's %d channels", partial_pitch, partial_offset, Cout);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_forward_c8_narrow_init: bf16 / fp16 only");
+  UPF_REQUIRE(aligned_to(x8, 16) && x8_batch_stride % 8 == 0 && aligned_to(partial, 16) && partial_batch_stride % 4 == 0, UPF_EINVAL,
+              "conv_forward_c8_narrow_init: the C8 input and the partial must be 16-byte aligned");
+  UPF_REQUIRE(!y_is_c8 || (aligned_to(y, 16) && y_batch_stride % 8 == 0), UPF_EINVAL, "conv_forward_c8_narrow_init: the C8 output must be 16-byte aligned");
+  UPF_REQUIRE((long long)n8_oct * H * W * 16 < (1ll << 31) && (long long)H * W * partial_pitch * 4 < (1ll << 31), UPF_EINVAL,
+              "conv_forward_c8_narrow_init: image too large for one buffer descriptor");
+  UPF_REQUIRE((long long)(y_is_c8 ? (Cout + 7) / 8 * 8 : Cout) * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv_forward_c8_narrow_init: output too large for one buffer descriptor");
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv_forward_c8_narrow_init: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  conv::ArgsC8 a{x8, x8_batch_stride, n8_oct, nullptr, 0, 0, w_packed16, nullptr, y, y_batch_stride, B, Cout, H, W, 1, 1, 9,
+                 leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream, W, W};
+  const conv::AccInit ai{partial, partial_batch_stride, partial_pitch, partial_offset};
+#define UPF_N16I(T) return y_is_c8 ? conv::launch_accinit<T, 2, true>(a, ai) : conv::launch_accinit<T, 2, false>(a, ai);
+  if (dtype == UPF_BF16) { UPF_N16I(bf16_t) }
+  UPF_N16I(f16_t)
+#undef UPF_N16I
+}

@@ -122,9 +122,31 @@ __device__ __forceinline__ void stage_store(uint4* tile, int enc, int sh, const 
 // activation.  Removing those passes from the captured config-3 step took 1.13 ms off 9.51 (tools/act_grad_cost_probe.py), so the
 // two operands are applied HERE, to the 16-bit values the epilogue is about to store — the same arithmetic on the same rounded
 // values, in the same order, as the pass it replaces (conv_wgrad.hip act_grad_kernel): bit-identical outputs.
-struct NoGate { static constexpr bool on = false; };
+struct NoGate { static constexpr bool on = false, split = false, init = false; };
+// ---- merged narrow tail of a dense stack (round 6; inference, octet operands).  The layers of a dense stack read NESTED channel
+// suffixes of one buffer (pwc_modules.py:279-286, model/upflow.py:53-60): conv_last reads [conv5 | what conv5 read], so
+//   conv_last = W_last[:, conv5 part] * conv5_out + W_last[:, rest] * rest
+// and the second term shares its input with conv5 exactly.  A launch with 2 ... 32 output channels costs what its staging costs
+// (the 563 -> 2 head of the flow estimator took as long as the 531 -> 32 layer before it), so ONE pass over the shared input
+// computes the first layer of the tail completely and, in the unused output channels of the same 32-channel block(s), the
+// shared-input part of every later layer:
+//   SplitOut: output channels [0, cmain) are a layer's own — bias, LeakyReLU, 16-bit octets, as always; channels [cmain, Cout)
+//             are fp32 PARTIAL pre-activations of later layers (their bias included, no activation), stored pixel-major
+//             [n][y][x][ppitch] — 16 bytes per lane and register quad;
+//   AccInit:  the finishing launch of a later layer (16-channel matrix instruction, its input = the few channels the tail's earlier
+//             layers produced) starts its accumulators from that partial instead of from the bias.
+// The sum is the same fp32 sum in another order (the layer's own K order put the tail's channels first, here they come last);
+// no 16-bit rounding happens in between.
+struct SplitOut {
+  static constexpr bool on = false, split = true, init = false;
+  float* part; long long pbs; int ppitch; int cmain;      // cmain % 8 == 0
+};
+struct AccInit {
+  static constexpr bool on = false, split = false, init = true;
+  const float* part; long long pbs; int ppitch; int coff;  // coff % 4 == 0: first float of this layer's partial within a pixel
+};
 template <typename T> struct ActGate {
-  static constexpr bool on = true;
+  static constexpr bool on = true, split = false, init = false;
   const T* add; long long abs_;        // optional [B,Cout,Ho,Wo] channel slice added first (16-bit sum, rounded)
   const T* y; long long ybs;           // optional forward activation output: elements with !(y > 0) are scaled by slope
   float slope;
@@ -312,6 +334,8 @@ void conv_body(const T* __restrict__ x, long long xbs, const T* __restrict__ wp,
                TO* __restrict__ y, long long ybs, int Cin, int Cout, int H, int W, int Ho, int Wo, int d_rt,
                int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, int xpitch, int ypitch, const G gate) {
   static_assert(!G::on || (XL == 0 && !YC8 && !N16 && sizeof(TO) == sizeof(T)), "gated epilogue: NCHW operands of one type");
+  static_assert(!G::split || (XL == 1 && YC8 && !N16 && D == 1 && S == 1), "split epilogue: octet operands, 3x3, dilation 1, stride 1");
+  static_assert(!G::init || (N16 && XL == 1), "accumulator initialisation from a partial: the 16-channel kernel");
   // xpitch / ypitch (round 5): elements between consecutive rows of the NCHW operands x / y (plane stride = rows * pitch).  The
   // LOGICAL width stays W / Wo: with a pitch that is a multiple of 8 every row is 16-byte aligned whatever W is, so ragged
   // pyramid levels (KITTI's native 375x1242: W = 621, 311, 156, 78, 39, 20) take the aligned staging (!GEN) and the 16-byte
@@ -365,7 +389,21 @@ void conv_body(const T* __restrict__ x, long long xbs, const T* __restrict__ wp,
   f32x16 acc[N16 ? 1 : RPW];
   f32x4 acc16[N16 ? RPW : 1][2];                     // N16: [tile row][pixel half], channels 4 * (lane / 16) + i of pixel lane % 16 (+ 16)
   const int p16 = lane & 15, ko = lane >> 4;         // N16 operand lane: pixel of its half / k-octet (= output channel quad)
-  if constexpr (N16) {
+  if constexpr (N16 && G::init) {
+    // the accumulators start at the fp32 partial the merged pass left for this layer (its bias is in there): one 16-byte load per
+    // (tile row, pixel half); pixels outside the image and channel quads past Cout start at 0 (they are never stored)
+    __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gate.part + (size_t)n * gate.pbs), 0,
+                                                                  (uint32_t)(H * W) * (uint32_t)gate.ppitch * 4u, 0x00020000);
+    const int gyi = y0 + RPW * rg;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gx = x0 + p16 + 16 * h, gy = gyi + r;
+        const uint32_t off = (gx < W && gy < H && slab * 16 + 4 * ko < Cout) ? (uint32_t)((gy * W + gx) * gate.ppitch + gate.coff + slab * 16 + 4 * ko) * 4u : 0x80000000u;
+        acc16[r][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, off, 0, 0));
+      }
+  } else if constexpr (N16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (uint32_t)(slab * 16 + 4 * ko + i) * 4u, 0, 0));
@@ -652,15 +690,33 @@ void conv_body(const T* __restrict__ x, long long xbs, const T* __restrict__ wp,
     // together write 32 whole entries = 512 contiguous bytes per (octet, row).  Octets past ceil(Cout / 8) fall off the
     // descriptor; the channels that pad the last octet are exact zeros (zero weights, zero bias).
     const uint32_t plane16 = (uint32_t)(Ho * Wo) * 16u;
-    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * ybs, 0, (uint32_t)((Cout + 7) / 8) * plane16, 0x00020000);
+    int cout_y = Cout;                                // channels that leave as octets
+    if constexpr (G::split) cout_y = gate.cmain;
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * ybs, 0, (uint32_t)((cout_y + 7) / 8) * plane16, 0x00020000);
     const int gx = x0 + px;
     const uint32_t lane_off = (gx < Wo) ? (uint32_t)(slab * 4) * plane16 + (uint32_t)gx * 16u + (uint32_t)kg * 8u : 0x80000000u;
+    __amdgpu_buffer_rsrc_t pr;
+    if constexpr (G::split)
+      pr = __builtin_amdgcn_make_buffer_rsrc(gate.part + (size_t)n * gate.pbs, 0, (uint32_t)(Ho * Wo) * (uint32_t)gate.ppitch * 4u, 0x00020000);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       const int gy = gy0 + r * RS;                   // uniform
       if (gy < Ho) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          if constexpr (G::split) {
+            // registers 4g .. 4g+3 = channels c0 .. c0+3, c0 = 32*slab + 8*g + 4*kg: past cmain (uniform: cmain % 8 == 0) they are
+            // partial pre-activations of later layers -> raw fp32, floats [c0 - cmain, +4) of the pixel's partial record
+            if (slab * 32 + 8 * g >= gate.cmain) {
+              const int c0 = slab * 32 + 8 * g + 4 * kg;
+              const uint32_t off = (gx < Wo && c0 < Cout) ? (uint32_t)((gy * Wo + gx) * gate.ppitch + (c0 - gate.cmain)) * 4u : 0x80000000u;
+              f32x4 pv;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) pv[q] = acc[r][4 * g + q];
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), pr, off, 0, 0);
+              continue;
+            }
+          }
           float v[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) { v[q] = acc[r][4 * g + q]; v[q] = fmaxf(v[q], v[q] * slope); }
@@ -720,6 +776,23 @@ void conv_gated_kernel(const T* __restrict__ x, long long xbs, const T* __restri
                        int tiles_x, int tiles_y, float slope, int xpitch, int ypitch, const ActGate<T> gate) {
   conv_body<T, MTW, RPW, S, NOCTS, D, GEN, ONE, 0, false, false, T, ActGate<T>>(x, xbs, wp, bias, y, ybs, Cin, Cout, H, W, Ho, Wo, d_rt, tiles_x, tiles_y, slope,
                                                                                 nullptr, 0ll, 0, xpitch, ypitch, gate);
+}
+
+// the merged narrow tail of a dense stack (SplitOut / AccInit above): octet input, octet output + fp32 partials; and the finishing
+// launch of a later layer on the 16-channel instruction, its accumulators starting from the partial
+template <typename T, int MTW, int RPW, int NOCTS>
+__global__ __launch_bounds__(NTHREADS, 2)
+void conv_split_kernel(const T* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ y, long long ybs, int Cout, int H, int W,
+                       int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, const SplitOut so) {
+  conv_body<T, MTW, RPW, 1, NOCTS, 1, false, false, 1, true, false, T, SplitOut>(nullptr, 0ll, wp, bias, y, ybs, 0, Cout, H, W, H, W, 0, tiles_x, tiles_y, slope,
+                                                                                  x8, x8bs, n8oct, W, W, so);
+}
+template <typename T, int RPW, bool YC8>
+__global__ __launch_bounds__(NTHREADS, 2)
+void conv_accinit_kernel(const T* __restrict__ wp, T* __restrict__ y, long long ybs, int Cout, int H, int W,
+                         int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, const AccInit ai) {
+  conv_body<T, 1, RPW, 1, 4, 1, false, false, 1, YC8, true, T, AccInit>(nullptr, 0ll, wp, nullptr, y, ybs, 0, Cout, H, W, H, W, 0, tiles_x, tiles_y, slope,
+                                                                        x8, x8bs, n8oct, W, W, ai);
 }
 
 // launch heuristics and experiment switches (upf_conv_set_option)

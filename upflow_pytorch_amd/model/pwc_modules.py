@@ -223,6 +223,7 @@ def packed_operands(net):
     ts = []
     for pc in packed_convs(net):
         ts += [t for t in (getattr(pc, 'packed', None), getattr(pc, 'packed32', None), getattr(pc, 'bias', None)) if torch.is_tensor(t)]
+        ts += [t for t in getattr(pc, 'extra_operands', lambda: [])() if torch.is_tensor(t)]
     return ts
 
 
@@ -262,6 +263,124 @@ class _PackedConvC8(object):
         if self.narrow:
             return ops.conv_c8_forward_narrow_raw(x8, packed, bias, y, self.slope)
         return ops.conv_c8_forward_raw(x8, x2, packed, bias, y, self.conv.dilation[0], self.slope, self.conv.kernel_size[0], self.conv.stride[0])
+
+
+class _PackedTailC8(object):
+    """The MERGED NARROW TAIL of a dense stack in the channel-octet layout (round 6; include/upflow_hip.h: upf_conv_forward_c8_split /
+    upf_conv_forward_c8_narrow_init).  The stack's layers read nested channel suffixes of one buffer (pwc_modules.py:279-286), so a layer
+    j > m reads [conv_{j-1} | ... | conv_m | what conv_m read]:  y_j = W_j[:, front part] * (outputs of conv_m .. conv_{j-1}) + W_j[:, rest] *
+    (conv_m's input), and the second term shares its input with conv_m.  A launch with 2 ... 16 output channels costs what the staging of
+    its input costs, and a layer whose width is not a whole number of the kernel's 32-channel blocks computes padding anyway: the pass of
+    conv_m computes, in those padding channels, the second term of the later narrow layers J as fp32 partials (bias included), and each
+    layer of J then is a 16-channel-instruction launch over the few channels IN FRONT of conv_m's input, starting from its partial.
+      SGU estimator (model/upflow.py:24-60), m = conv4, J = {conv5, conv_last}: 16 + [8 | 3 -> 4] = 28 channels in one block; 160->16,
+          176->8, 184->3 (three passes over >= 160 channels) become 160->28, 16->8, 24->3;
+      flow estimator (pwc_modules.py:250-286), m = conv3 (96 channels = three blocks of a four-block workgroup), J = {conv_last}: 371->96
+          and 563->2 become 371->100 (the same launch shape) and 192->2.
+    seqs: the stack's six Sequentials; m, J: indices into them; kmap: the octet-position map of conv_m's input (as _PackedConvC8's)."""
+
+    def __init__(self, seqs, m, J, kmap):
+        self.m, self.J = int(m), sorted(int(j) for j in J)
+        self.kmap = list(kmap)
+        self.main = seqs[m][0]
+        self.convs = [seqs[m][0]] + [seqs[j][0] for j in self.J]
+        self.widths = [q[0].out_channels for q in seqs]
+        self.slopes = {j: (0.1 if any(isinstance(m_, nn.LeakyReLU) for m_ in seqs[j]) else 0.0) for j in [m] + self.J}
+        self.cmain = self.main.out_channels
+        self.cin = self.main.in_channels
+        # partial record of a pixel: every layer of J padded to a multiple of 4 floats
+        self.offsets, off = {}, 0
+        for j in self.J:
+            self.offsets[j] = off
+            off += (self.widths[j] + 3) // 4 * 4
+        self.pp = off
+        self.cout = self.cmain + off
+        self.key = None
+        self.packed = self.bias = None
+        self.finish = {}                                 # layer index -> packed operand of its finishing launch
+
+    @staticmethod
+    def plan(widths):
+        """widths: output channels of conv1..conv5, conv_last -> (m, J) or None.  J: later layers of at most 16 channels, taken from the
+        head backwards while their partial rows fit the padding of conv_m's blocks (a workgroup computes 1, 2 or 4 blocks of 32
+        channels: csrc/conv_c8.hip launch_c8); m: the choice that removes the most staged input, sum over J of conv_m's input."""
+        n = len(widths)
+        cin = [None] * n                                  # input channels relative to the stack's input: only differences matter
+        acc = 0
+        for k in range(n):
+            cin[k] = acc
+            acc += widths[k]
+        best, best_score = None, 0
+        for m in range(n - 2, -1, -1):
+            if widths[m] % 8:
+                continue
+            mt = (widths[m] + 31) // 32
+            free = 32 * (4 if mt >= 3 else mt) - widths[m]
+            if mt > 4:
+                continue
+            J, used = [], 0
+            for j in range(n - 1, m, -1):
+                need = (widths[j] + 3) // 4 * 4
+                if widths[j] > 16 or used + need > free or (j < n - 1 and widths[j] % 8):
+                    break
+                J.append(j); used += need
+            # every layer between m and a member of J must have whole-octet outputs (the finishing launch reads them as octets)
+            if not J or any(widths[k] % 8 for k in range(m, n - 1)):
+                continue
+            score = len(J) * (cin[m] + 1000)              # (+ the stack's input, a constant: more members first, then the later m)
+            if score > best_score:
+                best, best_score = (m, sorted(J)), score
+        return best
+
+    def _key(self):
+        k = []
+        for c in self.convs:
+            k += [c.weight._version, c.weight.dtype, c.weight.device, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()]
+        return tuple(k)
+
+    def get(self):
+        key = self._key()
+        if key != self.key:
+            c0 = self.main
+            rows, bias = [c0.weight.detach()], [c0.bias.detach().float()]
+            self.finish = {}
+            for j, c in zip(self.J, self.convs[1:]):
+                front = sum(self.widths[self.m:j])               # layer input = [outputs of conv_m .. conv_{j-1} (front) | conv_m's input (cin)]
+                w = c.weight.detach()
+                assert w.shape[1] == front + self.cin
+                pad = (c.out_channels + 3) // 4 * 4 - c.out_channels
+                rows.append(w[:, front:])
+                bias.append(c.bias.detach().float())
+                if pad:
+                    rows.append(w.new_zeros((pad, self.cin) + tuple(w.shape[2:])))
+                    bias.append(bias[0].new_zeros(pad))
+                self.finish[j] = ops.conv_c8_pack16(w[:, :front].contiguous(), list(range(front)))
+            self.packed = ops.conv_c8_pack(torch.cat(rows, 0).contiguous(), self.kmap)
+            self.bias = torch.cat(bias).contiguous()
+            self.key = key
+        return self.packed, self.bias
+
+    def extra_operands(self):
+        return list(self.finish.values())
+
+    def invalidate(self):
+        self.key = None
+
+    def main_pass(self, x8, y8):
+        """conv_m: x8 = its input octets, y8 = its output octets -> the fp32 partial records of the layers J."""
+        packed, bias = self.get()
+        B, _, H, W, _ = x8.shape
+        part = torch.empty((B, H, W, self.pp), dtype=torch.float32, device=x8.device)
+        ops.conv_c8_forward_split_raw(x8, packed, bias, y8, part, self.slopes[self.m])
+        return part
+
+    def finish_pass(self, j, x8_front, part, y):
+        """layer j of J: x8_front = the octets in front of conv_m's input that layer j reads, y = its destination."""
+        self.get()
+        return ops.conv_c8_forward_narrow_init_raw(x8_front, self.finish[j], part, self.offsets[j], self.widths[j], y, self.slopes[j])
+
+
+MERGE_TAIL = [True]          # experiment / parity switch: False = every layer of a dense stack its own pass (rounds 3-5)
 
 
 def c8_level_ok(nb, H, W, dtype):
@@ -420,16 +539,35 @@ class _DenseStack(tools.abstract_model):
                 packed.append(_PackedConvC8(getattr(self, name), list(range(nconv)) + [m + nconv if m >= 0 else -1 for m in imap]))
                 nconv += f
             packed.append(_PackedConvC8(self.conv_last, list(range(nconv)) + [m + nconv if m >= 0 else -1 for m in imap]))
+            # the merged narrow tail (_PackedTailC8): the narrow last layers' shared-input part computed by an earlier layer's pass
+            widths = list(self._f) + [self.conv_last[0].out_channels]
+            seqs = [getattr(self, n_) for n_ in self._NAMES] + [self.conv_last]
+            plain = all(all(isinstance(x_, (nn.Conv2d, nn.LeakyReLU)) for x_ in q_) for q_ in seqs)
+            pl = _PackedTailC8.plan(widths) if plain else None
+            if pl is not None:
+                nbefore = sum(self._f[:pl[0]])
+                packed.append(_PackedTailC8(seqs, pl[0], pl[1], list(range(nbefore)) + [q + nbefore if q >= 0 else -1 for q in imap]))
             cache[key] = (packed, len(imap) // 8)
         packed, n_in = cache[key]
-        hi = sum(self._f) // 8
-        no = hi + n_in
-        for pc, f in zip(packed[:5], self._f):
-            pc(buf8[:, hi:no], None, buf8[:, hi - f // 8:hi])
+        nl = len(self._f)
+        no = sum(self._f) // 8 + n_in
+        starts, hi = [], sum(self._f) // 8                  # layer k reads octets [starts[k], no) and writes [starts[k + 1], starts[k])
+        for f in self._f:
+            starts.append(hi)
             hi -= f // 8
+        starts.append(hi)
         if out is None:
             out = torch.empty((buf8.shape[0], self.conv_last[0].out_channels) + tuple(buf8.shape[2:4]), dtype=buf8.dtype, device=buf8.device)
-        packed[5](buf8[:, :no], None, out)
+        tail = packed[nl + 1] if (len(packed) > nl + 1 and MERGE_TAIL[0] and not getattr(self, '_no_merge_tail', False)) else None
+        part = None
+        for k in range(nl + 1):
+            y = buf8[:, starts[k + 1]:starts[k]] if k < nl else out
+            if tail is not None and k == tail.m:
+                part = tail.main_pass(buf8[:, starts[k]:no], y)
+            elif tail is not None and k in tail.J:
+                tail.finish_pass(k, buf8[:, starts[k]:starts[tail.m]], part, y)
+            else:
+                packed[k](buf8[:, starts[k]:no], None, y)
         return out
 
     def _train_convs(self):
