@@ -499,14 +499,6 @@ int upf_robust_loss_forward(const float* x, const float* y, const float* occ, fl
 int upf_robust_loss_backward(const float* x, const float* y, const float* occ, const float* coef,
                              float* grad_x, float* grad_y, int B, int C, int HW, float eps, float q, void* stream);
 
-/* The finished 'abs_robust' term in two launches: out2[0] = S / den, out2[1] = den, with S and sum occ as above and
- * den = den_scale * sum occ + 1e-6 (den_scale 1: photo_loss_multi_type, model/upflow.py:265-288; 2: the census term, utils/loss.py:28-31),
- * or the element count B*C*HW when occ is NULL.  y may be NULL (= 0: the census distance against zero).  Backward: the gradients of
- * out2[0] times grad_out[0] (device scalars: no host round trip, capturable). */
-int upf_robust_loss_ratio_forward(const float* x, const float* y, const float* occ, float* partials, float* out2,
-                                  int B, int C, int HW, float eps, float q, float den_scale, void* stream);
-int upf_robust_loss_ratio_backward(const float* x, const float* y, const float* occ, const float* grad_out, const float* fwd_out2,
-                                   float* grad_x, float* grad_y, int B, int C, int HW, float eps, float q, void* stream);
 /* grey = 0.2989 r + 0.5870 g + 0.1140 b of an RGB image [B,3,HW] -> [B,1,HW], the reference's left-to-right evaluation
  * (utils/loss.py:53-55). */
 int upf_grey_forward(const float* image, float* grey, int B, int HW, void* stream);

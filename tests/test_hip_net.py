@@ -316,21 +316,21 @@ def test_fp16_overflow_check_raises():
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, 'bf16+fp16pyr'])
 def test_bench_path_vs_reference_at_realistic_motion(dtype):
     """EXACTLY what bench.py times — 384x1280, batch 4, 16-bit, every convolution on the hand-written kernels, octet
-    estimator, hipGraph replays with two steps in flight (PipelinedInference) — against the REFERENCE's fp32 output at realistic motion
+    estimator, hipGraph replays with four steps in flight (PipelinedInference) — against the REFERENCE's fp32 output at realistic motion
     (tests/golden/net_384x1280_hs1_robust.npz: two distinct pairs, mean |flow| 15.6 px; batch = [p0, p1, p1, p0]).  The
     reference has no 16-bit path, so this is a measured distance with a bound, reported in px and as a
     fraction of the mean flow magnitude; items that hold the same pair must agree bit for bit."""
     from upflow_pytorch_amd.runtime import PipelinedInference
     im1, im2, g, occ, meta = _hs1_case('net_384x1280_hs1_robust', 384, 1280, (2, 12))
     net = build_mixed() if dtype == 'bf16+fp16pyr' else build('robust', dtype, head_scale=1.0)
-    # bench.py keeps two steps in flight on two HIP streams (runtime.PipelinedInference): slot 0 runs [p0, p1, p1, p0], slot 1
-    # [p1, p0, p0, p1], several rounds, concurrently
-    pipe = PipelinedInference(net, 4, 384, 1280, streams=2, device=im1.device)
-    idxs = ([0, 1, 1, 0], [1, 0, 0, 1])
+    # bench.py keeps FOUR steps in flight on four HIP streams (runtime.PipelinedInference; `steps_in_flight` of its line): slots 0 / 2 run
+    # [p0, p1, p1, p0], slots 1 / 3 [p1, p0, p0, p1], several rounds, concurrently
+    pipe = PipelinedInference(net, 4, 384, 1280, streams=4, device=im1.device)
+    idxs = ([0, 1, 1, 0], [1, 0, 0, 1], [0, 1, 1, 0], [1, 0, 0, 1])
     for slot, idx in enumerate(idxs):
         pipe.load(slot, im1[idx].contiguous(), im2[idx].contiguous())
     for _ in range(3):
-        for slot in range(2):
+        for slot in range(4):
             pipe.replay(slot)
     worst = 0.0
     for slot, idx in enumerate(idxs):
@@ -344,7 +344,7 @@ def test_bench_path_vs_reference_at_realistic_motion(dtype):
         p99 = float(per.flatten()[::7].quantile(0.99))
         eb = oracle.epe(out['flow_b_out'].float()[:, :, ::4, ::4].cpu(), g['flow_b_out'][idx])
         occ_mis = float((out['occ_fw'].float().cpu() != occ[idx]).float().mean())
-        print('bench path %s 384x1280 B=4 graphed, 2 steps in flight, slot %d vs REFERENCE: EPE fwd %.4f px (p99 %.3f) bwd %.4f px = %.3f %% of mean |flow| %.2f px; occlusion-mask mismatches %.3f %%'
+        print('bench path %s 384x1280 B=4 graphed, 4 steps in flight, slot %d vs REFERENCE: EPE fwd %.4f px (p99 %.3f) bwd %.4f px = %.3f %% of mean |flow| %.2f px; occlusion-mask mismatches %.3f %%'
               % (dtype, slot, e, p99, eb, 100 * e / meta['mean_flow_px'], meta['mean_flow_px'], 100 * occ_mis))
         assert e <= BENCH_PATH_VS_REFERENCE_PX[dtype] and eb <= BENCH_PATH_VS_REFERENCE_PX[dtype]
         assert e <= BENCH_PATH_VS_REFERENCE_FRAC[dtype] * meta['mean_flow_px']
@@ -352,6 +352,7 @@ def test_bench_path_vs_reference_at_realistic_motion(dtype):
     # the two slots hold the same pairs in another order: concurrent execution must not change a bit
     a, b = pipe.result(0)['flow_f_out'], pipe.result(1)['flow_f_out']
     assert torch.equal(a[0], b[1]) and torch.equal(a[1], b[0])
+    assert torch.equal(pipe.result(2)['flow_f_out'], a) and torch.equal(pipe.result(3)['flow_f_out'], b)
 
 
 def test_pipelined_inference_equals_one_step_at_a_time():

@@ -555,27 +555,6 @@ def test_fused_distillation_term_matches_the_composition(shape, use_occ):
     assert all(torch.equal(a, b) for a, b in zip(ggot, again))
 
 
-@pytest.mark.parametrize('case', [('occ', 1.0, True), ('occ', 2.0, False), ('mean', 1.0, True)])
-def test_robust_loss_ratio_matches_sums_and_division(case):
-    """upf_robust_loss_ratio_forward / _backward == robust_loss_sums followed by the reference's division (model/upflow.py:265-288,
-    utils/loss.py:28-33), value and gradients; y = None is the census form (against zero); deterministic."""
-    from upflow_pytorch_amd import ops
-    mode, scale, with_y = case
-    g = torch.Generator().manual_seed(11)
-    x = (torch.randn(3, 2, 37, 53, generator=g)).cuda().requires_grad_(True)
-    y = (torch.randn(3, 2, 37, 53, generator=g)).cuda().requires_grad_(True) if with_y else None
-    occ = (torch.rand(3, 1, 37, 53, generator=g) > 0.4).float().cuda() if mode == 'occ' else None
-    got = ops.robust_loss_ratio(x, y, occ, q=0.4, eps=0.01, den_scale=scale)
-    yy = y if with_y else torch.zeros_like(x)
-    s, so = ops.robust_loss_sums(x, yy, occ, q=0.4, eps=0.01)
-    ref = s / (so * scale + 1e-6) if mode == 'occ' else s / float(x.numel())
-    assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
-    ins = [x] + ([y] if with_y else [])
-    for a, b in zip(torch.autograd.grad(got, ins), torch.autograd.grad(ref, ins)):
-        assert relerr(a.cpu(), b.cpu()) <= 1e-5
-    assert float(got) == float(ops.robust_loss_ratio(x, y, occ, q=0.4, eps=0.01, den_scale=scale))
-
-
 def test_grey_is_the_reference_expression_bit_for_bit():
     from upflow_pytorch_amd import ops
     img = torch.randn(2, 3, 33, 47, generator=torch.Generator().manual_seed(5)).cuda()

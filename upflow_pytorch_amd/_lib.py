@@ -82,8 +82,6 @@ SIGNATURES = {
     'upf_boundary_warp_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_robust_loss_forward': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     'upf_robust_loss_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
-    'upf_robust_loss_ratio_forward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp],
-    'upf_robust_loss_ratio_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     'upf_grey_forward': [_vp, _vp, _i, _i, _vp],
     'upf_msd_upup_forward': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp],
     'upf_msd_upup_backward': [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp],

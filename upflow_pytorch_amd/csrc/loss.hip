@@ -131,37 +131,6 @@ void robust_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
   if (gy) gy[e] = -g;
 }
 
-// The finished term in one more launch instead of a reduction and 2-3 scalar kernels each way:
-//   out2[0] = S / den,  out2[1] = den;   den = den_scale * sum occ + 1e-6  (den_scale 1: photo_loss_multi_type, 2: the census term,
-//   utils/loss.py:28-31)  or, den_const > 0 (no mask), that constant (the element count).
-__global__ __launch_bounds__(NT)
-void robust_finish_kernel(const float* __restrict__ partials, int nb, float den_scale, float den_const, float* __restrict__ out2) {
-  __shared__ float sh[NT / 64];
-  float a = 0.f, b = 0.f;
-  for (int k = threadIdx.x; k < nb; k += NT) { a += partials[2 * k]; b += partials[2 * k + 1]; }
-  const float S = block_sum(a, sh), So = block_sum(b, sh);
-  if (threadIdx.x != 0) return;
-  const float den = den_const > 0.f ? den_const : den_scale * So + 1e-6f;
-  out2[0] = S / den; out2[1] = den;
-}
-// robust_bwd_kernel with the coefficient gout[0] / den[0] (the backward of the finished term)
-__global__ __launch_bounds__(NT)
-void robust_bwd_ratio_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ occ,
-                             const float* __restrict__ gout, const float* __restrict__ out2, float* __restrict__ gx, float* __restrict__ gy,
-                             int C, int HW, long long total, float eps, float q) {
-  const long long e = blockIdx.x * (long long)NT + threadIdx.x;
-  if (e >= total) return;
-  const long long nc = e / HW;
-  const int i = (int)(e - nc * HW);
-  const long long n = nc / C;
-  const float d = x[e] - (y ? y[e] : 0.f);
-  const float o = occ ? occ[n * HW + i] : 1.0f;
-  const float sg = (d > 0.f) ? 1.0f : ((d < 0.f) ? -1.0f : 0.f);
-  const float g = (gout[0] / out2[1]) * o * q * powf(fabsf(d) + eps, q - 1.0f) * sg;
-  if (gx) gx[e] = g;
-  if (gy) gy[e] = -g;
-}
-
 // grey = 0.2989 r + 0.5870 g + 0.1140 b, evaluated left to right with separate roundings like the reference's expression
 // (utils/loss.py:53-55; this file is compiled with -ffp-contract=off): one launch instead of five element-wise ones per image
 __global__ void grey_kernel(const float* __restrict__ img, float* __restrict__ out, int HW, long long total) {
@@ -287,32 +256,6 @@ extern "C" int upf_robust_loss_backward(const float* x, const float* y, const fl
   hipLaunchKernelGGL(loss::robust_bwd_kernel, dim3((unsigned)((total + loss::NT - 1) / loss::NT)), dim3(loss::NT), 0, (hipStream_t)stream,
                      x, y, occ, coef, grad_x, grad_y, C, HW, total, eps, q);
   return check_launch("robust_loss_backward");
-}
-
-extern "C" int upf_robust_loss_ratio_forward(const float* x, const float* y, const float* occ, float* partials, float* out2,
-                                             int B, int C, int HW, float eps, float q, float den_scale, void* stream) {
-  using namespace upf;
-  UPF_REQUIRE(x && partials && out2, UPF_EINVAL, "robust_loss_ratio_forward: null pointer");
-  UPF_REQUIRE(B > 0 && C > 0 && HW > 0 && den_scale > 0.f, UPF_EINVAL, "robust_loss_ratio_forward: bad shape / den_scale");
-  const long long npix = (long long)B * HW;
-  const int nb = loss::red_blocks(npix);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss::robust_fwd_kernel, dim3(nb), dim3(loss::NT), 0, s, x, y, occ, partials, C, HW, npix, eps, q);
-  hipLaunchKernelGGL(loss::robust_finish_kernel, dim3(1), dim3(loss::NT), 0, s, (const float*)partials, nb, den_scale,
-                     occ ? 0.f : (float)((double)B * C * HW), out2);
-  return check_launch("robust_loss_ratio_forward");
-}
-
-extern "C" int upf_robust_loss_ratio_backward(const float* x, const float* y, const float* occ, const float* grad_out, const float* fwd_out2,
-                                              float* grad_x, float* grad_y, int B, int C, int HW, float eps, float q, void* stream) {
-  using namespace upf;
-  UPF_REQUIRE(x && grad_out && fwd_out2 && (grad_x || grad_y), UPF_EINVAL, "robust_loss_ratio_backward: null pointer");
-  UPF_REQUIRE(B > 0 && C > 0 && HW > 0, UPF_EINVAL, "robust_loss_ratio_backward: bad shape");
-  const long long total = (long long)B * C * HW;
-  UPF_REQUIRE((total + loss::NT - 1) / loss::NT < (1ll << 31), UPF_EINVAL, "robust_loss_ratio_backward: grid too large");
-  hipLaunchKernelGGL(loss::robust_bwd_ratio_kernel, dim3((unsigned)((total + loss::NT - 1) / loss::NT)), dim3(loss::NT), 0, (hipStream_t)stream,
-                     x, y, occ, grad_out, fwd_out2, grad_x, grad_y, C, HW, total, eps, q);
-  return check_launch("robust_loss_ratio_backward");
 }
 
 extern "C" int upf_grey_forward(const float* image, float* grey, int B, int HW, void* stream) {

@@ -186,9 +186,6 @@ class network_tools():
         occ_weight = occ_mask
         if photo_loss_type == 'abs_robust':
             # sub / abs / add / pow / mul / sum of the reference as ONE deterministic reduction (csrc/loss.hip)
-            if x.is_cuda and hasattr(ops, 'robust_loss_ratio') and os.environ.get('UPF_FUSED_RATIO') == '1':
-                # the reduction AND its denominator in two launches each way (ops.RobustRatioFunction) — OPT-IN: see utils/loss.py
-                return ops.robust_loss_ratio(x, y, occ_mask if photo_loss_use_occ else None, q=photo_loss_delta, eps=0.01)
             s, s_occ = ops.robust_loss_sums(x, y, occ_mask if photo_loss_use_occ else None, q=photo_loss_delta, eps=0.01)
             return s / (s_occ + 1e-6) if photo_loss_use_occ else s / float(x.numel())
         elif photo_loss_type == 'charbonnier':
@@ -764,8 +761,10 @@ class UPFlow_net(tools.abstract_model):
         fine_2 = self.context_networks(torch.cat([feat_2, (flow_2_up + res_2).to(feat_2.dtype)], dim=1)).float()
         return flow_1_up, flow_2_up, res_1 + fine_1, res_2 + fine_2
 
-    def to_inference(self, dtype=torch.bfloat16, pyramid_dtype=None, device=None):
-        """Cast the network for 16-bit inference; with `pyramid_dtype` (torch.float16) the feature pyramid and the 1x1 projections —
+    def to_inference(self, dtype=torch.bfloat16, pyramid_dtype='auto', device=None):
+        """Cast the network for 16-bit inference; with `pyramid_dtype` (torch.float16; 'auto', the default: fp16 under dtype = bfloat16
+        — round 6: measured in bench.py's own line, 0.097 px to the reference instead of 0.179 px for -0.9 % throughput —, otherwise
+        `dtype` itself; None or `dtype`: one type everywhere, like `net.to(dtype)`) the feature pyramid and the 1x1 projections —
         1.5 % of a step's flop, but > 60 % of the bf16 path's distance to the reference (profiles/r04_precision_localise.txt: their
         weights 0.156 px, their activations 0.091 px of 0.175 px at 384x1280) — keep fp16 weights, features and warped features, the
         cost volume reads fp16 features (its fp16 matrix instruction) and everything downstream (cost volume output, estimator,
@@ -773,6 +772,10 @@ class UPFlow_net(tools.abstract_model):
         from their bf16 roundings.  Returns self (in eval mode)."""
         if device is not None:
             self.to(device)
+        if isinstance(pyramid_dtype, str):
+            if pyramid_dtype != 'auto':
+                raise ValueError("to_inference: pyramid_dtype must be a torch dtype, None or 'auto'")
+            pyramid_dtype = torch.float16 if dtype == torch.bfloat16 else None
         if pyramid_dtype is None or pyramid_dtype == dtype:
             return self.to(dtype).eval()
         if dtype not in (torch.bfloat16, torch.float16) or pyramid_dtype not in (torch.bfloat16, torch.float16):

@@ -1134,63 +1134,6 @@ def robust_loss_sums(x, y, occ=None, q=0.4, eps=0.01):
     return RobustLossFunction.apply(x, y, occ, q, eps)
 
 
-class RobustRatioFunction(Function):
-    """The finished 'abs_robust' term: sum((|x - y| + eps)^q * occ) / (den_scale * sum(occ) + 1e-6), or / numel without a mask — the
-    reduction, its denominator and their backward in two launches each way instead of a reduction plus 2-3 scalar kernels
-    (upf_robust_loss_ratio_forward / _backward).  y None: against zero (the census distance)."""
-
-    @staticmethod
-    def forward(ctx, x, y, occ, q, eps, den_scale):
-        x = _f32(x).contiguous()
-        if x.dim() != 4:
-            raise UpflowHipError('robust_loss_ratio: a [B,C,H,W] tensor expected, got %s' % (tuple(x.shape),))
-        B, C, H, W = x.shape
-        if y is not None:
-            y = _f32(y).contiguous()
-            if y.shape != x.shape:
-                raise UpflowHipError('robust_loss_ratio: x and y must have one shape, got %s / %s' % (tuple(x.shape), tuple(y.shape)))
-        if occ is not None:
-            occ = _f32(occ).contiguous()
-            if tuple(occ.shape) != (B, 1, H, W):
-                raise UpflowHipError('robust_loss_ratio: occlusion mask must be [B,1,H,W], got %s' % (tuple(occ.shape),))
-            if occ.requires_grad:
-                raise UpflowHipError('robust_loss_ratio: the occlusion weights are treated as constants (hard masks)')
-        dev = _lib.check_gpu(x, y, occ)
-        nb = _lib.lib().upf_loss_partials(B * H * W)
-        partials = torch.empty((nb, 2), dtype=torch.float32, device=x.device)
-        out2 = torch.empty((2,), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(dev):
-            _lib.call('upf_robust_loss_ratio_forward', _lib.ptr(x), _lib.ptr(y), _lib.ptr(occ), _lib.ptr(partials), _lib.ptr(out2), B, C, H * W,
-                      float(eps), float(q), float(den_scale), _lib.stream_ptr(dev))
-        ctx.save_for_backward(x, y, occ, out2)
-        ctx.qe = (float(q), float(eps))
-        ctx.set_materialize_grads(False)
-        return out2[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        if g is None:
-            return None, None, None, None, None, None
-        x, y, occ, out2 = ctx.saved_tensors
-        q, eps = ctx.qe
-        B, C, H, W = x.shape
-        g = _f32(g).reshape(1).contiguous()
-        dev = _lib.check_gpu(x, g)
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gy = torch.empty_like(x) if (y is not None and ctx.needs_input_grad[1]) else None
-        if gx is None and gy is None:
-            return None, None, None, None, None, None
-        with torch.cuda.device(dev):
-            _lib.call('upf_robust_loss_ratio_backward', _lib.ptr(x), _lib.ptr(y), _lib.ptr(occ), _lib.ptr(g), _lib.ptr(out2), _lib.ptr(gx), _lib.ptr(gy),
-                      B, C, H * W, eps, q, _lib.stream_ptr(dev))
-        return gx, gy, None, None, None, None
-
-
-def robust_loss_ratio(x, y=None, occ=None, q=0.4, eps=0.01, den_scale=1.0):
-    """sum((|x - y| + eps)^q * occ) / (den_scale * sum(occ) + 1e-6)  (occ None: / x.numel()) as one differentiable scalar."""
-    return RobustRatioFunction.apply(x, y, occ, q, eps, den_scale)
-
-
 def grey(image):
     """[B,3,H,W] fp32 RGB -> [B,1,H,W]: 0.2989 r + 0.5870 g + 0.1140 b evaluated left to right (utils/loss.py:53-55), one launch."""
     image = _f32(image).contiguous()

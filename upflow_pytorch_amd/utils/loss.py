@@ -66,15 +66,6 @@ def _zeros_like_cached(t):
     return z
 
 
-def _fused_ratio(ops):
-    """ops.robust_loss_ratio (the finished 'abs_robust' term in two launches each way, -0.06 ms of a 9.6 ms config-3 step) is OPT-IN
-    (UPF_FUSED_RATIO=1).  It is the same function — values to 2e-6, gradients to 1e-5 of the composition, tests/test_hip_ops.py — but with it
-    the plateau of tests/test_hip_train.py's 120-step single-pair trajectories (a chaotic system: MIOpen's fp32 gradient kernels sum in
-    arrival order) left the reference's by 4-8.5 % in 8 of 78 runs against 0 of 78 (largest 2.7 %) without it (tools/trajectory_spread.sh,
-    round 5); no mechanism was found, so the default stays the composition whose trajectories were pinned."""
-    return hasattr(ops, 'robust_loss_ratio') and os.environ.get('UPF_FUSED_RATIO') == '1'
-
-
 class loss_functions():
 
     @classmethod
@@ -107,8 +98,6 @@ class loss_functions():
         if (not charbonnier_or_abs_robust) and if_use_occ and dist.is_cuda and dist.dtype == torch.float32:
             # sum((|d| + 0.01)^q * m) / (sum(m) * 2 + 1e-6), utils/loss.py:28-31, as the one-launch reduction of csrc/loss.hip
             # (ops.robust_loss_sums with y = 0) instead of nine element-wise / reduction launches each way
-            if _fused_ratio(ops):
-                return ops.robust_loss_ratio(dist, None, mask * valid, q=q, eps=0.01, den_scale=2.0)
             s, s_m = ops.robust_loss_sums(dist, _zeros_like_cached(dist), mask * valid, q=q, eps=0.01)
             return s / (s_m * 2 + 1e-6)
         if (not charbonnier_or_abs_robust) and (not if_use_occ) and dist.is_cuda and dist.dtype == torch.float32:
@@ -116,8 +105,6 @@ class loss_functions():
             # multi-block `mean()` zeroes its semaphores with a memset node, the node class that was seen mis-ordered inside
             # replayed hipGraphs on this ROCm (api.hip: zero_fill_u64_kernel): inside a captured training step whose allocation
             # pattern had shifted it returned 9.8e3 for inputs whose mean is 2.0 — tools/frozen_graph_probe.py.)
-            if averge and _fused_ratio(ops):
-                return ops.robust_loss_ratio(dist, None, None, q=q, eps=0.01)            # (sum / numel in the same two launches)
             s, _ = ops.robust_loss_sums(dist, _zeros_like_cached(dist), None, q=q, eps=0.01)
             return s / dist.numel() if averge else s
         return cls.photo_loss_function(diff=dist, mask=mask * valid, q=q, charbonnier_or_abs_robust=charbonnier_or_abs_robust,
