@@ -355,7 +355,8 @@ def train_main(args, rank, world, device):
             'dtype': dname, 'data': 'synthetic',
             'config': {'workload': 'config3: photometric + smooth + census + pyramid-distillation loss, fwd+bwd+Adam(amsgrad), '
                                    '256x832 crops of 288x864 frames, batch 4 per GPU', 'global_batch': world * B,
-                       'parallelism': 'dp%d (DDP, one 25 MB gradient bucket, RCCL all-reduce)' % world, 'ranks': world, 'rank_ms_per_step': spread,
+                       'parallelism': 'dp%d (DDP, %d gradient bucket(s) in completion order, RCCL all-reduce inside the captured step)' % (world, max(1, len(parallel.ddp_bucket_bytes(tr.net)))),
+                       'gradient_buckets_bytes': parallel.ddp_bucket_bytes(tr.net) or None, 'ranks': world, 'rank_ms_per_step': spread,
                        'hip_graph': tr.use_graph,
                        'capture_fallback': tr.capture_fallback,      # True: the hipGraph capture failed and the steps ran eagerly
                        'optimizer': 'torch.optim.Adam(amsgrad, weight_decay 1e-4, %s)' % ('fused: one multi-tensor kernel' if tr.fused_adam else 'foreach'),

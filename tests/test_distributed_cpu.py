@@ -191,6 +191,49 @@ def test_real_upflow_net_trainer_under_ddp_two_ranks():
     assert abs(res[0][1]['loss'] - (ref[0][0]['loss'] + ref[1][0]['loss']) / 2) <= 1e-5 * abs(res[0][1]['loss'])
 
 
+def _bucket_worker(rank, world, port, q, cap_mb):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      UPF_DDP_BUCKET_MB=str(cap_mb))
+    torch.set_num_threads(2)
+    net, batch = _real_net()
+    from upflow_pytorch_amd import parallel
+    from upflow_pytorch_amd.train import Trainer
+    parallel.init_from_env(backend='gloo')
+    tr = Trainer(net, lr=1e-4)
+    first = parallel.ddp_bucket_bytes(tr.net)
+    for _ in range(3):                                   # (DDP rebuilds its buckets in gradient-ready order after the first step)
+        stats = tr.step(tr.shard(batch))
+    params = torch.cat([p.detach().flatten() for _, p in sorted(tr.raw_net.named_parameters())])
+    q.put((rank, stats, _flat_grads(tr.raw_net).numpy(), params.numpy(), first, parallel.ddp_bucket_bytes(tr.net)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_three_gradient_buckets_equal_the_single_bucket():
+    """parallel.ddp_wrap's default (round 6): three ~5 MB gradient buckets in completion order instead of one 25 MB bucket — the
+    all-reduced gradients and the parameters after three optimizer steps are BIT-identical to the single-bucket run (an element's
+    sum over ranks does not depend on which message carried it), on both ranks; the buckets cover all 13,978,196 bytes."""
+    ctx = mp.get_context('spawn')
+    runs = {}
+    for cap in (25, 5):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q, cap)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=400) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(30)
+            assert p.exitcode == 0
+        assert (res[0][2] == res[1][2]).all() and (res[0][3] == res[1][3]).all()
+        runs[cap] = res[0]
+    assert len(runs[25][5]) == 1 and sum(runs[25][5]) == 13978196
+    assert len(runs[5][5]) == 3 and sum(runs[5][5]) == 13978196 and max(runs[5][5]) <= 7 * 2 ** 20, runs[5][5]      # (a bucket closes with the parameter that crosses the cap: 5.8 + 5.4 + 2.8 MB)
+    assert (runs[25][2] == runs[5][2]).all() and (runs[25][3] == runs[5][3]).all()
+    assert runs[25][1] == runs[5][1]
+
+
 @pytest.mark.timeout(300)
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it re-executes under torch.distributed.run (here: gloo,

@@ -3,7 +3,7 @@
 The reference's only multi-GPU construct is single-process nn.DataParallel
 (/root/reference/utils/tools.py:140).  Here image pairs shard across ranks: inference needs no
 collective at all (replicas); training needs one exchange per step — the all-reduce(mean) of the
-3,494,549 fp32 gradients (13.98 MB, one DDP bucket) — see DESIGN.md §multi-GPU.
+3,494,549 fp32 gradients (13.98 MB, three DDP buckets in gradient-completion order) — see DESIGN.md §multi-GPU.
 """
 import os
 
@@ -28,15 +28,36 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def ddp_wrap(model, device=None):
-    """DistributedDataParallel with one 25 MB bucket: the whole 13.98 MB gradient fits one ring
-    all-reduce (xGMI is per-link bound, so fewer and larger messages win)."""
+DDP_BUCKET_MB = 5
+
+
+def ddp_wrap(model, device=None, bucket_cap_mb=None):
+    """DistributedDataParallel over the 13.98 MB of fp32 gradients in THREE buckets (cap 5 MB -> 5.8 + 5.4 + 2.8 MB; round 6 —
+    rounds 1-5 used one 25 MB bucket, whose all-reduce could only start when the LAST gradient existed, with nothing left to overlap).
+    DDP orders its buckets by the order in which the gradients became ready in the first step (it rebuilds them once, before the
+    Trainer captures the step): here the SGU / context / estimator weights — whose multi-level contractions run first at the end of
+    backward (ops.shared_conv_grads) — then the feature pyramid, so the ring all-reduce of a finished bucket runs under the
+    remaining weight-gradient contractions, on RCCL's own stream, inside the captured graph.  xGMI is per-link bound: three
+    messages of ~5 MB are still far above the size where a ring's latency term matters (8 ranks: 7 x 2 steps of 0.66 MB each).
+    bucket_cap_mb: None = UPF_DDP_BUCKET_MB from the environment, else DDP_BUCKET_MB; 25 restores the single bucket."""
     from torch.nn.parallel import DistributedDataParallel as DDP
+    if bucket_cap_mb is None:
+        bucket_cap_mb = float(os.environ.get('UPF_DDP_BUCKET_MB', DDP_BUCKET_MB))
     if device is None and torch.cuda.is_available():
         device = torch.device('cuda', torch.cuda.current_device())
     if device is not None and device.type == 'cuda':
-        return DDP(model.to(device), device_ids=[device.index], bucket_cap_mb=25, gradient_as_bucket_view=True)
-    return DDP(model, bucket_cap_mb=25)
+        return DDP(model.to(device), device_ids=[device.index], bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    return DDP(model, bucket_cap_mb=bucket_cap_mb)
+
+
+def ddp_bucket_bytes(ddp):
+    """Sizes (bytes) of the gradient buckets `ddp` all-reduces per step, in launch order: the rebuilt ones once DDP has rebuilt them
+    (after its first steps), the initial assignment before that.  [] for a module that is not DDP-wrapped."""
+    if not hasattr(ddp, '_get_ddp_logging_data'):
+        return []
+    ld = ddp._get_ddp_logging_data()
+    txt = ld.get('rebuilt_bucket_sizes') or ld.get('bucket_sizes') or ''
+    return [int(t) for t in str(txt).replace(' ', '').split(',') if t]
 
 
 def shard_indices(n_items, rank, world):

@@ -10,8 +10,8 @@ What the reference intends (its published scripts do not run: SURVEY.md §3.3):
 Multi-GPU: the reference wraps the net in single-process nn.DataParallel (utils/tools.py:140); here the
 global batch is sharded across ranks, each rank runs the whole forward/backward on its shard through
 the HIP operators, and the ONLY exchange per step is DDP's all-reduce(mean) of the 3,494,549 fp32
-gradients (13.98 MB — one 25 MB bucket, one ring all-reduce over xGMI) plus a 4-float all-reduce for
-logging.
+gradients (13.98 MB — three ~5 MB buckets in gradient-completion order, ring all-reduces over xGMI that overlap the
+remaining weight-gradient contractions: parallel.ddp_wrap) plus a 5-float all-reduce for logging.
 """
 import torch
 import torch.distributed as dist
