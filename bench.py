@@ -56,7 +56,7 @@ def build_net(dtype, device, hip_pyramid_convs=True, fp32_conv='hip_x3', pyramid
     return net.to(device).to(dtype).eval()
 
 
-def roofline_probe(B, H, W, dtype, device):
+def roofline_probe(B, H, W, dtype, device, feature_dtype=None):
     """Dominant hand-written kernel: corr81 forward at the 1/4-resolution level (C=32) of this workload, with the shape
     of the launch the model makes there ([2B,32,H/4,W/4]: both flow directions of the B frame pairs in one launch).
 
@@ -71,7 +71,9 @@ def roofline_probe(B, H, W, dtype, device):
     B = 2 * B            # the launch the model makes: both flow directions stacked along the batch (UPFlow_net._forward_stacked)
     g = torch.Generator(device='cpu').manual_seed(2004)
     # (the [features; warped] pair buffer of the level as the step allocates it: row-pitched when the level width is ragged)
-    pair = ops.empty_nchw((2, B, C, h, w), dtype, device)
+    # feature_dtype: the pyramid's type when it differs from the decoder's (`pyramid_dtype`: fp16 features, bf16 cost volume)
+    fdt = feature_dtype if (feature_dtype is not None and dtype != torch.float32) else dtype
+    pair = ops.empty_nchw((2, B, C, h, w), fdt, device)
     pair[0].copy_(torch.randn(B, C, h, w, generator=g).to(device))
     pair[1].copy_(torch.randn(B, C, h, w, generator=g).to(device))
     f1, f2 = pair[0], pair[1]
@@ -85,6 +87,10 @@ def roofline_probe(B, H, W, dtype, device):
     pitched = ops.nchw_pitch(f1) != w
     if pitched and not c8:
         f1, f2 = f1.contiguous(), f2.contiguous()                            # (the timed NCHW-output helpers take contiguous features)
+    if fdt != dtype and not c8:
+        fdt = dtype                                   # (only the octet form has a timed mixed entry: time the single-type launch)
+        pair = pair.to(dtype)
+        f1, f2 = pair[0], pair[1]
     if c8:
         out8 = ops.c8_empty(B, 88, h, w, dtype, device)
         timed = lambda f1_, f2_, out_, slope, nrep: ops.corr81_norm_forward_c8_timed(f1_, f2_, out8, slope, nrep=nrep)
@@ -93,6 +99,8 @@ def roofline_probe(B, H, W, dtype, device):
     timed(f1, f2, out, 0.1, nrep=20)                                         # warm
     avg_us, min_us = timed(f1, f2, out, 0.1, nrep=200)
     fc1, fc2 = (f1.contiguous(), f2.contiguous()) if pitched else (f1, f2)
+    if fdt != dtype:
+        fc1, fc2 = fc1.to(dtype), fc2.to(dtype)       # (the side variants are single-type launches)
     nchw_norm_us = ops.corr81_norm_forward_timed(fc1, fc2, out, 0.1, nrep=200)[0] if c8 else None
     plain_us = ops.corr81_forward_timed(fc1, fc2, out, 0.1, nrep=200)[0] if norm else avg_us
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
@@ -128,6 +136,8 @@ def roofline_probe(B, H, W, dtype, device):
     extra = {'nchw_output_variant_us': round(nchw_norm_us, 2), 'stored_over_algorithmic_bytes': round((2 * C + 88) / (2 * C + 81), 4)} if c8 else {}
     if pitched:
         extra['feature_row_pitch'] = ops.nchw_pitch(f1)
+    if fdt != dtype:
+        kname += ' [features %s -> cost volume %s]' % (str(fdt).replace('torch.', ''), str(dtype).replace('torch.', ''))
     return {'bound': 'hbm', 'kernel': kname, 'shape': [B, C, h, w], **extra,
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes': alg_bytes, 'avg_kernel_us': round(avg_us, 2), 'min_kernel_us': round(min_us, 2),
@@ -736,7 +746,7 @@ def main():
                        'pyramid_convs': 'PyTorch-ROCm' if args.torch_pyramid or (dtype == torch.float32 and args.fp32_conv == 'miopen') else 'HIP (MFMA kernel)',
                        'fp32_conv': args.fp32_conv if dtype == torch.float32 else None,
                        'pyramid_dtype': args.pyramid_dtype},
-            'roofline': roofline_probe(B, H, W, dtype, device),
+            'roofline': roofline_probe(B, H, W, dtype, device, feature_dtype=DT[args.pyramid_dtype] if args.pyramid_dtype else None),
         }
         conv_rf = conv_roofline_probe(B, H, W, dtype, device, args.fp32_conv)
         if conv_rf is not None:

@@ -118,6 +118,12 @@ int upf_corr81_norm_forward_c8_timed_pitched(const void* f1, const void* f2, int
                                              int B, int C, int H, int W, int dtype, float leaky_slope, void* workspace, void* stream,
                                              int nrep, float* avg_us, float* min_us);
 
+/* ... with the output's storage type given separately (upf_corr81_norm_forward_c8_mixed: fp16 features -> bf16 octets, what the
+ * bf16 step launches since its feature pyramid stays fp16 — UPFlow_net.to_inference, round 6) */
+int upf_corr81_norm_forward_c8_timed_mixed(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride,
+                                           int B, int C, int H, int W, int dtype, int out_dtype, float leaky_slope, void* workspace, void* stream,
+                                           int nrep, float* avg_us, float* min_us);
+
 /* Launch heuristics of the 16-bit cost volume, for tuning and for the tests to reach every kernel variant:
  *   "variant"  (-1)  -1 = choose by shape; 0..3 = force tile geometry 8x32 / 4x32 / 2x32 / 4x16 where C fits
  *   "old_path" (0)   1 = the channel-chunked kernels (corr81_mfma_kernel / corr81_fwd_kernel) instead of the

@@ -12,7 +12,7 @@ from upflow_pytorch_amd import ops
 B, C, H, W = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (4, 32, 96, 320)))
 dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[sys.argv[5] if len(sys.argv) > 5 else 'bf16']
 var = sys.argv[6] if len(sys.argv) > 6 else 'plain'      # norm: the normalising variant (upf_corr81_norm_forward); norm_c8: the same with octet output (the kernel inside the step at the fine levels)
-if var == 'norm_c8':
+if var in ('norm_c8', 'norm_c8_mixed'):      # norm_c8_mixed (round 6): fp16 features -> octets of type `dt`: the bf16 step's launch since its pyramid stays fp16
     fwd = lambda: ops.corr81_norm_forward_c8(f1, f2, out8, leaky_slope=0.1)
 elif var == 'norm':
     fwd = lambda: ops.corr81_norm_forward_raw(f1, f2, out=out, leaky_slope=0.1)
@@ -20,7 +20,8 @@ else:
     fwd = lambda: ops.corr81_forward_raw(f1, f2, out=out, leaky_slope=0.1)
 g = torch.Generator().manual_seed(2004)
 # (norm_c8 at a ragged width — KITTI's native 94x311 level — takes ROW-PITCHED features, like the step's pair buffers: ops.empty_nchw)
-pair = ops.empty_nchw((2, B, C, H, W), dt, 'cuda', pitched=(var == 'norm_c8')) if dt != torch.float32 else torch.empty(2, B, C, H, W, device='cuda')
+fdt = torch.float16 if var == 'norm_c8_mixed' else dt
+pair = ops.empty_nchw((2, B, C, H, W), fdt, 'cuda', pitched=var.startswith('norm_c8')) if dt != torch.float32 else torch.empty(2, B, C, H, W, device='cuda')
 pair[0].copy_(torch.randn(B, C, H, W, generator=g).cuda())
 pair[1].copy_(torch.randn(B, C, H, W, generator=g).cuda())
 f1, f2 = pair[0], pair[1]

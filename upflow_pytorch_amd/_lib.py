@@ -29,6 +29,7 @@ SIGNATURES = {
     'upf_corr81_norm_forward_pitched': [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp],
     'upf_corr81_norm_forward_c8_pitched': [_vp, _vp, _i, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp],
     'upf_corr81_norm_forward_c8_timed_pitched': [_vp, _vp, _i, _vp, _ll, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
+    'upf_corr81_norm_forward_c8_timed_mixed': [_vp, _vp, _i, _vp, _ll, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _c.POINTER(_f), _c.POINTER(_f)],
     'upf_warp_forward_pitched': [_vp, _ll, _i, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_forward_gated': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _vp, _ll, _vp, _ll, _f, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_forward_pitched': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],

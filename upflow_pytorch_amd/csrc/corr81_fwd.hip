@@ -455,8 +455,11 @@ extern "C" int upf_corr81_norm_forward_c8(const void* f1, const void* f2, void* 
 // launch, then nrep launches of the cost-volume kernel, each between its own pair of HIP events on the launch stream.
 static int norm_forward_timed_impl(bool c8, const void* f1, const void* f2, void* out, int B, int C, int H, int W, int dtype,
                                    long long out_batch_stride, float leaky_slope, void* workspace, void* stream, int nrep,
-                                   float* avg_us, float* min_us, int fp = 0) {
+                                   float* avg_us, float* min_us, int fp = 0, int out_dtype = -1) {
   using namespace upf;
+  if (out_dtype < 0) out_dtype = dtype;
+  UPF_REQUIRE(out_dtype == dtype || (c8 && dtype == UPF_F16 && out_dtype == UPF_BF16), UPF_EUNSUPPORTED,
+              "corr81_norm_forward_timed: a second output type is timed for fp16 features -> bf16 octets only (the `pyramid_dtype` step)");
   UPF_REQUIRE(f1 && f2 && out && workspace && avg_us, UPF_EINVAL, "corr81_norm_forward_timed: null pointer");
   UPF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && nrep > 0 && nrep <= 1024, UPF_EINVAL, "corr81_norm_forward_timed: bad arguments");
   if (fp == 0) fp = W;
@@ -480,7 +483,9 @@ static int norm_forward_timed_impl(bool c8, const void* f1, const void* f2, void
   hipEvent_t* ev = new hipEvent_t[2 * nrep];
   for (int i = 0; i < 2 * nrep; ++i) (void)hipEventCreate(&ev[i]);
   for (int i = 0; i < nrep && rc == UPF_OK; ++i) {
-    if (padw && dtype == UPF_BF16) rc = corr::launch_allc_c8<bf16_t, true>(vc8, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
+    if (out_dtype != dtype) rc = padw ? corr::launch_allc_c8<f16_t, true, bf16_t>(vc8, (const f16_t*)f1, (const f16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp)
+                                      : corr::launch_allc_c8<f16_t, false, bf16_t>(vc8, (const f16_t*)f1, (const f16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
+    else if (padw && dtype == UPF_BF16) rc = corr::launch_allc_c8<bf16_t, true>(vc8, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
     else if (padw) rc = corr::launch_allc_c8<f16_t, true>(vc8, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
     else if (c8 && dtype == UPF_BF16) rc = corr::launch_allc_c8<bf16_t>(vc8, (const bf16_t*)f1, (const bf16_t*)f2, (bf16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
     else if (c8) rc = corr::launch_allc_c8<f16_t>(vc8, (const f16_t*)f1, (const f16_t*)f2, (f16_t*)out, B, C, H, W, out_batch_stride, leaky_slope, ws1, ws2, nseg, s, ev[2 * i], ev[2 * i + 1], fp);
@@ -516,6 +521,11 @@ extern "C" int upf_corr81_norm_forward_c8_timed(const void* f1, const void* f2, 
 extern "C" int upf_corr81_norm_forward_c8_timed_pitched(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
                                                         int dtype, float leaky_slope, void* workspace, void* stream, int nrep, float* avg_us, float* min_us) {
   return norm_forward_timed_impl(true, f1, f2, out8, B, C, H, W, dtype, out8_batch_stride, leaky_slope, workspace, stream, nrep, avg_us, min_us, f_row_pitch);
+}
+
+extern "C" int upf_corr81_norm_forward_c8_timed_mixed(const void* f1, const void* f2, int f_row_pitch, void* out8, long long out8_batch_stride, int B, int C, int H, int W,
+                                                      int dtype, int out_dtype, float leaky_slope, void* workspace, void* stream, int nrep, float* avg_us, float* min_us) {
+  return norm_forward_timed_impl(true, f1, f2, out8, B, C, H, W, dtype, out8_batch_stride, leaky_slope, workspace, stream, nrep, avg_us, min_us, f_row_pitch, out_dtype);
 }
 
 extern "C" int upf_corr_set_option(const char* name, int value) {

@@ -253,8 +253,9 @@ def corr81_norm_forward_c8_timed(f1, f2, out8, leaky_slope=0.0, nrep=50):
     ws = torch.empty((_lib.lib().upf_corr81_norm_workspace_bytes(B, C, H, W),), dtype=torch.uint8, device=f1.device)
     avg, mn = ctypes.c_float(), ctypes.c_float()
     with torch.cuda.device(dev):
-        _lib.call('upf_corr81_norm_forward_c8_timed_pitched', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out8), out8.stride(0), B, C, H, W,
-                  _lib.dtype_code(f1), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev), int(nrep),
+        # (out8 may be the OTHER 16-bit type: fp16 features into bf16 octets — the launch of the bf16 step with its fp16 pyramid)
+        _lib.call('upf_corr81_norm_forward_c8_timed_mixed', _lib.ptr(f1), _lib.ptr(f2), fp, _lib.ptr(out8), out8.stride(0), B, C, H, W,
+                  _lib.dtype_code(f1), _lib.dtype_code(out8), float(leaky_slope), _lib.ptr(ws), _lib.stream_ptr(dev), int(nrep),
                   ctypes.byref(avg), ctypes.byref(mn))
     return avg.value, mn.value
 
