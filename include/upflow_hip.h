@@ -354,14 +354,14 @@ int upf_conv_forward_c8_narrow(const void* x8, long long x8_batch_stride, int n8
  * with conv5.  A launch with 2 ... 32 output channels costs what the staging of its input costs, so
  *   upf_conv_forward_c8_split: ONE pass over the shared octet input computes a layer of C_main (a multiple of 8) output channels
  *     completely — bias, LeakyReLU, octets into y8 — and, as output channels [C_main, Cout) of the same packed operand (Cout <=
- *     128: they occupy what would be padding of the layer's last 32-channel block(s)), the shared-input part of later layers INCLUDING their bias: raw fp32, pixel-major partial[n][y][x][partial_pitch]
- *     (channel c -> float c - C_main);
+ *     128: they occupy what would be padding of the layer's last 32-channel block(s)), the shared-input part of later layers INCLUDING their bias: raw fp32,
+ *     as planes of channel quads partial[n][partial_pitch / 4][y][x][4] (channel c -> float c - C_main; 16 bytes per pixel and quad);
  *   upf_conv_forward_c8_narrow_init: upf_conv_forward_c8_narrow (Cout <= 16) for a later layer on the channels the tail itself
  *     produced, its accumulators starting from floats [partial_offset, +Cout) of that record instead of from a bias.
  * The result is the layer's own fp32 sum in another order; nothing is rounded to 16 bits in between.  3x3, dilation 1, stride 1. */
 int upf_conv_forward_c8_split(const void* x8, long long x8_batch_stride, int n8_oct, const void* w_packed /* upf_conv_pack_weights_kmap, Cout rows */,
                               const float* bias /* [Cout] */, void* y8, long long y_batch_stride, int C_main,
-                              float* partial, long long partial_batch_stride /* floats */, int partial_pitch /* floats per pixel, % 4 == 0 */,
+                              float* partial, long long partial_batch_stride /* floats */, int partial_pitch /* partial channels per pixel, % 4 == 0 */,
                               int B, int Cout, int H, int W, float leaky_slope, int dtype, void* stream);
 int upf_conv_forward_c8_narrow_init(const void* x8, long long x8_batch_stride, int n8_oct, const void* w_packed16,
                                     const float* partial, long long partial_batch_stride, int partial_pitch, int partial_offset /* % 4 == 0 */,

@@ -131,8 +131,9 @@ struct NoGate { static constexpr bool on = false, split = false, init = false; }
 // computes the first layer of the tail completely and, in the unused output channels of the same 32-channel block(s), the
 // shared-input part of every later layer:
 //   SplitOut: output channels [0, cmain) are a layer's own — bias, LeakyReLU, 16-bit octets, as always; channels [cmain, Cout)
-//             are fp32 PARTIAL pre-activations of later layers (their bias included, no activation), stored pixel-major
-//             [n][y][x][ppitch] — 16 bytes per lane and register quad;
+//             are fp32 PARTIAL pre-activations of later layers (their bias included, no activation), stored as planes of channel
+//             QUADS [n][ppitch / 4][y][x][4] — the 16 bytes of a lane's register quad next to its neighbour pixels' (a half-wave
+//             writes, and the finishing launch's 16 lanes read, whole contiguous segments);
 //   AccInit:  the finishing launch of a later layer (16-channel matrix instruction, its input = the few channels the tail's earlier
 //             layers produced) starts its accumulators from that partial instead of from the bias.
 // The sum is the same fp32 sum in another order (the layer's own K order put the tail's channels first, here they come last);
@@ -400,7 +401,7 @@ void conv_body(const T* __restrict__ x, long long xbs, const T* __restrict__ wp,
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int gx = x0 + p16 + 16 * h, gy = gyi + r;
-        const uint32_t off = (gx < W && gy < H && slab * 16 + 4 * ko < Cout) ? (uint32_t)((gy * W + gx) * gate.ppitch + gate.coff + slab * 16 + 4 * ko) * 4u : 0x80000000u;
+        const uint32_t off = (gx < W && gy < H && slab * 16 + 4 * ko < Cout) ? (uint32_t)(((gate.coff >> 2) + slab * 4 + ko) * (H * W) + gy * W + gx) * 16u : 0x80000000u;
         acc16[r][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, off, 0, 0));
       }
   } else if constexpr (N16) {
@@ -706,10 +707,10 @@ void conv_body(const T* __restrict__ x, long long xbs, const T* __restrict__ wp,
         for (int g = 0; g < 4; ++g) {
           if constexpr (G::split) {
             // registers 4g .. 4g+3 = channels c0 .. c0+3, c0 = 32*slab + 8*g + 4*kg: past cmain (uniform: cmain % 8 == 0) they are
-            // partial pre-activations of later layers -> raw fp32, floats [c0 - cmain, +4) of the pixel's partial record
+            // partial pre-activations of later layers -> raw fp32, quad plane (c0 - cmain) / 4 of the partial
             if (slab * 32 + 8 * g >= gate.cmain) {
               const int c0 = slab * 32 + 8 * g + 4 * kg;
-              const uint32_t off = (gx < Wo && c0 < Cout) ? (uint32_t)((gy * Wo + gx) * gate.ppitch + (c0 - gate.cmain)) * 4u : 0x80000000u;
+              const uint32_t off = (gx < Wo && c0 < Cout) ? (uint32_t)(((c0 - gate.cmain) >> 2) * (Ho * Wo) + gy * Wo + gx) * 16u : 0x80000000u;
               f32x4 pv;
 #pragma unroll
               for (int q = 0; q < 4; ++q) pv[q] = acc[r][4 * g + q];

@@ -370,7 +370,7 @@ class _PackedTailC8(object):
         """conv_m: x8 = its input octets, y8 = its output octets -> the fp32 partial records of the layers J."""
         packed, bias = self.get()
         B, _, H, W, _ = x8.shape
-        part = torch.empty((B, H, W, self.pp), dtype=torch.float32, device=x8.device)
+        part = torch.empty((B, self.pp // 4, H, W, 4), dtype=torch.float32, device=x8.device)      # planes of channel quads
         ops.conv_c8_forward_split_raw(x8, packed, bias, y8, part, self.slopes[self.m])
         return part
 

@@ -882,31 +882,35 @@ def conv_c8_forward_narrow_raw(x8, packed16, bias32, y, leaky_slope=0.0):
     return y
 
 
+def _partial_ok(partial, B, H, W):
+    return (partial.dtype == torch.float32 and partial.dim() == 5 and partial.shape[0] == B and tuple(partial.shape[2:]) == (H, W, 4)
+            and partial.stride()[1:] == (H * W * 4, W * 4, 4, 1))
+
+
 def conv_c8_forward_split_raw(x8, packed, bias32, y8, partial, leaky_slope=0.0):
     """The merged narrow tail of a dense stack, first launch (upf_conv_forward_c8_split): ONE pass over the octet slice x8 computes
     a layer of C_main = 8 * y8.shape[1] output channels completely (bias, LeakyReLU, octets into y8) and, as the remaining rows of the
     packed operand (Cout = bias32.shape[0] <= 64 rows), the shared-input part of later layers as raw fp32 (bias included) into
-    partial [B, H, W, P] (floats [0, Cout - C_main) of a pixel's record)."""
+    partial [B, Q, H, W, 4] (planes of channel quads: partial channel c is partial[:, c // 4, :, :, c % 4])."""
     B, n, H, W, _ = x8.shape
     Cout = bias32.shape[0]
     if not _c8_view_ok(x8) or not _c8_view_ok(y8) or tuple(y8.shape[0:1] + y8.shape[2:]) != (B, H, W, 8):
         raise UpflowHipError('conv_c8_split: x8 / y8 must be octet slices of contiguous C8 buffers of one size')
     cmain = 8 * y8.shape[1]
-    if (partial.dtype != torch.float32 or partial.dim() != 4 or tuple(partial.shape[:3]) != (B, H, W) or partial.stride()[1:] != (W * partial.shape[3], partial.shape[3], 1)
-            or partial.shape[3] % 4 or partial.shape[3] < (Cout - cmain + 3) // 4 * 4):
-        raise UpflowHipError('conv_c8_split: partial must be fp32 [B,H,W,P] (pixel-major, P % 4 == 0, P >= the partial channels), got %s' % (tuple(partial.shape),))
+    if not _partial_ok(partial, B, H, W) or 4 * partial.shape[1] < (Cout - cmain + 3) // 4 * 4:
+        raise UpflowHipError('conv_c8_split: partial must be fp32 [B,Q,H,W,4] (planes of channel quads, 4 Q >= the partial channels), got %s' % (tuple(partial.shape),))
     dev = x8.device
     if not (x8.is_cuda and y8.is_cuda and partial.is_cuda) or x8.dtype != y8.dtype:
         raise UpflowHipError('conv_c8_split: GPU tensors of one 16-bit dtype expected (there is no CPU fallback)')
     with torch.cuda.device(dev):
         _lib.call('upf_conv_forward_c8_split', _lib.ptr(x8), x8.stride(0), n, _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y8), y8.stride(0), cmain,
-                  _lib.ptr(partial), partial.stride(0), partial.shape[3], B, Cout, H, W, float(leaky_slope), _lib.dtype_code(x8), _lib.stream_ptr(dev))
+                  _lib.ptr(partial), partial.stride(0), 4 * partial.shape[1], B, Cout, H, W, float(leaky_slope), _lib.dtype_code(x8), _lib.stream_ptr(dev))
     return y8
 
 
 def conv_c8_forward_narrow_init_raw(x8, packed16, partial, offset, Cout, y, leaky_slope=0.0):
     """The merged narrow tail, a finishing launch (upf_conv_forward_c8_narrow_init): conv_c8_forward_narrow_raw whose accumulators start
-    from floats [offset, offset + Cout) of the pixel records of `partial` (conv_c8_forward_split_raw) instead of from a bias."""
+    from partial channels [offset, offset + Cout) of `partial` (conv_c8_forward_split_raw) instead of from a bias."""
     B, n, H, W, _ = x8.shape
     y_is_c8 = y.dim() == 5
     if not _c8_view_ok(x8):
@@ -916,14 +920,13 @@ def conv_c8_forward_narrow_init_raw(x8, packed16, partial, offset, Cout, y, leak
             raise UpflowHipError('conv_c8_narrow_init: C8 output must be [%d,%d,%d,%d,8], got %s' % (B, (Cout + 7) // 8, H, W, tuple(y.shape)))
     elif tuple(y.shape) != (B, Cout, H, W) or y.stride()[1:] != (H * W, W, 1):
         raise UpflowHipError('conv_c8_narrow_init: NCHW output must be a [%d,%d,%d,%d] channel slice' % (B, Cout, H, W))
-    if (partial.dtype != torch.float32 or partial.dim() != 4 or tuple(partial.shape[:3]) != (B, H, W)
-            or partial.stride()[1:] != (W * partial.shape[3], partial.shape[3], 1)):
-        raise UpflowHipError('conv_c8_narrow_init: partial must be fp32 [B,H,W,P] (pixel-major)')
+    if not _partial_ok(partial, B, H, W):
+        raise UpflowHipError('conv_c8_narrow_init: partial must be fp32 [B,Q,H,W,4] (planes of channel quads)')
     dev = x8.device
     if not (x8.is_cuda and y.is_cuda and partial.is_cuda) or x8.dtype != y.dtype:
         raise UpflowHipError('conv_c8_narrow_init: GPU tensors of one 16-bit dtype expected (there is no CPU fallback)')
     with torch.cuda.device(dev):
-        _lib.call('upf_conv_forward_c8_narrow_init', _lib.ptr(x8), x8.stride(0), n, _lib.ptr(packed16), _lib.ptr(partial), partial.stride(0), partial.shape[3],
+        _lib.call('upf_conv_forward_c8_narrow_init', _lib.ptr(x8), x8.stride(0), n, _lib.ptr(packed16), _lib.ptr(partial), partial.stride(0), 4 * partial.shape[1],
                   int(offset), _lib.ptr(y), y.stride(0), int(y_is_c8), B, int(Cout), H, W, float(leaky_slope), _lib.dtype_code(x8), _lib.stream_ptr(dev))
     return y
 
