@@ -410,3 +410,101 @@ def test_whole_net_with_merged_tails_stays_within_the_16_bit_envelope():
         print('%s: EPE vs fp32: merged tails %.5f px, layer per pass %.5f px; merged vs layer per pass %.5f px' % (k, ea, eb, eab))
         assert torch.isfinite(a[k]).all()
         assert ea <= 1.25 * eb + 1e-4 and eab <= 1.5 * eb + 1e-4
+
+
+# ----------------------------------------------------------------------------------------------- two convolutions, one launch (round 6)
+PAIR_CASES = [  # B, Cin, C1, C2, H, W
+    (2, 3, 16, 16, 48, 96), (1, 3, 16, 16, 37, 70), (1, 3, 16, 16, 33, 131), (1, 16, 32, 32, 24, 80), (2, 16, 32, 32, 19, 46), (1, 16, 32, 32, 188, 621),
+    (1, 3, 32, 32, 20, 40), (1, 16, 16, 16, 21, 64), (1, 8, 16, 24, 16, 32), (1, 12, 32, 20, 17, 34), (8, 3, 16, 16, 384, 1280), (8, 16, 32, 32, 192, 640),
+]
+
+
+@pytest.mark.parametrize('case', PAIR_CASES)
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('y_c8', [False, True])
+def test_conv_pair_matches_the_two_layer_composition(case, dt, y_c8):
+    """upf_conv_pair_s1s2_forward (csrc/conv_pair.hip): [3x3 + LeakyReLU, 3x3 stride 2 + LeakyReLU] in one launch against conv2d x 2 with the
+    intermediate rounded to the 16-bit type, and against this library's two launches; ragged and odd sizes (row-pitched inputs, the
+    last pixel pair straddling W), NCHW and octet outputs, every instantiated (Cin, C1) class."""
+    from upflow_pytorch_amd import ops
+    B, Cin, C1, C2, H, W = case
+    if B == 8 and (dt == torch.float16 or y_c8 != (Cin == 16)):
+        pytest.skip('full-size case: one combination')
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).to(dt).cuda()
+    wa = (torch.randn(C1, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(dt).cuda()
+    wb = (torch.randn(C2, C1, 3, 3, generator=g) * (2.0 / (C1 * 9)) ** 0.5).to(dt).cuda()
+    ba, bb = torch.randn(C1, generator=g).cuda() * 0.1, torch.randn(C2, generator=g).cuda() * 0.1
+    mid = F.leaky_relu(F.conv2d(x.float(), wa.float(), ba, padding=1), 0.1).to(dt)
+    want = F.leaky_relu(F.conv2d(mid.float(), wb.float(), bb, padding=1, stride=2), 0.1)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xin = ops.empty_nchw((B, Cin, H, W), dt, 'cuda')              # (row-pitched at ragged widths, NaN in the padding)
+    if xin.stride(2) != W:
+        xin.as_strided((B, Cin, H, xin.stride(2)), xin.stride()).fill_(float('nan'))
+    xin.copy_(x)
+    if ops.nchw_pitch(xin) % 2:
+        pytest.skip('odd contiguous width: the pair kernel needs an even pitch (the model falls back to two launches)')
+    pa, pb = ops.conv_pair_pack(wa, wb)
+    if y_c8:
+        buf = torch.full((B, (C2 + 7) // 8 + 2, Ho, Wo, 8), 3.0, dtype=dt, device='cuda')
+        y = buf[:, 1:1 + (C2 + 7) // 8]
+        ops.conv_pair_forward_raw(xin, pa, ba, 0.1, pb, bb, 0.1, y)
+        got = ops.from_c8(y, C2).float()
+        assert bool((buf[:, 0] == 3).all()) and bool((buf[:, -1] == 3).all())
+        if C2 % 8:
+            assert float(ops.from_c8(y)[:, C2:].float().abs().max()) == 0.0      # the padding channels of the last octet are zeros
+    else:
+        big = torch.full((B, C2 + 3, Ho, Wo), 5.0, dtype=dt, device='cuda')
+        ops.conv_pair_forward_raw(xin, pa, ba, 0.1, pb, bb, 0.1, big[:, 2:2 + C2])
+        got = big[:, 2:2 + C2].float()
+        assert bool((big[:, :2] == 5).all()) and bool((big[:, 2 + C2:] == 5).all())
+    eps = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    scale = float(want.abs().max())
+    # (one rounding step of the output + the rare intermediate element that rounds the other way: both forms carry those)
+    assert (got - want).abs().max() <= 3 * eps * scale + 1e-3, float((got - want).abs().max())
+    assert float((got - want).abs().mean()) <= 0.3 * eps * scale
+    # ... and against the two launches of this library (same products, another summation order inside the first layer)
+    m2 = torch.empty(B, C1, H, W, dtype=dt, device='cuda')
+    ops.conv3x3_forward_raw(x, ops.conv3x3_pack(wa), ba, m2, 1, 0.1, 1, 3)
+    y2 = torch.empty(B, C2, Ho, Wo, dtype=dt, device='cuda')
+    ops.conv3x3_forward_raw(m2, ops.conv3x3_pack(wb), bb, y2, 1, 0.1, 2, 3)
+    assert (got - y2.float()).abs().max() <= 3 * eps * scale + 1e-3
+    assert float((got != y2.float()).float().mean()) <= 0.02                       # the overwhelming majority of the outputs: the same bits
+
+
+def test_whole_net_with_the_fused_guidance_stem_stays_within_the_16_bit_envelope():
+    """The SGU guidance stem as two fused launches (default) against four launches: the whole config-2 forward moves by less than the
+    16-bit envelope, and is as close to the fp32 forward."""
+    import _weights
+    from upflow_pytorch_amd.model.upflow import UPFlow_net
+    from upflow_pytorch_amd.model import pwc_modules
+    conf = UPFlow_net.config()
+    conf.update({'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False, 'norm_moments_across_images': False,
+                 'if_sgu_upsample': True, 'warp_mask_mode': 'robust'}, verbose=False)
+    net = conf()
+    net.load_state_dict(_weights.make_state_dict(0))
+    net = net.cuda().eval()
+    im1, im2 = _weights.make_images(2, 4, 384, 1280)
+    with torch.no_grad():
+        ref = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        net = net.bfloat16()
+        calls = []
+        orig = pwc_modules._PackedConvPair.__call__
+        pwc_modules._PackedConvPair.__call__ = lambda self, *a, **k: (calls.append(self.convs[0].in_channels), orig(self, *a, **k))[1]
+        try:
+            a = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        finally:
+            pwc_modules._PackedConvPair.__call__ = orig
+        prev = pwc_modules.FUSE_PAIRS[0]
+        pwc_modules.FUSE_PAIRS[0] = False
+        try:
+            b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
+        finally:
+            pwc_modules.FUSE_PAIRS[0] = prev
+    assert calls == [3, 16]
+    for k in ('flow_f_out', 'flow_b_out'):
+        ea = float((a[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())
+        eb = float((b[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())
+        eab = float((a[k].float() - b[k].float()).pow(2).sum(1).sqrt().mean())
+        print('%s: EPE vs fp32: fused stem %.5f px, four launches %.5f px; fused vs four launches %.5f px' % (k, ea, eb, eab))
+        assert ea <= 1.25 * eb + 1e-4 and eab <= 1.5 * eb + 1e-4

@@ -277,6 +277,8 @@ def test_native_kitti_frames_pitched_octet_path_vs_the_ragged_path(size, dtype):
         saved = (pwc_modules._NO_NARROW[0], ops.conv_c8_set_option('rpw4', 0), ops.conv_set_option('rpw4_min', 1 << 30), pwc_modules.MERGE_TAIL[0])
         pwc_modules._NO_NARROW[0] = True
         pwc_modules.MERGE_TAIL[0] = False        # (the merged narrow tail of the octet stacks, round 6: another summation order too)
+        saved_pairs = pwc_modules.FUSE_PAIRS[0]
+        pwc_modules.FUSE_PAIRS[0] = False        # (the fused guidance stem, round 6, reads pixel pairs: it needs an even row pitch, which a contiguous odd-width frame lacks)
         try:
             for m in net.modules():
                 m.__dict__.pop('_packed8', None)
@@ -289,6 +291,7 @@ def test_native_kitti_frames_pitched_octet_path_vs_the_ragged_path(size, dtype):
         finally:
             pwc_modules._NO_NARROW[0] = saved[0]
             pwc_modules.MERGE_TAIL[0] = saved[3]
+            pwc_modules.FUSE_PAIRS[0] = saved_pairs
             ops.conv_c8_set_option('rpw4', saved[1])
             ops.conv_set_option('rpw4_min', saved[2])
     for k in ('flow_f_out', 'flow_b_out', 'occ_fw', 'occ_bw'):

@@ -24,8 +24,10 @@ for v in variants:
     from upflow_pytorch_amd.model import pwc_modules
     pwc_modules._NO_NARROW[0] = bool(int(opts.pop('no_narrow', 0)))   # (Cout <= 16 octet layers on the 32-channel kernel)
     pwc_modules.MERGE_TAIL[0] = not bool(int(opts.pop('no_merge', 0)))  # (merged narrow tails of the octet stacks, round 6)
+    pwc_modules.FUSE_PAIRS[0] = not bool(int(opts.pop('no_pairs', 0)))  # (fused SGU guidance stem, round 6)
     for m in net.modules():
         m.__dict__.pop('_packed8', None)                  # (packed operands are cached per module: rebuild for this variant)
+        m.__dict__.pop('_fast_cache', None)
     prev = {k: ops.conv_set_option(k, int(val)) for k, val in opts.items()}
     if STREAMS > 1:                                       # UPF_AB_STREAMS=4: the headline's form, S captured steps in flight on S streams
         from upflow_pytorch_amd.runtime import PipelinedInference

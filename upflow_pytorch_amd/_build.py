@@ -19,6 +19,7 @@ SOURCES = [
     ('corr81_bwd.hip', []),
     ('conv3x3.hip', []),
     ('conv_c8.hip', []),
+    ('conv_pair.hip', []),
     ('conv_x3.hip', []),
     ('conv_wgrad.hip', []),
     ('warp.hip', ['-ffp-contract=off']),

@@ -380,6 +380,43 @@ class _PackedTailC8(object):
         return ops.conv_c8_forward_narrow_init_raw(x8_front, self.finish[j], part, self.offsets[j], self.widths[j], y, self.slopes[j])
 
 
+class _PackedConvPair(object):
+    """Packed operands of TWO conv(...) Sequentials run as one launch (ops.conv_pair_forward_raw / csrc/conv_pair.hip): a 3x3 stride-1
+    layer followed by a 3x3 stride-2 layer, the halves of the SGU guidance stem (model/upflow.py:30-33)."""
+
+    def __init__(self, seq_a, seq_b):
+        self.convs = (seq_a[0], seq_b[0])
+        self.slopes = tuple(0.1 if any(isinstance(m_, nn.LeakyReLU) for m_ in q) else 0.0 for q in (seq_a, seq_b))
+        self.key = None
+        self.packed = self.packed_b = self.bias = self.bias_b = None
+
+    def _key(self):
+        k = []
+        for c in self.convs:
+            k += [c.weight._version, c.weight.dtype, c.weight.device, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()]
+        return tuple(k)
+
+    def get(self):
+        key = self._key()
+        if key != self.key:
+            a, b = self.convs
+            self.packed, self.packed_b = ops.conv_pair_pack(a.weight, b.weight)
+            self.bias, self.bias_b = a.bias.detach().float().contiguous(), b.bias.detach().float().contiguous()
+            self.key = key
+        return self.packed, self.bias, self.packed_b, self.bias_b
+
+    def extra_operands(self):
+        return [self.packed_b, self.bias_b]
+
+    def invalidate(self):
+        self.key = None
+
+    def __call__(self, x, y):
+        pa, ba, pb, bb = self.get()
+        return ops.conv_pair_forward_raw(x, pa, ba, self.slopes[0], pb, bb, self.slopes[1], y)
+
+
+FUSE_PAIRS = [True]          # experiment / parity switch: False = every layer of the SGU guidance stem its own launch (rounds 1-5)
 MERGE_TAIL = [True]          # experiment / parity switch: False = every layer of a dense stack its own pass (rounds 3-5)
 
 

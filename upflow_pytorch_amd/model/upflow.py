@@ -101,6 +101,24 @@ class network_tools():
             pitched: intermediates with 16-byte aligned rows at ragged widths (ops.empty_nchw)."""
             cache = self.__dict__.setdefault('_fast_cache', {})
             n = len(self.upsample_output_conv)
+            from . import pwc_modules as _pm
+            if n == 4 and _pm.FUSE_PAIRS[0] and not getattr(self, '_no_fuse_pairs', False) and all(len(q) == 2 for q in self.upsample_output_conv):
+                # (round 6) [3x3, 3x3 stride 2] x 2 as TWO launches whose intermediates stay in LDS (csrc/conv_pair.hip): the full-resolution
+                # 16-channel and the half-resolution 32-channel activations (126 + 63 MB at 384x1280) are never written
+                sq = self.upsample_output_conv
+                if ops.conv_pair_supported(x, sq[0][0], sq[1][0]):
+                    B_, _, H_, W_ = x.shape
+                    h1, w1 = ops.conv3x3_out_hw(H_, W_, 2)
+                    mid = ops.empty_nchw((B_, sq[1][0].out_channels, h1, w1), x.dtype, x.device, pitched=True)
+                    if ops.conv_pair_supported(mid, sq[2][0], sq[3][0]):
+                        pa = cache.get('pair01') or cache.setdefault('pair01', _pm._PackedConvPair(sq[0], sq[1]))
+                        pb = cache.get('pair23') or cache.setdefault('pair23', _pm._PackedConvPair(sq[2], sq[3]))
+                        pa(x, mid)
+                        h2, w2 = ops.conv3x3_out_hw(h1, w1, 2)
+                        if out8 is not None:
+                            return pb(mid, out8)
+                        y = out if out is not None else ops.empty_nchw((B_, sq[3][0].out_channels, h2, w2), x.dtype, x.device, pitched=pitched)
+                        return pb(mid, y)
             for i, seq in enumerate(self.upsample_output_conv):       # matrix-core kernel when eligible
                 if i == n - 1 and out8 is not None:
                     pc = cache.get('c8_last')
