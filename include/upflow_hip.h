@@ -368,22 +368,23 @@ int upf_conv_forward_c8_narrow_init(const void* x8, long long x8_batch_stride, i
                                     void* y, long long y_batch_stride, int y_is_c8, int B, int Cout, int H, int W, float leaky_slope,
                                     int dtype, void* stream);
 
-/* TWO convolutions as one launch (round 6): a 3x3 stride-1 layer (Cin <= 16 -> C1 = 16 | 32 channels, LeakyReLU) followed by a 3x3
- * stride-2 layer (C1 -> C2 <= 32 channels, LeakyReLU) — the two halves of the SGU guidance stem (model/upflow.py:30-33: conv(3, 16),
- * conv(16, 16, stride=2), conv(16, 32), conv(32, 32, stride=2) on both frames at full resolution), whose intermediate (126 MB / 63 MB at
- * 384x1280) then never leaves the chip: a workgroup computes the first layer on the pixels its tile of the second layer reads —
- * rounded to the 16-bit type, zero outside the image: the values the two-launch form reads back — into LDS and multiplies from there.
- * x: NCHW [B,Cin,H,W] with an EVEN row pitch (rows are read as pixel pairs); y: NCHW [B,C2,Ho,Wo] (row pitch given) or octets
- * [B,ceil(C2/8),Ho,Wo,8], Ho = ceil(H/2), Wo = ceil(W/2).  leaky slope 0 = no activation.
+/* TWO convolutions as one launch (round 6): a 3x3 layer (Cin <= 16 -> C1 = 16 | 32 channels, LeakyReLU) followed by a 3x3 layer (C1 -> C2 <= 32
+ * channels, LeakyReLU) with strides (1, 2) — the two halves of the SGU guidance stem (model/upflow.py:30-33: conv(3, 16), conv(16, 16, stride=2),
+ * conv(16, 32), conv(32, 32, stride=2) on both frames at full resolution) — or (2, 1) — the first two stages of the feature pyramid
+ * (model/pwc_modules.py:122-142) — whose intermediate (126 / 63 / 31 / 16 MB at 384x1280) then never leaves the chip: a workgroup computes the
+ * first layer on the pixels its tile of the second layer reads — rounded to the 16-bit type, zero outside the image: the values the two-launch
+ * form reads back — into LDS and multiplies from there.
+ * x: NCHW [B,Cin,H,W] with an EVEN row pitch (rows are read as pixel pairs); y: NCHW [B,C2,Ho,Wo] (row pitch given) or, strides (1, 2) only,
+ * octets [B,ceil(C2/8),Ho,Wo,8]; Ho = ceil(H/2), Wo = ceil(W/2).  leaky slope 0 = no activation.
  * Packed operands (16-bit, MFMA lane order; lane = co + 32 kg, 8 consecutive k per lane):
  *   wa [S][64][8], S = 5 for Cin <= 8 (k-octet kg of step s = tap 2s + kg, channels 0..7), S = 9 for Cin <= 16 (step = tap, kg = channel octet);
  *   wb [9][C1/16][64][8] (tap, k-step of 16 channels, kg = channel octet within the step); rows co >= C / absent taps / channels are zero.
  * The sums are the layers' own fp32 sums in another order than upf_conv_forward's (two taps per instruction in the first layer). */
-int upf_conv_pair_s1s2_forward(const void* x, long long x_batch_stride, int x_row_pitch, int Cin,
-                               const void* wa_packed, const float* bias_a /* [C1] */, float slope_a, int C1,
-                               const void* wb_packed, const float* bias_b /* [C2] */, float slope_b, int C2,
-                               void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8,
-                               int B, int H, int W, int dtype, void* stream);
+int upf_conv_pair_forward(const void* x, long long x_batch_stride, int x_row_pitch, int Cin,
+                          const void* wa_packed, const float* bias_a /* [C1] */, float slope_a, int C1, int stride_a,
+                          const void* wb_packed, const float* bias_b /* [C2] */, float slope_b, int C2, int stride_b,
+                          void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8,
+                          int B, int H, int W, int dtype, void* stream);
 
 /* ---- the same convolutions under autograd: training on the matrix cores  (model/pwc_modules.py:250-286, :396-412) ----
  * forward      upf_conv_forward on weights packed straight from the fp32 master copy: upf_conv_pack_weights_f32(dgrad=0)

@@ -421,22 +421,24 @@ PAIR_CASES = [  # B, Cin, C1, C2, H, W
 
 @pytest.mark.parametrize('case', PAIR_CASES)
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('y_c8', [False, True])
-def test_conv_pair_matches_the_two_layer_composition(case, dt, y_c8):
-    """upf_conv_pair_s1s2_forward (csrc/conv_pair.hip): [3x3 + LeakyReLU, 3x3 stride 2 + LeakyReLU] in one launch against conv2d x 2 with the
-    intermediate rounded to the 16-bit type, and against this library's two launches; ragged and odd sizes (row-pitched inputs, the
-    last pixel pair straddling W), NCHW and octet outputs, every instantiated (Cin, C1) class."""
+@pytest.mark.parametrize('y_c8,strides', [(False, (1, 2)), (True, (1, 2)), (False, (2, 1))])
+def test_conv_pair_matches_the_two_layer_composition(case, dt, y_c8, strides):
+    """upf_conv_pair_forward (csrc/conv_pair.hip): two 3x3 + LeakyReLU layers with strides (1, 2) (the SGU guidance stem) or (2, 1) (a stage of
+    the feature pyramid) in one launch against conv2d x 2 with the intermediate rounded to the 16-bit type, and against this library's
+    two launches; ragged and odd sizes (row-pitched inputs, the last pixel pair straddling W), NCHW and octet outputs, every instantiated
+    (Cin, C1) class."""
     from upflow_pytorch_amd import ops
     B, Cin, C1, C2, H, W = case
-    if B == 8 and (dt == torch.float16 or y_c8 != (Cin == 16)):
-        pytest.skip('full-size case: one combination')
+    if B == 8 and (dt == torch.float16 or (strides == (1, 2) and y_c8 != (Cin == 16))):
+        pytest.skip('full-size case: one combination per stride order')
+    sa, sb = strides
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, H, W, generator=g).to(dt).cuda()
     wa = (torch.randn(C1, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(dt).cuda()
     wb = (torch.randn(C2, C1, 3, 3, generator=g) * (2.0 / (C1 * 9)) ** 0.5).to(dt).cuda()
     ba, bb = torch.randn(C1, generator=g).cuda() * 0.1, torch.randn(C2, generator=g).cuda() * 0.1
-    mid = F.leaky_relu(F.conv2d(x.float(), wa.float(), ba, padding=1), 0.1).to(dt)
-    want = F.leaky_relu(F.conv2d(mid.float(), wb.float(), bb, padding=1, stride=2), 0.1)
+    mid = F.leaky_relu(F.conv2d(x.float(), wa.float(), ba, padding=1, stride=sa), 0.1).to(dt)
+    want = F.leaky_relu(F.conv2d(mid.float(), wb.float(), bb, padding=1, stride=sb), 0.1)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     xin = ops.empty_nchw((B, Cin, H, W), dt, 'cuda')              # (row-pitched at ragged widths, NaN in the padding)
     if xin.stride(2) != W:
@@ -448,14 +450,14 @@ def test_conv_pair_matches_the_two_layer_composition(case, dt, y_c8):
     if y_c8:
         buf = torch.full((B, (C2 + 7) // 8 + 2, Ho, Wo, 8), 3.0, dtype=dt, device='cuda')
         y = buf[:, 1:1 + (C2 + 7) // 8]
-        ops.conv_pair_forward_raw(xin, pa, ba, 0.1, pb, bb, 0.1, y)
+        ops.conv_pair_forward_raw(xin, pa, ba, 0.1, pb, bb, 0.1, y, strides)
         got = ops.from_c8(y, C2).float()
         assert bool((buf[:, 0] == 3).all()) and bool((buf[:, -1] == 3).all())
         if C2 % 8:
             assert float(ops.from_c8(y)[:, C2:].float().abs().max()) == 0.0      # the padding channels of the last octet are zeros
     else:
         big = torch.full((B, C2 + 3, Ho, Wo), 5.0, dtype=dt, device='cuda')
-        ops.conv_pair_forward_raw(xin, pa, ba, 0.1, pb, bb, 0.1, big[:, 2:2 + C2])
+        ops.conv_pair_forward_raw(xin, pa, ba, 0.1, pb, bb, 0.1, big[:, 2:2 + C2], strides)
         got = big[:, 2:2 + C2].float()
         assert bool((big[:, :2] == 5).all()) and bool((big[:, 2 + C2:] == 5).all())
     eps = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
@@ -464,10 +466,10 @@ def test_conv_pair_matches_the_two_layer_composition(case, dt, y_c8):
     assert (got - want).abs().max() <= 3 * eps * scale + 1e-3, float((got - want).abs().max())
     assert float((got - want).abs().mean()) <= 0.3 * eps * scale
     # ... and against the two launches of this library (same products, another summation order inside the first layer)
-    m2 = torch.empty(B, C1, H, W, dtype=dt, device='cuda')
-    ops.conv3x3_forward_raw(x, ops.conv3x3_pack(wa), ba, m2, 1, 0.1, 1, 3)
+    m2 = torch.empty((B, C1) + ((H, W) if sa == 1 else (Ho, Wo)), dtype=dt, device='cuda')
+    ops.conv3x3_forward_raw(x, ops.conv3x3_pack(wa), ba, m2, 1, 0.1, sa, 3)
     y2 = torch.empty(B, C2, Ho, Wo, dtype=dt, device='cuda')
-    ops.conv3x3_forward_raw(m2, ops.conv3x3_pack(wb), bb, y2, 1, 0.1, 2, 3)
+    ops.conv3x3_forward_raw(m2, ops.conv3x3_pack(wb), bb, y2, 1, 0.1, sb, 3)
     assert (got - y2.float()).abs().max() <= 3 * eps * scale + 1e-3
     assert float((got != y2.float()).float().mean()) <= 0.02                       # the overwhelming majority of the outputs: the same bits
 
@@ -501,7 +503,7 @@ def test_whole_net_with_the_fused_guidance_stem_stays_within_the_16_bit_envelope
             b = net({'im1': im1.cuda(), 'im2': im2.cuda(), 'if_loss': False})
         finally:
             pwc_modules.FUSE_PAIRS[0] = prev
-    assert calls == [3, 16]
+    assert calls == [3, 16, 3, 16]                                  # feature pyramid stages 0 and 1 (strides 2, 1), then the guidance stem's halves (1, 2)
     for k in ('flow_f_out', 'flow_b_out'):
         ea = float((a[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())
         eb = float((b[k].float() - ref[k]).pow(2).sum(1).sqrt().mean())

@@ -68,7 +68,7 @@ SIGNATURES = {
     'upf_conv_forward_c8_narrow': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_conv_forward_c8_split': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _vp],
     'upf_conv_forward_c8_narrow_init': [_vp, _ll, _i, _vp, _vp, _ll, _i, _i, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _vp],
-    'upf_conv_pair_s1s2_forward': [_vp, _ll, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _f, _i, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_conv_pair_forward': [_vp, _ll, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _f, _i, _i, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
     'upf_leaky_backward': [_vp, _vp, _vp, _ll, _f, _i, _vp],
     'upf_conv_wgrad': [_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_conv_bias_grad': [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp],

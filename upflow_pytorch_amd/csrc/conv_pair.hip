@@ -1,6 +1,7 @@
-// Two convolutions as ONE launch: a 3x3 stride-1 layer (Cin <= 16 -> C1 = 16 | 32 channels, LeakyReLU) followed by a 3x3 stride-2 layer
-// (C1 -> C2 <= 32 channels, LeakyReLU) — the two halves of the SGU guidance stem (/root/reference/model/upflow.py:30-33: conv(3, 16),
-// conv(16, 16, stride=2), conv(16, 32), conv(32, 32, stride=2), run on both frames at full resolution) — gfx950.
+// Two convolutions as ONE launch: a 3x3 layer (Cin <= 16 -> C1 = 16 | 32 channels, LeakyReLU) followed by a 3x3 layer (C1 -> C2 <= 32 channels,
+// LeakyReLU), strides (1, 2) — the two halves of the SGU guidance stem (/root/reference/model/upflow.py:30-33: conv(3, 16), conv(16, 16,
+// stride=2), conv(16, 32), conv(32, 32, stride=2), run on both frames at full resolution) — or (2, 1) — the first two stages of the feature
+// pyramid (model/pwc_modules.py:122-142: conv(3, 16, stride=2), conv(16, 16); conv(16, 32, stride=2), conv(32, 32)) — gfx950.
 //
 // Why (round 6): these layers are pure bandwidth — at 384x1280, 2B = 8 frames, the first layer WRITES 126 MB of 16-channel activations
 // that the second reads straight back (52 + 36 us), the third writes 63 MB for the fourth (21 + 28 us): 7 % of a 2.8 ms step moving
@@ -24,14 +25,22 @@ using conv::f32x16;
 using conv::Mma32;
 using conv::u32x2;
 
-constexpr int NT = 256, MC = 65, IC = 68;
+constexpr int NT = 256;
+// geometry of a TH x 32 output tile: layer B (stride SB) reads MR x MC mid pixels, layer A (stride SA) computes them from IR x IC
+// input pixels; XO: the input columns start one pixel early where that makes the first column even (rows are loaded as pixel pairs)
+template <int SA, int SB, int TH> struct Geo {
+  static constexpr int MR = SB * (TH - 1) + 3, MC = SB * 31 + 3;
+  static constexpr int XO = (SA == 2) ? 1 : 0;
+  static constexpr int IR = SA * (MR - 1) + 3, IC = (SA * (MC - 1) + 3 + XO + 1) / 2 * 2;
+};
 
-template <typename T, int K0, int C1O, int TH, bool YC8>
+template <typename T, int K0, int C1O, int TH, bool YC8, int SA, int SB>
 __global__ __launch_bounds__(NT, 2)
 void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Cin, const T* __restrict__ wa, const float* __restrict__ ba, float slope_a,
                       const T* __restrict__ wb, const float* __restrict__ bb, float slope_b, T* __restrict__ y, long long ybs, int ypitch, int C2,
-                      int H, int W, int Ho, int Wo, int tiles_x, int tiles_y) {
-  constexpr int MR = 2 * TH + 1, IR = 2 * TH + 3;
+                      int H, int W, int Hm, int Wm, int Ho, int Wo, int tiles_x, int tiles_y) {
+  using G = Geo<SA, SB, TH>;
+  constexpr int MR = G::MR, MC = G::MC, IR = G::IR, IC = G::IC, XO = G::XO;
   constexpr int NSTEP = (K0 == 1) ? 5 : 9;
   constexpr int KSB = C1O / 2;                       // k-steps of 16 channels of layer B
   constexpr int RPWB = TH / 4;                       // output rows per wave
@@ -41,16 +50,17 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-  const int x0 = tx * 32, y0 = ty * TH;              // output (half-resolution) coordinates of the tile
+  const int x0 = tx * 32, y0 = ty * TH;              // output coordinates of the tile
+  const int my0 = SB * y0 - 1, mx0 = SB * x0 - 1;    // mid (layer A's output) coordinates of the mid tile's first pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 31, kg = lane >> 5;
 
-  // ---- phase 0: the input tile + halo, rows [2 y0 - 2, +IR), columns [2 x0 - 2, +68) as pixel PAIRS (4-byte loads: even pitch),
+  // ---- phase 0: the input tile + halo, rows [SA my0 - 1, +IR), columns [SA mx0 - 1 - XO, +IC) as pixel PAIRS (4-byte loads: even pitch),
   // transposed to octet entries.  Planes >= Cin fall off the descriptor, pixels outside the image get the offset marker: zeros.
   {
     const uint32_t plane = (uint32_t)(H * xpitch) * 2u;
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (size_t)n * xbs), 0, (uint32_t)Cin * plane, 0x00020000);
-    const int iy0 = 2 * y0 - 2, ix0 = 2 * x0 - 2;
+    const int iy0 = SA * my0 - 1, ix0 = SA * mx0 - 1 - XO;
     for (int item = tid; item < IR * (IC / 2); item += NT) {
       const int ir = item / (IC / 2), pp = item - ir * (IC / 2);
       const int gy = iy0 + ir, gx = ix0 + 2 * pp;
@@ -85,7 +95,7 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
   }
   __syncthreads();
 
-  // ---- phase A: layer A on the (2 TH + 1) x 65 pixels layer B reads, 32 at a time -> mid tile (16-bit, zero outside the image)
+  // ---- phase A: layer A on the MR x MC pixels layer B reads, 32 at a time -> mid tile (16-bit, zero outside layer A's output)
   {
     constexpr int NPX = MR * MC, NTILE = (NPX + 31) / 32;
     for (int t = wave; t < NTILE; t += 4) {
@@ -100,11 +110,11 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
         if constexpr (K0 == 1) { tap = 2 * s + kg; if (tap > 8) tap = 8; oct = 0; }       // (tap 9 does not exist: its weights are zero)
         else { tap = s; oct = kg; }
         const int ky = tap / 3, kx = tap - 3 * ky;
-        const uint4 b = in_s[(oct * IR + mr + ky) * IC + mc + kx];
+        const uint4 b = in_s[(oct * IR + SA * mr + ky) * IC + SA * mc + kx + XO];
         acc = Mma32<T>::mma(wA[s], b, acc);
       }
-      const int my = 2 * y0 - 1 + mr, mx = 2 * x0 - 1 + mc;
-      const bool inside = my >= 0 && my < H && mx >= 0 && mx < W;
+      const int my = my0 + mr, mx = mx0 + mc;
+      const bool inside = my >= 0 && my < Hm && mx >= 0 && mx < Wm;
       if (pv) {
 #pragma unroll
         for (int o = 0; o < C1O; ++o) {
@@ -135,7 +145,7 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
   }
   __syncthreads();
 
-  // ---- phase B: the stride-2 layer from the mid tile
+  // ---- phase B: the second layer from the mid tile
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - 3 * ky;
@@ -144,7 +154,7 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
 #pragma unroll
       for (int rr = 0; rr < RPWB; ++rr) {
         const int r = wave * RPWB + rr;
-        const uint4 b = mid_s[((2 * ks + kg) * MR + 2 * r + ky) * MC + 2 * px + kx];
+        const uint4 b = mid_s[((2 * ks + kg) * MR + SB * r + ky) * MC + SB * px + kx];
         acc[rr] = Mma32<T>::mma(wB[tap][ks], b, acc[rr]);
       }
   }
@@ -184,56 +194,71 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
 struct PairArgs {
   const void* x; long long xbs; int xpitch, Cin; const void* wa; const float* ba; float slope_a; int C1;
   const void* wb; const float* bb; float slope_b; int C2; void* y; long long ybs; int ypitch; int B, H, W; hipStream_t stream;
+  int sa, sb;
 };
 
-template <typename T, int K0, int C1O, int TH, bool YC8>
+template <typename T, int K0, int C1O, int TH, bool YC8, int SA, int SB>
 int launch_pair(const PairArgs& a) {
-  constexpr int MR = 2 * TH + 1, IR = 2 * TH + 3;
-  const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
+  using G = Geo<SA, SB, TH>;
+  const int Hm = (a.H - 1) / SA + 1, Wm = (a.W - 1) / SA + 1;
+  const int Ho = (Hm - 1) / SB + 1, Wo = (Wm - 1) / SB + 1;
   const int tiles_x = cdiv(Wo, 32), tiles_y = cdiv(Ho, TH);
-  const size_t ldsb = (size_t)(K0 * IR * IC + C1O * MR * MC) * 16;
+  const size_t ldsb = (size_t)(K0 * G::IR * G::IC + C1O * G::MR * G::MC) * 16;
   static LdsOptIn opt;
-  auto kern = &conv_pair_kernel<T, K0, C1O, TH, YC8>;
+  auto kern = &conv_pair_kernel<T, K0, C1O, TH, YC8, SA, SB>;
   opt.ensure(reinterpret_cast<const void*>(kern), ldsb);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y)), dim3(NT), ldsb, a.stream, (const T*)a.x, a.xbs, a.xpitch, a.Cin,
-                     (const T*)a.wa, a.ba, a.slope_a, (const T*)a.wb, a.bb, a.slope_b, (T*)a.y, a.ybs, a.ypitch, a.C2, a.H, a.W, Ho, Wo, tiles_x, tiles_y);
-  return check_launch("conv_pair_s1s2_forward");
+                     (const T*)a.wa, a.ba, a.slope_a, (const T*)a.wb, a.bb, a.slope_b, (T*)a.y, a.ybs, a.ypitch, a.C2, a.H, a.W, Hm, Wm, Ho, Wo, tiles_x, tiles_y);
+  return check_launch("conv_pair_forward");
 }
 
+// tile heights: two workgroups per CU (LDS: input tile + mid tile <= 80 KB)
 template <typename T, bool YC8>
 int dispatch_pair(const PairArgs& a) {
   const int k0 = a.Cin <= 8 ? 1 : 2, c1o = a.C1 / 8;
-  if (k0 == 1 && c1o == 2) return launch_pair<T, 1, 2, 8, YC8>(a);
-  if (k0 == 1 && c1o == 4) return launch_pair<T, 1, 4, 4, YC8>(a);
-  if (k0 == 2 && c1o == 2) return launch_pair<T, 2, 2, 8, YC8>(a);
-  return launch_pair<T, 2, 4, 4, YC8>(a);
+  if (a.sa == 1) {                                   // [stride 1, stride 2]: the SGU guidance stem
+    if (k0 == 1 && c1o == 2) return launch_pair<T, 1, 2, 8, YC8, 1, 2>(a);
+    if (k0 == 1 && c1o == 4) return launch_pair<T, 1, 4, 4, YC8, 1, 2>(a);
+    if (k0 == 2 && c1o == 2) return launch_pair<T, 2, 2, 8, YC8, 1, 2>(a);
+    return launch_pair<T, 2, 4, 4, YC8, 1, 2>(a);
+  }
+  if constexpr (!YC8) {                              // [stride 2, stride 1]: a stage of the feature pyramid (NCHW out)
+    if (k0 == 1 && c1o == 2) return launch_pair<T, 1, 2, 8, false, 2, 1>(a);
+    if (k0 == 1 && c1o == 4) return launch_pair<T, 1, 4, 8, false, 2, 1>(a);
+    if (k0 == 2 && c1o == 2) return launch_pair<T, 2, 2, 8, false, 2, 1>(a);
+    return launch_pair<T, 2, 4, 8, false, 2, 1>(a);
+  }
+  set_error("conv_pair_forward: [stride 2, stride 1] writes NCHW");
+  return UPF_EUNSUPPORTED;
 }
 
 }  // namespace convp
 }  // namespace upf
 
-extern "C" int upf_conv_pair_s1s2_forward(const void* x, long long x_batch_stride, int x_row_pitch, int Cin,
-                                          const void* wa_packed, const float* bias_a, float slope_a, int C1,
-                                          const void* wb_packed, const float* bias_b, float slope_b, int C2,
-                                          void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8,
-                                          int B, int H, int W, int dtype, void* stream) {
+extern "C" int upf_conv_pair_forward(const void* x, long long x_batch_stride, int x_row_pitch, int Cin,
+                                     const void* wa_packed, const float* bias_a, float slope_a, int C1, int stride_a,
+                                     const void* wb_packed, const float* bias_b, float slope_b, int C2, int stride_b,
+                                     void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8,
+                                     int B, int H, int W, int dtype, void* stream) {
   using namespace upf;
-  UPF_REQUIRE(x && wa_packed && bias_a && wb_packed && bias_b && y, UPF_EINVAL, "conv_pair_s1s2_forward: null pointer");
-  UPF_REQUIRE(B > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_pair_s1s2_forward: bad shape B=%d H=%d W=%d", B, H, W);
-  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_pair_s1s2_forward: bf16 / fp16 only");
+  UPF_REQUIRE(x && wa_packed && bias_a && wb_packed && bias_b && y, UPF_EINVAL, "conv_pair_forward: null pointer");
+  UPF_REQUIRE(B > 0 && H > 0 && W > 0, UPF_EINVAL, "conv_pair_forward: bad shape B=%d H=%d W=%d", B, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "conv_pair_forward: bf16 / fp16 only");
   UPF_REQUIRE(Cin >= 1 && Cin <= 16 && (C1 == 16 || C1 == 32) && C2 >= 1 && C2 <= 32, UPF_EUNSUPPORTED,
-              "conv_pair_s1s2_forward: Cin <= 16, C1 = 16 | 32, C2 <= 32 (got %d, %d, %d)", Cin, C1, C2);
+              "conv_pair_forward: Cin <= 16, C1 = 16 | 32, C2 <= 32 (got %d, %d, %d)", Cin, C1, C2);
+  UPF_REQUIRE((stride_a == 1 && stride_b == 2) || (stride_a == 2 && stride_b == 1), UPF_EUNSUPPORTED,
+              "conv_pair_forward: strides (1, 2) or (2, 1), got (%d, %d)", stride_a, stride_b);
   if (x_row_pitch == 0) x_row_pitch = W;
-  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;      // (one of the two layers halves the size)
   if (y_row_pitch == 0) y_row_pitch = Wo;
   UPF_REQUIRE(x_row_pitch >= W && x_row_pitch % 2 == 0 && aligned_to(x, 4) && x_batch_stride % 2 == 0, UPF_EUNSUPPORTED,
-              "conv_pair_s1s2_forward: the input rows are read as pixel pairs: an even row pitch (%d) and a 4-byte aligned base", x_row_pitch);
-  UPF_REQUIRE(slope_a >= 0.f && slope_a <= 1.f && slope_b >= 0.f && slope_b <= 1.f, UPF_EINVAL, "conv_pair_s1s2_forward: leaky slopes in [0,1]");
-  UPF_REQUIRE(aligned_to(wa_packed, 16) && aligned_to(wb_packed, 16), UPF_EINVAL, "conv_pair_s1s2_forward: packed weights must be 16-byte aligned");
-  UPF_REQUIRE(y_is_c8 ? (aligned_to(y, 16) && y_batch_stride % 8 == 0) : (y_row_pitch >= Wo), UPF_EINVAL, "conv_pair_s1s2_forward: bad output layout");
-  UPF_REQUIRE((long long)Cin * H * x_row_pitch * 2 < (1ll << 31), UPF_EINVAL, "conv_pair_s1s2_forward: image too large for one buffer descriptor");
+              "conv_pair_forward: the input rows are read as pixel pairs: an even row pitch (%d) and a 4-byte aligned base", x_row_pitch);
+  UPF_REQUIRE(slope_a >= 0.f && slope_a <= 1.f && slope_b >= 0.f && slope_b <= 1.f, UPF_EINVAL, "conv_pair_forward: leaky slopes in [0,1]");
+  UPF_REQUIRE(aligned_to(wa_packed, 16) && aligned_to(wb_packed, 16), UPF_EINVAL, "conv_pair_forward: packed weights must be 16-byte aligned");
+  UPF_REQUIRE(y_is_c8 ? (aligned_to(y, 16) && y_batch_stride % 8 == 0) : (y_row_pitch >= Wo), UPF_EINVAL, "conv_pair_forward: bad output layout");
+  UPF_REQUIRE((long long)Cin * H * x_row_pitch * 2 < (1ll << 31), UPF_EINVAL, "conv_pair_forward: image too large for one buffer descriptor");
   convp::PairArgs a{x, x_batch_stride, x_row_pitch, Cin, wa_packed, bias_a, slope_a == 0.f ? 1.f : slope_a, C1,
-                    wb_packed, bias_b, slope_b == 0.f ? 1.f : slope_b, C2, y, y_batch_stride, y_row_pitch, B, H, W, (hipStream_t)stream};
+                    wb_packed, bias_b, slope_b == 0.f ? 1.f : slope_b, C2, y, y_batch_stride, y_row_pitch, B, H, W, (hipStream_t)stream, stride_a, stride_b};
   if (dtype == UPF_BF16) return y_is_c8 ? convp::dispatch_pair<bf16_t, true>(a) : convp::dispatch_pair<bf16_t, false>(a);
   return y_is_c8 ? convp::dispatch_pair<f16_t, true>(a) : convp::dispatch_pair<f16_t, false>(a);
 }

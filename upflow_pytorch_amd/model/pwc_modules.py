@@ -102,6 +102,16 @@ class FeatureExtractor(nn.Module):
         cache = self.__dict__.setdefault('_fast_cache', {})
         hip = getattr(self, 'hip_convs', True)         # False: PyTorch-ROCm (MIOpen) even where the MFMA kernel applies
         for i, stage in enumerate(self.convs):
+            if (hip and FUSE_PAIRS[0] and not getattr(self, '_no_fuse_pairs', False) and len(stage[0]) == 2 and len(stage[1]) == 2
+                    and ops.conv_pair_supported(x, stage[0][0], stage[1][0])):
+                # (round 6) the first stages — 3 -> 16 -> 16 at 1/2, 16 -> 32 -> 32 at 1/4 resolution — as ONE launch each, the stride-2 layer's
+                # output staying in LDS (csrc/conv_pair.hip)
+                pc = cache.get(('pair', i)) or cache.setdefault(('pair', i), _PackedConvPair(stage[0], stage[1]))
+                ho, wo = ops.conv3x3_out_hw(x.shape[2], x.shape[3], 2)
+                y = outs[i] if (outs is not None and outs[i] is not None) else ops.empty_nchw((x.shape[0], stage[1][0].out_channels, ho, wo), x.dtype, x.device, pitched=pitched)
+                x = pc(x, y)
+                pyramid.append(x)
+                continue
             x = fast_conv_seq(stage[0], x, cache, allow_hip=hip, pitched=pitched)      # stride-2 conv
             x = fast_conv_seq(stage[1], x, cache, out=None if outs is None else outs[i], allow_hip=hip, pitched=pitched)   # stride-1 conv
             pyramid.append(x)
@@ -381,11 +391,13 @@ class _PackedTailC8(object):
 
 
 class _PackedConvPair(object):
-    """Packed operands of TWO conv(...) Sequentials run as one launch (ops.conv_pair_forward_raw / csrc/conv_pair.hip): a 3x3 stride-1
-    layer followed by a 3x3 stride-2 layer, the halves of the SGU guidance stem (model/upflow.py:30-33)."""
+    """Packed operands of TWO conv(...) Sequentials run as one launch (ops.conv_pair_forward_raw / csrc/conv_pair.hip): 3x3 layers with
+    strides (1, 2) — the halves of the SGU guidance stem (model/upflow.py:30-33) — or (2, 1) — the first stages of the feature pyramid
+    (pwc_modules.py:122-142)."""
 
     def __init__(self, seq_a, seq_b):
         self.convs = (seq_a[0], seq_b[0])
+        self.strides = (seq_a[0].stride[0], seq_b[0].stride[0])
         self.slopes = tuple(0.1 if any(isinstance(m_, nn.LeakyReLU) for m_ in q) else 0.0 for q in (seq_a, seq_b))
         self.key = None
         self.packed = self.packed_b = self.bias = self.bias_b = None
@@ -413,7 +425,7 @@ class _PackedConvPair(object):
 
     def __call__(self, x, y):
         pa, ba, pb, bb = self.get()
-        return ops.conv_pair_forward_raw(x, pa, ba, self.slopes[0], pb, bb, self.slopes[1], y)
+        return ops.conv_pair_forward_raw(x, pa, ba, self.slopes[0], pb, bb, self.slopes[1], y, self.strides)
 
 
 FUSE_PAIRS = [True]          # experiment / parity switch: False = every layer of the SGU guidance stem its own launch (rounds 1-5)

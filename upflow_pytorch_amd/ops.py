@@ -932,8 +932,8 @@ def conv_c8_forward_narrow_init_raw(x8, packed16, partial, offset, Cout, y, leak
 
 
 def conv_pair_pack(w_a, w_b):
-    """Packed operands of upf_conv_pair_s1s2_forward (include/upflow_hip.h) for a 3x3 layer w_a [C1,Cin,3,3] (Cin <= 16, C1 = 16 | 32)
-    followed by a 3x3 stride-2 layer w_b [C2,C1,3,3] (C2 <= 32): MFMA lane order, built with torch indexing (the operands are a few KB)."""
+    """Packed operands of upf_conv_pair_forward (include/upflow_hip.h) for a 3x3 layer w_a [C1,Cin,3,3] (Cin <= 16, C1 = 16 | 32)
+    followed by a 3x3 layer w_b [C2,C1,3,3] (C2 <= 32): MFMA lane order, built with torch indexing (the operands are a few KB)."""
     C1, Cin, C2 = w_a.shape[0], w_a.shape[1], w_b.shape[0]
     if tuple(w_a.shape[2:]) != (3, 3) or tuple(w_b.shape[2:]) != (3, 3) or w_b.shape[1] != C1 or Cin > 16 or C1 not in (16, 32) or C2 > 32:
         raise UpflowHipError('conv_pair_pack: 3x3 layers with Cin <= 16, C1 = 16 | 32, C2 <= 32 expected, got %s / %s' % (tuple(w_a.shape), tuple(w_b.shape)))
@@ -959,9 +959,9 @@ def conv_pair_pack(w_a, w_b):
     return pa.contiguous(), pb.contiguous()
 
 
-def conv_pair_forward_raw(x, packed_a, bias_a, slope_a, packed_b, bias_b, slope_b, y):
-    """One launch of upf_conv_pair_s1s2_forward: x [B,Cin,H,W] (a channel slice of a possibly row-pitched NCHW buffer, EVEN pitch) ->
-    y: NCHW [B,C2,Ho,Wo] channel slice or octets [B,ceil(C2/8),Ho,Wo,8]."""
+def conv_pair_forward_raw(x, packed_a, bias_a, slope_a, packed_b, bias_b, slope_b, y, strides=(1, 2)):
+    """One launch of upf_conv_pair_forward: x [B,Cin,H,W] (a channel slice of a possibly row-pitched NCHW buffer, EVEN pitch) ->
+    y: NCHW [B,C2,Ho,Wo] channel slice or (strides (1, 2)) octets [B,ceil(C2/8),Ho,Wo,8].  strides: (1, 2) or (2, 1)."""
     B, Cin, H, W = x.shape
     C1, C2 = bias_a.shape[0], bias_b.shape[0]
     Ho, Wo = conv3x3_out_hw(H, W, 2)
@@ -979,19 +979,21 @@ def conv_pair_forward_raw(x, packed_a, bias_a, slope_a, packed_b, bias_b, slope_
     if not (x.is_cuda and y.is_cuda) or x.dtype != y.dtype or x.dtype not in (torch.bfloat16, torch.float16) or packed_a.dtype != x.dtype:
         raise UpflowHipError('conv_pair: GPU tensors of one 16-bit dtype expected (there is no CPU fallback)')
     with torch.cuda.device(dev):
-        _lib.call('upf_conv_pair_s1s2_forward', _lib.ptr(x), x.stride(0), xp, Cin, _lib.ptr(packed_a), _lib.ptr(bias_a), float(slope_a), C1,
-                  _lib.ptr(packed_b), _lib.ptr(bias_b), float(slope_b), C2, _lib.ptr(y), y.stride(0), yp, int(y_is_c8), B, H, W,
+        _lib.call('upf_conv_pair_forward', _lib.ptr(x), x.stride(0), xp, Cin, _lib.ptr(packed_a), _lib.ptr(bias_a), float(slope_a), C1, int(strides[0]),
+                  _lib.ptr(packed_b), _lib.ptr(bias_b), float(slope_b), C2, int(strides[1]), _lib.ptr(y), y.stride(0), yp, int(y_is_c8), B, H, W,
                   _lib.dtype_code(x), _lib.stream_ptr(dev))
     return y
 
 
 def conv_pair_supported(x, conv_a, conv_b):
-    """The fused pair applies: 16-bit GPU inference, 3x3 / stride 1 then 3x3 / stride 2, both undilated with 'same' padding, Cin <= 16,
+    """The fused pair applies: 16-bit GPU inference, two undilated 3x3 layers with 'same' padding and strides (1, 2) or (2, 1), Cin <= 16,
     C1 = 16 | 32, C2 <= 32, rows readable as pixel pairs (even pitch, 4-byte aligned)."""
     if torch.is_grad_enabled() or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or x.dim() != 4:
         return False
-    for c, st in ((conv_a, 1), (conv_b, 2)):
-        if c.kernel_size != (3, 3) or c.stride != (st, st) or c.dilation != (1, 1) or c.padding != (1, 1) or c.groups != 1 or c.bias is None or c.weight.dtype != x.dtype:
+    if (conv_a.stride, conv_b.stride) not in (((1, 1), (2, 2)), ((2, 2), (1, 1))):
+        return False
+    for c in (conv_a, conv_b):
+        if c.kernel_size != (3, 3) or c.dilation != (1, 1) or c.padding != (1, 1) or c.groups != 1 or c.bias is None or c.weight.dtype != x.dtype:
             return False
     p = nchw_pitch(x)
     return (conv_a.in_channels <= 16 and conv_a.out_channels in (16, 32) and conv_b.in_channels == conv_a.out_channels and conv_b.out_channels <= 32
