@@ -457,6 +457,7 @@ extern "C" int upf_conv_set_option(const char* name, int value) {
   else if (name && !strcmp(name, "ph_fit")) slot = &g_ph_fit;          // 0: row-phase layers always on 8-row tiles (round-2 behaviour)
   else if (name && !strcmp(name, "force_mtw")) slot = &g_force_mtw;    // experiments: 0 = heuristic, 1 / 2 / 4
   else if (name && !strcmp(name, "force_sk")) slot = &g_force_sk;      // experiments: -1 = heuristic, 0 = never, 1 = wherever eligible
+  else if (name && !strcmp(name, "pair_th")) slot = &g_pair_th;        // experiments (conv_pair.hip): 0 = default tile height, 4 | 8
   if (!slot) return INT32_MIN;
   const int prev = *slot;
   *slot = value;

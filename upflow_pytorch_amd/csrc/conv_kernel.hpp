@@ -797,6 +797,7 @@ void conv_accinit_kernel(const T* __restrict__ wp, T* __restrict__ y, long long 
 }
 
 // launch heuristics and experiment switches (upf_conv_set_option)
+inline int g_pair_th = 0;              // conv_pair.hip: tile height override (experiments): 0 = the default per class, 4 | 8
 inline int g_sk_grid = 48, g_sk_grid_narrow = 96, g_sk_grid_d4 = 16, g_small_grid = 256, g_rpw4_min = 256, g_ph_fit = 1, g_force_mtw = 0, g_force_sk = -1, g_ablate = 0;
 
 struct Args {

@@ -71,7 +71,9 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
       for (int o = 0; o < K0; ++o) {
         uint32_t ch[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) ch[c] = __builtin_amdgcn_raw_buffer_load_b32(xr, off + (uint32_t)(8 * o + c) * plane, 0, 0) & hm;
+        for (int c = 0; c < 8; ++c)          // (planes >= Cin: out of the descriptor's range, zeros without a memory access.  A uniform branch
+                                             // around those loads serialises the others — measured: the kernel twice as slow)
+          ch[c] = __builtin_amdgcn_raw_buffer_load_b32(xr, off + (uint32_t)(8 * o + c) * plane, 0, 0) & hm;
         uint4 e0, e1;
         e0.x = __builtin_amdgcn_perm(ch[1], ch[0], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1], ch[0], 0x07060302u);
         e0.y = __builtin_amdgcn_perm(ch[3], ch[2], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3], ch[2], 0x07060302u);
@@ -93,6 +95,16 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
     const int c = (e & 3) + 8 * (e >> 2) + 4 * kg;
     biasA[e] = (c < C1) ? ba[c] : 0.f;
   }
+  // this lane's B-operand offset of every k-step inside the input tile: (channel octet, kernel row, kernel column)
+  int offA[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    int tap, oct;
+    if constexpr (K0 == 1) { tap = 2 * s + kg; if (tap > 8) tap = 8; oct = 0; }       // (tap 9 does not exist: its weights are zero)
+    else { tap = s; oct = kg; }
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    offA[s] = (oct * IR + ky) * IC + kx + XO;
+  }
   __syncthreads();
 
   // ---- phase A: layer A on the MR x MC pixels layer B reads, 32 at a time -> mid tile (16-bit, zero outside layer A's output)
@@ -104,15 +116,9 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
       const int pc = pv ? p : NPX - 1;
       const int mr = pc / MC, mc = pc - mr * MC;
       f32x16 acc = biasA;
+      const uint4* ib = in_s + SA * (mr * IC + mc);
 #pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        int tap, oct;
-        if constexpr (K0 == 1) { tap = 2 * s + kg; if (tap > 8) tap = 8; oct = 0; }       // (tap 9 does not exist: its weights are zero)
-        else { tap = s; oct = kg; }
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const uint4 b = in_s[(oct * IR + SA * mr + ky) * IC + SA * mc + kx + XO];
-        acc = Mma32<T>::mma(wA[s], b, acc);
-      }
+      for (int s = 0; s < NSTEP; ++s) acc = Mma32<T>::mma(wA[s], ib[offA[s]], acc);
       const int my = my0 + mr, mx = mx0 + mc;
       const bool inside = my >= 0 && my < Hm && mx >= 0 && mx < Wm;
       if (pv) {
@@ -157,6 +163,16 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
         const uint4 b = mid_s[((2 * ks + kg) * MR + SB * r + ky) * MC + SB * px + kx];
         acc[rr] = Mma32<T>::mma(wB[tap][ks], b, acc[rr]);
       }
+  }
+  if constexpr (!YC8) {
+    // 16-byte stores through a per-wave LDS patch (conv_kernel.hpp epilogue_wide: 2-byte stores issue at ~2 B/clk/CU — 31 MB of output
+    // would take 29 us by themselves) when the output rows are 16-byte aligned; the patches reuse the tiles' LDS
+    if (((ypitch & 7) | (int)(ybs & 7) | (int)(reinterpret_cast<uintptr_t>(y) & 15)) == 0) {
+      __syncthreads();                               // every wave is done with the mid tile
+      conv::epilogue_wide<T, RPWB>(acc, reinterpret_cast<unsigned char*>(lds) + wave * conv::EPI_WAVE_BYTES, y + (size_t)n * ybs, C2, Ho, Wo,
+                                   0, lane, x0, __builtin_amdgcn_readfirstlane(y0 + wave * RPWB), 1, slope_b, ypitch);
+      return;
+    }
   }
   const int gx = x0 + px;
 #pragma unroll
@@ -217,12 +233,14 @@ template <typename T, bool YC8>
 int dispatch_pair(const PairArgs& a) {
   const int k0 = a.Cin <= 8 ? 1 : 2, c1o = a.C1 / 8;
   if (a.sa == 1) {                                   // [stride 1, stride 2]: the SGU guidance stem
+    if (k0 == 1 && c1o == 2 && conv::g_pair_th == 4) return launch_pair<T, 1, 2, 4, YC8, 1, 2>(a);
     if (k0 == 1 && c1o == 2) return launch_pair<T, 1, 2, 8, YC8, 1, 2>(a);
     if (k0 == 1 && c1o == 4) return launch_pair<T, 1, 4, 4, YC8, 1, 2>(a);
     if (k0 == 2 && c1o == 2) return launch_pair<T, 2, 2, 8, YC8, 1, 2>(a);
     return launch_pair<T, 2, 4, 4, YC8, 1, 2>(a);
   }
   if constexpr (!YC8) {                              // [stride 2, stride 1]: a stage of the feature pyramid (NCHW out)
+    if (k0 == 1 && c1o == 2 && conv::g_pair_th == 4) return launch_pair<T, 1, 2, 4, false, 2, 1>(a);
     if (k0 == 1 && c1o == 2) return launch_pair<T, 1, 2, 8, false, 2, 1>(a);
     if (k0 == 1 && c1o == 4) return launch_pair<T, 1, 4, 8, false, 2, 1>(a);
     if (k0 == 2 && c1o == 2) return launch_pair<T, 2, 2, 8, false, 2, 1>(a);
