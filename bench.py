@@ -41,6 +41,7 @@ DT = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
 FLAGS = {'if_norm_before_cost_volume': True, 'norm_moments_across_channels': False,
          'norm_moments_across_images': False, 'if_froze_pwc': False, 'if_sgu_upsample': True}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+PEAK_SUSTAINED_TFLOPS = 1420.0  # measured: the vendor bf16 GEMM's best case on random data on this part (profiles/r06_gemm_ceiling.txt)
 
 
 def build_net(dtype, device, hip_pyramid_convs=True, fp32_conv='hip_x3', pyramid_dtype=None):
@@ -191,7 +192,11 @@ def _conv_roofline_probe(B, H, W, dtype, device, x3):
                 'issued_frac': round(3 * achieved / 2500.0, 4), 'traffic': None, 'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
     return {'bound': 'mfma', 'kernel': 'conv_kernel<MTW=4> (context network layer 1, 565->128, 3x3)', 'shape': [N, Cin, h, w],
             'achieved': round(achieved, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(achieved / 2500.0, 4), 'traffic': None,
-            'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
+            'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2),
+            # what the vendor's bf16 GEMM sustains on this part on random data in its best case (hipBLASLt 8192^3: 1410-1433 TFLOP/s at
+            # 1320 W / 1.97 GHz; at this layer's own M x N x K it holds 510-660): tools/gemm_ceiling.py, DESIGN.md 4.2
+            'peak_sustained': PEAK_SUSTAINED_TFLOPS, 'frac_of_sustained': round(achieved / PEAK_SUSTAINED_TFLOPS, 4),
+            'peak_sustained_source': 'profiles/r06_gemm_ceiling.txt'}
 
 
 def conv_flop_per_step(net, B, H, W):

@@ -1646,6 +1646,7 @@ class _TailGroup(object):
         self.cout = sum(m[2] for m in members)
         self.cin = members[0][3]
         self.uses, self.result, self.pending = [], None, 0
+        self.sig = None
 
     def take(self, sink):
         if self.result is None:
@@ -2116,8 +2117,15 @@ class DenseStackTrainFunction(Function):
         grouped = set()
         if len(tail) >= 2 and not getattr(DenseStackTrainFunction, 'no_tail_group', False):
             grp = sinks[nf].group
-            if grp is None:
+            # (the sinks — and with them the group — are made anew by every forward, ops.shared_conv_grads.__enter__; within one backward
+            # every level must describe the same tail: a group whose members or offsets differ — the set of trainable tail layers
+            # changed between two uses — is replaced, not fed a P slice of another width: ADVICE r5)
+            sig = tuple((id(sinks[k]), poff[k]) for k in tail)
+            if grp is None or grp.sig != sig:
+                if grp is not None and (grp.uses or grp.result is not None):
+                    raise UpflowHipError('dense stack: the trainable narrow tail changed between two uses of one backward pass')
                 grp = _TailGroup([(sinks[k], poff[k], (oc if k == nf else f[k]), nt - hi_of[k]) for k in tail])
+                grp.sig = sig
                 for k in tail:
                     sinks[k].group = grp
             if len(grp.uses) < 6:
