@@ -629,3 +629,26 @@ def test_bf16_training_mode_at_realistic_motion_stays_in_the_envelope():
           % (max(lrel.values()), e, rel.max(), names[int(rel.argmax())], np.median(rel), cos.min(), np.median(cos), floor.min(), np.median(floor)))
     assert max(lrel.values()) <= BF16_HS1['loss'] and e <= BF16_HS1['epe'] and rel.max() <= BF16_HS1['gnorm']
     assert np.median(cos) >= np.median(floor) - BF16_HS1['cos_median_slack'] and cos.min() >= floor.min() - BF16_HS1['cos_min_slack']
+
+
+def test_fp16_training_mode_at_realistic_motion_meets_the_tight_bars():
+    """VERDICT r5 next 3 (gradient cosine min >= 0.97, norms <= 6 % at realistic motion).  Round 6 localised the bf16 mode's distance on this
+    vector (profiles/r06_train_precision_localise.txt, r06_train_forward_trace.txt): bf16 rounding injected at EVERY tensor class of the fp32
+    step moves the flow by 0.07 px and the worst cosine to 0.970 — the 0.83 px / 0.910 of the real bf16 forward is ONE validity-mask flip of
+    the feature warp at the 4x13 level (1 pixel of 208; then 6, 12, 45 at the finer levels), a discrete event of the reference's hard masks
+     that any perturbation of that size can trigger, not a precision defect of one tensor class.  The fp16 matrix-core mode
+    (`train_conv_dtype='fp16'`, 11 mantissa bits; measured: flow 0.012 px, loss terms 1.2e-4, gradient norms <= 3.2 % (median 0.5 %),
+    cosines min 0.997 / median 0.9998) stays on the reference's side of every mask on this vector and meets the bars."""
+    g = load_golden('train_128x416_hs1')
+    out, terms, names, params = _realistic_step('fp16')
+    lrel = {k: abs(float(v) - float(g[k])) / max(1.0, abs(float(g[k]))) for k, v in terms.items()}
+    e = oracle.epe(out['flow_f_out'].detach().cpu(), g['flow_f_out'])
+    got = np.array([float(params[n].grad.norm()) for n in names])
+    want = g['grad_norms'].numpy()
+    rel = np.abs(got - want) / np.maximum(want, 1e-3)
+    cos, worst = grad_direction_check({n: params[n].grad for n in names}, g)
+    print('realistic motion, fp16: loss terms rel. error max %.5f, flow EPE %.4f px, max rel grad-norm error %.3g median %.3g, cosine min %.5f median %.5f'
+          % (max(lrel.values()), e, rel.max(), np.median(rel), cos.min(), np.median(cos)))
+    assert all(torch.isfinite(params[n].grad).all() for n in names)
+    assert max(lrel.values()) <= 1e-3 and e <= 0.05
+    assert rel.max() <= 0.06 and cos.min() >= 0.97 and np.median(cos) >= 0.998
