@@ -251,7 +251,7 @@ def _median(v):
 def cpu_baseline():
     """The reference's CPU fallback (pure-PyTorch unfold correlation inside the full fp32 forward), as restated in
     oracle/ (kind "port"), on this box's host cores — BASELINE.md §3: full UPFlow_net forward at 384x1280 B=1 (the
-    metric's shape; `value`) and 256x256 B=1 (config 1), median of 5 timed runs after 2 warm-ups, the share of the time
+    metric's shape; `value`) and 256x256 B=1 (config 1), median of 4 timed runs after 1 warm-up, the share of the time
     spent inside the 10 fallback-correlation calls, and the correlation alone at the five pyramid-level shapes."""
     from upflow_pytorch_amd import synthetic as _weights
     from oracle import net as onet
@@ -272,12 +272,12 @@ def cpu_baseline():
             for name, (H, W, cid) in (('256x256', (256, 256, 1)), ('384x1280', (384, 1280, 2))):
                 im1, im2 = _weights.make_images(cid, 1, H, W)
                 times, shares = [], []
-                for it in range(7):
+                for it in range(5):                          # (a bounded sample: ~25 s of host time in all)
                     spent[0] = 0.0
                     t0 = time.perf_counter()
                     onet.forward(sd, im1, im2, mask_mode='literal', corr='unfold')
                     dt = time.perf_counter() - t0
-                    if it >= 2:
+                    if it >= 1:
                         times.append(dt)
                         shares.append(spent[0] / dt)
                 res[name] = {'s_per_pair': round(_median(times), 4), 'frame_pairs_per_s': round(1.0 / _median(times), 5),
@@ -299,7 +299,7 @@ def cpu_baseline():
     return {'value': main_['frame_pairs_per_s'], 'unit': 'frame-pairs/s', 'cores': torch.get_num_threads(),
             'host_cpus': os.cpu_count(), 'kind': 'port',
             'sample': 'full UPFlow_net fp32 forward of ONE 384x1280 frame pair with the unfold-based fallback correlation '
-                      '(utils/pytorch_correlation.py:27-50 restated in oracle/): median of 5 timed runs after 2 warm-ups, '
+                      '(utils/pytorch_correlation.py:27-50 restated in oracle/): median of 4 timed runs after 1 warm-up, '
                       '%.2f s per pair, %.0f %% of it inside the 10 correlation calls' % (main_['s_per_pair'], 100 * main_['correlation_share']),
             'shapes': res, 'correlation_alone_ms': levels}
 
@@ -406,14 +406,19 @@ def train_probe(device, steps=30):
         for _ in range(tr.graph_warmup + 1 + 20):
             tr.step(batch)
         torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            stats = tr.step(batch, sync_stats=False)
-        torch.cuda.synchronize(device)
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        wins = []
+        for _w in range(3):                                  # three windows of `steps` steps: the median
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                stats = tr.step(batch, sync_stats=False)
+            torch.cuda.synchronize(device)
+            wins.append((time.perf_counter() - t0) / steps * 1e3)
+        wins.sort()
+        ms = wins[1]
         loss = float(stats.cpu()[tr._names.index('loss')]) if 'loss' in tr._names else None
         return {'workload': 'config3: unsupervised training step, 256x832 crops, batch 4, bf16 activations / fp32 master weights, '
                             'forward + losses + backward + Adam(amsgrad) in one hipGraph', 'dtype': 'bf16', 'ms_per_step': round(ms, 3),
+                'ms_per_step_min': round(wins[0], 3), 'ms_per_step_max': round(wins[2], 3), 'windows': 3,
                 'frame_pairs_per_s': round(4e3 / ms, 2), 'steps': steps, 'hip_graph': tr.use_graph, 'capture_fallback': tr.capture_fallback, 'final_loss': loss,
                 'roofline_train': train_roofline(tr.raw_net, 4, 256, 832, ms)}
     except Exception as e:                                   # (an extra: it must never take the headline line down)
