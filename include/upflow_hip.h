@@ -281,6 +281,12 @@ int upf_conv_forward_pitched(const void* x, long long x_batch_stride, int x_row_
 int upf_conv1x1_forward_mixed(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
                               void* y, long long y_batch_stride, int y_row_pitch, int y_is_c8, int B, int Cin, int Cout, int H, int W,
                               float leaky_slope, int dtype, int out_dtype, void* stream);
+/* The 1x1 projection of a level's features, NCHW -> octets, stored into TWO octet buffers by one launch (round 6): it is the input of
+ * both dense stacks of a level — the flow estimator's buffer and the SGU estimator's (model/upflow.py:546-553 with :71-75) — and
+ * used to be computed twice.  Same arithmetic and bits as upf_conv_forward_c8 / upf_conv1x1_forward_mixed (out_dtype may equal dtype). */
+int upf_conv1x1_forward_c8_dual(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
+                                void* y8_a, long long ya_batch_stride, void* y8_b, long long yb_batch_stride,
+                                int B, int Cin, int Cout, int H, int W, float leaky_slope, int dtype, int out_dtype, void* stream);
 int upf_conv_set_option(const char* name, int value);
 
 /* ---- the same convolutions for the fp32 PARITY mode: split-precision products on the fp16 matrix cores  (round 4;

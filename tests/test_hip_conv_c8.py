@@ -510,3 +510,28 @@ def test_whole_net_with_the_fused_guidance_stem_stays_within_the_16_bit_envelope
         eab = float((a[k].float() - b[k].float()).pow(2).sum(1).sqrt().mean())
         print('%s: EPE vs fp32: fused stem %.5f px, four launches %.5f px; fused vs four launches %.5f px' % (k, ea, eb, eab))
         assert ea <= 1.25 * eb + 1e-4 and eab <= 1.5 * eb + 1e-4
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 48, 160), (1, 64, 32, 23, 78), (8, 32, 32, 96, 320), (1, 96, 20, 9, 156)])
+@pytest.mark.parametrize('dts', [(torch.bfloat16, torch.bfloat16), (torch.float16, torch.bfloat16), (torch.float16, torch.float16)])
+def test_conv1x1_dual_destination_equals_two_launches(case, dts):
+    """upf_conv1x1_forward_c8_dual: the 1x1 projection NCHW -> octets stored into two buffers by one launch == the two launches it
+    replaces, bit for bit, in both buffers; nothing outside the destination octets is written; mixed types (fp16 features -> bf16 octets)."""
+    from upflow_pytorch_amd import ops
+    B, Cin, Cout, H, W = case
+    dti, dto = dts
+    g = torch.Generator().manual_seed(sum(case))
+    x = ops.empty_nchw((B, Cin, H, W), dti, 'cuda')
+    x.copy_(torch.randn(B, Cin, H, W, generator=g))
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).to(dti).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    packed = ops.conv_c8_pack(w, (), range(Cin))
+    no = (Cout + 7) // 8
+    want = ops.c8_empty(B, Cout, H, W, dto, 'cuda')
+    ops.conv_c8_forward_raw(None, x, packed, b, want, dilation=1, leaky_slope=0.1, kernel_size=1)
+    a = torch.full((B, no + 2, H, W, 8), 3.0, dtype=dto, device='cuda')
+    c = torch.full((B, no + 3, H, W, 8), 5.0, dtype=dto, device='cuda')
+    ops.conv1x1_c8_dual_raw(x, packed, b, a[:, 1:1 + no], c[:, 2:2 + no], 0.1)
+    assert torch.equal(a[:, 1:1 + no].contiguous().view(torch.int16), want.view(torch.int16))
+    assert torch.equal(c[:, 2:2 + no].contiguous().view(torch.int16), want.view(torch.int16))
+    assert bool((a[:, 0] == 3).all()) and bool((a[:, -1] == 3).all()) and bool((c[:, :2] == 5).all()) and bool((c[:, -1] == 5).all())

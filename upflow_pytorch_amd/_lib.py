@@ -37,6 +37,7 @@ SIGNATURES = {
     'upf_corr81_norm_forward_mixed': [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _ll, _f, _vp, _vp],
     'upf_corr81_norm_forward_c8_mixed': [_vp, _vp, _i, _vp, _ll, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     'upf_conv1x1_forward_mixed': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    'upf_conv1x1_forward_c8_dual': [_vp, _ll, _i, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     'upf_corr81_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_forward': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_correlation_backward': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

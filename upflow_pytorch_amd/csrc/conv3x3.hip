@@ -633,6 +633,43 @@ extern "C" int upf_conv1x1_forward_mixed(const void* x, long long x_batch_stride
   return gen ? conv::launch_1x1_mixed<bf16_t, f16_t, true>(a) : conv::launch_1x1_mixed<bf16_t, f16_t, false>(a);
 }
 
+namespace upf {
+namespace conv {
+template <typename T, typename TO>
+int launch_1x1_dual(const Args& a, void* y2, long long y2bs) {
+  constexpr int TH = 4 * 2;
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
+  const size_t lds = (size_t)4 * TH * (xw(1, margin_of(0)) + xw(1, margin_of(0)) / 16) * 16;
+  static LdsOptIn opt;
+  auto kern = &conv1x1_dual_kernel<T, TO>;
+  opt.ensure(reinterpret_cast<const void*>(kern), lds);
+  const DualOut<TO> d{(TO*)y2, y2bs};
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * tiles_x * tiles_y), 1), dim3(NTHREADS), lds, a.stream, (const T*)a.x, a.xbs,
+                     (const T*)a.wp, a.bias, (TO*)a.y, a.ybs, a.Cin, a.Cout, a.H, a.W, tiles_x, tiles_y, a.slope, a.xpitch, d);
+  return check_launch("conv1x1_forward_c8_dual");
+}
+}  // namespace conv
+}  // namespace upf
+
+extern "C" int upf_conv1x1_forward_c8_dual(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
+                                           void* y8_a, long long ya_batch_stride, void* y8_b, long long yb_batch_stride,
+                                           int B, int Cin, int Cout, int H, int W, float leaky_slope, int dtype, int out_dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(x && w_packed && bias && y8_a && y8_b, UPF_EINVAL, "conv1x1_forward_c8_dual: null pointer");
+  UPF_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Cout <= 32 && H > 0 && W > 0, UPF_EINVAL, "conv1x1_forward_c8_dual: bad shape B=%d Cin=%d Cout=%d (<= 32) H=%d W=%d", B, Cin, Cout, H, W);
+  UPF_REQUIRE((dtype == UPF_BF16 || dtype == UPF_F16) && (out_dtype == UPF_BF16 || out_dtype == UPF_F16), UPF_EDTYPE, "conv1x1_forward_c8_dual: bf16 / fp16");
+  if (x_row_pitch == 0) x_row_pitch = W;
+  UPF_REQUIRE(x_row_pitch >= W && x_row_pitch % 8 == 0 && aligned_to(x, 16) && x_batch_stride % 8 == 0, UPF_EUNSUPPORTED,
+              "conv1x1_forward_c8_dual: the input rows must be 16-byte aligned (W %% 8 == 0 or a row pitch that is a multiple of 8)");
+  UPF_REQUIRE(aligned_to(y8_a, 16) && ya_batch_stride % 8 == 0 && aligned_to(y8_b, 16) && yb_batch_stride % 8 == 0, UPF_EINVAL, "conv1x1_forward_c8_dual: the octet outputs must be 16-byte aligned");
+  UPF_REQUIRE((long long)Cin * H * x_row_pitch * 2 < (1ll << 31) && (long long)32 * H * W * 2 < (1ll << 31), UPF_EINVAL, "conv1x1_forward_c8_dual: image too large for one buffer descriptor");
+  UPF_REQUIRE(leaky_slope >= 0.f && leaky_slope <= 1.f, UPF_EINVAL, "conv1x1_forward_c8_dual: leaky_slope %g not in [0,1]", (double)leaky_slope);
+  conv::Args a{x, x_batch_stride, w_packed, bias, y8_a, ya_batch_stride, B, Cin, Cout, H, W, 0, 1, 1, leaky_slope == 0.f ? 1.f : leaky_slope, (hipStream_t)stream,
+               x_row_pitch, W};
+  if (dtype == UPF_F16) return out_dtype == UPF_F16 ? conv::launch_1x1_dual<f16_t, f16_t>(a, y8_b, yb_batch_stride) : conv::launch_1x1_dual<f16_t, bf16_t>(a, y8_b, yb_batch_stride);
+  return out_dtype == UPF_BF16 ? conv::launch_1x1_dual<bf16_t, bf16_t>(a, y8_b, yb_batch_stride) : conv::launch_1x1_dual<bf16_t, f16_t>(a, y8_b, yb_batch_stride);
+}
+
 extern "C" int upf_conv_forward_pitched(const void* x, long long x_batch_stride, int x_row_pitch, const void* w_packed, const float* bias,
                                         void* y, long long y_batch_stride, int y_row_pitch, int B, int Cin, int Cout, int H, int W,
                                         int kernel_size, int dilation, int stride, float leaky_slope, int dtype, void* stream) {

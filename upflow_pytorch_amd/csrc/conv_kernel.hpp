@@ -122,7 +122,7 @@ __device__ __forceinline__ void stage_store(uint4* tile, int enc, int sh, const 
 // activation.  Removing those passes from the captured config-3 step took 1.13 ms off 9.51 (tools/act_grad_cost_probe.py), so the
 // two operands are applied HERE, to the 16-bit values the epilogue is about to store — the same arithmetic on the same rounded
 // values, in the same order, as the pass it replaces (conv_wgrad.hip act_grad_kernel): bit-identical outputs.
-struct NoGate { static constexpr bool on = false, split = false, init = false; };
+struct NoGate { static constexpr bool on = false, split = false, init = false, dual = false; };
 // ---- merged narrow tail of a dense stack (round 6; inference, octet operands).  The layers of a dense stack read NESTED channel
 // suffixes of one buffer (pwc_modules.py:279-286, model/upflow.py:53-60): conv_last reads [conv5 | what conv5 read], so
 //   conv_last = W_last[:, conv5 part] * conv5_out + W_last[:, rest] * rest
@@ -139,15 +139,21 @@ struct NoGate { static constexpr bool on = false, split = false, init = false; }
 // The sum is the same fp32 sum in another order (the layer's own K order put the tail's channels first, here they come last);
 // no 16-bit rounding happens in between.
 struct SplitOut {
-  static constexpr bool on = false, split = true, init = false;
+  static constexpr bool on = false, split = true, init = false, dual = false;
   float* part; long long pbs; int ppitch; int cmain;      // cmain % 8 == 0
 };
 struct AccInit {
-  static constexpr bool on = false, split = false, init = true;
+  static constexpr bool on = false, split = false, init = true, dual = false;
   const float* part; long long pbs; int ppitch; int coff;  // coff % 4 == 0: first float of this layer's partial within a pixel
 };
+// DualOut (round 6): the octets are stored TWICE — the 1x1 projection of a level's features is the input of two dense stacks (the flow
+// estimator's buffer and the SGU estimator's, model/upflow.py:546-553 + :71-75) and used to be computed by two launches.
+template <typename TO> struct DualOut {
+  static constexpr bool on = false, split = false, init = false, dual = true;
+  TO* y2; long long y2bs;
+};
 template <typename T> struct ActGate {
-  static constexpr bool on = true, split = false, init = false;
+  static constexpr bool on = true, split = false, init = false, dual = false;
   const T* add; long long abs_;        // optional [B,Cout,Ho,Wo] channel slice added first (16-bit sum, rounded)
   const T* y; long long ybs;           // optional forward activation output: elements with !(y > 0) are scaled by slope
   float slope;
@@ -724,6 +730,10 @@ void conv_body(const T* __restrict__ x, long long xbs, const T* __restrict__ wp,
           u32x2 o;
           o.x = pack2<TO>(v[0], v[1]); o.y = pack2<TO>(v[2], v[3]);
           __builtin_amdgcn_raw_buffer_store_b64(o, yr, lane_off + (uint32_t)g * plane16 + (uint32_t)(gy * Wo) * 16u, 0, 0);
+          if constexpr (G::dual) {
+            __amdgpu_buffer_rsrc_t yr2 = __builtin_amdgcn_make_buffer_rsrc(gate.y2 + (size_t)n * gate.y2bs, 0, (uint32_t)((cout_y + 7) / 8) * plane16, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(o, yr2, lane_off + (uint32_t)g * plane16 + (uint32_t)(gy * Wo) * 16u, 0, 0);
+          }
         }
       }
     }
@@ -794,6 +804,15 @@ void conv_accinit_kernel(const T* __restrict__ wp, T* __restrict__ y, long long 
                          int tiles_x, int tiles_y, float slope, const T* __restrict__ x8, long long x8bs, int n8oct, const AccInit ai) {
   conv_body<T, 1, RPW, 1, 4, 1, false, false, 1, YC8, true, T, AccInit>(nullptr, 0ll, wp, nullptr, y, ybs, 0, Cout, H, W, H, W, 0, tiles_x, tiles_y, slope,
                                                                         x8, x8bs, n8oct, W, W, ai);
+}
+
+// the 1x1 projection NCHW -> octets, stored into two buffers (DualOut)
+template <typename T, typename TO>
+__global__ __launch_bounds__(NTHREADS, 2)
+void conv1x1_dual_kernel(const T* __restrict__ x, long long xbs, const T* __restrict__ wp, const float* __restrict__ bias, TO* __restrict__ y, long long ybs,
+                         int Cin, int Cout, int H, int W, int tiles_x, int tiles_y, float slope, int xpitch, const DualOut<TO> d) {
+  conv_body<T, 1, 2, 1, 4, 0, false, false, 0, true, false, TO, DualOut<TO>>(x, xbs, wp, bias, y, ybs, Cin, Cout, H, W, H, W, 0, tiles_x, tiles_y, slope,
+                                                                            nullptr, 0ll, 0, xpitch, W, d);
 }
 
 // launch heuristics and experiment switches (upf_conv_set_option)

@@ -268,6 +268,18 @@ class _PackedConvC8(object):
     def invalidate(self):
         self.key = None
 
+    def dual(self, x2, y_a, y_b):
+        """A 1x1 projection NCHW -> octets stored into two buffers by one launch (ops.conv1x1_c8_dual_raw); falls back to two launches
+        where the rows are not 16-byte aligned."""
+        packed, bias = self.get()
+        c = self.conv
+        p = ops.nchw_pitch(x2)
+        if (DUAL_1X1[0] and c.kernel_size == (1, 1) and not self.narrow and c.out_channels <= 32 and p is not None and p % 8 == 0
+                and x2.data_ptr() % 16 == 0 and x2.stride(0) % 8 == 0):
+            return ops.conv1x1_c8_dual_raw(x2, packed, bias, y_a, y_b, self.slope)
+        self(None, x2, y_a)
+        return self(None, x2, y_b)
+
     def __call__(self, x8, x2, y):
         packed, bias = self.get()
         if self.narrow:
@@ -428,6 +440,7 @@ class _PackedConvPair(object):
         return ops.conv_pair_forward_raw(x, pa, ba, self.slopes[0], pb, bb, self.slopes[1], y, self.strides)
 
 
+DUAL_1X1 = [True]            # experiment / parity switch: False = the 1x1 projection computed once per destination buffer (rounds 3-5)
 FUSE_PAIRS = [True]          # experiment / parity switch: False = every layer of the SGU guidance stem its own launch (rounds 1-5)
 MERGE_TAIL = [True]          # experiment / parity switch: False = every layer of a dense stack its own pass (rounds 3-5)
 

@@ -666,14 +666,17 @@ class UPFlow_net(tools.abstract_model):
         pc = cache.get(('c8_1x1', level))
         if pc is None:
             pc = cache[('c8_1x1', level)] = _PackedConvC8(self.conv_1x1[level], (), range(C))
-        pc(None, Fm, buf8[:, o_feat:o_feat + 4])
-        flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
-        self._tap('L%d.flow_bilinear' % level, flow_up)
         if use_sgu:
+            # (round 6: the projection is the input of BOTH stacks of the level: one launch stores it into both buffers)
             em = sgi.dense_estimator_mask
             sbuf8 = ops.c8_empty(nb, em._n_total, H, W, dt, dev)
             o0 = (em._n_total - em._ch_in) // 8
-            pc(None, Fm, sbuf8[:, o0:o0 + 4])
+            pc.dual(Fm, buf8[:, o_feat:o_feat + 4], sbuf8[:, o0:o0 + 4])
+        else:
+            pc(None, Fm, buf8[:, o_feat:o_feat + 4])
+        flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
+        self._tap('L%d.flow_bilinear' % level, flow_up)
+        if use_sgu:
             flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B, tap=lambda n_, t_: self._tap('L%d.%s' % (level, n_), t_))[1]
             self._tap('L%d.sbuf8' % level, sbuf8)
             self._tap('L%d.flow_sgu' % level, flow_up)

@@ -1051,6 +1051,24 @@ def conv_c8_forward_raw(x8, x2, packed, bias32, y, dilation=1, leaky_slope=0.0, 
     return y
 
 
+def conv1x1_c8_dual_raw(x2, packed, bias32, y_a, y_b, leaky_slope=0.0):
+    """The 1x1 projection x2 [B,Cin,H,W] (NCHW, 16-byte aligned rows) -> octets, stored into BOTH y_a and y_b [B, ceil(Cout/8), H, W, 8]
+    (upf_conv1x1_forward_c8_dual): one launch instead of two for a tensor that is the input of two dense stacks."""
+    B, Cin, H, W = x2.shape
+    Cout = bias32.shape[0]
+    for y in (y_a, y_b):
+        if y.dim() != 5 or not _c8_view_ok(y) or tuple(y.shape) != (B, (Cout + 7) // 8, H, W, 8) or y.dtype != y_a.dtype:
+            raise UpflowHipError('conv1x1_c8_dual: outputs must be octet slices [%d,%d,%d,%d,8] of one type' % (B, (Cout + 7) // 8, H, W))
+    xp = _pitch_or_raise(x2, 'conv1x1_c8_dual: x')
+    dev = x2.device
+    if not (x2.is_cuda and y_a.is_cuda and y_b.is_cuda) or x2.dtype not in (torch.bfloat16, torch.float16) or y_a.dtype not in (torch.bfloat16, torch.float16):
+        raise UpflowHipError('conv1x1_c8_dual: 16-bit GPU tensors expected (there is no CPU fallback)')
+    with torch.cuda.device(dev):
+        _lib.call('upf_conv1x1_forward_c8_dual', _lib.ptr(x2), x2.stride(0), xp, _lib.ptr(packed), _lib.ptr(bias32), _lib.ptr(y_a), y_a.stride(0),
+                  _lib.ptr(y_b), y_b.stride(0), B, Cin, Cout, H, W, float(leaky_slope), _lib.dtype_code(x2), _lib.dtype_code(y_a), _lib.stream_ptr(dev))
+    return y_a
+
+
 def conv_c8_set_option(name, value):
     prev = _lib.lib().upf_conv_c8_set_option(name.encode(), int(value))
     if prev == -2 ** 31:
