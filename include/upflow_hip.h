@@ -383,7 +383,8 @@ int upf_conv_forward_c8_narrow_init(const void* x8, long long x8_batch_stride, i
  * x: NCHW [B,Cin,H,W] with an EVEN row pitch (rows are read as pixel pairs); y: NCHW [B,C2,Ho,Wo] (row pitch given) or, strides (1, 2) only,
  * octets [B,ceil(C2/8),Ho,Wo,8]; Ho = ceil(H/2), Wo = ceil(W/2).  leaky slope 0 = no activation.
  * Packed operands (16-bit, MFMA lane order; lane = co + 32 kg, 8 consecutive k per lane):
- *   wa [S][64][8], S = 5 for Cin <= 8 (k-octet kg of step s = tap 2s + kg, channels 0..7), S = 9 for Cin <= 16 (step = tap, kg = channel octet);
+ *   wa [S][64][8], S = 3 for Cin <= 4 (k-octet kg of step s = taps 4s + 2kg and 4s + 2kg + 1, 4 channels each), S = 5 for Cin <= 8 (k-octet kg of
+ *   step s = tap 2s + kg, channels 0..7), S = 9 for Cin <= 16 (step = tap, kg = channel octet);
  *   wb [9][C1/16][64][8] (tap, k-step of 16 channels, kg = channel octet within the step); rows co >= C / absent taps / channels are zero.
  * The sums are the layers' own fp32 sums in another order than upf_conv_forward's (two taps per instruction in the first layer). */
 int upf_conv_pair_forward(const void* x, long long x_batch_stride, int x_row_pitch, int Cin,

@@ -13,7 +13,8 @@
 //
 // Both layers are v_mfma_f32_32x32x16 implicit GEMMs, D[co][pixel]:
 //   layer A: B operand = one LDS entry (8 input channels of a pixel) per lane; with Cin <= 8 a k-step of 16 holds TWO TAPS (lane half kg
-//            reads tap 2s + kg): 5 instructions per 32 pixels; with Cin <= 16 a k-step is one tap (kg = channel octet): 9;
+//            reads tap 2s + kg): 5 instructions per 32 pixels; with Cin <= 4 (the frames) entries are 4 channels and a k-step holds FOUR
+//            taps (3 instructions); with Cin <= 16 a k-step is one tap (kg = channel octet): 9;
 //   layer B: as conv_kernel's stride-2 form, entries (octet 2ks + kg, row 2r + ky, column 2px + kx) of the mid tile.
 // Packed weights (host side, ops.conv_pair_pack): A: [step][lane = co + 32 kg][8 k], B: [tap][k-step][lane][8 k].
 #include "conv_kernel.hpp"
@@ -41,12 +42,14 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
                       int H, int W, int Hm, int Wm, int Ho, int Wo, int tiles_x, int tiles_y) {
   using G = Geo<SA, SB, TH>;
   constexpr int MR = G::MR, MC = G::MC, IR = G::IR, IC = G::IC, XO = G::XO;
-  constexpr int NSTEP = (K0 == 1) ? 5 : 9;
+  constexpr bool QUAD = (K0 == 0);                   // Cin <= 4 (RGB): 8-byte entries of 4 channels, FOUR taps per k-step of 16
+  constexpr int KO = QUAD ? 1 : K0;                  // staged channel planes (octets, or the one quad)
+  constexpr int NSTEP = QUAD ? 3 : ((K0 == 1) ? 5 : 9);
   constexpr int KSB = C1O / 2;                       // k-steps of 16 channels of layer B
   constexpr int RPWB = TH / 4;                       // output rows per wave
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  uint4* in_s = lds;                                 // [K0][IR][IC] entries: 8 input channels of one pixel
-  uint4* mid_s = lds + K0 * IR * IC;                 // [C1O][MR][MC] entries: 8 channels of layer A's output
+  uint4* in_s = lds;                                 // [KO][IR][IC] entries: 8 (QUAD: 4) input channels of one pixel
+  uint4* mid_s = lds + (QUAD ? (IR * IC + 1) / 2 : K0 * IR * IC);   // [C1O][MR][MC] entries: 8 channels of layer A's output
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
@@ -67,6 +70,17 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
       const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
       const uint32_t off = in ? (uint32_t)(gy * xpitch + gx) * 2u : 0x80000000u;
       const uint32_t hm = (gx + 1 < W) ? 0xffffffffu : 0x0000ffffu;       // odd W: the second pixel of the last pair is padding
+      if constexpr (QUAD) {
+        uint32_t ch[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ch[c] = __builtin_amdgcn_raw_buffer_load_b32(xr, off + (uint32_t)c * plane, 0, 0) & hm;
+        uint2 e0, e1;
+        e0.x = __builtin_amdgcn_perm(ch[1], ch[0], 0x05040100u); e1.x = __builtin_amdgcn_perm(ch[1], ch[0], 0x07060302u);
+        e0.y = __builtin_amdgcn_perm(ch[3], ch[2], 0x05040100u); e1.y = __builtin_amdgcn_perm(ch[3], ch[2], 0x07060302u);
+        uint2* q = reinterpret_cast<uint2*>(in_s);
+        q[ir * IC + 2 * pp] = e0;
+        q[ir * IC + 2 * pp + 1] = e1;
+      }
 #pragma unroll
       for (int o = 0; o < K0; ++o) {
         uint32_t ch[8];
@@ -96,14 +110,16 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
     biasA[e] = (c < C1) ? ba[c] : 0.f;
   }
   // this lane's B-operand offset of every k-step inside the input tile: (channel octet, kernel row, kernel column)
-  int offA[NSTEP];
+  int offA[NSTEP], offA2[NSTEP];                     // (offA2: QUAD only — the second tap of the lane's k-octet)
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
     int tap, oct;
-    if constexpr (K0 == 1) { tap = 2 * s + kg; if (tap > 8) tap = 8; oct = 0; }       // (tap 9 does not exist: its weights are zero)
+    if constexpr (QUAD) { tap = 4 * s + 2 * kg; oct = 0; }
+    else if constexpr (K0 == 1) { tap = 2 * s + kg; oct = 0; }
     else { tap = s; oct = kg; }
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    offA[s] = (oct * IR + ky) * IC + kx + XO;
+    const int t1 = tap > 8 ? 8 : tap, t2 = tap + 1 > 8 ? 8 : tap + 1;      // (taps 9 .. 11 do not exist: their weights are zero)
+    offA[s] = (oct * IR + t1 / 3) * IC + t1 % 3 + XO;
+    offA2[s] = (t2 / 3) * IC + t2 % 3 + XO;
   }
   __syncthreads();
 
@@ -116,9 +132,18 @@ void conv_pair_kernel(const T* __restrict__ x, long long xbs, int xpitch, int Ci
       const int pc = pv ? p : NPX - 1;
       const int mr = pc / MC, mc = pc - mr * MC;
       f32x16 acc = biasA;
-      const uint4* ib = in_s + SA * (mr * IC + mc);
+      if constexpr (QUAD) {
+        const uint2* ib = reinterpret_cast<const uint2*>(in_s) + SA * (mr * IC + mc);
 #pragma unroll
-      for (int s = 0; s < NSTEP; ++s) acc = Mma32<T>::mma(wA[s], ib[offA[s]], acc);
+        for (int s = 0; s < NSTEP; ++s) {
+          const uint2 lo = ib[offA[s]], hi = ib[offA2[s]];
+          acc = Mma32<T>::mma(wA[s], make_uint4(lo.x, lo.y, hi.x, hi.y), acc);
+        }
+      } else {
+        const uint4* ib = in_s + SA * (mr * IC + mc);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) acc = Mma32<T>::mma(wA[s], ib[offA[s]], acc);
+      }
       const int my = my0 + mr, mx = mx0 + mc;
       const bool inside = my >= 0 && my < Hm && mx >= 0 && mx < Wm;
       if (pv) {
@@ -219,7 +244,7 @@ int launch_pair(const PairArgs& a) {
   const int Hm = (a.H - 1) / SA + 1, Wm = (a.W - 1) / SA + 1;
   const int Ho = (Hm - 1) / SB + 1, Wo = (Wm - 1) / SB + 1;
   const int tiles_x = cdiv(Wo, 32), tiles_y = cdiv(Ho, TH);
-  const size_t ldsb = (size_t)(K0 * G::IR * G::IC + C1O * G::MR * G::MC) * 16;
+  const size_t ldsb = (size_t)((K0 == 0 ? (G::IR * G::IC + 1) / 2 : K0 * G::IR * G::IC) + C1O * G::MR * G::MC) * 16;
   static LdsOptIn opt;
   auto kern = &conv_pair_kernel<T, K0, C1O, TH, YC8, SA, SB>;
   opt.ensure(reinterpret_cast<const void*>(kern), ldsb);
@@ -231,8 +256,10 @@ int launch_pair(const PairArgs& a) {
 // tile heights: two workgroups per CU (LDS: input tile + mid tile <= 80 KB)
 template <typename T, bool YC8>
 int dispatch_pair(const PairArgs& a) {
-  const int k0 = a.Cin <= 8 ? 1 : 2, c1o = a.C1 / 8;
+  const int k0 = a.Cin <= 4 ? 0 : (a.Cin <= 8 ? 1 : 2), c1o = a.C1 / 8;
   if (a.sa == 1) {                                   // [stride 1, stride 2]: the SGU guidance stem
+    if (k0 == 0 && c1o == 2) return launch_pair<T, 0, 2, 8, YC8, 1, 2>(a);
+    if (k0 == 0 && c1o == 4) return launch_pair<T, 0, 4, 4, YC8, 1, 2>(a);
     if (k0 == 1 && c1o == 2 && conv::g_pair_th == 4) return launch_pair<T, 1, 2, 4, YC8, 1, 2>(a);
     if (k0 == 1 && c1o == 2) return launch_pair<T, 1, 2, 8, YC8, 1, 2>(a);
     if (k0 == 1 && c1o == 4) return launch_pair<T, 1, 4, 4, YC8, 1, 2>(a);
@@ -240,6 +267,8 @@ int dispatch_pair(const PairArgs& a) {
     return launch_pair<T, 2, 4, 4, YC8, 1, 2>(a);
   }
   if constexpr (!YC8) {                              // [stride 2, stride 1]: a stage of the feature pyramid (NCHW out)
+    if (k0 == 0 && c1o == 2) return launch_pair<T, 0, 2, 8, false, 2, 1>(a);
+    if (k0 == 0 && c1o == 4) return launch_pair<T, 0, 4, 8, false, 2, 1>(a);
     if (k0 == 1 && c1o == 2 && conv::g_pair_th == 4) return launch_pair<T, 1, 2, 4, false, 2, 1>(a);
     if (k0 == 1 && c1o == 2) return launch_pair<T, 1, 2, 8, false, 2, 1>(a);
     if (k0 == 1 && c1o == 4) return launch_pair<T, 1, 4, 8, false, 2, 1>(a);

@@ -941,9 +941,12 @@ def conv_pair_pack(w_a, w_b):
     lane = torch.arange(64, device=dev)
     co, kg, j = (lane % 32).view(1, 64, 1), (lane // 32).view(1, 64, 1), torch.arange(8, device=dev).view(1, 1, 8)
     # layer A: zero-padded copy [32, 16, 10 taps] (tap 9 = the absent second tap of the last step)
-    wa = torch.zeros((32, 16, 10), dtype=dt, device=dev)
+    wa = torch.zeros((32, 16, 12), dtype=dt, device=dev)
     wa[:C1, :Cin, :9] = w_a.detach().reshape(C1, Cin, 9)
-    if Cin <= 8:
+    if Cin <= 4:                                     # four taps per k-step: k-octet kg of step s = taps 4s + 2kg, 4s + 2kg + 1 x 4 channels
+        s = torch.arange(3, device=dev).view(3, 1, 1)
+        pa = wa[co.expand(3, 64, 8), (j % 4).expand(3, 64, 8), (4 * s + 2 * kg + j // 4).expand(3, 64, 8)]
+    elif Cin <= 8:
         s = torch.arange(5, device=dev).view(5, 1, 1)
         pa = wa[co.expand(5, 64, 8), j.expand(5, 64, 8), (2 * s + kg).expand(5, 64, 8)]
     else:
