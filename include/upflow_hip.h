@@ -222,6 +222,11 @@ long long upf_sgu_blend_forward_workspace_bytes(int B, int h, int w, int Hf, int
 int upf_sgu_blend_forward(const float* flow_init, const void* x_out, float* flow_up,
                           float* inter_flow, float* inter_mask, void* workspace,
                           int B, int h, int w, int Hf, int Wf, int dtype, void* stream);
+/* The decoder-level blend (x_out at the flow's own resolution) that ALSO stores the blended flow rounded to x_out's 16-bit type into the
+ * flow estimator's input buffer — two NCHW planes [B,2,H,W] (batch stride given) or one octet entry per pixel [u, v, 0 x 6] — which
+ * upf_flow_update / upf_flow_update_c8 wrote in a launch of their own (round 6; inference). */
+int upf_sgu_blend_forward_flow16(const float* flow_init, const void* x_out, float* flow_up, void* flow16, long long flow16_batch_stride,
+                                 int flow16_is_c8, int B, int H, int W, int dtype, void* stream);
 /* g_flow_init32 [B,2,Hf,Wf] and g_x_out32 [B,3,h,w] fp32, fully produced by the call.  The scatters accumulate in 64-bit
  * fixed point (bit-reproducible); `workspace`: upf_sgu_blend_backward_workspace_bytes(B,h,w,Hf,Wf) bytes, zero-filled
  * by the call itself on `stream`. */

@@ -535,3 +535,26 @@ def test_conv1x1_dual_destination_equals_two_launches(case, dts):
     assert torch.equal(a[:, 1:1 + no].contiguous().view(torch.int16), want.view(torch.int16))
     assert torch.equal(c[:, 2:2 + no].contiguous().view(torch.int16), want.view(torch.int16))
     assert bool((a[:, 0] == 3).all()) and bool((a[:, -1] == 3).all()) and bool((c[:, :2] == 5).all()) and bool((c[:, -1] == 5).all())
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 24, 80), (1, 13, 37), (8, 96, 320)])
+def test_blend_stores_the_estimators_flow_slot_itself(shape, dt):
+    """upf_sgu_blend_forward_flow16 == upf_sgu_blend_forward followed by upf_flow_update / upf_flow_update_c8 of its output, bit for bit, for
+    both slot layouts (two NCHW planes of a wider buffer / one octet of a channel-octet buffer); nothing else in the buffers is touched."""
+    from upflow_pytorch_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 7 + H + W)
+    flow = (torch.randn(B, 2, H, W, generator=g) * 3).cuda()
+    x_out = torch.randn(B, 3, H, W, generator=g).to(dt).cuda()
+    want_up = ops.sgu_blend(flow, x_out, None, want_inter=False)[1]
+    big = torch.full((B, 7, H, W), 5.0, dtype=dt, device='cuda')
+    up_a = ops.sgu_blend_flow16(flow, x_out, big[:, 3:5])
+    ref = torch.full((B, 7, H, W), 5.0, dtype=dt, device='cuda')
+    ops.flow_update(want_up, out=ref[:, 3:5])
+    assert torch.equal(up_a, want_up) and torch.equal(big.view(torch.int16), ref.view(torch.int16))
+    b8 = torch.full((B, 3, H, W, 8), 3.0, dtype=dt, device='cuda')
+    up_b = ops.sgu_blend_flow16(flow, x_out, b8[:, 1:2])
+    r8 = torch.full((B, 3, H, W, 8), 3.0, dtype=dt, device='cuda')
+    ops.flow_update_c8(want_up, None, None, r8[:, 1:2])
+    assert torch.equal(up_b, want_up) and torch.equal(b8.view(torch.int16), r8.view(torch.int16))

@@ -25,6 +25,8 @@ for v in variants:
     pwc_modules._NO_NARROW[0] = bool(int(opts.pop('no_narrow', 0)))   # (Cout <= 16 octet layers on the 32-channel kernel)
     pwc_modules.MERGE_TAIL[0] = not bool(int(opts.pop('no_merge', 0)))  # (merged narrow tails of the octet stacks, round 6)
     pwc_modules.FUSE_PAIRS[0] = not bool(int(opts.pop('no_pairs', 0)))  # (fused SGU guidance stem, round 6)
+    from upflow_pytorch_amd.model import upflow as _mu
+    _mu.FLOW16_IN_BLEND[0] = not bool(int(opts.pop('no_flow16', 0)))    # (the blend stores the estimator's flow slot itself, round 6)
     pwc_modules.DUAL_1X1[0] = not bool(int(opts.pop('no_dual', 0)))     # (1x1 projection stored into both stacks' buffers by one launch, round 6)
     for m in net.modules():
         m.__dict__.pop('_packed8', None)                  # (packed operands are cached per module: rebuild for this variant)

@@ -52,6 +52,7 @@ SIGNATURES = {
     'upf_flow_upsample_forward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_flow_upsample_backward': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     'upf_sgu_blend_forward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'upf_sgu_blend_forward_flow16': [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp],
     'upf_sgu_blend_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'upf_normalize_forward': [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     'upf_normalize_backward': [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp],

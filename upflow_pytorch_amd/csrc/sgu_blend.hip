@@ -65,7 +65,8 @@ template <typename T>
 __global__ __launch_bounds__(THREADS)
 void blend_fwd_kernel(const float* __restrict__ flow_init, const T* __restrict__ x_out, const float* __restrict__ sig,
                       float* __restrict__ flow_up, float* __restrict__ inter_flow, float* __restrict__ inter_mask,
-                      int h, int w, int Hf, int Wf, float scale_y, float scale_x, float su, float sv, SampleGeom geo) {
+                      int h, int w, int Hf, int Wf, float scale_y, float scale_x, float su, float sv, SampleGeom geo,
+                      T* __restrict__ flow16 = nullptr, long long f16bs = 0, int f16_c8 = 0) {
   const int HW = Hf * Wf, hw = h * w;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -97,11 +98,23 @@ void blend_fwd_kernel(const float* __restrict__ flow_init, const T* __restrict__
   const float w0 = t.in[0] ? t.w[0] : 0.f, w1 = t.in[1] ? t.w[1] : 0.f;
   const float w2 = t.in[2] ? t.w[2] : 0.f, w3 = t.in[3] ? t.w[3] : 0.f;
   const float om = 1.0f - m;
+  float fu[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const float* f = f0 + c * HW;
     const float warped = ((f[o0] * w0 + f[o1] * w1) + f[o2] * w2) + f[o3] * w3;
-    flow_up[((size_t)n * 2 + c) * HW + p] = warped * om + f[p] * m;     // upflow.py:88
+    fu[c] = warped * om + f[p] * m;                                     // upflow.py:88
+    flow_up[((size_t)n * 2 + c) * HW + p] = fu[c];
+  }
+  if (flow16) {
+    // (round 6) the blended flow rounded to the decoder's 16-bit type straight into the flow estimator's input buffer — an octet entry
+    // [u, v, 0 x 6] or two NCHW planes — what upf_flow_update(_c8)(flow_up) wrote in a launch of its own (the same rounding of the same value)
+    if (f16_c8) {
+      *reinterpret_cast<uint4*>(flow16 + (size_t)n * f16bs + (size_t)p * 8) = make_uint4(pack2<T>(fu[0], fu[1]), 0u, 0u, 0u);
+    } else {
+      Elem<T>::store(flow16 + (size_t)n * f16bs + p, fu[0]);
+      Elem<T>::store(flow16 + (size_t)n * f16bs + HW + p, fu[1]);
+    }
   }
   if (inter_flow) {
     inter_flow[((size_t)n * 2 + 0) * HW + p] = ifx;
@@ -645,6 +658,24 @@ extern "C" int upf_sgu_blend_forward(const float* flow_init, const void* x_out, 
                hipLaunchKernelGGL((sgu::blend_fwd_kernel<T>), grid, dim3(sgu::THREADS), 0, st, flow_init, (const T*)x_out, sig, flow_up, inter_flow, inter_mask,
                                   h, w, Hf, Wf, scale_y, scale_x, su, sv, make_sample_geom(Hf, Wf)));
   return check_launch("sgu_blend_forward");
+}
+
+extern "C" int upf_sgu_blend_forward_flow16(const float* flow_init, const void* x_out, float* flow_up, void* flow16, long long flow16_batch_stride,
+                                            int flow16_is_c8, int B, int H, int W, int dtype, void* stream) {
+  using namespace upf;
+  UPF_REQUIRE(flow_init && x_out && flow_up && flow16, UPF_EINVAL, "sgu_blend_forward_flow16: null pointer");
+  UPF_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && H <= 4 * 65535, UPF_EINVAL, "sgu_blend_forward_flow16: bad shape B=%d %dx%d", B, H, W);
+  UPF_REQUIRE(dtype == UPF_BF16 || dtype == UPF_F16, UPF_EDTYPE, "sgu_blend_forward_flow16: bf16 / fp16 x_out (the 16-bit flow takes its type)");
+  UPF_REQUIRE(!flow16_is_c8 || (aligned_to(flow16, 16) && flow16_batch_stride % 8 == 0), UPF_EINVAL, "sgu_blend_forward_flow16: the octet output must be 16-byte aligned");
+  dim3 grid(cdiv(W, 64), cdiv(H, 4), B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UPF_BF16)
+    hipLaunchKernelGGL((sgu::blend_fwd_kernel<bf16_t>), grid, dim3(sgu::THREADS), 0, st, flow_init, (const bf16_t*)x_out, (const float*)nullptr, flow_up, (float*)nullptr, (float*)nullptr,
+                       H, W, H, W, 1.f, 1.f, 1.f, 1.f, make_sample_geom(H, W), (bf16_t*)flow16, flow16_batch_stride, flow16_is_c8);
+  else
+    hipLaunchKernelGGL((sgu::blend_fwd_kernel<f16_t>), grid, dim3(sgu::THREADS), 0, st, flow_init, (const f16_t*)x_out, (const float*)nullptr, flow_up, (float*)nullptr, (float*)nullptr,
+                       H, W, H, W, 1.f, 1.f, 1.f, 1.f, make_sample_geom(H, W), (f16_t*)flow16, flow16_batch_stride, flow16_is_c8);
+  return check_launch("sgu_blend_forward_flow16");
 }
 
 extern "C" long long upf_sgu_blend_backward_workspace_bytes(int B, int h, int w, int Hf, int Wf) {

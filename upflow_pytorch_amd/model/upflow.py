@@ -36,6 +36,9 @@ from .pwc_modules import (conv, initialize_msra, upsample2d_flow_as, upsample_fl
 from .correlation_package.correlation import Correlation
 
 
+FLOW16_IN_BLEND = [True]     # experiment / parity switch: False = the estimator's flow slot written by upf_flow_update(_c8) in its own launch (rounds 1-5)
+
+
 class network_tools():
     class sgu_model(tools.abstract_model):
         """Self-guided upsample module (model/upflow.py:20-92)."""
@@ -74,16 +77,19 @@ class network_tools():
             # slice + sigmoid + (up-sampling) + torch_warp + blend: ONE launch (csrc/sgu_blend.hip)
             return ops.sgu_blend(flow_init, x_out, output_level_flow)
 
-        def forward_in_buffer(self, flow_init, buf, slot, output_level_flow=None, batch_shift=0):
+        def forward_in_buffer(self, flow_init, buf, slot, output_level_flow=None, batch_shift=0, flow16=None):
             """Inference fast path of forward(): `slot` (the estimator's input slot of `buf`, from
             dense_estimator_mask.alloc_buffer) already holds feature_1 in its first half — written there by the conv
             that produced it; the other frame's features are warped straight into the second half."""
             c1 = slot.shape[1] // 2
             ops.warp_into(slot[:, :c1], flow_init, slot[:, c1:], self.warping_layer.mask_mode, batch_shift)
             _, x_out = self.dense_estimator_mask.forward_in_buffer(buf)
+            if flow16 is not None:
+                # (round 6) flow16: the flow slot of the flow estimator's input buffer — the blend stores the rounded flow there itself
+                return flow_init, ops.sgu_blend_flow16(flow_init, x_out, flow16), None, None
             return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)   # (flow_init, flow_up, None, None)
 
-        def forward_in_buffer_c8(self, flow_init, buf8, output_level_flow=None, batch_shift=0, tap=None):
+        def forward_in_buffer_c8(self, flow_init, buf8, output_level_flow=None, batch_shift=0, tap=None, flow16=None):
             """forward_in_buffer with the estimator's buffer in the channel-octet layout (pwc_modules.c8_level_ok): feature_1 is
             already in its octets (written there by the 1x1 convolution); the other frame's features are warped from those
             octets into the second half, the stack runs on octets, x_out comes back as NCHW planes for the blend."""
@@ -94,6 +100,8 @@ class network_tools():
             x_out = est.forward_in_buffer_c8(buf8)
             if tap is not None:
                 tap('sgu_x_out', x_out)
+            if flow16 is not None:
+                return flow_init, ops.sgu_blend_flow16(flow_init, x_out, flow16), None, None
             return ops.sgu_blend(flow_init, x_out, output_level_flow, want_inter=False)
 
         def output_conv(self, x, out=None, out8=None, pitched=False):
@@ -583,14 +591,16 @@ class UPFlow_net(tools.abstract_model):
                 fast_conv_seq(self.conv_1x1[level], Fm, cache, out=slot[:, nc:nc + 32])
             # (level 0: the initial zero flow already has the coarsest size — the resize is the identity: no launch)
             flow_up = flow if (level == 0 and tuple(flow.shape[2:]) == (H, W)) else upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
+            f16 = None
             if level == 0:                                                    # no warp at the coarsest level (:539-541)
                 pair[1, :B].copy_(Fm[B:])
                 pair[1, B:].copy_(Fm[:B])
             else:
+                f16 = slot[:, nc + 32:] if (use_sgu and FLOW16_IN_BLEND[0]) else None
                 if sbuf8 is not None:
-                    flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B)[1]
+                    flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B, flow16=f16)[1]
                 elif use_sgu:
-                    flow_up = sgi.forward_in_buffer(flow_up, sbuf, sslot, batch_shift=B)[1]
+                    flow_up = sgi.forward_in_buffer(flow_up, sbuf, sslot, batch_shift=B, flow16=f16)[1]
                 ops.warp_into(Fm, flow_up, pair[1], self.warping_layer.mask_mode, B)
             if ops.corr81_norm_supported(pair) and not getattr(self, '_no_fused_norm', False):
                 # statistics pass + cost volume whose loader normalises: the normalised maps are never materialised
@@ -598,7 +608,8 @@ class UPFlow_net(tools.abstract_model):
             else:
                 normed = ops.normalize(pair.reshape(2 * nb, C, H, W))         # rows are (item, channel): one launch pair
                 ops.corr81_forward_raw(normed[:nb], normed[nb:], out=slot[:, :nc], leaky_slope=0.1)
-            ops.flow_update(flow_up, out=slot[:, nc + 32:])
+            if f16 is None:
+                ops.flow_update(flow_up, out=slot[:, nc + 32:])
             _, res = est.forward_in_buffer(buf)
             ops.flow_update(flow_up, res, out=buf[:, est._n_total:])          # flow_up + res -> context network input
             # (forward_c8's first layer reads `buf` as NCHW planes: a contiguous buffer has aligned rows only for W % 8 == 0)
@@ -677,12 +688,14 @@ class UPFlow_net(tools.abstract_model):
         flow_up = upsample2d_flow_as(flow, Fm, mode="bilinear", if_rate=True)
         self._tap('L%d.flow_bilinear' % level, flow_up)
         if use_sgu:
-            flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B, tap=lambda n_, t_: self._tap('L%d.%s' % (level, n_), t_))[1]
+            f16 = buf8[:, o_flow:o_flow + 1] if FLOW16_IN_BLEND[0] else None
+            flow_up = sgi.forward_in_buffer_c8(flow_up, sbuf8, batch_shift=B, tap=lambda n_, t_: self._tap('L%d.%s' % (level, n_), t_), flow16=f16)[1]
             self._tap('L%d.sbuf8' % level, sbuf8)
             self._tap('L%d.flow_sgu' % level, flow_up)
         ops.warp_into(Fm, flow_up, pair[1], self.warping_layer.mask_mode, B)
         ops.corr81_norm_forward_c8(pair[0], pair[1], buf8[:, nconv:nconv + ncorr], leaky_slope=0.1)
-        ops.flow_update_c8(flow_up, None, None, buf8[:, o_flow:o_flow + 1])
+        if not (use_sgu and FLOW16_IN_BLEND[0]):
+            ops.flow_update_c8(flow_up, None, None, buf8[:, o_flow:o_flow + 1])
         res = est.forward_in_buffer_c8(buf8, in_map=in_map)
         ops.flow_update_c8(flow_up, res, None, buf8[:, o_flow + 1:o_flow + 2])        # flow_up + res -> context network input
         # the context network reads [x5 | refined flow] = every octet of the buffer

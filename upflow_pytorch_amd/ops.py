@@ -599,6 +599,29 @@ class SguBlendFunction(Function):
         return g_init, g_xo.to(x_out.dtype), None
 
 
+def sgu_blend_flow16(flow_init, x_out, flow16):
+    """Inference: the decoder-level blend (upflow.py:79-88 at the flow's own resolution) -> flow_up (fp32), which is ALSO stored, rounded to
+    x_out's 16-bit type, into `flow16`: a [B,2,H,W] channel slice of a contiguous NCHW buffer or one octet [B,1,H,W,8] of a channel-octet
+    buffer (the flow slot of the estimator's input) — one launch instead of the blend + flow_update(_c8)."""
+    flow_init = _f32(flow_init).contiguous()
+    x_out = x_out.contiguous()
+    B, _, H, W = x_out.shape
+    if tuple(flow_init.shape) != (B, 2, H, W) or x_out.shape[1] != 3 or x_out.dtype not in (torch.bfloat16, torch.float16) or flow16.dtype != x_out.dtype:
+        raise UpflowHipError('sgu_blend_flow16: flow_init [B,2,H,W] fp32, x_out [B,3,H,W] 16-bit and a 16-bit flow slot of its type expected')
+    c8 = flow16.dim() == 5
+    if c8:
+        if tuple(flow16.shape) != (B, 1, H, W, 8) or not _c8_view_ok(flow16):
+            raise UpflowHipError('sgu_blend_flow16: the octet slot must be [B,1,H,W,8]')
+    elif tuple(flow16.shape) != (B, 2, H, W) or not _is_channel_slice(flow16):
+        raise UpflowHipError('sgu_blend_flow16: the NCHW slot must be a [B,2,H,W] channel slice of a contiguous buffer')
+    dev = _lib.check_gpu(flow_init, x_out)
+    flow_up = torch.empty_like(flow_init)
+    with torch.cuda.device(dev):
+        _lib.call('upf_sgu_blend_forward_flow16', _lib.ptr(flow_init), _lib.ptr(x_out), _lib.ptr(flow_up), _lib.ptr(flow16), flow16.stride(0), int(c8),
+                  B, H, W, _lib.dtype_code(x_out), _lib.stream_ptr(dev))
+    return flow_up
+
+
 def sgu_blend(flow_init, x_out, output_level_flow=None, want_inter=True):
     """model/upflow.py:79-89 -> (flow_init, flow_up, inter_flow, inter_mask).  With
     `output_level_flow` the blend runs at ITS resolution and it replaces flow_init (:84-87).
