@@ -190,9 +190,29 @@ def _conv_roofline_probe(B, H, W, dtype, device, x3):
         return {'bound': 'mfma', 'kernel': 'conv_x3_kernel<MTW=2> (split precision, fp16 hi/lo x 3; context network layer 1, 565->128, 3x3)',
                 'shape': [N, Cin, h, w], 'achieved': round(achieved, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(achieved / 2500.0, 4),
                 'issued_frac': round(3 * achieved / 2500.0, 4), 'traffic': None, 'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2)}
-    return {'bound': 'mfma', 'kernel': 'conv_kernel<MTW=4> (context network layer 1, 565->128, 3x3)', 'shape': [N, Cin, h, w],
+    nchw_us, nchw_tf = avg_us, achieved
+    kname = 'conv_kernel<MTW=4> (context network layer 1, 565->128, 3x3)'
+    from upflow_pytorch_amd.model.pwc_modules import c8_level_ok
+    if c8_level_ok(N, h, w, dtype):
+        # the launch the STEP makes at this level: operands in the channel-octet layout (LDS-DMA staging, octet epilogue), the 565 input
+        # channels in 72 octets as the estimator's buffer holds them (csrc/conv_c8.hip); the NCHW form above is reported beside it
+        n8 = (Cin + 7) // 8
+        x8 = ops.to_c8(x)
+        y8 = ops.c8_empty(N, Cout, h, w, dtype, device)
+        packed8 = ops.conv_c8_pack(wgt, list(range(Cin)) + [-1] * (n8 * 8 - Cin))
+        for _ in range(5):
+            ops.conv_c8_forward_raw(x8, None, packed8, bias, y8, 1, 0.1)
+        e0.record()
+        for _ in range(nrep):
+            ops.conv_c8_forward_raw(x8, None, packed8, bias, y8, 1, 0.1)
+        e1.record()
+        torch.cuda.synchronize(device)
+        avg_us = e0.elapsed_time(e1) * 1e3 / nrep
+        achieved = flop / (avg_us * 1e-6) / 1e12
+        kname = 'conv_kernel<MTW=4, octet operands> (context network layer 1, 565->128, 3x3: the launch inside the step)'
+    return {'bound': 'mfma', 'kernel': kname, 'shape': [N, Cin, h, w],
             'achieved': round(achieved, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(achieved / 2500.0, 4), 'traffic': None,
-            'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2),
+            'algorithmic_flop': flop, 'avg_kernel_us': round(avg_us, 2), 'nchw_form_us': round(nchw_us, 2), 'nchw_form_tflops': round(nchw_tf, 1),
             # what the vendor's bf16 GEMM sustains on this part on random data in its best case (hipBLASLt 8192^3: 1410-1433 TFLOP/s at
             # 1320 W / 1.97 GHz; at this layer's own M x N x K it holds 510-660): tools/gemm_ceiling.py, DESIGN.md 4.2
             'peak_sustained': PEAK_SUSTAINED_TFLOPS, 'frac_of_sustained': round(achieved / PEAK_SUSTAINED_TFLOPS, 4),
